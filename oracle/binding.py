@@ -1,0 +1,161 @@
+"""ctypes binding for the CPU oracle (oracle/mgx_oracle.c).
+
+TEST INFRASTRUCTURE.  Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under multigrid_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmgx_oracle.so")
+
+KIND = {"empty": 0, "blockedunlockpickup": 1}
+ERR_UNKNOWN_ACTION = -2
+
+
+class MgoSpec(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "num_agents", "view_size", "max_steps", "see_through_walls",
+        "allow_agent_overlap", "joint_reward", "success_any", "failure_any", "env_kind")]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "mgx_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "libmgx_oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.mgo_max_threads.restype = C.c_int
+        for name in ("mgo_gen_obs_ref", "mgo_step_ref", "mgo_step_batch", "mgo_gen_obs_batch"):
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def make_spec(d: dict) -> MgoSpec:
+    """d: the spec dict stored in the golden fixtures / EnvSpec.as_dict()."""
+    return MgoSpec(
+        width=d["width"], height=d["height"], num_agents=d["num_agents"], view_size=d["view_size"],
+        max_steps=d["max_steps"], see_through_walls=int(d["see_through_walls"]),
+        allow_agent_overlap=int(d["allow_agent_overlap"]), joint_reward=int(d["joint_reward"]),
+        success_any=int(d["success_termination_mode"] == "any"),
+        failure_any=int(d["failure_termination_mode"] == "any"),
+        env_kind=KIND[d["env_kind"]])
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def pcg64_random(state4: np.ndarray, n: int) -> np.ndarray:
+    """state4: u64[4] = [state_lo, state_hi, inc_lo, inc_hi]; advanced in place."""
+    out = np.empty(n, dtype=np.float64)
+    lib().mgo_pcg64_random(_p(state4, C.c_uint64), C.c_int64(n), _p(out, C.c_double))
+    return out
+
+
+def gen_obs_ref(grid_state: np.ndarray, agent_state: np.ndarray, view: int, see_through: bool) -> np.ndarray:
+    """Reference-layout single env: grid_state (W,H,3) int64, agent_state (A,9) int64 -> (A,v,v,3) int64."""
+    g = np.ascontiguousarray(grid_state, dtype=np.int64)
+    a = np.ascontiguousarray(agent_state, dtype=np.int64)
+    W, H, _ = g.shape
+    A = a.shape[0]
+    out = np.empty((A, view, view, 3), dtype=np.int64)
+    rc = lib().mgo_gen_obs_ref(_p(g, C.c_int64), _p(a, C.c_int64), W, H, A, view, int(see_through),
+                               _p(out, C.c_int64))
+    if rc:
+        raise ValueError(f"mgo_gen_obs_ref failed: {rc}")
+    return out
+
+
+class RefEnv:
+    """Single env in the reference's own array shapes, stepped by the oracle."""
+
+    def __init__(self, spec: dict, grid_state, agent_state, rng_lohi, target=None, step_count=0):
+        self.spec_dict = dict(spec)
+        self.spec = make_spec(spec)
+        self.grid_state = np.ascontiguousarray(grid_state, dtype=np.int64).copy()
+        self.agent_state = np.ascontiguousarray(agent_state, dtype=np.int64).copy()
+        self.rng = np.ascontiguousarray(rng_lohi, dtype=np.uint64).copy()
+        self.step_count = np.array([step_count], dtype=np.int64)
+        self.target = np.array(list(target) if target is not None else [0, 0, 0], dtype=np.int64)
+
+    def gen_obs(self):
+        return gen_obs_ref(self.grid_state, self.agent_state, self.spec.view_size,
+                           bool(self.spec.see_through_walls))
+
+    def step(self, actions):
+        A, v = self.spec.num_agents, self.spec.view_size
+        act = np.ascontiguousarray(actions, dtype=np.int8)
+        obs = np.empty((A, v, v, 3), dtype=np.int64)
+        direction = np.empty(A, dtype=np.int64)
+        reward = np.empty(A, dtype=np.float64)
+        terminated = np.empty(A, dtype=np.uint8)
+        truncated = np.zeros(1, dtype=np.uint8)
+        order = np.empty(A, dtype=np.int32)
+        rc = lib().mgo_step_ref(
+            C.byref(self.spec), _p(self.grid_state, C.c_int64), _p(self.agent_state, C.c_int64),
+            _p(self.rng, C.c_uint64), _p(self.step_count, C.c_int64), _p(act, C.c_int8),
+            _p(self.target, C.c_int64), _p(obs, C.c_int64), _p(direction, C.c_int64), _p(reward, C.c_double),
+            _p(terminated, C.c_uint8), _p(truncated, C.c_uint8), _p(order, C.c_int))
+        if rc == ERR_UNKNOWN_ACTION:
+            raise ValueError("Unknown action")
+        if rc:
+            raise RuntimeError(f"mgo_step_ref failed: {rc}")
+        return obs, direction, reward, terminated.astype(bool), bool(truncated[0]), order
+
+
+def step_batch(spec: dict, grid, agents, rng, step_count, actions, target=None, nthreads: int = 1):
+    """Product-layout batched step on numpy arrays (modified in place).  Returns (obs, dir, reward,
+    terminated, truncated)."""
+    sp = make_spec(spec)
+    B = grid.shape[0]
+    A, v = sp.num_agents, sp.view_size
+    for arr in (grid, agents, rng, step_count, actions):
+        assert arr.flags.c_contiguous
+    obs = np.empty((B, A, v, v, 3), dtype=np.uint8)
+    d = np.empty((B, A), dtype=np.uint8)
+    reward = np.empty((B, A), dtype=np.float64)
+    terminated = np.empty((B, A), dtype=np.uint8)
+    truncated = np.empty((B,), dtype=np.uint8)
+    err_env = C.c_int64(-1)
+    tgt = _p(target, C.c_uint8) if target is not None else None
+    rc = lib().mgo_step_batch(
+        C.byref(sp), C.c_int64(B), _p(grid, C.c_uint8), _p(agents, C.c_uint8), _p(rng, C.c_uint64),
+        _p(step_count, C.c_int32), _p(actions, C.c_int8), tgt, _p(obs, C.c_uint8), _p(d, C.c_uint8),
+        _p(reward, C.c_double), _p(terminated, C.c_uint8), _p(truncated, C.c_uint8), C.byref(err_env),
+        int(nthreads))
+    if rc == ERR_UNKNOWN_ACTION:
+        raise ValueError(f"Unknown action (env {err_env.value})")
+    if rc:
+        raise RuntimeError(f"mgo_step_batch failed: {rc}")
+    return obs, d, reward, terminated, truncated
+
+
+def gen_obs_batch(spec: dict, grid, agents, nthreads: int = 1):
+    sp = make_spec(spec)
+    B = grid.shape[0]
+    A, v = sp.num_agents, sp.view_size
+    obs = np.empty((B, A, v, v, 3), dtype=np.uint8)
+    d = np.empty((B, A), dtype=np.uint8)
+    rc = lib().mgo_gen_obs_batch(C.byref(sp), C.c_int64(B), _p(grid, C.c_uint8), _p(agents, C.c_uint8),
+                                 _p(obs, C.c_uint8), _p(d, C.c_uint8), int(nthreads))
+    if rc:
+        raise RuntimeError(f"mgo_gen_obs_batch failed: {rc}")
+    return obs, d
+
+
+def max_threads() -> int:
+    return int(lib().mgo_max_threads())

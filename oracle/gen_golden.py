@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (ini/multigrid) in the build container.
+
+TEST INFRASTRUCTURE -- not product code.  Runs only where /root/reference exists (never on the GPU box):
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+The reference's four absent third-party packages are satisfied by `oracle/standins/` (this repo's own
+stand-ins; see its README).  Every array written here is *data produced by the reference*: initial state
+tensors, the post-reset bit-generator state, the action script, and per step the reference's outputs
+(`MultiGridEnv.step`, multigrid/base.py:303-346) and post-step state.  No reference source is copied.
+
+Array conventions in the .npz files (reference layouts, narrowed to the smallest lossless dtype):
+    grid0        (W,H,3)   Grid.state after reset (+ scenario edits)       multigrid/core/grid.py:54
+    agents0      (A,9)     AgentState rows after reset                     multigrid/core/agent.py:222-232
+    rng0         (4,) u64  PCG64 [state_hi, state_lo, inc_hi, inc_lo] after reset returned (SURVEY A.6 trap)
+    actions      (T,A) i8  -1 = agent key absent from the actions dict     multigrid/base.py:403-404
+    order        (T,A)     handle_actions' random visiting order           multigrid/base.py:396-399
+    obs0         (A,v,v,3) reset observation images                        multigrid/base.py:295
+    obs          (T,A,v,v,3), direction (T,A), reward (T,A) f64, terminated (T,A), truncated (T,)
+    grid         (T,W,H,3), agents (T,A,9)  post-step state
+    rng_final    (4,) u64
+    spec_json    JSON: constructor-level parameters needed to rebuild the EnvSpec
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REFERENCE = os.environ.get("MGX_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, os.path.join(HERE, "standins"))
+
+import numpy as np  # noqa: E402
+
+import multigrid.envs as ref_envs  # noqa: E402
+from multigrid.core.world_object import Ball, Box, Door, Floor, Key, Lava, Wall  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+_MAKE_COUNT = [0]
+M64 = (1 << 64) - 1
+
+
+def rng_words(gen) -> np.ndarray:
+    st = gen.bit_generator.state["state"]
+    s, inc = int(st["state"]), int(st["inc"])
+    return np.array([s >> 64, s & M64, inc >> 64, inc & M64], dtype=np.uint64)
+
+
+def clone_order(gen, n):
+    """What handle_actions will draw next (base.py:396-399), without disturbing the env's generator."""
+    if n == 1:
+        return np.zeros(1, dtype=np.int64)
+    bg = np.random.PCG64()
+    bg.state = gen.bit_generator.state
+    return np.random.Generator(bg).random(size=n).argsort()
+
+
+def narrow(a):
+    a = np.asarray(a)
+    if a.dtype == np.bool_:
+        return a.astype(np.uint8)
+    if a.dtype.kind in "iu":
+        lo, hi = (int(a.min()), int(a.max())) if a.size else (0, 0)
+        if lo >= 0 and hi <= 255:
+            return a.astype(np.uint8)
+        if lo >= -128 and hi <= 127:
+            return a.astype(np.int8)
+        return a.astype(np.int32)
+    return a
+
+
+def make_env(name, **kwargs):
+    cls, cfg = ref_envs.CONFIGURATIONS[name]
+    # pin the construction-time (layout) generator so regeneration is reproducible; see standins/gymnasium
+    _MAKE_COUNT[0] += 1
+    cls._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
+    return cls(**{**cfg, **kwargs})
+
+
+def spec_of(env, kind, extra=None):
+    d = dict(
+        env_kind=kind,
+        width=int(env.width), height=int(env.height), num_agents=int(env.num_agents),
+        view_size=int(env.agents[0].view_size),
+        see_through_walls=bool(env.agents[0].see_through_walls),
+        allow_agent_overlap=bool(env.allow_agent_overlap),
+        joint_reward=bool(env.joint_reward),
+        success_termination_mode=str(env.success_termination_mode),
+        failure_termination_mode=str(env.failure_termination_mode),
+        max_steps=int(env.max_steps),
+    )
+    if kind == "blockedunlockpickup":
+        d["target"] = [int(v) for v in np.asarray(env.obj)]
+    d.update(extra or {})
+    return d
+
+
+def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, script=None, note=""):
+    obs0, _ = env.reset(seed=seed)
+    if edit is not None:
+        edit(env)
+        obs0 = env.gen_obs()
+    A = env.num_agents
+    rec = dict(
+        grid0=narrow(env.grid.state.copy()),
+        agents0=narrow(np.asarray(env.agent_states).copy()),
+        rng0=rng_words(env.np_random),
+        obs0=narrow(np.stack([obs0[i]["image"] for i in range(A)])),
+        dir0=narrow(np.array([int(obs0[i]["direction"]) for i in range(A)])),
+    )
+    if script is not None:
+        actions = np.asarray(script, dtype=np.int8)
+        T = len(actions)
+    else:
+        actions = action_rng.integers(0, 7, size=(T, A)).astype(np.int8)
+        if p_missing > 0:
+            actions[action_rng.random((T, A)) < p_missing] = -1
+    keys = ("order", "obs", "direction", "reward", "terminated", "truncated", "grid", "agents")
+    log = {k: [] for k in keys}
+    for t in range(T):
+        log["order"].append(clone_order(env.np_random, A))
+        act = {i: int(actions[t, i]) for i in range(A) if actions[t, i] >= 0}
+        obs, rew, term, trunc, _ = env.step(act)
+        log["obs"].append(np.stack([obs[i]["image"] for i in range(A)]))
+        log["direction"].append([int(obs[i]["direction"]) for i in range(A)])
+        log["reward"].append([float(rew[i]) for i in range(A)])
+        log["terminated"].append([bool(term[i]) for i in range(A)])
+        log["truncated"].append(bool(trunc[0]))
+        assert len(set(bool(trunc[i]) for i in range(A))) == 1
+        log["grid"].append(env.grid.state.copy())
+        log["agents"].append(np.asarray(env.agent_states).copy())
+    rec["actions"] = actions
+    for k in keys:
+        arr = np.asarray(log[k])
+        rec[k] = arr.astype(np.float64) if k == "reward" else narrow(arr)
+    rec["rng_final"] = rng_words(env.np_random)
+    rec["spec_json"] = np.array(json.dumps(spec_of(env, kind, dict(seed=seed, note=note))))
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, fname + ".npz")
+    np.savez_compressed(path, **rec)
+    n_succ = int((rec["reward"] > 0).any(axis=1).sum())
+    print(f"{fname:34s} T={T:4d} A={A:2d} grid={env.width}x{env.height} "
+          f"success-steps={n_succ:3d} terminated-end={rec['terminated'][-1].tolist()} "
+          f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def sprinkle(density, seed, doors=True):
+    """Scenario edit: scatter every object type over interior cells not under an agent (uses the
+    reference's own WorldObj classes and Grid.set, multigrid/core/grid.py:78-100)."""
+    colors = ["red", "green", "blue", "purple", "yellow", "grey"]
+
+    def edit(env):
+        r = np.random.default_rng(seed)
+        agent_cells = {tuple(int(v) for v in a.state.pos) for a in env.agents}
+        for x in range(1, env.width - 1):
+            for y in range(1, env.height - 1):
+                if (x, y) in agent_cells or env.grid.get(x, y) is not None:
+                    continue
+                if r.random() >= density:
+                    continue
+                c = colors[int(r.integers(6))]
+                k = int(r.integers(9 if doors else 6))
+                obj = [lambda: Lava(), lambda: Floor(c), lambda: Key(c), lambda: Ball(c), lambda: Box(c),
+                       lambda: Wall(), lambda: Door(c), lambda: Door(c, is_locked=True),
+                       lambda: Door(c, is_open=True)][k]()
+                env.grid.set(x, y, obj)
+    return edit
+
+
+def main():
+    # C1: the reference's own CPU-runnable case (BASELINE.json configs[0])
+    record("empty8_a2_seed0", make_env("MultiGrid-Empty-8x8-v0", agents=2), "empty", 0, 256,
+           np.random.default_rng(0), note="C1 plumbing case; actions default_rng(0).integers(0,7,(T,A))")
+    # C2/C4 shape: Empty-16x16, 4 agents, view 7
+    for seed in (1, 7):
+        record(f"empty16_a4_seed{seed}", make_env("MultiGrid-Empty-16x16-v0", agents=4), "empty", seed, 300,
+               np.random.default_rng(100 + seed), note="C2/C4 shape")
+    # biased towards 'forward' so agents reach the goal: exercises on_success ('any') + reward value
+    def fwd_script(T, A, seed):
+        r = np.random.default_rng(seed)
+        return r.choice([0, 1, 2, 2, 2, 2, 2, 5], size=(T, A)).astype(np.int8)
+    record("empty6_a3_goal", make_env("MultiGrid-Empty-6x6-v0", agents=3), "empty", 3, None, None,
+           script=fwd_script(120, 3, 5), note="goal reached under success 'any'; steps after termination")
+    record("empty6_a3_goal_all_joint",
+           make_env("MultiGrid-Empty-6x6-v0", agents=3, success_termination_mode="all", joint_reward=True),
+           "empty", 4, None, None, script=fwd_script(200, 3, 6), note="success 'all' + joint reward")
+    # every object type, doors in all 3 states, 5% missing actions
+    record("empty16_a4_objects", make_env("MultiGrid-Empty-16x16-v0", agents=4), "empty", 11, 400,
+           np.random.default_rng(211), p_missing=0.05, edit=sprinkle(0.30, 5), note="all object types")
+    record("empty8_a3_dense", make_env("MultiGrid-Empty-8x8-v0", agents=3), "empty", 12, 400,
+           np.random.default_rng(212), p_missing=0.05, edit=sprinkle(0.45, 6), note="dense pickup/drop/toggle")
+    # lava with failure 'any' and 'all'
+    record("empty8_a3_lava_any",
+           make_env("MultiGrid-Empty-8x8-v0", agents=3, failure_termination_mode="any"), "empty", 13, None, None,
+           edit=sprinkle(0.25, 7, doors=False), script=fwd_script(150, 3, 8), note="lava, failure 'any'")
+    record("empty8_a3_lava_all", make_env("MultiGrid-Empty-8x8-v0", agents=3), "empty", 14, None, None,
+           edit=sprinkle(0.25, 9, doors=False), script=fwd_script(150, 3, 10), note="lava, failure 'all'")
+    # no agent overlap, view 5, random starts
+    record("emptyrand6_a3_nooverlap_v5",
+           make_env("MultiGrid-Empty-Random-6x6-v0", agents=3, allow_agent_overlap=False, agent_view_size=5),
+           "empty", 21, 300, np.random.default_rng(221), p_missing=0.05, note="allow_agent_overlap=False, v=5")
+    # single agent (no RNG draw, no overlay), see_through_walls
+    record("empty8_a1_seethrough", make_env("MultiGrid-Empty-8x8-v0", agents=1, see_through_walls=True),
+           "empty", 22, 200, np.random.default_rng(222), edit=sprinkle(0.3, 11), note="A=1, see_through_walls")
+    record("empty8_a1_walls", make_env("MultiGrid-Empty-8x8-v0", agents=1),
+           "empty", 23, 200, np.random.default_rng(223), edit=sprinkle(0.3, 12), note="A=1, occlusion")
+    # 5 agents, v=9, success all / failure any / joint reward / random starts
+    record("empty16_a5_v9_modes",
+           make_env("MultiGrid-Empty-16x16-v0", agents=5, agent_view_size=9, agent_start_pos=None,
+                    success_termination_mode="all", failure_termination_mode="any", joint_reward=True),
+           "empty", 31, 300, np.random.default_rng(231), p_missing=0.05, edit=sprinkle(0.15, 13),
+           note="v=9, modes")
+    # tiny view / large view
+    record("empty8_a2_v3", make_env("MultiGrid-Empty-8x8-v0", agents=2, agent_view_size=3), "empty", 32, 150,
+           np.random.default_rng(232), edit=sprinkle(0.3, 14), note="v=3")
+    record("empty16_a2_v11", make_env("MultiGrid-Empty-16x16-v0", agents=2, agent_view_size=11,
+                                      agent_start_pos=None), "empty", 33, 150,
+           np.random.default_rng(233), edit=sprinkle(0.25, 15), note="v=11")
+    # max_steps truncation boundary
+    record("empty5_a2_trunc", make_env("MultiGrid-Empty-5x5-v0", agents=2, max_steps=20), "empty", 34, 40,
+           np.random.default_rng(234), note="truncation at step 20, stepping beyond")
+    # C5 shape: 64x64, 16 agents, view 9
+    record("empty64_a16_v9", make_env("MultiGrid-Empty-8x8-v0", size=64, agents=16, agent_view_size=9,
+                                      agent_start_pos=None), "empty", 41, 60,
+           np.random.default_rng(241), edit=sprinkle(0.08, 16), note="C5 shape")
+    # C3: BlockedUnlockPickup (RoomGrid draws from the seeded stream inside reset -> rng0 snapshot matters)
+    for A, seed in ((2, 51), (3, 52)):
+        record(f"bup_a{A}_seed{seed}", make_env("MultiGrid-BlockedUnlockPickup-v0", agents=A),
+               "blockedunlockpickup", seed, 300, np.random.default_rng(250 + A), p_missing=0.03, note="C3")
+
+    # C3 with the post-step success hook firing: teleport agent 0 next to the target box, facing it
+    def next_to_box(env):
+        bx, by = env.obj.cur_pos
+        for d, (dx, dy) in enumerate([(1, 0), (0, 1), (-1, 0), (0, -1)]):
+            x, y = bx - dx, by - dy
+            if env.grid.get(x, y) is None:
+                env.agents[0].state.pos = (x, y)
+                env.agents[0].state.dir = d
+                return
+        raise RuntimeError("box is boxed in")
+    hook = np.array([[6, 2]] * 3 + [[3, 0]] + [[2, 1], [4, 2], [3, 5], [5, 3], [0, 4]] * 4, dtype=np.int8)
+    record("bup_a2_hook", make_env("MultiGrid-BlockedUnlockPickup-v0", agents=2), "blockedunlockpickup",
+           53, None, None, edit=next_to_box, script=hook, note="post-step hook: carrying target box -> success")
+
+    # scripted key / locked-door protocol (world_object.py:458-474): wrong key, no key, unlock, close, reopen
+    def key_and_doors(env):
+        env.grid.set(2, 1, Key("blue"))
+        env.grid.set(3, 1, Door("blue", is_locked=True))
+        env.grid.set(2, 2, Door("red", is_locked=True))
+        for y in range(2, 7):
+            env.grid.set(3, y, Wall())
+    script = [[3, 6], [2, 2], [6, 5], [1, 6], [5, 6], [0, 6], [5, 6], [6, 5], [6, 5], [2, 2], [2, 6], [4, 6],
+              [6, 5]]
+    script += np.random.default_rng(77).integers(0, 7, size=(80, 2)).tolist()
+    record("empty8_a2_unlock", make_env("MultiGrid-Empty-8x8-v0", agents=2), "empty", 61, None, None,
+           edit=key_and_doors, script=script, note="scripted unlock / wrong key / close / reopen")
+
+
+if __name__ == "__main__":
+    main()
