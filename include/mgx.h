@@ -1,0 +1,107 @@
+/*
+ * mgx.h -- C ABI of the MI355X-native batched MultiGrid step/observation engine (libmgx.so).
+ *
+ * The reference (ini/multigrid) is pure Python and has no FFI of its own: the seam this
+ * library replaces is the pair of Python call sites
+ *     multigrid/base.py:361-366   image = gen_obs_grid_encoding(grid.state, agent_states, view_size, see_through_walls)
+ *     multigrid/base.py:333-340   step_count += 1; rewards = handle_actions(actions); gen_obs(); terminations; truncated
+ * batched over B independent environments.  Every entry point takes plain device pointers and sizes, returns 0 or
+ * a negative MGX_ERR_* code, never throws, never allocates, never frees and never retains a pointer.  All work is
+ * enqueued on the HIP stream passed by the caller (a hipStream_t cast to void*; NULL = the default stream); the
+ * functions do not synchronise.
+ *
+ * Tensor layouts (all contiguous, device memory):
+ *   grid        u8 [B, H, W, 3]   cell (x, y) = (type, color, state) at ((b*H + y)*W + x)*3.  This is the [y][x]
+ *                                 transpose of the reference's Grid.state (W,H,3) (multigrid/core/grid.py:54).
+ *   agents      u8 [B, A, 8]      packed AgentState row (multigrid/core/agent.py:222-232, 72 B -> 8 B):
+ *                                 [0]=color [1]=dir [2]=x [3]=y [4]=terminated [5]=carry.type [6]=carry.color
+ *                                 [7]=carry.state ; "carrying nothing" = the empty cell (1,0,0) (agent.py:337-346).
+ *   rng         u64[B, 4]         per-env numpy PCG64 state of `env.np_random`: [state_lo, state_hi, inc_lo, inc_hi].
+ *                                 Advanced by A draws per step when A > 1 (multigrid/base.py:396-399).
+ *   step_count  i32[B]            multigrid/base.py:292, 333
+ *   actions     i8 [B, A]         multigrid/core/actions.py:5-15 (0..6); -1 = agent absent from the actions dict
+ *                                 (multigrid/base.py:403-404); any other value = MGX_ERR_UNKNOWN_ACTION (base.py:473).
+ *   target      u8 [B, 4]         env_kind-specific per-env data.  BlockedUnlockPickup: (type, color, state, 0) of the
+ *                                 target box `self.obj` (multigrid/envs/blockedunlockpickup.py:147, 172).  May be NULL
+ *                                 for MGX_KIND_EMPTY.
+ *   obs         u8 [B, A, v, v, 3] image[i][j][c] exactly as multigrid/utils/obs.py:65-102 returns it
+ *   dir         u8 [B, A]         obs['direction'] (multigrid/base.py:359, 372)
+ *   reward      f64[B, A]         multigrid/base.py:393, 503-507, 598-602 (bit-identical Python float arithmetic)
+ *   terminated  u8 [B, A]         multigrid/base.py:338 (+ env hook)
+ *   truncated   u8 [B]            multigrid/base.py:339-340
+ *   err         i32[2]            err[0] += number of envs that met an unknown action; err[1] = min such env index.
+ *                                 The caller initialises it to {0, INT32_MAX} and inspects it after synchronising.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_ABI_VERSION 1
+
+enum {
+    MGX_OK = 0,
+    MGX_ERR_INVALID_ARGUMENT = -1, /* NULL pointer, bad spec (even / <3 view size: multigrid/core/agent.py:78-79) */
+    MGX_ERR_UNKNOWN_ACTION = -2,   /* reported through `err`, mirrors ValueError at multigrid/base.py:473-474 */
+    MGX_ERR_UNSUPPORTED = -3,      /* spec outside the compiled limits (MGX_MAX_AGENTS, MGX_MAX_VIEW, LDS budget) */
+    MGX_ERR_LAUNCH = -4            /* hipLaunchKernel failed; see mgx_last_hip_error() */
+};
+
+enum { MGX_KIND_EMPTY = 0, MGX_KIND_BLOCKEDUNLOCKPICKUP = 1 };
+
+#define MGX_MAX_AGENTS 32
+#define MGX_MAX_VIEW 15
+#define MGX_AGENT_STRIDE 8
+
+/* Constructor-level configuration of one env class: multigrid/base.py:85-103 plus the env-specific step hook. */
+typedef struct MgxSpec {
+    int32_t width;               /* grid width  W  (multigrid/base.py:152-155) */
+    int32_t height;              /* grid height H */
+    int32_t num_agents;          /* A */
+    int32_t view_size;           /* v, odd, 3..MGX_MAX_VIEW (multigrid/core/agent.py:78-80) */
+    int32_t max_steps;           /* multigrid/base.py:91 */
+    int32_t see_through_walls;   /* multigrid/base.py:92 (agents[0]'s value is used for all: base.py:364-365) */
+    int32_t allow_agent_overlap; /* multigrid/base.py:95 */
+    int32_t joint_reward;        /* multigrid/base.py:96 */
+    int32_t success_any;         /* success_termination_mode == 'any' (multigrid/base.py:97) */
+    int32_t failure_any;         /* failure_termination_mode == 'any' (multigrid/base.py:98) */
+    int32_t env_kind;            /* MGX_KIND_*: which subclass step() hook runs after the base step */
+} MgxSpec;
+
+/* Launch geometry chosen for (spec, batch); for diagnostics, benchmarks and DESIGN.md tables. */
+typedef struct MgxLaunchInfo {
+    int32_t envs_per_workgroup;
+    int32_t threads_per_workgroup;
+    int32_t workgroups;
+    int32_t lds_bytes;
+} MgxLaunchInfo;
+
+int mgx_abi_version(void);
+const char *mgx_error_string(int code);
+int mgx_last_hip_error(void);
+
+/* Replaces gen_obs_grid_encoding (multigrid/utils/obs.py:65-102) as called from MultiGridEnv.gen_obs
+ * (multigrid/base.py:361-366), for B envs.  `dir` may be NULL. */
+int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+                uint8_t *obs, uint8_t *dir, void *stream);
+
+/* Replaces MultiGridEnv.step (multigrid/base.py:303-346: step_count += 1, handle_actions 378-476, gen_obs
+ * 348-376, terminations, truncations) and the BlockedUnlockPickupEnv.step post-hook
+ * (multigrid/envs/blockedunlockpickup.py:166-175), for B envs, in one fused kernel launch.
+ * grid / agents / rng / step_count are updated in place. */
+int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+             int32_t *step_count, const int8_t *actions, const uint8_t *target,
+             uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+             int32_t *err, void *stream);
+
+/* Geometry the two calls above would use. */
+int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

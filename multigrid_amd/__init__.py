@@ -1,0 +1,11 @@
+"""multigrid_amd -- MI355X-native batched MultiGrid step/observation engine.
+
+A drop-in for the hot path of ini/multigrid (`MultiGridEnv.step` / `gen_obs`): thousands of independent
+gridworlds live in HBM as uint8 tensors and are stepped by one fused hand-written HIP kernel (gfx950).
+See DESIGN.md for the data layout and kernels, INTEGRATION.md for the C ABI, include/mgx.h for signatures.
+"""
+from .constants import Action, Color, Direction, State, Type  # noqa: F401
+from .spec import EnvSpec  # noqa: F401
+from .batched import BatchedMultiGridEnv  # noqa: F401
+
+__all__ = ["Action", "Color", "Direction", "State", "Type", "EnvSpec", "BatchedMultiGridEnv"]

@@ -1,0 +1,73 @@
+"""ctypes binding of libmgx.so (include/mgx.h).  Fails loudly when the HIP library is missing: there is no
+CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .spec import MgxSpecC
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmgx.so")
+
+ABI_VERSION = 1
+OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
+
+#: every symbol include/mgx.h declares
+EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
+           "mgx_launch_info")
+
+
+class MgxLaunchInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("envs_per_workgroup", "threads_per_workgroup", "workgroups", "lds_bytes")]
+
+
+class MgxError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        self.code = code
+        super().__init__(f"{what}: {error_string(code)} (code {code}, hip error {lib().mgx_last_hip_error()})")
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m multigrid_amd.build` "
+            "(or __graft_entry__.build()). multigrid_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64 = C.c_void_p, C.c_int64
+    L.mgx_abi_version.restype = C.c_int
+    L.mgx_error_string.restype = C.c_char_p
+    L.mgx_error_string.argtypes = [C.c_int]
+    L.mgx_last_hip_error.restype = C.c_int
+    L.mgx_gen_obs.restype = C.c_int
+    L.mgx_gen_obs.argtypes = [C.POINTER(MgxSpecC), i64, vp, vp, vp, vp, vp]
+    L.mgx_step.restype = C.c_int
+    L.mgx_step.argtypes = [C.POINTER(MgxSpecC), i64] + [vp] * 13
+    L.mgx_launch_info.restype = C.c_int
+    L.mgx_launch_info.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLaunchInfo)]
+    if L.mgx_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {L.mgx_abi_version()} != {ABI_VERSION}; rebuild it")
+    _lib = L
+    return L
+
+
+def error_string(code: int) -> str:
+    return lib().mgx_error_string(code).decode()
+
+
+def check(code: int, what: str):
+    if code != OK:
+        raise MgxError(code, what)
+
+
+def launch_info(spec, batch: int) -> dict:
+    info = MgxLaunchInfo()
+    sc = spec.to_c()
+    check(lib().mgx_launch_info(C.byref(sc), batch, C.byref(info)), "mgx_launch_info")
+    return {n: getattr(info, n) for n, _ in MgxLaunchInfo._fields_}

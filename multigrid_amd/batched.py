@@ -1,0 +1,163 @@
+"""BatchedMultiGridEnv: B independent MultiGrid environments resident in HBM, stepped by one fused HIP kernel.
+
+This is the tensor-level form of `multigrid.base.MultiGridEnv` (multigrid/base.py:36-841 of the reference):
+`reset` / `step` / `gen_obs` keep the reference's meaning, with dict-of-agents replaced by a leading
+(batch, agent) shape.  The per-env dict API lives in multigrid_amd/env.py on top of this class.
+
+State (device tensors, layouts in include/mgx.h):
+    grid u8[B,H,W,3]   agents u8[B,A,8]   rng i64[B,4] (PCG64 words)   step_count i32[B]   target u8[B,4]
+Outputs of `step` (pre-allocated, overwritten by every call -- clone what you keep):
+    obs u8[B,A,v,v,3]  dir u8[B,A]  reward f64[B,A]  terminated u8[B,A]  truncated u8[B]
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import layouts, rng as rnglib
+from .constants import NO_ACTION, Action
+from .spec import EnvSpec
+
+INT32_MAX = 2 ** 31 - 1
+
+
+class BatchedMultiGridEnv:
+    def __init__(self, spec: EnvSpec, batch: int, device="cuda", *, first_env: int = 0, backend=None):
+        """
+        spec       environment class configuration
+        batch      number of envs held by THIS process (its shard of the global batch)
+        device     HIP device ('cuda', 'cuda:3', ...).  CPU devices are refused: there is no CPU path.
+        first_env  global index of env 0 of this shard; per-env seeds are a function of the global index so
+                   results do not depend on how the batch is sharded over GPUs
+        backend    launcher override used by the test-suite to exercise this host logic without a GPU;
+                   product code leaves it None (= ops.HipBackend).
+        """
+        self.spec = spec
+        self.batch = int(batch)
+        self.first_env = int(first_env)
+        self.device = torch.device(device)
+        if backend is None:
+            from .ops import HipBackend
+            backend = HipBackend(spec, self.device)
+        self.backend = backend
+        B, A, dev = self.batch, spec.num_agents, self.device
+        self.grid = torch.zeros(spec.grid_shape(B), dtype=torch.uint8, device=dev)
+        self.agents = torch.zeros(spec.agents_shape(B), dtype=torch.uint8, device=dev)
+        self.rng = torch.zeros((B, 4), dtype=torch.int64, device=dev)
+        self.step_count = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.target = torch.zeros((B, 4), dtype=torch.uint8, device=dev)
+        self.err = torch.tensor([0, INT32_MAX], dtype=torch.int32, device=dev)
+        self.obs = torch.zeros(spec.obs_shape(B), dtype=torch.uint8, device=dev)
+        self.dir = torch.zeros((B, A), dtype=torch.uint8, device=dev)
+        self.reward = torch.zeros((B, A), dtype=torch.float64, device=dev)
+        self.terminated = torch.zeros((B, A), dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self._loaded = False
+
+    # ------------------------------------------------------------------------------------------ state in
+    def load_state(self, grid, agents, rng=None, target=None, step_count=None, validate: bool = True):
+        """Install an initial state (numpy arrays or tensors in the product layout).  A single env's state
+        (no batch dim) is broadcast to the whole batch.  This is also the parity-injection point: the
+        reference's `Grid.state` / `AgentState` go through layouts.grid_to_product / pack_agents."""
+        sp, B = self.spec, self.batch
+
+        def prep(x, shape, dtype):
+            t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+            if t.dim() == len(shape) - 1:
+                t = t.unsqueeze(0).expand(shape)
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+            return t.to(dtype=dtype).contiguous()
+
+        g = prep(grid, sp.grid_shape(B), torch.uint8)
+        a = prep(agents, sp.agents_shape(B), torch.uint8)
+        if validate:
+            layouts.check_walled(g.cpu().numpy() if g.device.type != "cpu" else g.numpy())
+            an = a.cpu().numpy()
+            if (an[..., 2] >= sp.width).any() or (an[..., 3] >= sp.height).any() or (an[..., 1] > 3).any():
+                raise ValueError("agent position / direction out of range")
+        self.grid.copy_(g)
+        self.agents.copy_(a)
+        if rng is not None:
+            r = np.asarray(rng.cpu() if torch.is_tensor(rng) else rng)
+            if r.dtype == np.uint64:
+                r = r.view(np.int64)
+            self.rng.copy_(prep(r, (B, 4), torch.int64))
+        if target is not None:
+            self.target.copy_(prep(target, (B, 4), torch.uint8))
+        if step_count is None:
+            self.step_count.zero_()
+        else:
+            self.step_count.copy_(prep(step_count, (B,), torch.int32))
+        self._reset_err()
+        self._loaded = True
+
+    def seed(self, seed: int):
+        """Per-env `np_random = Generator(PCG64(SeedSequence(seed + global_env_index)))` (what
+        `gym.Env.reset(seed=...)` does for one env, multigrid/base.py:269)."""
+        seeds = seed + self.first_env + np.arange(self.batch)
+        self.rng.copy_(torch.from_numpy(rnglib.words_from_seeds(seeds).view(np.int64)))
+
+    def seed_synthetic(self, seed: int):
+        """Benchmark-grade seeding: valid PCG64 states from a hash of the global env index (fast for large B)."""
+        words = rnglib.synthetic_words(self.batch, seed, self.first_env)
+        self.rng.copy_(torch.from_numpy(words.view(np.int64)))
+
+    def _reset_err(self):
+        self.err.copy_(torch.tensor([0, INT32_MAX], dtype=torch.int32))
+
+    # ------------------------------------------------------------------------------------------ hot path
+    def gen_obs(self):
+        """multigrid/base.py:348-376 for every env: returns (obs u8[B,A,v,v,3], dir u8[B,A])."""
+        self._need_state()
+        self.backend.gen_obs(self.batch, self.grid, self.agents, self.obs, self.dir)
+        return self.obs, self.dir
+
+    def step(self, actions: torch.Tensor):
+        """multigrid/base.py:303-346 for every env.
+
+        actions  i8[B,A] on the env's device; `Action` values 0..6, NO_ACTION (-1) = agent not acting
+                 (its key absent from the reference's actions dict, base.py:403-404).
+        Returns (obs, dir, reward, terminated, truncated) -- the env's output buffers.
+        An unknown action value does not raise here (no device sync on the hot path); it is recorded in
+        `err` and surfaced as ValueError by `check_errors()` (multigrid/base.py:473-474).
+        """
+        self._need_state()
+        sp = self.spec
+        if actions.dtype != torch.int8 or tuple(actions.shape) != (self.batch, sp.num_agents) \
+                or actions.device != self.grid.device or not actions.is_contiguous():
+            raise ValueError(f"actions must be a contiguous int8 tensor of shape {(self.batch, sp.num_agents)} "
+                             f"on {self.grid.device}")
+        self.backend.step(self.batch, self.grid, self.agents, self.rng, self.step_count, actions,
+                          self.target if sp.env_kind != "empty" else None, self.err,
+                          self.obs, self.dir, self.reward, self.terminated, self.truncated)
+        return self.obs, self.dir, self.reward, self.terminated, self.truncated
+
+    def check_errors(self):
+        """Synchronises and raises ValueError if any env met an unknown action since the last check."""
+        count, first = (int(v) for v in self.err.cpu())
+        if count:
+            self._reset_err()
+            raise ValueError(f"Unknown action in {count} env(s); first at local env {first} "
+                             f"(valid: {int(Action.left)}..{int(Action.done)}, or {NO_ACTION} for no action)")
+
+    def is_done(self) -> torch.Tensor:
+        """multigrid/base.py:534-539 per env: bool[B]."""
+        truncated = self.step_count >= self.spec.max_steps
+        return truncated | (self.agents[:, :, 4] != 0).all(dim=1)
+
+    def _need_state(self):
+        if not self._loaded:
+            raise RuntimeError("no state loaded: call load_state() / reset() first")
+
+    # ------------------------------------------------------------------------------------------ checkpoint
+    def state_dict(self) -> dict:
+        return {"spec": self.spec.as_dict(), "first_env": self.first_env,
+                "grid": self.grid.cpu().clone(), "agents": self.agents.cpu().clone(),
+                "rng": self.rng.cpu().clone(), "step_count": self.step_count.cpu().clone(),
+                "target": self.target.cpu().clone()}
+
+    def load_state_dict(self, sd: dict):
+        if EnvSpec.from_dict(sd["spec"]) != self.spec:
+            raise ValueError("state_dict was saved for a different EnvSpec")
+        self.load_state(sd["grid"], sd["agents"], sd["rng"], sd["target"], sd["step_count"], validate=False)

@@ -1,0 +1,142 @@
+"""PyTorch-ROCm custom ops over the C ABI of libmgx.so.
+
+    torch.ops.mgx.gen_obs(grid, agents, spec) -> (obs, dir)
+    torch.ops.mgx.step(grid!, agents!, rng!, step_count!, actions, target, err!, spec)
+                                               -> (obs, dir, reward, terminated, truncated)
+
+`spec` is the 11-int list of `struct MgxSpec` (include/mgx.h).  Only the CUDA (= HIP on ROCm) dispatch key is
+registered: calling the ops with CPU tensors raises NotImplementedError from the dispatcher -- there is no
+CPU implementation to fall back to.  Kernels are enqueued on torch's current HIP stream for the tensors'
+device; nothing synchronises.
+
+`HipBackend` is the allocation-free form used by BatchedMultiGridEnv (pre-bound output buffers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .spec import EnvSpec, MgxSpecC
+
+_SPEC_FIELDS = [n for n, _ in MgxSpecC._fields_]
+
+
+def spec_to_ints(spec: EnvSpec) -> list[int]:
+    c = spec.to_c()
+    return [int(getattr(c, n)) for n in _SPEC_FIELDS]
+
+
+def _spec_from_ints(ints) -> MgxSpecC:
+    if len(ints) != len(_SPEC_FIELDS):
+        raise ValueError(f"spec must have {len(_SPEC_FIELDS)} ints")
+    return MgxSpecC(*[int(v) for v in ints])
+
+
+def _want(t: torch.Tensor, name: str, dtype, shape=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"mgx: `{name}` must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"mgx: `{name}` must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"mgx: `{name}` must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"mgx: `{name}` must have shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _gen_obs_into(sc: MgxSpecC, B, grid, agents, obs, dirs):
+    with torch.cuda.device(grid.device):
+        rc = _lib.lib().mgx_gen_obs(C.byref(sc), B, grid.data_ptr(), agents.data_ptr(), obs.data_ptr(),
+                                    dirs.data_ptr() if dirs is not None else None, _stream(grid.device))
+    _lib.check(rc, "mgx_gen_obs")
+
+
+def _step_into(sc: MgxSpecC, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
+               terminated, truncated):
+    with torch.cuda.device(grid.device):
+        rc = _lib.lib().mgx_step(
+            C.byref(sc), B, grid.data_ptr(), agents.data_ptr(), rng.data_ptr() if rng is not None else None,
+            step_count.data_ptr(), actions.data_ptr(), target.data_ptr() if target is not None else None,
+            obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(), truncated.data_ptr(),
+            err.data_ptr() if err is not None else None, _stream(grid.device))
+    _lib.check(rc, "mgx_step")
+
+
+def _check_state(sc: MgxSpecC, grid, agents):
+    B = grid.shape[0]
+    _want(grid, "grid", torch.uint8, (B, sc.height, sc.width, 3))
+    _want(agents, "agents", torch.uint8, (B, sc.num_agents, 8))
+    return B
+
+
+def _gen_obs_impl(grid, agents, spec):
+    sc = _spec_from_ints(spec)
+    B = _check_state(sc, grid, agents)
+    A, v = sc.num_agents, sc.view_size
+    obs = torch.empty((B, A, v, v, 3), dtype=torch.uint8, device=grid.device)
+    dirs = torch.empty((B, A), dtype=torch.uint8, device=grid.device)
+    _gen_obs_into(sc, B, grid, agents, obs, dirs)
+    return obs, dirs
+
+
+def _step_impl(grid, agents, rng, step_count, actions, target, err, spec):
+    sc = _spec_from_ints(spec)
+    B = _check_state(sc, grid, agents)
+    A, v = sc.num_agents, sc.view_size
+    _want(rng, "rng", torch.int64, (B, 4))
+    _want(step_count, "step_count", torch.int32, (B,))
+    _want(actions, "actions", torch.int8, (B, A))
+    _want(err, "err", torch.int32, (2,))
+    if target is not None:
+        _want(target, "target", torch.uint8, (B, 4))
+    dev = grid.device
+    obs = torch.empty((B, A, v, v, 3), dtype=torch.uint8, device=dev)
+    dirs = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    reward = torch.empty((B, A), dtype=torch.float64, device=dev)
+    terminated = torch.empty((B, A), dtype=torch.uint8, device=dev)
+    truncated = torch.empty((B,), dtype=torch.uint8, device=dev)
+    _step_into(sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated)
+    return obs, dirs, reward, terminated, truncated
+
+
+_torch_lib = torch.library.Library("mgx", "DEF")
+_torch_lib.define("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
+_torch_lib.define(
+    "step(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+    "Tensor? target, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_torch_lib.impl("gen_obs", _gen_obs_impl, "CUDA")
+_torch_lib.impl("step", _step_impl, "CUDA")
+
+
+class HipBackend:
+    """Pre-bound launcher: the state and output tensors of one BatchedMultiGridEnv, validated once."""
+
+    name = "hip"
+
+    def __init__(self, spec: EnvSpec, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                f"multigrid_amd runs on MI355X only: device must be a HIP ('cuda') device, got '{device}'. "
+                "There is no CPU fallback.")
+        if not torch.cuda.is_available():
+            raise RuntimeError("multigrid_amd: no HIP device is visible (torch.cuda.is_available() is False)")
+        _lib.lib()  # raises ImportError if the extension is missing
+        self.spec = spec
+        self.sc = spec.to_c()
+        self.device = device
+
+    def gen_obs(self, B, grid, agents, obs, dirs):
+        _gen_obs_into(self.sc, B, grid, agents, obs, dirs)
+
+    def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated):
+        _step_into(self.sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
+                   terminated, truncated)
+
+    def launch_info(self, B) -> dict:
+        return _lib.launch_info(self.spec, B)

@@ -1,0 +1,65 @@
+"""PCG64 state plumbing between numpy (host) and the device `rng` tensor (u64[B,4], include/mgx.h).
+
+`gymnasium.Env.reset(seed=s)` sets `np_random = Generator(PCG64(SeedSequence(s)))`; the reference's
+`handle_actions` draws `np_random.random(size=A)` from it every step (multigrid/base.py:396-399).  The device
+kernel continues exactly that stream, so all the host has to do is hand over the 128-bit state and increment.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+M64 = (1 << 64) - 1
+
+
+def words_from_bitgen_state(state: dict) -> np.ndarray:
+    """numpy `PCG64().state` dict -> u64[4] = [state_lo, state_hi, inc_lo, inc_hi]."""
+    st = state["state"]
+    s, inc = int(st["state"]), int(st["inc"])
+    return np.array([s & M64, s >> 64, inc & M64, inc >> 64], dtype=np.uint64)
+
+
+def bitgen_state_from_words(words) -> dict:
+    w = [int(x) for x in np.asarray(words, dtype=np.uint64)]
+    return {"bit_generator": "PCG64",
+            "state": {"state": w[0] | (w[1] << 64), "inc": w[2] | (w[3] << 64)},
+            "has_uint32": 0, "uinteger": 0}
+
+
+def generator_from_words(words) -> np.random.Generator:
+    bg = np.random.PCG64()
+    bg.state = bitgen_state_from_words(words)
+    return np.random.Generator(bg)
+
+
+def seeded_generator(seed) -> np.random.Generator:
+    """What `gymnasium.utils.seeding.np_random(seed)` returns."""
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+
+def words_from_seed(seed) -> np.ndarray:
+    return words_from_bitgen_state(np.random.PCG64(np.random.SeedSequence(seed)).state)
+
+
+def words_from_seeds(seeds) -> np.ndarray:
+    """Per-env states for per-env integer seeds: env b gets Generator(PCG64(SeedSequence(seeds[b])))."""
+    seeds = np.asarray(seeds)
+    out = np.empty((len(seeds), 4), dtype=np.uint64)
+    for b, s in enumerate(seeds):
+        out[b] = words_from_seed(int(s))
+    return out
+
+
+def synthetic_words(batch: int, seed: int, first_env: int = 0) -> np.ndarray:
+    """Cheap valid PCG64 states for benchmarks (any 128-bit state, odd increment), a pure function of the
+    GLOBAL env index so that sharding the batch over ranks does not change any env's stream."""
+    idx = np.arange(first_env, first_env + batch, dtype=np.uint64)
+    out = np.empty((batch, 4), dtype=np.uint64)
+    x = idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+    for k in range(4):      # splitmix64 per word
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        out[:, k] = z ^ (z >> np.uint64(31))
+    out[:, 2] |= np.uint64(1)
+    return out

@@ -1,0 +1,123 @@
+"""GPU parity: the fused HIP kernel vs (a) the golden vectors recorded from the real reference and (b) the CPU
+oracle on seeded random states.  Bit-exact on every output and on the post-step state.  Calls go through the
+C ABI (libmgx.so) via BatchedMultiGridEnv / torch.ops.mgx."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts
+from oracle import binding as ob
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return "cuda:0"
+
+
+@pytest.mark.parametrize("path", util.GOLDEN, ids=util.GOLDEN_IDS)
+@pytest.mark.parametrize("replicas", [1, 5])
+def test_golden_replay(path, replicas):
+    z, d, spec = util.load_golden(path)
+    env = BatchedMultiGridEnv(spec, replicas, dev())
+    env.load_state(layouts.grid_to_product(z["grid0"]), layouts.pack_agents(z["agents0"]),
+                   rng=util.rng_words_lohi(z["rng0"]), target=util.golden_target(d))
+    obs, dirs = env.gen_obs()
+    for b in range(replicas):
+        np.testing.assert_array_equal(obs[b].cpu().numpy(), z["obs0"])
+        np.testing.assert_array_equal(dirs[b].cpu().numpy(), z["dir0"])
+    T = z["actions"].shape[0]
+    for t in range(T):
+        act = torch.from_numpy(np.repeat(z["actions"][t][None], replicas, 0)).to(dev())
+        obs, dirs, rew, term, trunc = env.step(act)
+        ctx = f"step {t}"
+        for b in (0, replicas - 1):
+            np.testing.assert_array_equal(obs[b].cpu().numpy(), z["obs"][t], err_msg=ctx)
+            np.testing.assert_array_equal(dirs[b].cpu().numpy(), z["direction"][t], err_msg=ctx)
+            assert rew[b].cpu().numpy().tobytes() == z["reward"][t].tobytes(), ctx
+            np.testing.assert_array_equal(term[b].cpu().numpy(), z["terminated"][t], err_msg=ctx)
+            assert int(trunc[b]) == int(z["truncated"][t]), ctx
+            np.testing.assert_array_equal(layouts.grid_from_product(env.grid[b].cpu().numpy()),
+                                          z["grid"][t].astype(np.int64), err_msg=ctx)
+            np.testing.assert_array_equal(layouts.unpack_agents(env.agents[b].cpu().numpy()),
+                                          z["agents"][t].astype(np.int64), err_msg=ctx)
+    env.check_errors()
+    np.testing.assert_array_equal(env.rng[0].cpu().numpy().view(np.uint64), util.rng_words_lohi(z["rng_final"]))
+    assert int(env.step_count[0]) == T
+
+
+CASES = [
+    # (name, spec, B, T)
+    ("C2_empty16_a4_v7", EnvSpec(16, 16, 4, 7, max_steps=1024), 4096, 24),
+    ("C3_bup_11x6_a2", EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup"), 16384, 12),
+    ("C5_64x64_a16_v9", EnvSpec(64, 64, 16, 9, max_steps=16384), 512, 6),
+    ("ragged_a3_v5_nooverlap", EnvSpec(9, 7, 3, 5, max_steps=50, allow_agent_overlap=False,
+                                       failure_termination_mode="any"), 1001, 16),
+    ("a1_v3_seethrough", EnvSpec(8, 8, 1, 3, max_steps=30, see_through_walls=True), 777, 12),
+    ("a5_v11_all_joint", EnvSpec(13, 12, 5, 11, max_steps=40, success_termination_mode="all", joint_reward=True), 333, 10),
+    ("a7_v13", EnvSpec(20, 17, 7, 13, max_steps=40), 129, 6),
+    ("a2_v15", EnvSpec(24, 24, 2, 15, max_steps=40), 65, 6),
+    ("a32_v7", EnvSpec(12, 12, 32, 7, max_steps=40), 37, 6),
+    ("single_env", EnvSpec(8, 8, 2, 7, max_steps=256), 1, 20),
+]
+
+
+@pytest.mark.parametrize("name,spec,B,T", CASES, ids=[c[0] for c in CASES])
+def test_random_states_vs_oracle(name, spec, B, T):
+    st = util.random_state(spec, B, seed=zlib.crc32(name.encode()) % 10000)
+    env = BatchedMultiGridEnv(spec, B, dev())
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    ref = {k: v.copy() for k, v in st.items()}
+    sd = spec.as_dict()
+    o_ref, d_ref = ob.gen_obs_batch(sd, ref["grid"], ref["agents"], nthreads=8)
+    obs, dirs = env.gen_obs()
+    np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
+    np.testing.assert_array_equal(dirs.cpu().numpy(), d_ref)
+    for t in range(T):
+        act = util.random_actions(B, spec.num_agents, seed=1000 + t)
+        o_ref, d_ref, r_ref, te_ref, tr_ref = ob.step_batch(
+            sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["target"], nthreads=8)
+        obs, dirs, rew, term, trunc = env.step(torch.from_numpy(act).to(dev()))
+        ctx = f"{name} step {t}"
+        np.testing.assert_array_equal(env.grid.cpu().numpy(), ref["grid"], err_msg=ctx)
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"], err_msg=ctx)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_ref, err_msg=ctx)
+        np.testing.assert_array_equal(dirs.cpu().numpy(), d_ref, err_msg=ctx)
+        assert rew.cpu().numpy().tobytes() == r_ref.tobytes(), ctx
+        np.testing.assert_array_equal(term.cpu().numpy(), te_ref, err_msg=ctx)
+        np.testing.assert_array_equal(trunc.cpu().numpy(), tr_ref, err_msg=ctx)
+        np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref["step_count"], err_msg=ctx)
+        if spec.num_agents > 1:
+            np.testing.assert_array_equal(env.rng.cpu().numpy().view(np.uint64), ref["rng"], err_msg=ctx)
+    env.check_errors()
+
+
+def test_torch_ops_registered_and_match():
+    import multigrid_amd.ops as ops
+    spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
+    st = util.random_state(spec, 64, seed=5)
+    g = torch.from_numpy(st["grid"]).to(dev()); a = torch.from_numpy(st["agents"]).to(dev())
+    obs, dirs = torch.ops.mgx.gen_obs(g, a, ops.spec_to_ints(spec))
+    o_ref, d_ref = ob.gen_obs_batch(spec.as_dict(), st["grid"], st["agents"])
+    np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
+    np.testing.assert_array_equal(dirs.cpu().numpy(), d_ref)
+    with pytest.raises(NotImplementedError):
+        torch.ops.mgx.gen_obs(g.cpu(), a.cpu(), ops.spec_to_ints(spec))
+
+
+def test_unknown_action_is_reported():
+    spec = EnvSpec(8, 8, 2, 7, max_steps=256)
+    st = util.random_state(spec, 32, seed=9, terminated_p=0.0)
+    env = BatchedMultiGridEnv(spec, 32, dev())
+    env.load_state(st["grid"], st["agents"], st["rng"])
+    act = torch.zeros((32, 2), dtype=torch.int8, device=dev())
+    act[17, 1] = 9
+    env.step(act)
+    with pytest.raises(ValueError, match="Unknown action"):
+        env.check_errors()
+    env.step(torch.zeros((32, 2), dtype=torch.int8, device=dev()))
+    env.check_errors()

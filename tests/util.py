@@ -1,0 +1,116 @@
+"""Shared helpers for the test-suite (test infrastructure; may import oracle/)."""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from multigrid_amd import layouts
+from multigrid_amd.spec import EnvSpec
+from oracle import binding as ob
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+GOLDEN_IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
+
+
+def load_golden(path):
+    z = np.load(path)
+    d = json.loads(str(z["spec_json"]))
+    return z, d, EnvSpec.from_dict(d)
+
+
+def rng_words_lohi(words_hilo) -> np.ndarray:
+    """golden order [state_hi, state_lo, inc_hi, inc_lo] -> product order [state_lo, state_hi, inc_lo, inc_hi]"""
+    hs, ls, hi, li = (int(w) for w in words_hilo)
+    return np.array([ls, hs, li, hi], dtype=np.uint64)
+
+
+def golden_target(d: dict) -> np.ndarray:
+    t = d.get("target", [0, 0, 0])
+    return np.array([t[0], t[1], t[2], 0], dtype=np.uint8)
+
+
+def random_state(spec: EnvSpec, B: int, seed: int, density: float = 0.25, terminated_p: float = 0.05,
+                 carry_p: float = 0.3):
+    """Random walled grids with every object type, agents on overlappable cells (possibly stacked),
+    some carrying, some already terminated.  Product layout."""
+    r = np.random.default_rng(seed)
+    H, W, A = spec.height, spec.width, spec.num_agents
+    grid = np.zeros((B, H, W, 3), dtype=np.uint8)
+    grid[..., 0] = 1
+    kinds = np.array([[9, 0, 0], [3, 2, 0], [5, 1, 0], [6, 3, 0], [7, 4, 0], [2, 5, 0], [4, 0, 1], [4, 1, 2],
+                      [4, 2, 0], [8, 1, 0]], dtype=np.uint8)
+    pick = r.integers(0, len(kinds), size=(B, H, W))
+    cells = kinds[pick]
+    cells[..., 1] = np.where(np.isin(cells[..., 0], (2, 8, 9)), cells[..., 1], r.integers(0, 6, size=(B, H, W)))
+    put = r.random((B, H, W)) < density
+    grid[put] = cells[put]
+    grid[:, 0, :] = (2, 5, 0); grid[:, -1, :] = (2, 5, 0); grid[:, :, 0] = (2, 5, 0); grid[:, :, -1] = (2, 5, 0)
+    agents = np.zeros((B, A, 8), dtype=np.uint8)
+    agents[..., 0] = np.arange(A) % 6
+    agents[..., 1] = r.integers(0, 4, size=(B, A))
+    t, s = grid[..., 0], grid[..., 2]
+    ok = (t == 1) | (t == 3) | (t == 8) | (t == 9) | ((t == 4) & (s == 0))
+    ok[:, 0, :] = ok[:, -1, :] = False
+    ok[:, :, 0] = ok[:, :, -1] = False
+    for b in range(B):
+        ys, xs = np.nonzero(ok[b])
+        if len(xs) == 0:
+            grid[b, 1, 1] = (1, 0, 0)
+            ys, xs = np.array([1]), np.array([1])
+        k = r.integers(0, len(xs), size=A)
+        agents[b, :, 2], agents[b, :, 3] = xs[k], ys[k]
+    agents[..., 4] = r.random((B, A)) < terminated_p
+    carry = kinds[r.integers(2, 5, size=(B, A))]
+    carry[..., 1] = r.integers(0, 6, size=(B, A))
+    has = r.random((B, A)) < carry_p
+    agents[..., 5:8] = np.where(has[..., None], carry, np.array([1, 0, 0], dtype=np.uint8))
+    rng = np.random.default_rng(seed + 1).integers(0, 2 ** 63, size=(B, 4), dtype=np.int64).astype(np.uint64)
+    rng[:, 2] |= np.uint64(1)
+    step_count = r.integers(0, max(1, spec.max_steps), size=B).astype(np.int32)
+    target = np.zeros((B, 4), dtype=np.uint8)
+    target[:, 0] = 7
+    target[:, 1] = r.integers(0, 6, size=B)
+    return dict(grid=grid, agents=agents, rng=rng, step_count=step_count, target=target)
+
+
+def random_actions(B, A, seed, p_missing=0.05):
+    r = np.random.default_rng(seed)
+    a = r.integers(0, 7, size=(B, A)).astype(np.int8)
+    a[r.random((B, A)) < p_missing] = -1
+    return a
+
+
+class OracleBackend:
+    """Test-only launcher with HipBackend's interface, computing on the CPU oracle.  Lets the `not gpu`
+    suite exercise the host logic (BatchedMultiGridEnv, the dict API, sharding).  Never used by product code."""
+
+    name = "oracle"
+
+    def __init__(self, spec: EnvSpec, nthreads: int = 1):
+        self.spec, self.d, self.nthreads = spec, spec.as_dict(), nthreads
+
+    def gen_obs(self, B, grid, agents, obs, dirs):
+        o, d = ob.gen_obs_batch(self.d, grid.numpy(), agents.numpy(), self.nthreads)
+        obs.copy_(torch.from_numpy(o))
+        if dirs is not None:
+            dirs.copy_(torch.from_numpy(d))
+
+    def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated):
+        try:
+            o, d, r, te, tr = ob.step_batch(
+                self.d, grid.numpy(), agents.numpy(), rng.numpy().view(np.uint64), step_count.numpy(),
+                actions.numpy(), target.numpy() if target is not None else None, self.nthreads)
+        except ValueError:
+            err[0] += 1
+            err[1] = 0
+            return
+        obs.copy_(torch.from_numpy(o)); dirs.copy_(torch.from_numpy(d)); reward.copy_(torch.from_numpy(r))
+        terminated.copy_(torch.from_numpy(te)); truncated.copy_(torch.from_numpy(tr))
+
+    def launch_info(self, B):
+        return {}
