@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused HIP step (action apply + gen_obs) on synthetic random-action rollouts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--mode graph|eager]
+
+One "step" = one `MultiGridEnv.step` over the whole per-GPU batch = one launch of the fused kernel.
+Workload at N=1 = BASELINE.json configs[1]: MultiGrid-Empty-16x16-v0, agents=4, view_size=7, batch=4096 envs.
+For N>1 (launched by `python -m torch.distributed.run --nproc-per-node N ...`, one rank per GPU) every rank owns
+an independent shard of `--batch` envs (weak scaling); the data path has NO collective -- envs never interact
+ -- and torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline            the fused kernel on the timed workload: algorithmic bytes per launch (SURVEY.md 8d:
+                      339 B per agent-step for this shape) / average launch duration from HIP events over the
+                      timed region on the launch stream
+  roofline_large      same kernel at a working set >> the 256 MiB Infinity Cache (HBM-resident regime)
+  gen_obs_large       the observation-only kernel (311 B per agent-view) at the same large working set
+  cpu_baseline        the CPU oracle (a port of the reference algorithm; the Python reference cannot travel to
+                      the GPU box) timed on this host's cores on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def workload_spec() -> EnvSpec:
+    # MultiGrid-Empty-16x16-v0: multigrid/envs/__init__.py:46, empty.py:145 (max_steps = 4*size^2)
+    return EnvSpec(width=16, height=16, num_agents=4, view_size=7, max_steps=4 * 16 * 16, env_kind="empty")
+
+
+def make_env(spec, batch, device, first_env, seed=1234):
+    env = BatchedMultiGridEnv(spec, batch, device, first_env=first_env)
+    grid, agents = layouts.empty_layout(spec.width, spec.num_agents)      # agents at (1,1) facing right
+    env.load_state(grid, agents)
+    env.seed_synthetic(seed)
+    return env
+
+
+def random_actions(steps, batch, agents, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.randint(0, 7, (steps, batch, agents), dtype=torch.int8, device=device, generator=g)
+
+
+def timed_rollout(env, actions, mode, dist_barrier):
+    """Time exactly len(actions) steps.  Returns (wall seconds incl. sync, HIP-event ms over the region)."""
+    K = actions.shape[0]
+    stream = torch.cuda.current_stream(env.device)
+    graph = None
+    if mode == "graph":
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(env.device)
+        s.wait_stream(stream)
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(graph, stream=s):
+                for t in range(K):
+                    env.step(actions[t])
+        stream.wait_stream(s)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dist_barrier()
+    torch.cuda.synchronize(env.device)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    if graph is not None:
+        graph.replay()
+    else:
+        for t in range(K):
+            env.step(actions[t])
+    ev1.record(stream)
+    torch.cuda.synchronize(env.device)
+    t1 = time.perf_counter()
+    dist_barrier()
+    return t1 - t0, ev0.elapsed_time(ev1)
+
+
+def kernel_time_ms(fn, iters, device):
+    """Average duration of `fn`'s single kernel launch: `iters` back-to-back launches between two HIP events."""
+    stream = torch.cuda.current_stream(device)
+    for _ in range(3):
+        fn()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    ev0.record(stream)
+    for _ in range(iters):
+        fn()
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    return ev0.elapsed_time(ev1) / iters
+
+
+def roofline(alg_bytes_per_launch, ms, traffic=None):
+    achieved = alg_bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
+
+
+def large_batch_points(spec, device, large_batch):
+    env = make_env(spec, large_batch, device, 0)
+    acts = random_actions(4, large_batch, spec.num_agents, device, 99)
+    i = [0]
+
+    def step():
+        env.step(acts[i[0] & 3]); i[0] += 1
+    ms_step = kernel_time_ms(step, 20, device)
+    ms_obs = kernel_time_ms(env.gen_obs, 20, device)
+    n = large_batch * spec.num_agents
+    r_step = roofline(n * spec.bytes_step(), ms_step)
+    r_step.update(batch=large_batch, kernel="mgx_fused_kernel<7,step>", ms_per_launch=round(ms_step, 4),
+                  agent_steps_per_s=round(n / (ms_step * 1e-3)))
+    r_obs = roofline(n * spec.bytes_gen_obs(), ms_obs)
+    r_obs.update(batch=large_batch, kernel="mgx_fused_kernel<7,gen_obs>", ms_per_launch=round(ms_obs, 4),
+                 agent_views_per_s=round(n / (ms_obs * 1e-3)))
+    del env
+    torch.cuda.empty_cache()
+    return r_step, r_obs
+
+
+def cpu_baseline(spec, batch, budget_s=12.0):
+    """Oracle (C port of the reference algorithm, OpenMP over envs) on this host, bounded sample."""
+    from oracle import binding as ob
+    cores = ob.max_threads()
+    grid, agents = layouts.empty_layout(spec.width, spec.num_agents)
+    from multigrid_amd import rng as rnglib
+    st = dict(grid=np.repeat(grid[None], batch, 0).copy(), agents=np.repeat(agents[None], batch, 0).copy(),
+              rng=rnglib.synthetic_words(batch, 1234), step_count=np.zeros(batch, np.int32))
+    r = np.random.default_rng(1234)
+    acts = r.integers(0, 7, size=(8, batch, spec.num_agents)).astype(np.int8)
+    d = spec.as_dict()
+    ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[0], None, cores)   # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[n & 7], None, cores)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= budget_s and n >= 8) or n >= 100000:
+            break
+    return {"value": round(n * batch * spec.num_agents / el), "unit": "agent-steps/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{n} steps of the same workload (batch {batch}, Empty-16x16, 4 agents) = "
+                      f"{n * batch * spec.num_agents} agent-steps in {el:.1f} s; oracle/mgx_oracle.c, OpenMP "
+                      f"over envs, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=4096, help="envs per GPU (BASELINE.json configs[1]: 4096)")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: the K timed steps are one hipGraph replay; eager: K Python-level env.step calls")
+    ap.add_argument("--large-batch", type=int, default=1 << 20)
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / cpu_baseline legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} "
+                     f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
+        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to benchmark")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    spec = workload_spec()
+    B, A = args.batch, spec.num_agents
+    env = make_env(spec, B, device, first_env=rank * B)
+    warm = random_actions(max(args.warmup, 1), B, A, device, 1000 + rank)
+    acts = random_actions(args.steps, B, A, device, 1234 + rank)
+    for t in range(args.warmup):
+        env.step(warm[t])
+    torch.cuda.synchronize(device)
+    wall_s, ev_ms = timed_rollout(env, acts, args.mode, barrier)
+    env.check_errors()
+
+    t = torch.tensor([wall_s], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+    total_agent_steps = world * B * A * args.steps
+    out = {
+        "metric": "agent-steps/sec", "value": round(total_agent_steps / wall_max), "unit": "agent-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall_max * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"MultiGrid-Empty-16x16-v0 agents=4 view_size=7 batch={B} envs per GPU "
+                               f"(BASELINE.json configs[1]), uniform random actions 0..6",
+                   "batch_per_gpu": B, "global_batch": world * B, "agents": A, "grid": "16x16", "view_size": 7,
+                   "mode": args.mode, "parallelism": f"env-sharded x{world}, no collective",
+                   "launch": env.backend.launch_info(B), "auto_reset": False},
+    }
+    if rank == 0:
+        ms_launch = ev_ms / args.steps
+        rf = roofline(B * A * spec.bytes_step(), ms_launch)
+        rf.update(kernel="mgx_fused_kernel<7,step>", ms_per_launch=round(ms_launch, 5),
+                  bytes_per_agent_step=spec.bytes_step(),
+                  note="working set fits the 256 MiB Infinity Cache at this batch: latency-bound, see roofline_large")
+        out["roofline"] = rf
+        if not args.no_extras:
+            r_step, r_obs = large_batch_points(spec, device, args.large_batch)
+            out["roofline_large"] = r_step
+            out["gen_obs_large"] = r_obs
+            out["cpu_baseline"] = cpu_baseline(spec, B)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

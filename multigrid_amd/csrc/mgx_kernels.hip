@@ -46,15 +46,19 @@ struct KernelArgs {
     uint8_t *truncated;
     int32_t *err;
     int32_t G;          // envs per workgroup
+    int32_t dbg;        // debug: bit p set = skip phase p (profiling only, mgx_debug_skip_phases)
     // LDS carve (byte offsets, all 16-byte aligned)
-    int32_t off_tile, off_ag, off_stage, off_sb, off_vis, off_ord, off_rnd;
+    int32_t off_tile, off_rows, off_act, off_rng, off_rnd, off_ord, off_rew, off_rec, off_mask, off_stage;
 };
 
 struct LdsPlan {
-    int32_t off_tile, off_ag, off_stage, off_sb, off_vis, off_ord, off_rnd, total;
+    int32_t off_tile, off_rows, off_act, off_rng, off_rnd, off_ord, off_rew, off_rec, off_mask, off_stage, total;
 };
 
 inline int align16(int x) { return (x + 15) & ~15; }
+
+// per-view record written by P1d and read (broadcast) by the view's wavefront in P2
+struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
 
 LdsPlan plan_lds(const MgxSpec &sp, int G) {
     const int V = sp.view_size, A = sp.num_agents;
@@ -63,12 +67,15 @@ LdsPlan plan_lds(const MgxSpec &sp, int G) {
     LdsPlan p;
     int o = 0;
     p.off_tile = o;  o = align16(o + G * sp.height * sp.width * 3 + 16 + 16);   // head misalignment + tail vector
-    p.off_ag = o;    o = align16(o + nv * MGX_AGENT_STRIDE);
-    p.off_stage = o; o = align16(o + nv * V * V * 4 + 4);                        // +1 cell read by the packer
-    p.off_sb = o;    o = align16(o + nv * nw * 8);
-    p.off_vis = o;   o = align16(o + nv * nw * 8);
-    p.off_ord = o;   o = align16(o + nv);
+    p.off_rows = o;  o = align16(o + nv * MGX_AGENT_STRIDE);
+    p.off_act = o;   o = align16(o + nv);
+    p.off_rng = o;   o = align16(o + G * 32);
     p.off_rnd = o;   o = align16(o + nv * 8);
+    p.off_ord = o;   o = align16(o + nv);
+    p.off_rew = o;   o = align16(o + nv * 8);
+    p.off_rec = o;   o = align16(o + nv * (int)sizeof(ViewRec));
+    p.off_mask = o;  o = align16(o + nv * nw * 8 * 2);                           // [view][NW] in-bounds, then see-behind/vis
+    p.off_stage = o; o = align16(o + nv * V * V * 4 + 32);                       // + cells over-read by the packer
     p.total = o;
     return p;
 }
@@ -86,6 +93,8 @@ int choose_G(const MgxSpec &sp, int64_t batch) {
     return G;
 }
 
+__device__ const JumpTable kJump{};
+
 template <int V, bool DO_STEP>
 __global__ __launch_bounds__(kThreads) void mgx_fused_kernel(const KernelArgs a) {
     constexpr int V2 = V * V;
@@ -93,74 +102,131 @@ __global__ __launch_bounds__(kThreads) void mgx_fused_kernel(const KernelArgs a)
     constexpr int NIT = NW;                      // wave passes per view
     extern __shared__ __align__(16) uint8_t lds[];
 
-    const MgxSpec &sp = a.sp;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = sp.width, H = sp.height, A = sp.num_agents;
+    const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents;
     const int HW3 = H * W * 3;
     const int64_t e0 = (int64_t)blockIdx.x * a.G;
     const int Gc = (int)min((int64_t)a.G, a.batch - e0);     // envs in this chunk
     const int NVc = Gc * A;                                   // views in this chunk
+    const int64_t v0 = e0 * A;                                // first (env, agent) row of the chunk
 
-    // ------------------------------------------------------------------ P0: HBM -> LDS
+    uint64_t *rows = reinterpret_cast<uint64_t *>(lds + a.off_rows);          // [view] packed agent rows
+    int8_t *acts = reinterpret_cast<int8_t *>(lds + a.off_act);               // [view]
+    uint64_t *rngs = reinterpret_cast<uint64_t *>(lds + a.off_rng);           // [env][4]
+    uint64_t *rnd = reinterpret_cast<uint64_t *>(lds + a.off_rnd);            // [view] 53-bit draws
+    uint8_t *ord = lds + a.off_ord;                                            // [view] visiting order per env
+    double *rew = reinterpret_cast<double *>(lds + a.off_rew);                // [view]
+    ViewRec *rec = reinterpret_cast<ViewRec *>(lds + a.off_rec);              // [view]
+    uint64_t *inbw = reinterpret_cast<uint64_t *>(lds + a.off_mask);          // [view][NW] in-bounds lanes
+    uint64_t *sbw = inbw + (size_t)a.G * A * NW;                               // [view][NW] see-behind, then visible
+    uint32_t *stage = reinterpret_cast<uint32_t *>(lds + a.off_stage);        // [view][i*V + j] packed cells
+
+    // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
     const int64_t g0 = e0 * HW3, g1 = g0 + (int64_t)Gc * HW3;       // chunk byte range in `grid`
     const int64_t gtotal = a.batch * (int64_t)HW3;
     const int64_t ga = g0 & ~(int64_t)15;
     uint8_t *tile_raw = lds + a.off_tile;                            // holds global bytes [ga, ...)
-    uint8_t *tile = tile_raw + (int)(g0 - ga);                       // env e's cells at tile + e*HW3
-    for (int64_t vo = ga + 16 * tid; vo < g1; vo += 16 * kThreads) {
-        uint8_t *dst = tile_raw + (int)(vo - ga);
-        if (vo + 16 <= gtotal) {
-            *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(a.grid + vo);
-        } else {
-            for (int k = 0; k < 16 && vo + k < gtotal; ++k) dst[k] = a.grid[vo + k];
+    const int tile_skew = (int)(g0 - ga);
+    uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HW3
+    if (!(a.dbg & 1)) {
+        constexpr int U = 4;
+        for (int64_t base = ga + 16 * tid; base < g1; base += (int64_t)16 * kThreads * U) {
+            uint4 v[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t vo = base + (int64_t)16 * kThreads * u;
+                ok[u] = vo < g1 && vo + 16 <= gtotal;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (ok[u]) v[u] = *reinterpret_cast<const uint4 *>(a.grid + vo);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t vo = base + (int64_t)16 * kThreads * u;
+                if (ok[u]) *reinterpret_cast<uint4 *>(tile_raw + (int)(vo - ga)) = v[u];
+            }
+        }
+        if (g1 == gtotal && (gtotal & 15)) {                      // last, partial 16-byte vector of the tensor
+            const int64_t t0 = gtotal & ~(int64_t)15;
+            for (int k = tid; k < (int)(gtotal & 15); k += kThreads) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
         }
     }
-    uint8_t *ag = lds + a.off_ag;
-    {
-        const uint64_t *src = reinterpret_cast<const uint64_t *>(a.agents) + e0 * A;
-        uint64_t *dst = reinterpret_cast<uint64_t *>(ag);
-        for (int t = tid; t < NVc; t += kThreads) dst[t] = src[t];
+    for (int t = tid; t < NVc; t += kThreads) {
+        rows[t] = reinterpret_cast<const uint64_t *>(a.agents)[v0 + t];
+        rew[t] = 0.0;                                                            // base.py:393
+        if (DO_STEP) acts[t] = a.actions[v0 + t];
     }
+    if (DO_STEP && A > 1)
+        for (int t = tid; t < Gc * 4; t += kThreads) rngs[t] = a.rng[e0 * 4 + t];
     __syncthreads();
 
-    // ------------------------------------------------------------------ P1: one lane per env
-    for (int e = tid; e < Gc; e += kThreads) {
-        const int64_t b = e0 + e;
-        uint8_t *etile = tile + e * HW3;
-        uint8_t *eag = ag + e * A * MGX_AGENT_STRIDE;
-        if (DO_STEP) {
-            const int32_t sc = a.step_count[b] + 1;                             // base.py:333
+    const StepCfg cf = make_cfg(a.sp);
+    if (DO_STEP && !(a.dbg & 2)) {
+        if (A > 1) {
+            // -------------------------------------------------------------- P1a: one lane per (env, agent): its draw
+            for (int t = tid; t < NVc; t += kThreads) {
+                const int e = t / A, ai = t - e * A;
+                uint64_t s_lo, s_hi;
+                rnd[t] = pcg64_draw_at(rngs + e * 4, kJump.w[ai + 1], s_lo, s_hi);    // base.py:399
+                if (ai == A - 1) { a.rng[(e0 + e) * 4 + 0] = s_lo; a.rng[(e0 + e) * 4 + 1] = s_hi; }
+            }
+            __syncthreads();
+            // -------------------------------------------------------------- P1b: argsort by ranking
+            for (int t = tid; t < NVc; t += kThreads) {
+                const int e = t / A, ai = t - e * A;
+                ord[e * A + draw_rank(rnd + e * A, A, ai)] = (uint8_t)ai;
+            }
+            __syncthreads();
+        }
+        // ------------------------------------------------------------------ P1c: one lane per env, LDS only
+        for (int e = tid; e < Gc; e += kThreads) {
+            const int64_t b = e0 + e;
+            uint8_t *etile = tile + e * HW3;
+            uint64_t *erows = rows + e * A;
+            double *erew = rew + e * A;
+            const int32_t sc = a.step_count[b] + 1;                              // base.py:333
             a.step_count[b] = sc;
-            uint64_t r4[4] = {0, 0, 0, 0};
-            if (A > 1) { r4[0] = a.rng[b * 4 + 0]; r4[1] = a.rng[b * 4 + 1]; r4[2] = a.rng[b * 4 + 2]; r4[3] = a.rng[b * 4 + 3]; }
-            double *rew = a.reward + b * A;
             uint8_t *ggrid = a.grid + b * HW3;
             auto dirty = [=](int off) {
                 ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2];
             };
-            const int rc = handle_actions(sp, etile, eag, r4, sc, a.actions + b * A,
-                                          lds + a.off_ord + e * A,
-                                          reinterpret_cast<uint64_t *>(lds + a.off_rnd) + e * A, rew, dirty);
-            if (A > 1) { a.rng[b * 4 + 0] = r4[0]; a.rng[b * 4 + 1] = r4[1]; }
+            const int rc = handle_actions(cf, etile, erows, acts + e * A, ord + e * A, erew, sc, dirty);
             if (rc != 0 && a.err) { atomicAdd(a.err, 1); atomicMin(a.err + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
-            overlay_agents(sp, etile, eag);                                     // uses pre-hook `terminated` (Q2)
-            post_step_hook(sp, eag, a.target ? a.target + b * 4 : eag, sc, rew);
-            for (int i = 0; i < A; ++i) a.terminated[b * A + i] = eag[i * MGX_AGENT_STRIDE + AG_TERM];  // base.py:338
-            a.truncated[b] = (uint8_t)(sc >= sp.max_steps);                      // base.py:339
-        } else {
-            overlay_agents(sp, etile, eag);
+            overlay_agents(cf, etile, erows);                                    // uses pre-hook `terminated` (Q2)
+            post_step_hook(cf, a.sp.env_kind, erows, a.target ? a.target + b * 4 : etile, sc, erew);
+            a.truncated[b] = (uint8_t)(sc >= cf.max_steps);                      // base.py:339
         }
+    } else {
+        for (int e = tid; e < Gc; e += kThreads) overlay_agents(cf, tile + e * HW3, rows + e * A);
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
+    const uint32_t tile_addr = (uint32_t)(a.off_tile + tile_skew);           // LDS byte address of env 0 cell 0
+    for (int t = tid; t < NVc; t += kThreads) {
+        const int e = t / A;
+        const uint64_t row = rows[t];
+        const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
+        ViewRec r;
+        r.origin = (int32_t)tile_addr + e * HW3 + g.origin;
+        r.stepF = g.stepF; r.stepL = g.stepL; r.carry = row_carry(row);
+        rec[t] = r;
+        uint64_t m[NW];
+        inbounds_mask<V, NW>(g, m);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) inbw[t * NW + k] = m[k];
+        if (DO_STEP) {
+            reinterpret_cast<uint64_t *>(a.agents)[v0 + t] = row;
+            a.reward[v0 + t] = rew[t];
+            a.terminated[v0 + t] = (uint8_t)row_term(row);                       // base.py:338 (+ env hook)
+        }
+        if (a.dir) a.dir[v0 + t] = (uint8_t)row_dir(row);                        // base.py:359, 372
     }
     __syncthreads();
 
     // ------------------------------------------------------------------ P2: one wavefront per view
-    uint32_t *stage = reinterpret_cast<uint32_t *>(lds + a.off_stage);       // [view][i*V + j] packed cells
-    uint64_t *sbw = reinterpret_cast<uint64_t *>(lds + a.off_sb);            // [view][NW]
-    uint64_t *visw = reinterpret_cast<uint64_t *>(lds + a.off_vis);          // [view][NW]
-    const uint32_t tile_addr = (uint32_t)(a.off_tile + (int)(g0 - ga));      // LDS byte address of env 0 cell 0
-
     // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
     // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
     int la[NIT], fw[NIT], q[NIT];
@@ -176,25 +242,23 @@ __global__ __launch_bounds__(kThreads) void mgx_fused_kernel(const KernelArgs a)
         own[it] = (i == V / 2) && (j == V - 1);
     }
 
+    if (!(a.dbg & 4))
     for (int view = wave; view < NVc; view += kWaves) {
-        const int e = view / A;
-        const uint2 s2 = *reinterpret_cast<const uint2 *>(ag + view * MGX_AGENT_STRIDE);
-        const uint32_t s_lo = __builtin_amdgcn_readfirstlane(s2.x), s_hi = __builtin_amdgcn_readfirstlane(s2.y);
-        const int d = (s_lo >> 8) & 0xff, x = (s_lo >> 16) & 0xff, y = s_lo >> 24;
-        const uint32_t carry = s_hi >> 8;                                   // type | color<<8 | state<<16
-        const int dx = dir_dx(d), dy = dir_dy(d);
-        const uint32_t ebase = tile_addr + (uint32_t)(e * HW3);
+        const ViewRec r = rec[view];                                            // broadcast read
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            // world cell seen at image[i][j]: pos + fw*forward + la*right, right = (-dy, dx)   (obs.py:182-202)
-            const int wx = x + fw[it] * dx - la[it] * dy;
-            const int wy = y + fw[it] * dy + la[it] * dx;
-            const bool inb = ((unsigned)wx < (unsigned)W) & ((unsigned)wy < (unsigned)H);
-            const uint32_t addr = ebase + (inb ? (uint32_t)((wy * W + wx) * 3) : 0u);
+            const uint64_t inb_m = inbw[view * NW + it];
+            // (readfirstlane returns a signed int: cast before widening)
+            const uint64_t inb_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(inb_m >> 32)) << 32)
+                                 | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)inb_m);
+            const bool inb = (inb_s >> lane) & 1;
+            // world cell seen at image[i][j]: pos + fw*forward + la*right                     (obs.py:182-202)
+            uint32_t addr = (uint32_t)(r.origin + fw[it] * r.stepF + la[it] * r.stepL);
+            addr = inb ? addr : (uint32_t)r.origin;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (addr & ~3u));
             uint32_t c = __builtin_amdgcn_alignbyte(p[1], p[0], addr & 3u) & 0xffffffu;
             c = inb ? c : CELL_WALL;                                            // obs.py:199-202
-            c = own[it] ? carry : c;                                            // obs.py:207
+            c = own[it] ? r.carry : c;                                          // obs.py:207
             const uint64_t m = __ballot(act[it] && see_behind(c));              // obs.py:211-233
             if (lane == 0) sbw[view * NW + it] = m;
             if (act[it]) stage[view * V2 + q[it]] = c;
@@ -202,55 +266,64 @@ __global__ __launch_bounds__(kThreads) void mgx_fused_kernel(const KernelArgs a)
     }
     __syncthreads();
 
-    if (!sp.see_through_walls) {                                                // obs.py:95-100
+    if (!a.sp.see_through_walls) {                                              // obs.py:95-100
         // -------------------------------------------------------------- P3: one lane per view
+        if (!(a.dbg & 8))
         for (int view = tid; view < NVc; view += kThreads) {
             uint64_t sb[NW], vis[NW];
 #pragma unroll
             for (int k = 0; k < NW; ++k) sb[k] = sbw[view * NW + k];
             vis_mask<V, NW>(sb, vis);
 #pragma unroll
-            for (int k = 0; k < NW; ++k) visw[view * NW + k] = vis[k];
+            for (int k = 0; k < NW; ++k) sbw[view * NW + k] = vis[k];
         }
         __syncthreads();
         // -------------------------------------------------------------- P4: wavefront per view
+        if (!(a.dbg & 16))
         for (int view = wave; view < NVc; view += kWaves) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const uint64_t m = visw[view * NW + it];
+                const uint64_t m = sbw[view * NW + it];
                 if (act[it] && !((m >> lane) & 1)) stage[view * V2 + q[it]] = CELL_UNSEEN;
             }
         }
         __syncthreads();
     }
 
-    // ------------------------------------------------------------------ P5: LDS -> HBM, dword-coalesced
-    {
-        const int64_t o0 = e0 * (int64_t)(A * V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;
-        const int64_t oa = o0 & ~(int64_t)3;
-        for (int64_t D = oa + 4 * tid; D < o1; D += 4 * kThreads) {
-            const int64_t lo_b = max(D, o0), hi_b = min(D + 4, o1);
-            // bytes [D, D+4) of the obs stream = bytes rel.. of the staged cells, 3 bytes per cell
-            const int rel = (int)(lo_b - o0);
-            const int q0 = rel / 3, r = rel - q0 * 3;
-            const uint32_t c0 = stage[q0], c1 = stage[q0 + 1];
-            const uint32_t lo = c0 | (c1 << 24), hi = c1 >> 8;
-            const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)r);   // bytes lo_b, lo_b+1, ...
-            if (lo_b == D && hi_b == D + 4) {
-                *reinterpret_cast<uint32_t *>(a.obs + D) = w;
+    // ------------------------------------------------------------------ P5: LDS -> HBM, 16-byte coalesced stores
+    if (!(a.dbg & 32)) {
+        const int64_t o0 = v0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;
+        const int64_t oa = o0 & ~(int64_t)15;
+        for (int64_t D = oa + 16 * tid; D < o1; D += 16 * kThreads) {
+            if (D >= o0 && D + 16 <= o1) {
+                // bytes [D, D+16) of the obs stream = bytes rel.. of the staged cells, 3 bytes per cell
+                const int rel = (int)(D - o0);
+                const int q0 = rel / 3, r = rel - q0 * 3;
+                const uint32_t *sp = stage + q0;
+                const uint32_t c0 = sp[0], c1 = sp[1], c2 = sp[2], c3 = sp[3], c4 = sp[4], c5 = sp[5], c6 = sp[6];
+                // the cells' 3-byte encodings as a byte stream, in dwords
+                const uint32_t w0 = c0 | (c1 << 24), w1 = (c1 >> 8) | (c2 << 16), w2 = (c2 >> 16) | (c3 << 8);
+                const uint32_t w3 = c4 | (c5 << 24), w4 = (c5 >> 8) | (c6 << 16);
+                uint4 out;
+                out.x = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)r);
+                out.y = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)r);
+                out.z = __builtin_amdgcn_alignbyte(w3, w2, (uint32_t)r);
+                out.w = __builtin_amdgcn_alignbyte(w4, w3, (uint32_t)r);
+                *reinterpret_cast<uint4 *>(a.obs + D) = out;
             } else {
-                for (int k = 0; k < (int)(hi_b - lo_b); ++k) a.obs[lo_b + k] = (uint8_t)(w >> (8 * k));
+                const int64_t lo_b = max(D, o0), hi_b = min(D + 16, o1);
+                for (int64_t B = lo_b; B < hi_b; ++B) {
+                    const int rel = (int)(B - o0);
+                    const int q0 = rel / 3, r = rel - q0 * 3;
+                    a.obs[B] = (uint8_t)(stage[q0] >> (8 * r));
+                }
             }
-        }
-        for (int t = tid; t < NVc; t += kThreads) {
-            const uint64_t row = reinterpret_cast<const uint64_t *>(ag)[t];
-            if (DO_STEP) reinterpret_cast<uint64_t *>(a.agents)[e0 * A + t] = row;
-            if (a.dir) a.dir[e0 * A + t] = (uint8_t)(row >> 8);                   // base.py:359, 372
         }
     }
 }
 
 int g_last_hip_error = 0;
+int g_debug_skip = 0;
 
 template <bool DO_STEP>
 int launch(const KernelArgs &ka, int lds_bytes, int64_t nwg, hipStream_t stream) {
@@ -291,9 +364,11 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &lds_bytes, 
     ka.sp = *sp;
     ka.batch = batch;
     ka.G = choose_G(*sp, batch);
+    ka.dbg = g_debug_skip;
     const LdsPlan p = plan_lds(*sp, ka.G);
-    ka.off_tile = p.off_tile; ka.off_ag = p.off_ag; ka.off_stage = p.off_stage; ka.off_sb = p.off_sb;
-    ka.off_vis = p.off_vis; ka.off_ord = p.off_ord; ka.off_rnd = p.off_rnd;
+    ka.off_tile = p.off_tile; ka.off_rows = p.off_rows; ka.off_act = p.off_act; ka.off_rng = p.off_rng;
+    ka.off_rnd = p.off_rnd; ka.off_ord = p.off_ord; ka.off_rew = p.off_rew; ka.off_rec = p.off_rec;
+    ka.off_mask = p.off_mask; ka.off_stage = p.off_stage;
     lds_bytes = p.total;
     nwg = (batch + ka.G - 1) / ka.G;
     if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
@@ -321,6 +396,10 @@ const char *mgx_error_string(int code) {
 
 int mgx_last_hip_error(void) { return g_last_hip_error; }
 
+// Profiling aid (not part of the product ABI): bit p set = the fused kernel skips phase Pp.  Results are
+// then meaningless; tools/phase_probe.py uses it to attribute kernel time to phases.
+void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
+
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     int rc = check_spec(spec, batch);
     if (rc) return rc;
@@ -342,7 +421,7 @@ int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const u
     if (rc) return rc;
     if (batch == 0) return MGX_OK;
     if (!grid || !agents || !obs) return MGX_ERR_INVALID_ARGUMENT;
-    if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 4)) return MGX_ERR_INVALID_ARGUMENT;
+    if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16)) return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int lds = 0; int64_t nwg = 0;
     rc = fill_args(ka, spec, batch, lds, nwg);
@@ -365,7 +444,7 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
         return MGX_ERR_INVALID_ARGUMENT;
     if (spec->num_agents > 1 && !rng) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP && !target) return MGX_ERR_INVALID_ARGUMENT;
-    if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 4) || misaligned(rng, 8)
+    if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16) || misaligned(rng, 8)
         || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4))
         return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};

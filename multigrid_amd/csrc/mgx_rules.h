@@ -117,19 +117,25 @@ MGX_HD void vis_mask(const uint64_t (&sb)[NW], uint64_t (&vis)[NW]) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// handle_actions + hooks for ONE env (multigrid/base.py:378-532, envs/blockedunlockpickup.py:166-175).
-//   tile   : H*W*3 bytes, [y][x][c]                ag : A*8 bytes (packed agent rows)
-//   rng    : 4 words, advanced in place            actions : A int8
-//   ord    : A bytes of scratch (visiting order)   rnd : A u64 of scratch (the drawn 53-bit values)
-//   rew    : A doubles (stride 1), fully written   dirty(off) : called with the byte offset of every
-//            tile cell this step changed (after the tile bytes are updated).
-// Returns 0, or MGX_ERR_UNKNOWN_ACTION at the first invalid action in visiting order.
+// Packed agent row as one 64-bit word (little-endian view of the 8 bytes in include/mgx.h):
+//   [0:8) color  [8:16) dir  [16:24) x  [24:32) y  [32:40) terminated  [40:64) carried cell (type|color<<8|state<<16)
 // ---------------------------------------------------------------------------------------------------
+MGX_HD int row_dir(uint64_t r) { return (int)((r >> 8) & 0xff); }
+MGX_HD int row_x(uint64_t r) { return (int)((r >> 16) & 0xff); }
+MGX_HD int row_y(uint64_t r) { return (int)((r >> 24) & 0xff); }
+MGX_HD bool row_term(uint64_t r) { return ((r >> 32) & 0xff) != 0; }
+MGX_HD uint32_t row_carry(uint64_t r) { return (uint32_t)(r >> 40); }
+MGX_HD uint64_t row_set_dir(uint64_t r, int d) { return (r & ~0xff00ull) | ((uint64_t)(d & 0xff) << 8); }
+MGX_HD uint64_t row_set_pos(uint64_t r, int x, int y) {
+    return (r & ~0xffff0000ull) | ((uint64_t)(x & 0xff) << 16) | ((uint64_t)(y & 0xff) << 24);
+}
+MGX_HD uint64_t row_set_carry(uint64_t r, uint32_t c) { return (r & 0xffffffffffull) | ((uint64_t)c << 40); }
+
 MGX_HD uint32_t load_cell(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
 MGX_HD void store_cell(uint8_t *p, uint32_t c) { p[0] = (uint8_t)c; p[1] = (uint8_t)(c >> 8); p[2] = (uint8_t)(c >> 16); }
 
 // base.py:598-602 `1 - 0.9 * (step_count / max_steps)` in Python float arithmetic: three correctly rounded
-// IEEE-754 binary64 operations, never contracted into an fma.
+// IEEE-754 binary64 operations, never contracted into an fma (the library is built with -ffp-contract=off).
 MGX_HD double reward_value(int32_t step_count, int32_t max_steps) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const double q = __ddiv_rn((double)step_count, (double)max_steps);
@@ -141,89 +147,126 @@ MGX_HD double reward_value(int32_t step_count, int32_t max_steps) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// PCG64 jump-ahead: state after k steps = state * M^k + inc * (M^(k-1) + ... + M + 1)  (mod 2^128), so the A
+// draws of one step (multigrid/base.py:399) are computed by A lanes in parallel instead of a serial chain.
+// kJump[k] = { M^k lo, M^k hi, C_k lo, C_k hi }.
+// ---------------------------------------------------------------------------------------------------
+struct JumpTable {
+    uint64_t w[MGX_MAX_AGENTS + 1][4];
+    constexpr JumpTable() : w{} {
+        typedef unsigned __int128 u128;
+        const u128 mult = ((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+        u128 m = 1, c = 0;
+        for (int k = 0; k <= MGX_MAX_AGENTS; ++k) {
+            w[k][0] = (uint64_t)m; w[k][1] = (uint64_t)(m >> 64);
+            w[k][2] = (uint64_t)c; w[k][3] = (uint64_t)(c >> 64);
+            c = c * mult + 1;      // C_{k+1} = C_k * M + 1
+            m = m * mult;
+        }
+    }
+};
+
+// k-th next draw (k >= 1) from the state in rng[0..3]; also returns the advanced state.
+MGX_HD uint64_t pcg64_draw_at(const uint64_t *rng, const uint64_t *jump_k, uint64_t &s_lo, uint64_t &s_hi) {
+    typedef unsigned __int128 u128;
+    const u128 s = ((u128)rng[1] << 64) | rng[0], inc = ((u128)rng[3] << 64) | rng[2];
+    const u128 mk = ((u128)jump_k[1] << 64) | jump_k[0], ck = ((u128)jump_k[3] << 64) | jump_k[2];
+    const u128 st = s * mk + inc * ck;
+    s_lo = (uint64_t)st; s_hi = (uint64_t)(st >> 64);
+    const uint64_t x = s_hi ^ s_lo;
+    const unsigned rot = (unsigned)(s_hi >> 58);
+    return ((x >> rot) | (x << ((64u - rot) & 63u))) >> 11;
+}
+
+// rank of draw `a` among the env's A draws = its position in argsort (stable; ties ~2^-53)   base.py:399
+MGX_HD int draw_rank(const uint64_t *rnd, int A, int a) {
+    const uint64_t ra = rnd[a];
+    int rank = 0;
+    for (int b = 0; b < A; ++b) { const uint64_t rb = rnd[b]; rank += (rb < ra) | ((rb == ra) & (b < a)); }
+    return rank;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// handle_actions for ONE env (multigrid/base.py:378-476 with on_success 478-507 / on_failure 509-532).
+//   tile : H*W*3 bytes [y][x][c]        rows : A packed agent rows      act : A int8
+//   ord  : A bytes, visiting order      rew  : A doubles, pre-zeroed (base.py:393)
+//   dirty(off): called with the byte offset of every tile cell this step changed (tile already updated).
+// Returns 0, or MGX_ERR_UNKNOWN_ACTION at the first invalid action in visiting order.
+// ---------------------------------------------------------------------------------------------------
+struct StepCfg {
+    int W, H, A, max_steps;
+    bool allow_overlap, joint_reward, success_any, failure_any;
+};
+
+MGX_HD StepCfg make_cfg(const MgxSpec &sp) {
+    return StepCfg{sp.width, sp.height, sp.num_agents, sp.max_steps, sp.allow_agent_overlap != 0,
+                   sp.joint_reward != 0, sp.success_any != 0, sp.failure_any != 0};
+}
+
+MGX_HD void set_terminated(uint64_t *rows, int A, int i, bool all) {
+    uint8_t *b = reinterpret_cast<uint8_t *>(rows);
+    if (all) { for (int a = 0; a < A; ++a) b[a * MGX_AGENT_STRIDE + AG_TERM] = 1; }
+    else b[i * MGX_AGENT_STRIDE + AG_TERM] = 1;
+}
+
 // base.py:478-507
-MGX_HD void on_success(const MgxSpec &sp, uint8_t *ag, int i, int32_t step_count, double *rew) {
-    const int A = sp.num_agents;
-    if (sp.success_any) { for (int a = 0; a < A; ++a) ag[a * MGX_AGENT_STRIDE + AG_TERM] = 1; }
-    else ag[i * MGX_AGENT_STRIDE + AG_TERM] = 1;
-    const double r = reward_value(step_count, sp.max_steps);
-    if (sp.joint_reward) { for (int a = 0; a < A; ++a) rew[a] = r; }
+MGX_HD void on_success(const StepCfg &cf, uint64_t *rows, int i, int32_t step_count, double *rew) {
+    set_terminated(rows, cf.A, i, cf.success_any);
+    const double r = reward_value(step_count, cf.max_steps);
+    if (cf.joint_reward) { for (int a = 0; a < cf.A; ++a) rew[a] = r; }
     else rew[i] = r;
 }
 
-// base.py:509-532
-MGX_HD void on_failure(const MgxSpec &sp, uint8_t *ag, int i) {
-    const int A = sp.num_agents;
-    if (sp.failure_any) { for (int a = 0; a < A; ++a) ag[a * MGX_AGENT_STRIDE + AG_TERM] = 1; }
-    else ag[i * MGX_AGENT_STRIDE + AG_TERM] = 1;
-}
-
 // base.py:426-427, 454-455: any agent, terminated or not
-MGX_HD bool agent_present(const uint8_t *ag, int A, int x, int y) {
+MGX_HD bool agent_present(const uint64_t *rows, int A, int x, int y) {
+    const uint32_t want = (uint32_t)x | ((uint32_t)y << 8);
     bool hit = false;
-    for (int a = 0; a < A; ++a)
-        hit |= (ag[a * MGX_AGENT_STRIDE + AG_X] == x) & (ag[a * MGX_AGENT_STRIDE + AG_Y] == y);
+    for (int a = 0; a < A; ++a) hit |= (((uint32_t)rows[a] >> 16) & 0xffffu) == want;
     return hit;
 }
 
-// base.py:396-399: order = argsort(np_random.random(A)); stable ranking (ties ~2^-53)
-MGX_HD void draw_order(int A, uint64_t *rng, uint64_t *rnd, uint8_t *ord) {
-    if (A == 1) { ord[0] = 0; return; }
-    uint64_t s_lo = rng[0], s_hi = rng[1];
-    const uint64_t i_lo = rng[2], i_hi = rng[3];
-    for (int a = 0; a < A; ++a) rnd[a] = pcg64_next53(s_lo, s_hi, i_lo, i_hi);
-    rng[0] = s_lo; rng[1] = s_hi;
-    for (int a = 0; a < A; ++a) {
-        const uint64_t ra = rnd[a];
-        int rank = 0;
-        for (int b = 0; b < A; ++b) { const uint64_t rb = rnd[b]; rank += (rb < ra) | ((rb == ra) & (b < a)); }
-        ord[rank] = (uint8_t)a;
-    }
-}
-
 template <class Dirty>
-MGX_HD int handle_actions(const MgxSpec &sp, uint8_t *tile, uint8_t *ag, uint64_t *rng, int32_t step_count,
-                          const int8_t *actions, uint8_t *ord, uint64_t *rnd, double *rew, Dirty dirty) {
-    const int W = sp.width, H = sp.height, A = sp.num_agents;
-    for (int a = 0; a < A; ++a) rew[a] = 0.0;                                   // base.py:393
-    draw_order(A, rng, rnd, ord);
+MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, const int8_t *act,
+                          const uint8_t *ord, double *rew, int32_t step_count, Dirty dirty) {
+    const int A = cf.A;
     for (int k = 0; k < A; ++k) {
-        const int i = ord[k];
-        const int action = actions[i];
+        const int i = (A == 1) ? 0 : ord[k];
+        const int action = act[i];
         if (action < 0) continue;                                                // base.py:403-404
-        uint8_t *s = ag + i * MGX_AGENT_STRIDE;
-        if (s[AG_TERM]) continue;                                                // base.py:408-409
+        uint64_t row = rows[i];
+        if (row_term(row)) continue;                                             // base.py:408-409
         if (action > ACT_DONE) return MGX_ERR_UNKNOWN_ACTION;                    // base.py:473-474
-        const int d = s[AG_DIR];
-        if (action == ACT_LEFT) { s[AG_DIR] = (uint8_t)((d + 3) & 3); continue; }   // base.py:412-413
-        if (action == ACT_RIGHT) { s[AG_DIR] = (uint8_t)((d + 1) & 3); continue; }  // base.py:416-417
+        const int d = row_dir(row);
+        if (action == ACT_LEFT) { rows[i] = row_set_dir(row, (d + 3) & 3); continue; }    // base.py:412-413
+        if (action == ACT_RIGHT) { rows[i] = row_set_dir(row, (d + 1) & 3); continue; }   // base.py:416-417
         if (action == ACT_DONE) continue;                                        // base.py:470-471
-        const int fx = s[AG_X] + dir_dx(d), fy = s[AG_Y] + dir_dy(d);           // agent.py:111-118
-        if ((unsigned)fx >= (unsigned)W || (unsigned)fy >= (unsigned)H) continue; // walled grids: never taken
-        const int off = (fy * W + fx) * 3;
+        const int fx = row_x(row) + dir_dx(d), fy = row_y(row) + dir_dy(d);     // agent.py:111-118
+        if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;  // walled grids: never
+        const int off = (fy * cf.W + fx) * 3;
         uint8_t *cp = tile + off;
         const uint32_t cell = load_cell(cp);
         const int type = cell & 0xff, state = (cell >> 16) & 0xff;
-        const uint32_t carry = load_cell(s + AG_CARRY);
+        const uint32_t carry = row_carry(row);
         if (action == ACT_FORWARD) {                                             // base.py:420-436
             const bool overlap = type == T_EMPTY || type == T_GOAL || type == T_FLOOR || type == T_LAVA
                               || (type == T_DOOR && state == S_OPEN);            // world_object.py:197-201,287,314,339,452
             if (!overlap) continue;
-            if (!sp.allow_agent_overlap && agent_present(ag, A, fx, fy)) continue;
-            s[AG_X] = (uint8_t)fx; s[AG_Y] = (uint8_t)fy;
-            if (type == T_GOAL) on_success(sp, ag, i, step_count, rew);
-            if (type == T_LAVA) on_failure(sp, ag, i);
+            if (!cf.allow_overlap && agent_present(rows, A, fx, fy)) continue;
+            rows[i] = row_set_pos(row, fx, fy);
+            if (type == T_GOAL) on_success(cf, rows, i, step_count, rew);
+            if (type == T_LAVA) set_terminated(rows, A, i, cf.failure_any);      // base.py:509-532
         } else if (action == ACT_PICKUP) {                                       // base.py:439-446
             const bool can_pickup = type == T_KEY || type == T_BALL || type == T_BOX;  // world_object.py:518,556,587
             if (can_pickup && (carry & 0xff) == T_EMPTY) {
-                store_cell(s + AG_CARRY, cell);
+                rows[i] = row_set_carry(row, cell);
                 store_cell(cp, CELL_EMPTY);
                 dirty(off);
             }
         } else if (action == ACT_DROP) {                                         // base.py:449-459
-            if ((carry & 0xff) != T_EMPTY && type == T_EMPTY && !agent_present(ag, A, fx, fy)) {
+            if ((carry & 0xff) != T_EMPTY && type == T_EMPTY && !agent_present(rows, A, fx, fy)) {
                 store_cell(cp, carry);
-                store_cell(s + AG_CARRY, CELL_EMPTY);
+                rows[i] = row_set_carry(row, CELL_EMPTY);
                 dirty(off);
             }
         } else {                                                                 // toggle, base.py:462-467
@@ -244,27 +287,62 @@ MGX_HD int handle_actions(const MgxSpec &sp, uint8_t *tile, uint8_t *ag, uint64_
     return 0;
 }
 
-// envs/blockedunlockpickup.py:166-175, run AFTER the observation has been rendered.
-MGX_HD void post_step_hook(const MgxSpec &sp, uint8_t *ag, const uint8_t *target, int32_t step_count, double *rew) {
-    if (sp.env_kind != MGX_KIND_BLOCKEDUNLOCKPICKUP) return;
-    const int A = sp.num_agents;
-    for (int a = 0; a < A; ++a) {
-        const uint8_t *c = ag + a * MGX_AGENT_STRIDE + AG_CARRY;
-        if (c[0] == target[0] && c[1] == target[1]) on_success(sp, ag, a, step_count, rew);
-    }
+// envs/blockedunlockpickup.py:166-175, run AFTER the observation inputs are fixed.
+MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint64_t *rows, const uint8_t *target,
+                           int32_t step_count, double *rew) {
+    if (env_kind != MGX_KIND_BLOCKEDUNLOCKPICKUP) return;
+    const uint32_t want = (uint32_t)target[0] | ((uint32_t)target[1] << 8);
+    for (int a = 0; a < cf.A; ++a)
+        if ((row_carry(rows[a]) & 0xffffu) == want) on_success(cf, rows, a, step_count, rew);
 }
 
 // obs.py:163-173: overlay every non-terminated agent's (10, color, dir) on the tile, ascending index.
-MGX_HD void overlay_agents(const MgxSpec &sp, uint8_t *tile, const uint8_t *ag) {
-    const int A = sp.num_agents;
-    if (A <= 1) return;
-    for (int a = 0; a < A; ++a) {
-        const uint8_t *s = ag + a * MGX_AGENT_STRIDE;
-        if (s[AG_TERM]) continue;
-        if (s[AG_X] >= sp.width || s[AG_Y] >= sp.height) continue;
-        uint8_t *c = tile + (s[AG_Y] * sp.width + s[AG_X]) * 3;
-        c[0] = T_AGENT; c[1] = s[AG_COLOR]; c[2] = s[AG_DIR];
+MGX_HD void overlay_agents(const StepCfg &cf, uint8_t *tile, const uint64_t *rows) {
+    if (cf.A <= 1) return;
+    for (int a = 0; a < cf.A; ++a) {
+        const uint64_t r = rows[a];
+        if (row_term(r)) continue;
+        const int x = row_x(r), y = row_y(r);
+        if (x >= cf.W || y >= cf.H) continue;
+        store_cell(tile + (y * cf.W + x) * 3, (uint32_t)T_AGENT | ((uint32_t)(r & 0xffffu) << 8));
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// View geometry.  image[i][j] shows world cell  pos + fw*forward + la*right,  fw = V-1-j, la = i - V/2,
+// right = (-dy, dx)  (equivalent to obs.py:182-202 + get_view_exts 275-316).  In tile byte offsets:
+//     off(i, j) = origin + fw*stepF + la*stepL
+// and the in-bounds region is a rectangle in (fw, la): fw <= fmax, imin <= i <= imax.
+// ---------------------------------------------------------------------------------------------------
+struct ViewGeom { int origin, stepF, stepL, fmax, imin, imax; };
+
+template <int V>
+MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d) {
+    const int dx = dir_dx(d), dy = dir_dy(d), h = V / 2;
+    ViewGeom g;
+    g.origin = (y * W + x) * 3;
+    g.stepF = (dy * W + dx) * 3;
+    g.stepL = (dx * W - dy) * 3;
+    int lmin, lmax;
+    if (d == 0)      { g.fmax = W - 1 - x; lmin = -y;          lmax = H - 1 - y; }
+    else if (d == 1) { g.fmax = H - 1 - y; lmin = x - (W - 1); lmax = x; }
+    else if (d == 2) { g.fmax = x;         lmin = y - (H - 1); lmax = y; }
+    else             { g.fmax = y;         lmin = -x;          lmax = W - 1 - x; }
+    g.imin = lmin + h < 0 ? 0 : lmin + h;
+    g.imax = lmax + h > V - 1 ? V - 1 : lmax + h;
+    return g;
+}
+
+// in-bounds bit mask in lane order k = j*V + i
+template <int V, int NW>
+MGX_HD void inbounds_mask(const ViewGeom &g, uint64_t (&m)[NW]) {
+    for (int k = 0; k < NW; ++k) m[k] = 0;
+    if (g.imax < g.imin) return;
+    const uint32_t cols = ((2u << g.imax) - 1u) & ~((1u << g.imin) - 1u);
+    const int jmin = (V - 1 - g.fmax) < 0 ? 0 : (V - 1 - g.fmax);
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+        if (j >= jmin) or_bits<V, NW>(m, j * V, cols);
 }
 
 }  // namespace mgx

@@ -1,0 +1,100 @@
+// hostshim.cpp -- TEST INFRASTRUCTURE.  Compiles multigrid_amd/csrc/mgx_rules.h (the per-env / per-view integer
+// rules the HIP kernels are built from) for the host with g++, so the `-m "not gpu"` suite can check them against
+// the oracle without a GPU.  This is not a product path: libmgx.so never runs these on the CPU.
+//
+// The functions below replay, lane by lane in scalar code, what the fused kernel's phases do for ONE env:
+//   shim_step_env : P1a (jump-ahead PCG64 draws) + P1b (rank -> order) + P1c (handle_actions, overlay, hook)
+//   shim_obs_env  : P1d (view geometry, in-bounds mask) + P2 (gather, see-behind bits) + P3 (visibility flood)
+//                   + P4 (mask) + byte packing
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../multigrid_amd/csrc/mgx_rules.h"
+
+using namespace mgx;
+
+static const JumpTable kJump{};
+
+extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated, NOT overlaid */,
+                             uint8_t *tile_overlaid /* out: tile with agent overlay (render input) */,
+                             uint64_t *rows /* A, updated */, const int8_t *act, uint64_t *rng /* 4, updated */,
+                             int32_t *step_count, const uint8_t *target, double *rew /* A out */,
+                             uint8_t *terminated /* A out */, uint8_t *truncated, uint8_t *order_out,
+                             int32_t *n_dirty) {
+    const StepCfg cf = make_cfg(*sp);
+    const int A = cf.A, HW3 = cf.H * cf.W * 3;
+    std::vector<uint64_t> rnd(A);
+    std::vector<uint8_t> ord(A, 0);
+    for (int a = 0; a < A; ++a) rew[a] = 0.0;
+    if (A > 1) {
+        uint64_t s_lo = 0, s_hi = 0;
+        for (int ai = 0; ai < A; ++ai) rnd[ai] = pcg64_draw_at(rng, kJump.w[ai + 1], s_lo, s_hi);
+        rng[0] = s_lo; rng[1] = s_hi;                       // lane A-1 holds the state after A steps
+        for (int ai = 0; ai < A; ++ai) ord[draw_rank(rnd.data(), A, ai)] = (uint8_t)ai;
+    }
+    for (int a = 0; a < A; ++a) order_out[a] = ord[a];
+    const int32_t sc = *step_count + 1;
+    *step_count = sc;
+    int nd = 0;
+    auto dirty = [&](int) { ++nd; };
+    const int rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty);
+    *n_dirty = nd;
+    std::memcpy(tile_overlaid, tile, HW3);
+    overlay_agents(cf, tile_overlaid, rows);
+    post_step_hook(cf, sp->env_kind, rows, target, sc, rew);
+    for (int a = 0; a < A; ++a) terminated[a] = (uint8_t)row_term(rows[a]);
+    *truncated = (uint8_t)(sc >= cf.max_steps);
+    return rc;
+}
+
+template <int V>
+static void obs_env(const MgxSpec *sp, const uint8_t *tile, const uint64_t *rows, uint8_t *obs) {
+    constexpr int V2 = V * V, NW = (V2 + 63) / 64;
+    const int A = sp->num_agents, W = sp->width, H = sp->height;
+    for (int a = 0; a < A; ++a) {
+        const uint64_t row = rows[a];
+        const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
+        uint64_t inb[NW], sb[NW], vis[NW];
+        inbounds_mask<V, NW>(g, inb);
+        uint32_t cells[V2];
+        for (int k = 0; k < NW; ++k) sb[k] = 0;
+        for (int k = 0; k < V2; ++k) {                       // "lane" k
+            const int j = k / V, i = k - j * V, la = i - V / 2, fw = V - 1 - j;
+            const bool in = (inb[k >> 6] >> (k & 63)) & 1;
+            uint32_t c = CELL_WALL;
+            if (in) c = load_cell(tile + g.origin + fw * g.stepF + la * g.stepL);
+            if (i == V / 2 && j == V - 1) c = row_carry(row);
+            if (see_behind(c)) sb[k >> 6] |= 1ull << (k & 63);
+            cells[i * V + j] = c;
+        }
+        if (!sp->see_through_walls) {
+            vis_mask<V, NW>(sb, vis);
+            for (int k = 0; k < V2; ++k) {
+                const int j = k / V, i = k - j * V;
+                if (!((vis[k >> 6] >> (k & 63)) & 1)) cells[i * V + j] = CELL_UNSEEN;
+            }
+        }
+        for (int qq = 0; qq < V2; ++qq) store_cell(obs + ((size_t)a * V2 + qq) * 3, cells[qq]);
+    }
+}
+
+extern "C" int shim_obs_env(const MgxSpec *sp, const uint8_t *tile_overlaid, const uint64_t *rows, uint8_t *obs) {
+    switch (sp->view_size) {
+    case 3: obs_env<3>(sp, tile_overlaid, rows, obs); break;
+    case 5: obs_env<5>(sp, tile_overlaid, rows, obs); break;
+    case 7: obs_env<7>(sp, tile_overlaid, rows, obs); break;
+    case 9: obs_env<9>(sp, tile_overlaid, rows, obs); break;
+    case 11: obs_env<11>(sp, tile_overlaid, rows, obs); break;
+    case 13: obs_env<13>(sp, tile_overlaid, rows, obs); break;
+    case 15: obs_env<15>(sp, tile_overlaid, rows, obs); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+// gen_obs for a state that has not been overlaid yet (reset observation)
+extern "C" int shim_overlay(const MgxSpec *sp, uint8_t *tile, const uint64_t *rows) {
+    overlay_agents(make_cfg(*sp), tile, rows);
+    return 0;
+}

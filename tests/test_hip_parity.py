@@ -58,6 +58,8 @@ CASES = [
     ("ragged_a3_v5_nooverlap", EnvSpec(9, 7, 3, 5, max_steps=50, allow_agent_overlap=False,
                                        failure_termination_mode="any"), 1001, 16),
     ("a1_v3_seethrough", EnvSpec(8, 8, 1, 3, max_steps=30, see_through_walls=True), 777, 12),
+    ("a3_v7_seethrough", EnvSpec(8, 9, 3, 7, max_steps=30, see_through_walls=True), 515, 10),
+    ("a2_v9_seethrough", EnvSpec(10, 8, 2, 9, max_steps=30, see_through_walls=True), 130, 8),
     ("a5_v11_all_joint", EnvSpec(13, 12, 5, 11, max_steps=40, success_termination_mode="all", joint_reward=True), 333, 10),
     ("a7_v13", EnvSpec(20, 17, 7, 13, max_steps=40), 129, 6),
     ("a2_v15", EnvSpec(24, 24, 2, 15, max_steps=40), 65, 6),
