@@ -74,6 +74,7 @@ typedef struct MgxSpec {
 
 /* Launch geometry chosen for (spec, batch); for diagnostics, benchmarks and DESIGN.md tables. */
 typedef struct MgxLaunchInfo {
+    int32_t envs_per_wavefront;
     int32_t envs_per_workgroup;
     int32_t threads_per_workgroup;
     int32_t workgroups;

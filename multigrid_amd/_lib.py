@@ -19,7 +19,8 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
 
 
 class MgxLaunchInfo(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("envs_per_workgroup", "threads_per_workgroup", "workgroups", "lds_bytes")]
+    _fields_ = [(n, C.c_int32) for n in ("envs_per_wavefront", "envs_per_workgroup", "threads_per_workgroup", "workgroups",
+                                          "lds_bytes")]
 
 
 class MgxError(RuntimeError):

@@ -27,8 +27,7 @@ namespace {
 
 using namespace mgx;
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
+constexpr int kMaxThreads = 256;
 
 struct KernelArgs {
     MgxSpec sp;
@@ -45,148 +44,287 @@ struct KernelArgs {
     uint8_t *terminated;
     uint8_t *truncated;
     int32_t *err;
-    int32_t G;          // envs per workgroup
+    int32_t Gw;         // envs per wavefront
     int32_t dbg;        // debug: bit p set = skip phase p (profiling only, mgx_debug_skip_phases)
-    // LDS carve (byte offsets, all 16-byte aligned)
-    int32_t off_tile, off_rows, off_act, off_rng, off_rnd, off_ord, off_rew, off_rec, off_mask, off_stage;
+    // per-wavefront LDS slice: stride and carve (byte offsets inside the slice, all 16-byte aligned)
+    int32_t wave_lds;
+    int32_t off_tile, off_rows, off_rec, off_inb, off_act, off_rng, off_rnd, off_ord, off_rew, off_scnt, off_tgt,
+        off_jump, off_out;
 };
 
 struct LdsPlan {
-    int32_t off_tile, off_rows, off_act, off_rng, off_rnd, off_ord, off_rew, off_rec, off_mask, off_stage, total;
+    int32_t off_tile, off_rows, off_rec, off_inb, off_act, off_rng, off_rnd, off_ord, off_rew, off_scnt, off_tgt,
+        off_jump, off_out, total;
 };
 
 inline int align16(int x) { return (x + 15) & ~15; }
 
-// per-view record written by P1d and read (broadcast) by the view's wavefront in P2
-struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
+// per-view record written by P1d and read (broadcast) by the wavefront in P2
+struct ViewRec { int32_t origin; int16_t stepF, stepL; uint32_t carry; uint32_t pad; };     // 16 bytes
 
-LdsPlan plan_lds(const MgxSpec &sp, int G) {
+typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
+
+constexpr int kRound = 16;        // view slots whose obs bytes are staged in LDS at a time (P4/P5)
+
+// View slots per wavefront = cell registers per lane (x passes per view).
+inline int slots_per_wave(int view_size) { return 32; (void)view_size; }
+
+// LDS slice of ONE wavefront holding Gw envs
+LdsPlan plan_lds(const MgxSpec &sp, int Gw) {
     const int V = sp.view_size, A = sp.num_agents;
     const int nw = (V * V + 63) / 64;
-    const int nv = G * A;
+    int vpw = (Gw * A + 15) & ~15;                 // slots in use (the kernel is compiled for slots_per_wave(V))
+    if (vpw > slots_per_wave(V)) vpw = slots_per_wave(V);
     LdsPlan p;
     int o = 0;
-    p.off_tile = o;  o = align16(o + G * sp.height * sp.width * 3 + 16 + 16);   // head misalignment + tail vector
-    p.off_rows = o;  o = align16(o + nv * MGX_AGENT_STRIDE);
-    p.off_act = o;   o = align16(o + nv);
-    p.off_rng = o;   o = align16(o + G * 32);
-    p.off_rnd = o;   o = align16(o + nv * 8);
-    p.off_ord = o;   o = align16(o + nv);
-    p.off_rew = o;   o = align16(o + nv * 8);
-    p.off_rec = o;   o = align16(o + nv * (int)sizeof(ViewRec));
-    p.off_mask = o;  o = align16(o + nv * nw * 8 * 2);                           // [view][NW] in-bounds, then see-behind/vis
-    p.off_stage = o; o = align16(o + nv * V * V * 4 + 32);                       // + cells over-read by the packer
+    p.off_tile = o;  o = align16(o + Gw * sp.height * sp.width * 3 + 16 + 16);   // head skew + over-read
+    p.off_rows = o;  o = align16(o + vpw * MGX_AGENT_STRIDE);
+    p.off_rec = o;   o = align16(o + vpw * (int)sizeof(ViewRec));
+    p.off_inb = o;   o = align16(o + vpw * nw * 8);
+    p.off_act = o;   o = align16(o + vpw);
+    p.off_rng = o;   o = align16(o + Gw * 32);
+    p.off_rnd = o;   o = align16(o + vpw * 8);
+    p.off_ord = o;   o = align16(o + vpw);
+    p.off_rew = o;   o = align16(o + vpw * 8);
+    p.off_scnt = o;  o = align16(o + Gw * 4);
+    p.off_tgt = o;   o = align16(o + Gw * 4);
+    p.off_jump = o;  o = align16(o + (A + 1) * 32);
+    p.off_out = o;   o = align16(o + kRound * V * V * 3 + 16 + 16);               // obs bytes of one round, head skew + pad
     p.total = o;
     return p;
 }
 
-// Envs per workgroup: enough views (G*A >= 64) to fill the one-lane-per-view and one-lane-per-env phases,
-// bounded by an LDS budget that still lets several workgroups share a CU (160 KiB LDS per CU).
-int choose_G(const MgxSpec &sp, int64_t batch) {
-    const int A = sp.num_agents;
-    int G = (64 + A - 1) / A;
-    if (G < 1) G = 1;
-    if (G > 64) G = 64;
-    while (G > 1 && plan_lds(sp, G).total > 40 * 1024) G = (G + 1) / 2;
-    // small batches: keep at least ~one workgroup per CU
-    while (G > 1 && (batch + G - 1) / G < 256 && G * A > 16) G = (G + 1) / 2;
-    return G;
+constexpr int kLdsPerCU = 160 * 1024;
+constexpr int kLdsWaveBudget = 12 * 1024;     // keeps >= 12 wavefronts per CU resident
+
+// Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
+// to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
+int choose_Gw(const MgxSpec &sp, int64_t batch) {
+    int Gw = slots_per_wave(sp.view_size) / sp.num_agents;
+    if (Gw < 1) Gw = 1;
+    while (Gw > 1 && plan_lds(sp, Gw).total > kLdsWaveBudget) --Gw;
+    while (Gw > 1 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;
+    return Gw;
 }
 
 __device__ const JumpTable kJump{};
 
-template <int V, bool DO_STEP>
-__global__ __launch_bounds__(kThreads) void mgx_fused_kernel(const KernelArgs a) {
+// LDS traffic between lanes of ONE wavefront needs no s_barrier (the LDS executes a wave's operations in order);
+// this only stops the compiler from moving LDS accesses across the phase boundary.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32)
+         | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+// lane `s` of `old` := the wave-uniform value `sval` (v_writelane_b32; clang has no builtin for it)
+#ifndef MGX_ASM_WRITELANE
+#define MGX_ASM_WRITELANE 1
+#endif
+__device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t sval, const int s) {
+#if MGX_ASM_WRITELANE
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(s));
+    return old;
+#else
+    return __builtin_amdgcn_inverse_ballot_w64(1ull << s) ? sval : old;
+#endif
+}
+
+template <int V, int NIT>
+struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V + i
+    int la[NIT], fw[NIT], q3[NIT];
+    bool act[NIT], own[NIT];
+};
+
+// ---- P2 for slots [S0, S0+N): one lane per cell: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
+// own cell -> carried object (obs.py:182-207); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.
+// Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
+template <int V, int NW, int S0, int N, int VPW>
+__device__ __forceinline__ void gather_group(const uint8_t *lds, const ViewRec *rec, const uint64_t *inbw,
+                                             const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
+                                             uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     constexpr int V2 = V * V;
-    constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view
-    constexpr int NIT = NW;                      // wave passes per view
+    ViewRec r[N];
+    uint64_t inbm[N][NW];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        r[n] = rec[S0 + n];                                                  // broadcast reads
+#pragma unroll
+        for (int it = 0; it < NW; ++it) inbm[n][it] = inbw[(S0 + n) * NW + it];
+    }
+    uint32_t lo[N][NW], hi[N][NW], sh[N][NW];
+    bool inb[N][NW];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            inb[n][it] = __builtin_amdgcn_inverse_ballot_w64(uniform64(inbm[n][it]));
+            // world cell seen at image[i][j]: pos + fw*forward + la*right
+            const int off = __mul24(lc.fw[it], r[n].stepF) + __mul24(lc.la[it], r[n].stepL) + r[n].origin;
+            const uint32_t addr = inb[n][it] ? (uint32_t)off : (uint32_t)r[n].origin;
+            const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(addr & ~3u);             // LDS byte address -> its dword pair
+            lo[n][it] = p[0]; hi[n][it] = p[1]; sh[n][it] = addr & 3u;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            constexpr uint64_t kAll = ~0ull;
+            const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
+            uint32_t c = __builtin_amdgcn_alignbyte(hi[n][it], lo[n][it], sh[n][it]);   // byte 3 is junk from here on
+            c = inb[n][it] ? c : CELL_WALL;                                 // obs.py:199-202
+            c = lc.own[it] ? r[n].carry : c;                                // obs.py:207
+            cell[S0 + n][it] = c;
+            const uint32_t t = c & 0xffu;                                   // obs.py:46-63 see_behind, as lane masks
+            const uint64_t m = __builtin_amdgcn_ballot_w64(t != (uint32_t)T_WALL)
+                             & (__builtin_amdgcn_ballot_w64(t != (uint32_t)T_DOOR)
+                                | __builtin_amdgcn_ballot_w64((c & 0xff0000u) == 0)) & act_mask;
+            sbLo[it] = set_lane(sbLo[it], (uint32_t)m, S0 + n);
+            sbHi[it] = set_lane(sbHi[it], (uint32_t)(m >> 32), S0 + n);
+        }
+    }
+}
+
+template <int V, int NW, int VPW, int S0, int N>
+__device__ __forceinline__ void gather_tail(int NVc, const uint8_t *lds, const ViewRec *rec, const uint64_t *inbw,
+                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
+                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+    if constexpr (N < 8 && S0 + N < VPW) {
+        if (S0 + N < NVc) {
+            gather_group<V, NW, S0 + N, 1, VPW>(lds, rec, inbw, lc, cell, sbLo, sbHi);
+            gather_tail<V, NW, VPW, S0, N + 1>(NVc, lds, rec, inbw, lc, cell, sbLo, sbHi);
+        }
+    }
+}
+
+constexpr int kGroup = 8;
+
+template <int V, int NW, int VPW, int S0 = 0>
+__device__ __forceinline__ void gather_all(int NVc, const uint8_t *lds, const ViewRec *rec, const uint64_t *inbw,
+                                           const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
+                                           uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+    if constexpr (S0 < VPW) {
+        if (S0 + kGroup <= NVc) {
+            gather_group<V, NW, S0, kGroup, VPW>(lds, rec, inbw, lc, cell, sbLo, sbHi);
+        } else if (S0 < NVc) {                                               // ragged last group: slot by slot
+            gather_tail<V, NW, VPW, S0, 0>(NVc, lds, rec, inbw, lc, cell, sbLo, sbHi);
+        }
+        gather_all<V, NW, VPW, S0 + kGroup>(NVc, lds, rec, inbw, lc, cell, sbLo, sbHi);
+    }
+}
+
+// Every wavefront is autonomous: it owns Gw consecutive envs (<= VPW agent views) and a private LDS slice, and
+// runs all phases for them without any workgroup barrier.  A workgroup is just a bundle of such wavefronts.
+template <int V, bool DO_STEP>
+__global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
+    constexpr int V2 = V * V;
+    constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
+    constexpr int VPW = 32;                      // view slots per wavefront (== slots_per_wave)
     extern __shared__ __align__(16) uint8_t lds[];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents;
     const int HW3 = H * W * 3;
-    const int64_t e0 = (int64_t)blockIdx.x * a.G;
-    const int Gc = (int)min((int64_t)a.G, a.batch - e0);     // envs in this chunk
-    const int NVc = Gc * A;                                   // views in this chunk
-    const int64_t v0 = e0 * A;                                // first (env, agent) row of the chunk
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const int64_t e0 = wid * a.Gw;
+    if (e0 >= a.batch) return;
+    const int Gc = (int)min((int64_t)a.Gw, a.batch - e0);    // envs of this wavefront
+    const int NVc = Gc * A;                                   // its views (<= VPW)
+    const int64_t v0 = e0 * A;                                // first (env, agent) row
 
-    uint64_t *rows = reinterpret_cast<uint64_t *>(lds + a.off_rows);          // [view] packed agent rows
-    int8_t *acts = reinterpret_cast<int8_t *>(lds + a.off_act);               // [view]
-    uint64_t *rngs = reinterpret_cast<uint64_t *>(lds + a.off_rng);           // [env][4]
-    uint64_t *rnd = reinterpret_cast<uint64_t *>(lds + a.off_rnd);            // [view] 53-bit draws
-    uint8_t *ord = lds + a.off_ord;                                            // [view] visiting order per env
-    double *rew = reinterpret_cast<double *>(lds + a.off_rew);                // [view]
-    ViewRec *rec = reinterpret_cast<ViewRec *>(lds + a.off_rec);              // [view]
-    uint64_t *inbw = reinterpret_cast<uint64_t *>(lds + a.off_mask);          // [view][NW] in-bounds lanes
-    uint64_t *sbw = inbw + (size_t)a.G * A * NW;                               // [view][NW] see-behind, then visible
-    uint32_t *stage = reinterpret_cast<uint32_t *>(lds + a.off_stage);        // [view][i*V + j] packed cells
+    uint8_t *L = lds + wave * a.wave_lds;
+    uint64_t *rows = reinterpret_cast<uint64_t *>(L + a.off_rows);            // [slot] packed agent rows
+    ViewRec *rec = reinterpret_cast<ViewRec *>(L + a.off_rec);                // [slot]
+    uint64_t *inbw = reinterpret_cast<uint64_t *>(L + a.off_inb);             // [slot][NW] in-bounds lanes
+    int8_t *acts = reinterpret_cast<int8_t *>(L + a.off_act);                 // [slot]
+    uint64_t *rngs = reinterpret_cast<uint64_t *>(L + a.off_rng);             // [env][4]
+    uint64_t *rnd = reinterpret_cast<uint64_t *>(L + a.off_rnd);              // [slot] 53-bit draws
+    uint8_t *ord = L + a.off_ord;                                              // [slot] visiting order per env
+    double *rew = reinterpret_cast<double *>(L + a.off_rew);                  // [slot]
+    int32_t *scnt = reinterpret_cast<int32_t *>(L + a.off_scnt);              // [env]
+    uint32_t *tgt = reinterpret_cast<uint32_t *>(L + a.off_tgt);              // [env]
+    uint64_t *jump = reinterpret_cast<uint64_t *>(L + a.off_jump);            // [A+1][4]
 
     // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
-    const int64_t g0 = e0 * HW3, g1 = g0 + (int64_t)Gc * HW3;       // chunk byte range in `grid`
+    const int64_t g0 = e0 * HW3, g1 = g0 + (int64_t)Gc * HW3;       // byte range of these envs in `grid`
     const int64_t gtotal = a.batch * (int64_t)HW3;
     const int64_t ga = g0 & ~(int64_t)15;
-    uint8_t *tile_raw = lds + a.off_tile;                            // holds global bytes [ga, ...)
+    uint8_t *tile_raw = L + a.off_tile;                              // holds global bytes [ga, ...)
     const int tile_skew = (int)(g0 - ga);
     uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HW3
     if (!(a.dbg & 1)) {
-        constexpr int U = 4;
-        for (int64_t base = ga + 16 * tid; base < g1; base += (int64_t)16 * kThreads * U) {
+        constexpr int U = 12;
+        for (int64_t base = ga + 16 * lane; base < g1; base += (int64_t)16 * 64 * U) {
             uint4 v[U];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t vo = base + (int64_t)16 * kThreads * u;
+                const int64_t vo = base + (int64_t)16 * 64 * u;
                 ok[u] = vo < g1 && vo + 16 <= gtotal;
                 v[u] = make_uint4(0, 0, 0, 0);
                 if (ok[u]) v[u] = *reinterpret_cast<const uint4 *>(a.grid + vo);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t vo = base + (int64_t)16 * kThreads * u;
+                const int64_t vo = base + (int64_t)16 * 64 * u;
                 if (ok[u]) *reinterpret_cast<uint4 *>(tile_raw + (int)(vo - ga)) = v[u];
             }
         }
         if (g1 == gtotal && (gtotal & 15)) {                      // last, partial 16-byte vector of the tensor
             const int64_t t0 = gtotal & ~(int64_t)15;
-            for (int k = tid; k < (int)(gtotal & 15); k += kThreads) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
+            for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
         }
     }
-    for (int t = tid; t < NVc; t += kThreads) {
-        rows[t] = reinterpret_cast<const uint64_t *>(a.agents)[v0 + t];
-        rew[t] = 0.0;                                                            // base.py:393
-        if (DO_STEP) acts[t] = a.actions[v0 + t];
+    if (lane < NVc) {
+        rows[lane] = reinterpret_cast<const uint64_t *>(a.agents)[v0 + lane];
+        rew[lane] = 0.0;                                                         // base.py:393
+        if (DO_STEP) acts[lane] = a.actions[v0 + lane];
     }
-    if (DO_STEP && A > 1)
-        for (int t = tid; t < Gc * 4; t += kThreads) rngs[t] = a.rng[e0 * 4 + t];
-    __syncthreads();
+    if (DO_STEP) {
+        if (A > 1) {
+            for (int t = lane; t < Gc * 4; t += 64) rngs[t] = a.rng[e0 * 4 + t];
+            for (int t = lane; t < (A + 1) * 4; t += 64) jump[t] = kJump.w[0][t];
+        }
+        if (lane < Gc) {
+            scnt[lane] = a.step_count[e0 + lane];
+            if (a.target) tgt[lane] = reinterpret_cast<const uint32_t *>(a.target)[e0 + lane];
+        }
+    }
+    wave_sync();
 
     const StepCfg cf = make_cfg(a.sp);
     if (DO_STEP && !(a.dbg & 2)) {
         if (A > 1) {
             // -------------------------------------------------------------- P1a: one lane per (env, agent): its draw
-            for (int t = tid; t < NVc; t += kThreads) {
-                const int e = t / A, ai = t - e * A;
+            if (lane < NVc) {
+                const int e = lane / A, ai = lane - e * A;
                 uint64_t s_lo, s_hi;
-                rnd[t] = pcg64_draw_at(rngs + e * 4, kJump.w[ai + 1], s_lo, s_hi);    // base.py:399
+                rnd[lane] = pcg64_draw_at(rngs + e * 4, jump + (ai + 1) * 4, s_lo, s_hi);   // base.py:399
                 if (ai == A - 1) { a.rng[(e0 + e) * 4 + 0] = s_lo; a.rng[(e0 + e) * 4 + 1] = s_hi; }
             }
-            __syncthreads();
+            wave_sync();
             // -------------------------------------------------------------- P1b: argsort by ranking
-            for (int t = tid; t < NVc; t += kThreads) {
-                const int e = t / A, ai = t - e * A;
+            if (lane < NVc) {
+                const int e = lane / A, ai = lane - e * A;
                 ord[e * A + draw_rank(rnd + e * A, A, ai)] = (uint8_t)ai;
             }
-            __syncthreads();
+            wave_sync();
         }
         // ------------------------------------------------------------------ P1c: one lane per env, LDS only
-        for (int e = tid; e < Gc; e += kThreads) {
+        if (lane < Gc) {
+            const int e = lane;
             const int64_t b = e0 + e;
             uint8_t *etile = tile + e * HW3;
             uint64_t *erows = rows + e * A;
             double *erew = rew + e * A;
-            const int32_t sc = a.step_count[b] + 1;                              // base.py:333
+            const int32_t sc = scnt[e] + 1;                                      // base.py:333
             a.step_count[b] = sc;
             uint8_t *ggrid = a.grid + b * HW3;
             auto dirty = [=](int off) {
@@ -195,138 +333,134 @@ __global__ __launch_bounds__(kThreads) void mgx_fused_kernel(const KernelArgs a)
             const int rc = handle_actions(cf, etile, erows, acts + e * A, ord + e * A, erew, sc, dirty);
             if (rc != 0 && a.err) { atomicAdd(a.err, 1); atomicMin(a.err + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
             overlay_agents(cf, etile, erows);                                    // uses pre-hook `terminated` (Q2)
-            post_step_hook(cf, a.sp.env_kind, erows, a.target ? a.target + b * 4 : etile, sc, erew);
+            post_step_hook(cf, a.sp.env_kind, erows, reinterpret_cast<const uint8_t *>(tgt + e), sc, erew);
             a.truncated[b] = (uint8_t)(sc >= cf.max_steps);                      // base.py:339
         }
     } else {
-        for (int e = tid; e < Gc; e += kThreads) overlay_agents(cf, tile + e * HW3, rows + e * A);
+        if (lane < Gc) overlay_agents(cf, tile + lane * HW3, rows + lane * A);
     }
-    __syncthreads();
+    wave_sync();
 
     // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
-    const uint32_t tile_addr = (uint32_t)(a.off_tile + tile_skew);           // LDS byte address of env 0 cell 0
-    for (int t = tid; t < NVc; t += kThreads) {
-        const int e = t / A;
-        const uint64_t row = rows[t];
+    const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + a.off_tile + tile_skew);   // LDS address of env 0 cell 0
+    if (lane < NVc) {
+        const int e = lane / A;
+        const uint64_t row = rows[lane];
         const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
         ViewRec r;
         r.origin = (int32_t)tile_addr + e * HW3 + g.origin;
-        r.stepF = g.stepF; r.stepL = g.stepL; r.carry = row_carry(row);
-        rec[t] = r;
+        r.stepF = (int16_t)g.stepF; r.stepL = (int16_t)g.stepL; r.carry = row_carry(row); r.pad = 0;
+        rec[lane] = r;
         uint64_t m[NW];
         inbounds_mask<V, NW>(g, m);
 #pragma unroll
-        for (int k = 0; k < NW; ++k) inbw[t * NW + k] = m[k];
+        for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = m[k];
         if (DO_STEP) {
-            reinterpret_cast<uint64_t *>(a.agents)[v0 + t] = row;
-            a.reward[v0 + t] = rew[t];
-            a.terminated[v0 + t] = (uint8_t)row_term(row);                       // base.py:338 (+ env hook)
+            reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = row;
+            a.reward[v0 + lane] = rew[lane];
+            a.terminated[v0 + lane] = (uint8_t)row_term(row);                    // base.py:338 (+ env hook)
         }
-        if (a.dir) a.dir[v0 + t] = (uint8_t)row_dir(row);                        // base.py:359, 372
+        if (a.dir) a.dir[v0 + lane] = (uint8_t)row_dir(row);                     // base.py:359, 372
     }
-    __syncthreads();
+    wave_sync();
 
-    // ------------------------------------------------------------------ P2: one wavefront per view
+    // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
     // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
     // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
-    int la[NIT], fw[NIT], q[NIT];
-    bool act[NIT], own[NIT];
+    LaneConst<V, NW> lc;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int it = 0; it < NW; ++it) {
         const int k = lane + 64 * it;
         const int j = k / V, i = k - j * V;
-        act[it] = k < V2;
-        la[it] = i - V / 2;
-        fw[it] = V - 1 - j;
-        q[it] = i * V + j;
-        own[it] = (i == V / 2) && (j == V - 1);
+        lc.act[it] = k < V2;
+        lc.la[it] = i - V / 2;
+        lc.fw[it] = V - 1 - j;
+        lc.q3[it] = (i * V + j) * 3;
+        lc.own[it] = (i == V / 2) && (j == V - 1);
     }
 
-    if (!(a.dbg & 4))
-    for (int view = wave; view < NVc; view += kWaves) {
-        const ViewRec r = rec[view];                                            // broadcast read
+    uint32_t cell[VPW][NW];                      // registers: every slot's cells, one per lane (and pass)
+    uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const uint64_t inb_m = inbw[view * NW + it];
-            // (readfirstlane returns a signed int: cast before widening)
-            const uint64_t inb_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(inb_m >> 32)) << 32)
-                                 | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)inb_m);
-            const bool inb = (inb_s >> lane) & 1;
-            // world cell seen at image[i][j]: pos + fw*forward + la*right                     (obs.py:182-202)
-            uint32_t addr = (uint32_t)(r.origin + fw[it] * r.stepF + la[it] * r.stepL);
-            addr = inb ? addr : (uint32_t)r.origin;
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(lds + (addr & ~3u));
-            uint32_t c = __builtin_amdgcn_alignbyte(p[1], p[0], addr & 3u) & 0xffffffu;
-            c = inb ? c : CELL_WALL;                                            // obs.py:199-202
-            c = own[it] ? r.carry : c;                                          // obs.py:207
-            const uint64_t m = __ballot(act[it] && see_behind(c));              // obs.py:211-233
-            if (lane == 0) sbw[view * NW + it] = m;
-            if (act[it]) stage[view * V2 + q[it]] = c;
-        }
-    }
-    __syncthreads();
+    for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
+#pragma unroll
+    for (int s = 0; s < VPW; ++s)
+#pragma unroll
+        for (int it = 0; it < NW; ++it) cell[s][it] = 0;
+    if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, lds, rec, inbw, lc, cell, sbLo, sbHi);
 
-    if (!a.sp.see_through_walls) {                                              // obs.py:95-100
-        // -------------------------------------------------------------- P3: one lane per view
-        if (!(a.dbg & 8))
-        for (int view = tid; view < NVc; view += kThreads) {
-            uint64_t sb[NW], vis[NW];
+    // ------------------------------------------------------------------ P3: lane s floods the visibility of slot s
+    const bool masked = !a.sp.see_through_walls;                                // obs.py:95-100
+    uint32_t visLo[NW], visHi[NW];
 #pragma unroll
-            for (int k = 0; k < NW; ++k) sb[k] = sbw[view * NW + k];
-            vis_mask<V, NW>(sb, vis);
+    for (int k = 0; k < NW; ++k) { visLo[k] = 0xffffffffu; visHi[k] = 0xffffffffu; }
+    if (masked && !(a.dbg & 8)) {
+        uint64_t sb[NW], vis[NW];
 #pragma unroll
-            for (int k = 0; k < NW; ++k) sbw[view * NW + k] = vis[k];
-        }
-        __syncthreads();
-        // -------------------------------------------------------------- P4: wavefront per view
-        if (!(a.dbg & 16))
-        for (int view = wave; view < NVc; view += kWaves) {
+        for (int k = 0; k < NW; ++k) sb[k] = ((uint64_t)sbHi[k] << 32) | sbLo[k];
+        vis_mask<V, NW>(sb, vis);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const uint64_t m = sbw[view * NW + it];
-                if (act[it] && !((m >> lane) & 1)) stage[view * V2 + q[it]] = CELL_UNSEEN;
-            }
-        }
-        __syncthreads();
+        for (int k = 0; k < NW; ++k) { visLo[k] = (uint32_t)vis[k]; visHi[k] = (uint32_t)(vis[k] >> 32); }
     }
 
-    // ------------------------------------------------------------------ P5: LDS -> HBM, 16-byte coalesced stores
-    if (!(a.dbg & 32)) {
-        const int64_t o0 = v0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;
-        const int64_t oa = o0 & ~(int64_t)15;
-        for (int64_t D = oa + 16 * tid; D < o1; D += 16 * kThreads) {
-            if (D >= o0 && D + 16 <= o1) {
-                // bytes [D, D+16) of the obs stream = bytes rel.. of the staged cells, 3 bytes per cell
-                const int rel = (int)(D - o0);
-                const int q0 = rel / 3, r = rel - q0 * 3;
-                const uint32_t *sp = stage + q0;
-                const uint32_t c0 = sp[0], c1 = sp[1], c2 = sp[2], c3 = sp[3], c4 = sp[4], c5 = sp[5], c6 = sp[6];
-                // the cells' 3-byte encodings as a byte stream, in dwords
-                const uint32_t w0 = c0 | (c1 << 24), w1 = (c1 >> 8) | (c2 << 16), w2 = (c2 >> 16) | (c3 << 8);
-                const uint32_t w3 = c4 | (c5 << 24), w4 = (c5 >> 8) | (c6 << 16);
-                uint4 out;
-                out.x = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)r);
-                out.y = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)r);
-                out.z = __builtin_amdgcn_alignbyte(w3, w2, (uint32_t)r);
-                out.w = __builtin_amdgcn_alignbyte(w4, w3, (uint32_t)r);
-                *reinterpret_cast<uint4 *>(a.obs + D) = out;
-            } else {
-                const int64_t lo_b = max(D, o0), hi_b = min(D + 16, o1);
-                for (int64_t B = lo_b; B < hi_b; ++B) {
-                    const int rel = (int)(B - o0);
-                    const int q0 = rel / 3, r = rel - q0 * 3;
-                    a.obs[B] = (uint8_t)(stage[q0] >> (8 * r));
+    // ------------------------------------------------------------------ P4/P5 in rounds of kRound slots:
+    // P4 masks each cell and transposes it into the obs byte layout in LDS, P5 streams the round to HBM in 16-byte vectors
+    const int64_t o0 = v0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;   // this wave's obs bytes
+    const int out_skew = (int)(o0 & 15);                                        // the same for every round
+    uint8_t *out_raw = L + a.off_out;                                          // obs bytes [oa_r, ...) of round r
+    uint8_t *outb = out_raw + out_skew;
+    constexpr int kRoundBytes = kRound * V2 * 3;                                // multiple of 16
+#pragma unroll
+    for (int r0 = 0; r0 < VPW; r0 += kRound) {
+        if (r0 < NVc) {
+            if (!(a.dbg & 16)) {
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    if (lc.act[it]) {
+                        uint8_t *d0 = outb + lc.q3[it];
+#pragma unroll
+                        for (int sl = 0; sl < kRound; ++sl) {
+                            const int s = r0 + sl;
+                            if (s < NVc) {
+                                uint32_t c = cell[s][it];
+                                if (masked) {
+                                    const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
+                                                     | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
+                                    c = __builtin_amdgcn_inverse_ballot_w64(m) ? c : CELL_UNSEEN;
+                                }
+                                uint8_t *d = d0 + sl * (V2 * 3);
+                                d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+                            }
+                        }
+                    }
                 }
             }
+            wave_sync();
+            if (!(a.dbg & 32)) {
+                const int64_t ro0 = o0 + (int64_t)r0 * (V2 * 3);                // this round's obs bytes [ro0, ro1)
+                const int64_t ro1 = min(ro0 + kRoundBytes, o1);
+                const int64_t roa = ro0 - out_skew;
+                for (int64_t D = roa + 16 * lane; D < ro1; D += 16 * 64) {
+                    const uint8_t *src = out_raw + (int)(D - roa);
+                    if (D >= ro0 && D + 16 <= ro1) {
+                        *reinterpret_cast<uint4 *>(a.obs + D) = *reinterpret_cast<const uint4 *>(src);
+                    } else {
+                        const int64_t lo_b = max(D, ro0), hi_b = min(D + 16, ro1);
+                        for (int64_t B = lo_b; B < hi_b; ++B) a.obs[B] = src[(int)(B - D)];
+                    }
+                }
+            }
+            wave_sync();
         }
     }
 }
 
 int g_last_hip_error = 0;
 int g_debug_skip = 0;
+int g_debug_G = 0;
 
 template <bool DO_STEP>
-int launch(const KernelArgs &ka, int lds_bytes, int64_t nwg, hipStream_t stream) {
+int launch(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
     void (*kern)(const KernelArgs) = nullptr;
     switch (ka.sp.view_size) {
     case 3:  kern = mgx_fused_kernel<3, DO_STEP>;  break;
@@ -343,7 +477,7 @@ int launch(const KernelArgs &ka, int lds_bytes, int64_t nwg, hipStream_t stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) { g_last_hip_error = (int)e; return MGX_ERR_LAUNCH; }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kThreads), (size_t)lds_bytes, stream, ka);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, stream, ka);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = (int)e; return MGX_ERR_LAUNCH; }
     return MGX_OK;
@@ -356,21 +490,31 @@ int check_spec(const MgxSpec *sp, int64_t batch) {
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
     if (sp->env_kind != MGX_KIND_EMPTY && sp->env_kind != MGX_KIND_BLOCKEDUNLOCKPICKUP) return MGX_ERR_UNSUPPORTED;
-    if (plan_lds(*sp, 1).total > 160 * 1024) return MGX_ERR_UNSUPPORTED;
+    if (plan_lds(*sp, 1).total > kLdsPerCU) return MGX_ERR_UNSUPPORTED;              // one env must fit one CU's LDS
     return MGX_OK;
 }
 
-int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &lds_bytes, int64_t &nwg) {
+int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg) {
     ka.sp = *sp;
     ka.batch = batch;
-    ka.G = choose_G(*sp, batch);
+    ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch);
+    const int max_gw = slots_per_wave(sp->view_size) / sp->num_agents;
+    if (ka.Gw > max_gw) ka.Gw = max_gw;
+    if (ka.Gw < 1) ka.Gw = 1;
+    while (ka.Gw > 1 && plan_lds(*sp, ka.Gw).total > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
-    const LdsPlan p = plan_lds(*sp, ka.G);
-    ka.off_tile = p.off_tile; ka.off_rows = p.off_rows; ka.off_act = p.off_act; ka.off_rng = p.off_rng;
-    ka.off_rnd = p.off_rnd; ka.off_ord = p.off_ord; ka.off_rew = p.off_rew; ka.off_rec = p.off_rec;
-    ka.off_mask = p.off_mask; ka.off_stage = p.off_stage;
-    lds_bytes = p.total;
-    nwg = (batch + ka.G - 1) / ka.G;
+    const LdsPlan p = plan_lds(*sp, ka.Gw);
+    ka.wave_lds = p.total;
+    ka.off_tile = p.off_tile; ka.off_rows = p.off_rows; ka.off_rec = p.off_rec; ka.off_inb = p.off_inb;
+    ka.off_act = p.off_act; ka.off_rng = p.off_rng; ka.off_rnd = p.off_rnd; ka.off_ord = p.off_ord;
+    ka.off_rew = p.off_rew; ka.off_scnt = p.off_scnt; ka.off_tgt = p.off_tgt; ka.off_jump = p.off_jump;
+    ka.off_out = p.off_out;
+    int wpb = 4;                                          // wavefronts bundled per workgroup
+    while (wpb > 1 && wpb * p.total > 64 * 1024) wpb >>= 1;
+    threads = 64 * wpb;
+    lds_bytes = wpb * p.total;
+    const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
+    nwg = (nwaves + wpb - 1) / wpb;
     if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
     return MGX_OK;
 }
@@ -399,17 +543,19 @@ int mgx_last_hip_error(void) { return g_last_hip_error; }
 // Profiling aid (not part of the product ABI): bit p set = the fused kernel skips phase Pp.  Results are
 // then meaningless; tools/phase_probe.py uses it to attribute kernel time to phases.
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
+void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     int rc = check_spec(spec, batch);
     if (rc) return rc;
     if (!out) return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
-    int lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, lds, nwg);
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg);
     if (rc) return rc;
-    out->envs_per_workgroup = ka.G;
-    out->threads_per_workgroup = kThreads;
+    out->envs_per_wavefront = ka.Gw;
+    out->envs_per_workgroup = ka.Gw * (threads / 64);
+    out->threads_per_workgroup = threads;
     out->workgroups = (int32_t)nwg;
     out->lds_bytes = lds;
     return MGX_OK;
@@ -423,14 +569,14 @@ int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const u
     if (!grid || !agents || !obs) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16)) return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
-    int lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, lds, nwg);
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg);
     if (rc) return rc;
     ka.grid = const_cast<uint8_t *>(grid);
     ka.agents = const_cast<uint8_t *>(agents);
     ka.obs = obs;
     ka.dir = dir;
-    return launch<false>(ka, lds, nwg, static_cast<hipStream_t>(stream));
+    return launch<false>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
 int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
@@ -445,16 +591,16 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
     if (spec->num_agents > 1 && !rng) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP && !target) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16) || misaligned(rng, 8)
-        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4))
+        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(target, 4))
         return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
-    int lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, lds, nwg);
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg);
     if (rc) return rc;
     ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
     ka.target = target; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
-    return launch<true>(ka, lds, nwg, static_cast<hipStream_t>(stream));
+    return launch<true>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -226,65 +226,67 @@ MGX_HD bool agent_present(const uint64_t *rows, int A, int x, int y) {
     return hit;
 }
 
+// Written as straight-line predicated code (selects instead of early exits): the lanes of a wavefront hold
+// different envs whose agents take different actions, so every branch that ANY lane takes is paid by all.
 template <class Dirty>
 MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, const int8_t *act,
                           const uint8_t *ord, double *rew, int32_t step_count, Dirty dirty) {
     const int A = cf.A;
+    int rc = 0;
     for (int k = 0; k < A; ++k) {
         const int i = (A == 1) ? 0 : ord[k];
         const int action = act[i];
-        if (action < 0) continue;                                                // base.py:403-404
-        uint64_t row = rows[i];
-        if (row_term(row)) continue;                                             // base.py:408-409
-        if (action > ACT_DONE) return MGX_ERR_UNKNOWN_ACTION;                    // base.py:473-474
-        const int d = row_dir(row);
-        if (action == ACT_LEFT) { rows[i] = row_set_dir(row, (d + 3) & 3); continue; }    // base.py:412-413
-        if (action == ACT_RIGHT) { rows[i] = row_set_dir(row, (d + 1) & 3); continue; }   // base.py:416-417
-        if (action == ACT_DONE) continue;                                        // base.py:470-471
-        const int fx = row_x(row) + dir_dx(d), fy = row_y(row) + dir_dy(d);     // agent.py:111-118
-        if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;  // walled grids: never
-        const int off = (fy * cf.W + fx) * 3;
-        uint8_t *cp = tile + off;
-        const uint32_t cell = load_cell(cp);
-        const int type = cell & 0xff, state = (cell >> 16) & 0xff;
-        const uint32_t carry = row_carry(row);
-        if (action == ACT_FORWARD) {                                             // base.py:420-436
-            const bool overlap = type == T_EMPTY || type == T_GOAL || type == T_FLOOR || type == T_LAVA
-                              || (type == T_DOOR && state == S_OPEN);            // world_object.py:197-201,287,314,339,452
-            if (!overlap) continue;
-            if (!cf.allow_overlap && agent_present(rows, A, fx, fy)) continue;
-            rows[i] = row_set_pos(row, fx, fy);
-            if (type == T_GOAL) on_success(cf, rows, i, step_count, rew);
-            if (type == T_LAVA) set_terminated(rows, A, i, cf.failure_any);      // base.py:509-532
-        } else if (action == ACT_PICKUP) {                                       // base.py:439-446
-            const bool can_pickup = type == T_KEY || type == T_BALL || type == T_BOX;  // world_object.py:518,556,587
-            if (can_pickup && (carry & 0xff) == T_EMPTY) {
-                rows[i] = row_set_carry(row, cell);
-                store_cell(cp, CELL_EMPTY);
-                dirty(off);
-            }
-        } else if (action == ACT_DROP) {                                         // base.py:449-459
-            if ((carry & 0xff) != T_EMPTY && type == T_EMPTY && !agent_present(rows, A, fx, fy)) {
-                store_cell(cp, carry);
-                rows[i] = row_set_carry(row, CELL_EMPTY);
-                dirty(off);
-            }
-        } else {                                                                 // toggle, base.py:462-467
-            if (type == T_DOOR) {                                                // world_object.py:458-474
-                int ns = state;
-                if (state == S_LOCKED) {
-                    if ((carry & 0xff) == T_KEY && ((carry >> 8) & 0xff) == ((cell >> 8) & 0xff)) ns = S_OPEN;
-                } else {
-                    ns = (state == S_OPEN) ? S_CLOSED : S_OPEN;
-                }
-                if (ns != state) { cp[2] = (uint8_t)ns; dirty(off); }
-            } else if (type == T_BOX) {                                          // world_object.py:599-605
-                store_cell(cp, CELL_EMPTY);                                      // `contains` is None in scope
-                dirty(off);
-            }
+        const uint64_t row = rows[i];
+        // base.py:403-404 absent, 408-409 terminated; after an unknown action the reference has raised
+        const bool live = (rc == 0) & (action >= 0) & !row_term(row);
+        if (live & (action > ACT_DONE)) rc = MGX_ERR_UNKNOWN_ACTION;            // base.py:473-474
+        const bool go = live & (action <= ACT_DONE);
+        const int d = row_dir(row), x = row_x(row), y = row_y(row);
+        const int fx = x + dir_dx(d), fy = y + dir_dy(d);                       // agent.py:111-118
+        const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
+        const int off = inb ? (fy * cf.W + fx) * 3 : 0;
+        const uint32_t cell = load_cell(tile + off);
+        const uint32_t type = cell & 0xff, state = (cell >> 16) & 0xff;
+        const uint32_t carry = row_carry(row), ctype = carry & 0xff;
+        const bool on_cell = go & inb;
+        // base.py:412-417 turns
+        const int nd = (action == ACT_LEFT) ? ((d + 3) & 3) : ((action == ACT_RIGHT) ? ((d + 1) & 3) : d);
+        // base.py:420-436 forward; world_object.py:197-201, 287, 314, 339, 452 can_overlap
+        const bool overlap = (type == T_EMPTY) | (type == T_GOAL) | (type == T_FLOOR) | (type == T_LAVA)
+                           | ((type == T_DOOR) & (state == S_OPEN));
+        bool fwd = on_cell & (action == ACT_FORWARD) & overlap;
+        // base.py:449-459 drop
+        bool drop = on_cell & (action == ACT_DROP) & (ctype != T_EMPTY) & (type == T_EMPTY);
+        if ((fwd & !cf.allow_overlap) | drop) {                                  // base.py:425-429, 453-456
+            const bool present = agent_present(rows, A, fx, fy);
+            fwd = fwd & (cf.allow_overlap | !present);
+            drop = drop & !present;
         }
+        // base.py:439-446 pickup; world_object.py:518, 556, 587 can_pickup
+        const bool pick = on_cell & (action == ACT_PICKUP) & (ctype == T_EMPTY)
+                        & ((type == T_KEY) | (type == T_BALL) | (type == T_BOX));
+        // base.py:462-467 toggle; world_object.py:458-474 Door.toggle, 599-605 Box.toggle (contains is None)
+        const bool tog = on_cell & (action == ACT_TOGGLE);
+        const bool unlock = (ctype == T_KEY) & (((carry >> 8) & 0xff) == ((cell >> 8) & 0xff));
+        const uint32_t ns = (state == S_LOCKED) ? (unlock ? (uint32_t)S_OPEN : state)
+                                                : ((state == S_OPEN) ? (uint32_t)S_CLOSED : (uint32_t)S_OPEN);
+        const bool door = tog & (type == T_DOOR) & (ns != state);
+        const bool box = tog & (type == T_BOX);
+
+        uint32_t ncell = cell;
+        ncell = door ? ((cell & 0xffffu) | (ns << 16)) : ncell;
+        ncell = (pick | box) ? CELL_EMPTY : ncell;
+        ncell = drop ? carry : ncell;
+        const uint32_t ncarry = pick ? cell : (drop ? CELL_EMPTY : carry);
+        uint64_t nrow = row_set_dir(row, nd);
+        nrow = row_set_pos(nrow, fwd ? fx : x, fwd ? fy : y);
+        nrow = row_set_carry(nrow, ncarry);
+        if (go) rows[i] = nrow;
+        if (door | pick | box | drop) { store_cell(tile + off, ncell); dirty(off); }
+        if (fwd & (type == T_GOAL)) on_success(cf, rows, i, step_count, rew);    // base.py:433-434
+        if (fwd & (type == T_LAVA)) set_terminated(rows, A, i, cf.failure_any);  // base.py:435-436, 509-532
     }
-    return 0;
+    return rc;
 }
 
 // envs/blockedunlockpickup.py:166-175, run AFTER the observation inputs are fixed.

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 CSVs written by tools/pmc_probe.sh: per-kernel average duration and counter means."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+lines = []
+
+
+def short(n):
+    return "mgx_fused<step>" if "true>" in n or "Lb1" in n else ("mgx_fused<gen_obs>" if "mgx_fused" in n else n[:40])
+
+
+for f in sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+    for r in csv.DictReader(open(f)):
+        if "mgx" in r.get("Name", ""):
+            lines.append(f"kernel_stats {short(r['Name'])}: calls={r['Calls']} avg_ns={r['AverageNs']} "
+                         f"min_ns={r['MinNs']} max_ns={r['MaxNs']}")
+for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            if "mgx" in r["Kernel_Name"]:
+                acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            for c, v in sorted(cs.items()):
+                lines.append(f"{os.path.basename(d)} {k} {c}: mean={sum(v) / len(v):.6g} n={len(v)}")
+txt = "\n".join(lines)
+print(txt)
+open(os.path.join(out, "summary.txt"), "w").write(txt + "\n")
