@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts  # noqa: E402
+from multigrid_amd.sharding import shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -192,7 +193,9 @@ def main():
 
     spec = workload_spec()
     B, A = args.batch, spec.num_agents
-    env = make_env(spec, B, device, first_env=rank * B)
+    first_env, count = shard_range(world * B, rank, world)      # weak scaling: every rank owns `--batch` envs
+    assert count == B
+    env = make_env(spec, B, device, first_env=first_env)
     warm = random_actions(max(args.warmup, 1), B, A, device, 1000 + rank)
     acts = random_actions(args.steps, B, A, device, 1234 + rank)
     for t in range(args.warmup):

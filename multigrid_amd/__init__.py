@@ -9,3 +9,9 @@ from .spec import EnvSpec  # noqa: F401
 from .batched import BatchedMultiGridEnv  # noqa: F401
 
 __all__ = ["Action", "Color", "Direction", "State", "Type", "EnvSpec", "BatchedMultiGridEnv"]
+from .env import MultiGridEnv  # noqa: F401,E402
+from .envs import CONFIGURATIONS, BlockedUnlockPickupEnv, EmptyEnv, make, spec_for  # noqa: F401,E402
+from .rllib import RLlibWrapper, to_rllib_env  # noqa: F401,E402
+
+__all__ += ["MultiGridEnv", "CONFIGURATIONS", "BlockedUnlockPickupEnv", "EmptyEnv", "make", "spec_for",
+            "RLlibWrapper", "to_rllib_env"]

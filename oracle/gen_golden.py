@@ -260,6 +260,56 @@ def main():
     record("empty8_a2_unlock", make_env("MultiGrid-Empty-8x8-v0", agents=2), "empty", 61, None, None,
            edit=key_and_doors, script=script, note="scripted unlock / wrong key / close / reopen")
 
+    record_layouts()
+
+
+def record_layouts():
+    """Layout / reset parity fixtures: a sequence of resets (seeded and unseeded, with steps in between) of one
+    env object whose construction-time generator is known.  Pins multigrid_amd/layouts.py + MultiGridEnv.reset
+    against multigrid/base.py:250-301, envs/empty.py:151-170, envs/blockedunlockpickup.py:142-164."""
+    cases = [
+        ("layout_bup_a2", "MultiGrid-BlockedUnlockPickup-v0", dict(agents=2), "blockedunlockpickup"),
+        ("layout_bup_a3", "MultiGrid-BlockedUnlockPickup-v0", dict(agents=3), "blockedunlockpickup"),
+        ("layout_emptyrandom6_a3", "MultiGrid-Empty-Random-6x6-v0", dict(agents=3), "empty"),
+        ("layout_empty8_a2", "MultiGrid-Empty-8x8-v0", dict(agents=2), "empty"),
+    ]
+    for fname, name, kw, kind in cases:
+        env = make_env(name, **kw)
+        construct_seed = type(env)._default_seed
+        A = env.num_agents
+        reset_seeds = [5, -1, -1, 17, -1, 123456789, -1, -1]
+        ar = np.random.default_rng(99)
+        rec = dict(construct_seed=np.array(construct_seed), reset_seeds=np.array(reset_seeds),
+                   spec_json=np.array(json.dumps(spec_of_noreset(env, kind))))
+        grids, agents, rngs, obs0s, missions, acts_all, targets = [], [], [], [], [], [], []
+        for k, sd in enumerate(reset_seeds):
+            obs, _ = env.reset(seed=None if sd < 0 else sd)
+            grids.append(env.grid.state.copy()); agents.append(np.asarray(env.agent_states).copy())
+            rngs.append(rng_words(env.np_random))
+            obs0s.append(np.stack([obs[i]["image"] for i in range(A)]))
+            missions.append(str(obs[0]["mission"]))
+            targets.append([int(v) for v in np.asarray(env.obj)] if kind == "blockedunlockpickup" else [0, 0, 0])
+            acts = ar.integers(0, 7, size=(5, A)).astype(np.int8)
+            acts_all.append(acts)
+            for t in range(5):
+                env.step({i: int(acts[t, i]) for i in range(A)})
+        rec.update(grid0=narrow(np.asarray(grids)), agents0=narrow(np.asarray(agents)), rng0=np.asarray(rngs),
+                   obs0=narrow(np.asarray(obs0s)), missions=np.array(missions), actions=np.asarray(acts_all),
+                   targets=narrow(np.asarray(targets)))
+        path = os.path.join(OUT, fname + ".npz")
+        np.savez_compressed(path, **rec)
+        print(f"{fname:34s} resets={len(reset_seeds)} missions={sorted(set(missions))[:2]} "
+              f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def spec_of_noreset(env, kind):
+    return dict(
+        env_kind=kind, width=int(env.width), height=int(env.height), num_agents=int(env.num_agents),
+        view_size=int(env.agents[0].view_size), see_through_walls=bool(env.agents[0].see_through_walls),
+        allow_agent_overlap=bool(env.allow_agent_overlap), joint_reward=bool(env.joint_reward),
+        success_termination_mode=str(env.success_termination_mode),
+        failure_termination_mode=str(env.failure_termination_mode), max_steps=int(env.max_steps))
+
 
 if __name__ == "__main__":
     main()

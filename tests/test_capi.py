@@ -1,0 +1,69 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/mgx.h declares; argument validation
+(which happens before any launch) returns the documented codes.  No compute is attempted here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from multigrid_amd import EnvSpec, _lib
+from multigrid_amd.spec import MgxSpecC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    names = declared_functions()
+    assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
+    L = _lib.lib()
+    for n in names:
+        assert getattr(L, n) is not None
+    assert L.mgx_abi_version() == 1
+    assert _lib.error_string(0) == "ok" and "action" in _lib.error_string(-2)
+
+
+def test_header_struct_matches_python_mirror():
+    src = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    body = re.search(r"typedef struct MgxSpec \{(.*?)\} MgxSpec;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"int32_t\s+(\w+);", body)
+    assert fields == [n for n, _ in MgxSpecC._fields_]
+    assert C.sizeof(MgxSpecC) == 4 * len(fields)
+
+
+def test_argument_validation_codes():
+    L = _lib.lib()
+    info = _lib.MgxLaunchInfo()
+    ok = EnvSpec(16, 16, 4).to_c()
+    assert L.mgx_launch_info(C.byref(ok), 4096, C.byref(info)) == _lib.OK
+    assert info.threads_per_workgroup % 64 == 0 and info.workgroups > 0 and info.lds_bytes <= 160 * 1024
+    assert info.envs_per_wavefront * ok.num_agents <= 64
+    bad = EnvSpec(16, 16, 4).to_c()
+    bad.view_size = 6                                                   # even view: agent.py:78
+    assert L.mgx_launch_info(C.byref(bad), 16, C.byref(info)) == _lib.ERR_INVALID_ARGUMENT
+    bad.view_size = 17
+    assert L.mgx_launch_info(C.byref(bad), 16, C.byref(info)) == _lib.ERR_UNSUPPORTED
+    many = EnvSpec(16, 16, 4).to_c()
+    many.num_agents = 33
+    assert L.mgx_launch_info(C.byref(many), 16, C.byref(info)) == _lib.ERR_UNSUPPORTED
+    # NULL tensors are rejected before anything is launched
+    assert L.mgx_gen_obs(C.byref(ok), 8, None, None, None, None, None) == _lib.ERR_INVALID_ARGUMENT
+    assert L.mgx_step(C.byref(ok), 8, *([None] * 13)) == _lib.ERR_INVALID_ARGUMENT
+    # an empty batch is a no-op
+    assert L.mgx_gen_obs(C.byref(ok), 0, None, None, None, None, None) == _lib.OK
+    with pytest.raises(_lib.MgxError):
+        _lib.check(_lib.ERR_UNSUPPORTED, "x")
+
+
+def test_launch_geometry_for_baseline_configs():
+    for spec, batch in [(EnvSpec(16, 16, 4, max_steps=1024), 4096), (EnvSpec(11, 6, 2, env_kind="blockedunlockpickup"), 16384),
+                        (EnvSpec(16, 16, 4, max_steps=1024), 65536), (EnvSpec(64, 64, 16, view_size=9), 32768 // 8)]:
+        li = _lib.launch_info(spec, batch)
+        assert li["envs_per_wavefront"] >= 1
+        assert li["workgroups"] * li["envs_per_workgroup"] >= batch

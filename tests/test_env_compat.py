@@ -1,0 +1,141 @@
+"""Host logic of the drop-in surface (multigrid_amd/env.py, envs.py, rllib.py, layouts.py) on CPU.
+
+The compute launcher is replaced by tests.util.OracleBackend (test-only injection), so these tests check what the
+Python layer adds: dict-of-agents plumbing, reset/seed/RNG-stream hand-over, layout generation draw-for-draw,
+missing / unknown actions, the RLlib '__all__' keys -- against fixtures recorded from the real reference."""
+import numpy as np
+import pytest
+
+import multigrid_amd as mg
+from multigrid_amd import layouts
+from tests import util
+
+
+def backend_factory(spec):
+    return util.OracleBackend(spec)
+
+
+def make(env_id, **kw):
+    return mg.make(env_id, device="cpu", _backend=backend_factory, **kw)
+
+
+@pytest.mark.parametrize("path", util.LAYOUT_GOLDEN, ids=util.LAYOUT_IDS)
+def test_reset_sequence_matches_reference(path):
+    z = np.load(path)
+    name = {"layout_bup_a2": "MultiGrid-BlockedUnlockPickup-v0", "layout_bup_a3": "MultiGrid-BlockedUnlockPickup-v0",
+            "layout_emptyrandom6_a3": "MultiGrid-Empty-Random-6x6-v0",
+            "layout_empty8_a2": "MultiGrid-Empty-8x8-v0"}[path.split("/")[-1][:-4]]
+    A = z["agents0"].shape[1]
+    env = make(name, agents=A, layout_seed=int(z["construct_seed"]))
+    for k, sd in enumerate(z["reset_seeds"]):
+        obs, infos = env.reset(seed=None if sd < 0 else int(sd))
+        ctx = f"reset {k}"
+        np.testing.assert_array_equal(env.grid.state, z["grid0"][k].astype(np.int64), err_msg=ctx)
+        np.testing.assert_array_equal(env.agent_states, z["agents0"][k].astype(np.int64), err_msg=ctx)
+        got = env._benv.rng[0].numpy().view(np.uint64)
+        np.testing.assert_array_equal(got, util.rng_words_lohi(z["rng0"][k]), err_msg=ctx)
+        for i in range(A):
+            np.testing.assert_array_equal(obs[i]["image"], z["obs0"][k][i], err_msg=ctx)
+            assert obs[i]["image"].dtype == np.int64
+            if sd >= 0:   # mission_space.seed(None) draws OS entropy in the reference too (base.py:272)
+                assert str(obs[i]["mission"]) == str(z["missions"][k]), ctx
+        assert env.step_count == 0
+        if "bup" in path:
+            np.testing.assert_array_equal(env._benv.target[0].numpy()[:3], z["targets"][k], err_msg=ctx)
+        for t in range(5):
+            env.step({i: int(z["actions"][k][t, i]) for i in range(A)})
+
+
+@pytest.mark.parametrize("path", [p for p in util.GOLDEN if "empty8_a2_seed0" in p or "empty16_a4_seed7" in p])
+def test_dict_api_replays_reference_from_reset(path):
+    """Empty envs with the fixed start are fully determined by reset(seed): no state injection at all."""
+    z, d, spec = util.load_golden(path)
+    size = spec.width
+    env = make(f"MultiGrid-Empty-{size}x{size}-v0", agents=spec.num_agents)
+    obs, _ = env.reset(seed=d["seed"])
+    for i in range(spec.num_agents):
+        np.testing.assert_array_equal(obs[i]["image"], z["obs0"][i])
+        assert obs[i]["direction"] == z["dir0"][i]
+    for t in range(z["actions"].shape[0]):
+        obs, rew, term, trunc, info = env.step({i: int(a) for i, a in enumerate(z["actions"][t])})
+        for i in range(spec.num_agents):
+            np.testing.assert_array_equal(obs[i]["image"], z["obs"][t][i])
+            assert obs[i]["direction"] == z["direction"][t][i]
+            assert rew[i] == z["reward"][t][i]
+            assert term[i] == bool(z["terminated"][t][i])
+            assert trunc[i] == bool(z["truncated"][t])
+        assert env.step_count == t + 1
+    assert isinstance(info, dict)
+
+
+def test_missing_agents_are_skipped_and_unknown_actions_raise():
+    env = make("MultiGrid-Empty-8x8-v0", agents=3)
+    env.reset(seed=1)
+    before = env.agent_states.copy()
+    env.step({1: int(mg.Action.right)})                       # agents 0 and 2 absent: base.py:403-404
+    after = env.agent_states
+    np.testing.assert_array_equal(after[[0, 2]], before[[0, 2]])
+    assert after[1, 2] == (before[1, 2] + 1) % 4
+    with pytest.raises(ValueError, match="Unknown action"):
+        env.step({0: 7})
+    with pytest.raises(ValueError, match="Unknown action"):
+        env.step({0: -1})
+    env.step({0: 0})                                          # still usable afterwards
+
+
+def test_attribute_surface():
+    env = make("MultiGrid-Empty-16x16-v0", agents=4, agent_view_size=5)
+    obs, infos = env.reset(seed=0)
+    assert env.unwrapped is env and env.num_agents == 4 and env.max_steps == 1024
+    assert set(obs) == {0, 1, 2, 3} and set(obs[0]) == {"image", "direction", "mission"}
+    assert obs[0]["image"].shape == (5, 5, 3)
+    assert env.grid.state.shape == (16, 16, 3) and env.agent_states.shape == (4, 9)
+    a = env.agents[2]
+    assert (a.index, a.view_size, a.pos, int(a.dir), a.terminated, a.carrying) == (2, 5, (1, 1), 0, False, None)
+    assert a.color == mg.Color.blue and a.front_pos == (2, 1)
+    assert env.observation_space[2]["image"].shape == (5, 5, 3) and env.action_space[0].n == 7
+    assert env.agents[0].observation_space["direction"].n == 4
+    assert not env.is_done()
+    assert env.grid.get(14, 14) == (8, 1, 0) and env.grid.get(1, 1) is None
+    with pytest.raises(AssertionError):
+        make("MultiGrid-Empty-8x8-v0", agent_view_size=4)     # agent.py:78
+    with pytest.raises(NotImplementedError):
+        env.render()
+
+
+def test_rllib_wrapper_adds_all_keys():
+    env = mg.RLlibWrapper(make("MultiGrid-Empty-5x5-v0", agents=2, max_steps=3))
+    obs, infos = env.reset(seed=3)
+    assert env.agents == [0, 1] and env.possible_agents == [0, 1]
+    assert env.get_action_space(1).n == 7 and env.get_observation_space(0)["image"].shape == (7, 7, 3)
+    for t in range(3):
+        obs, rew, term, trunc, infos = env.step({0: 6, 1: 6})
+    assert term["__all__"] is False and trunc["__all__"] is True and trunc[0] is True
+    cls = mg.to_rllib_env(mg.EmptyEnv, default_config={"size": 6, "device": "cpu", "_backend": backend_factory})
+    e2 = cls({"agents": 2})
+    assert e2.env.width == 6 and e2.env.num_agents == 2
+
+
+def test_cpu_device_is_refused_without_injection():
+    with pytest.raises(RuntimeError, match="no CPU"):
+        mg.make("MultiGrid-Empty-8x8-v0", device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU"):
+        mg.BatchedMultiGridEnv(mg.EnvSpec(8, 8), 4, "cpu")
+
+
+def test_state_dict_round_trip():
+    spec = mg.EnvSpec(8, 8, 2, max_steps=64)
+    st = util.random_state(spec, 6, seed=2)
+    env = mg.BatchedMultiGridEnv(spec, 6, "cpu", backend=util.OracleBackend(spec))
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    import torch
+    for t in range(3):
+        env.step(torch.from_numpy(util.random_actions(6, 2, t)))
+    sd = env.state_dict()
+    a = [x.clone() for x in env.step(torch.from_numpy(util.random_actions(6, 2, 9)))]
+    env2 = mg.BatchedMultiGridEnv(spec, 6, "cpu", backend=util.OracleBackend(spec))
+    env2.load_state_dict(sd)
+    b = env2.step(torch.from_numpy(util.random_actions(6, 2, 9)))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(env.grid, env2.grid) and torch.equal(env.rng, env2.rng)

@@ -123,3 +123,74 @@ def test_unknown_action_is_reported():
         env.check_errors()
     env.step(torch.zeros((32, 2), dtype=torch.int8, device=dev()))
     env.check_errors()
+
+
+@pytest.mark.parametrize("path", util.LAYOUT_GOLDEN, ids=util.LAYOUT_IDS)
+def test_dict_api_reset_sequence_on_gpu(path):
+    """multigrid_amd.make(...) on the HIP backend reproduces the reference's reset()/step() sequence."""
+    import multigrid_amd as mg
+    z = np.load(path)
+    name = {"layout_bup_a2": "MultiGrid-BlockedUnlockPickup-v0", "layout_bup_a3": "MultiGrid-BlockedUnlockPickup-v0",
+            "layout_emptyrandom6_a3": "MultiGrid-Empty-Random-6x6-v0",
+            "layout_empty8_a2": "MultiGrid-Empty-8x8-v0"}[path.split("/")[-1][:-4]]
+    A = z["agents0"].shape[1]
+    env = mg.make(name, agents=A, layout_seed=int(z["construct_seed"]), device=dev())
+    for k, sd in enumerate(z["reset_seeds"]):
+        obs, _ = env.reset(seed=None if sd < 0 else int(sd))
+        np.testing.assert_array_equal(env.grid.state, z["grid0"][k].astype(np.int64))
+        np.testing.assert_array_equal(env.agent_states, z["agents0"][k].astype(np.int64))
+        np.testing.assert_array_equal(env._benv.rng[0].cpu().numpy().view(np.uint64), util.rng_words_lohi(z["rng0"][k]))
+        for i in range(A):
+            np.testing.assert_array_equal(obs[i]["image"], z["obs0"][k][i])
+        for t in range(5):
+            env.step({i: int(z["actions"][k][t, i]) for i in range(A)})
+
+
+def test_dict_api_replays_c1_on_gpu():
+    """BASELINE.json configs[0]: MultiGrid-Empty-8x8-v0, agents=2, batch=1 -- from reset(seed) alone."""
+    import multigrid_amd as mg
+    z, d, spec = util.load_golden([p for p in util.GOLDEN if "empty8_a2_seed0" in p][0])
+    env = mg.RLlibWrapper(mg.make("MultiGrid-Empty-8x8-v0", agents=2, device=dev()))
+    obs, _ = env.reset(seed=d["seed"])
+    for t in range(z["actions"].shape[0]):
+        obs, rew, term, trunc, _ = env.step({i: int(a) for i, a in enumerate(z["actions"][t])})
+        for i in range(2):
+            np.testing.assert_array_equal(obs[i]["image"], z["obs"][t][i])
+            assert obs[i]["direction"] == z["direction"][t][i] and rew[i] == z["reward"][t][i]
+            assert term[i] == bool(z["terminated"][t][i]) and trunc[i] == bool(z["truncated"][t])
+        assert term["__all__"] == all(bool(x) for x in z["terminated"][t])
+    with pytest.raises(ValueError, match="Unknown action"):
+        env.step({0: 9})
+
+
+def test_full_size_properties_c4_shape():
+    """BASELINE.json full size (Empty-16x16, 4 agents, 65536 envs): size-independent properties instead of an oracle
+    run: (1) determinism / shard invariance: two halves stepped separately == the whole batch; (2) replicated envs
+    with identical RNG and actions stay identical; (3) gen_obs is idempotent and equals the step's obs."""
+    spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
+    B = 65536
+    grid, agents = layouts.empty_layout(16, 4)
+    whole = BatchedMultiGridEnv(spec, B, dev()); whole.load_state(grid, agents); whole.seed_synthetic(7)
+    lo = BatchedMultiGridEnv(spec, B // 2, dev(), first_env=0); lo.load_state(grid, agents); lo.seed_synthetic(7)
+    hi = BatchedMultiGridEnv(spec, B // 2, dev(), first_env=B // 2); hi.load_state(grid, agents); hi.seed_synthetic(7)
+    g = torch.Generator(device=dev()); g.manual_seed(5)
+    for t in range(16):
+        act = torch.randint(0, 7, (B, 4), dtype=torch.int8, device=dev(), generator=g)
+        ow = whole.step(act)
+        ol = lo.step(act[:B // 2].contiguous()); oh = hi.step(act[B // 2:].contiguous())
+        for w, a, b in zip(ow, ol, oh):
+            assert torch.equal(w, torch.cat([a, b]))
+    assert torch.equal(whole.grid, torch.cat([lo.grid, hi.grid]))
+    obs_step = whole.obs.clone()
+    o1, _ = whole.gen_obs(); o1 = o1.clone()
+    o2, _ = whole.gen_obs()
+    assert torch.equal(o1, o2) and torch.equal(o1, obs_step)
+    # replicas: same RNG words + same actions -> same trajectories
+    rep = BatchedMultiGridEnv(spec, 4096, dev()); rep.load_state(grid, agents)
+    rep.rng.copy_(whole.rng[:1].expand(4096, 4))
+    for t in range(32):
+        a1 = torch.randint(0, 7, (1, 4), dtype=torch.int8, device=dev(), generator=g).expand(4096, 4).contiguous()
+        o = rep.step(a1)
+        for x in o:
+            assert bool((x == x[:1]).all())
+    whole.check_errors(); rep.check_errors()

@@ -13,8 +13,12 @@ from multigrid_amd.spec import EnvSpec
 from oracle import binding as ob
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+_ALL = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+#: rollout fixtures (state + actions + per-step outputs) and reset/layout fixtures, both written by oracle/gen_golden.py
+GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith("layout_")]
 GOLDEN_IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
+LAYOUT_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("layout_")]
+LAYOUT_IDS = [os.path.basename(p)[:-4] for p in LAYOUT_GOLDEN]
 
 
 def load_golden(path):
