@@ -104,6 +104,16 @@ def kernel_time_ms(fn, iters, device):
     return ev0.elapsed_time(ev1) / iters
 
 
+def pmc_traffic(kernel: str, batch: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None if this
+    (kernel, batch) was not profiled.  bench.py cannot collect PMC counters on itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            return json.load(fh)[kernel][str(batch)]["bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline(alg_bytes_per_launch, ms, traffic=None):
     achieved = alg_bytes_per_launch / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -120,10 +130,10 @@ def large_batch_points(spec, device, large_batch):
     ms_step = kernel_time_ms(step, 20, device)
     ms_obs = kernel_time_ms(env.gen_obs, 20, device)
     n = large_batch * spec.num_agents
-    r_step = roofline(n * spec.bytes_step(), ms_step)
+    r_step = roofline(n * spec.bytes_step(), ms_step, pmc_traffic("step", large_batch))
     r_step.update(batch=large_batch, kernel="mgx_fused_kernel<7,step>", ms_per_launch=round(ms_step, 4),
                   agent_steps_per_s=round(n / (ms_step * 1e-3)))
-    r_obs = roofline(n * spec.bytes_gen_obs(), ms_obs)
+    r_obs = roofline(n * spec.bytes_gen_obs(), ms_obs, pmc_traffic("gen_obs", large_batch))
     r_obs.update(batch=large_batch, kernel="mgx_fused_kernel<7,gen_obs>", ms_per_launch=round(ms_obs, 4),
                  agent_views_per_s=round(n / (ms_obs * 1e-3)))
     del env
@@ -222,9 +232,10 @@ def main():
     }
     if rank == 0:
         ms_launch = ev_ms / args.steps
-        rf = roofline(B * A * spec.bytes_step(), ms_launch)
+        rf = roofline(B * A * spec.bytes_step(), ms_launch, pmc_traffic("step", B))
         rf.update(kernel="mgx_fused_kernel<7,step>", ms_per_launch=round(ms_launch, 5),
-                  bytes_per_agent_step=spec.bytes_step(),
+                  bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=B * A * spec.bytes_step(),
+                  traffic_unit="bytes per launch (rocprofv3 PMC, profiles/traffic.json)",
                   note="working set fits the 256 MiB Infinity Cache at this batch: latency-bound, see roofline_large")
         out["roofline"] = rf
         if not args.no_extras:
