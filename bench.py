@@ -177,6 +177,10 @@ def main():
                     help="graph: the K timed steps are one hipGraph replay; eager: K Python-level env.step calls")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / cpu_baseline legs")
+    ap.add_argument("--skip-phases", type=int, default=0,
+                    help="profiling probe: bit p set = the kernel skips phase Pp (results are then garbage)")
+    ap.add_argument("--envs-per-wavefront", type=int, default=0,
+                    help="tuning probe: override the launcher's choice of envs per wavefront (0 = automatic)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,6 +205,12 @@ def main():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
 
+    if args.skip_phases:
+        from multigrid_amd import _lib
+        _lib.lib().mgx_debug_skip_phases(args.skip_phases)
+    if args.envs_per_wavefront:
+        from multigrid_amd import _lib
+        _lib.lib().mgx_debug_set_envs_per_wavefront(args.envs_per_wavefront)
     spec = workload_spec()
     B, A = args.batch, spec.num_agents
     first_env, count = shard_range(world * B, rank, world)      # weak scaling: every rank owns `--batch` envs
@@ -212,7 +222,8 @@ def main():
         env.step(warm[t])
     torch.cuda.synchronize(device)
     wall_s, ev_ms = timed_rollout(env, acts, args.mode, barrier)
-    env.check_errors()
+    if not args.skip_phases:
+        env.check_errors()
 
     t = torch.tensor([wall_s], dtype=torch.float64, device=device)
     if dist is not None:

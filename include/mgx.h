@@ -102,6 +102,29 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
 /* Geometry the two calls above would use. */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
 
+/* Replaces OneHotObsWrapper.one_hot (multigrid/wrappers.py:158-190; the wrapper RLlib registration applies to every
+ * env, multigrid/rllib/__init__.py:110-111) for a flat array of cells:
+ *   cells u8[n_cells, 3]  ->  out u8[n_cells, D],  D = dim_sizes[0] + dim_sizes[1] + dim_sizes[2]  (<= 32),
+ *   out[c, off_d + cells[c, d]] = 1, off = (0, dim_sizes[0], dim_sizes[0] + dim_sizes[1]); everything else 0.
+ * The reference uses dim_sizes = (11, 6, 4) (wrappers.py:139-140).  `out` must be 16-byte aligned. */
+int mgx_one_hot(const uint8_t *cells, int64_t n_cells, const int32_t *dim_sizes, uint8_t *out, void *stream);
+
+/* Replaces FullyObsWrapper.observation (multigrid/wrappers.py:48-58): out u8[B, W, H, 3] = Grid.state ([x][y], the
+ * reference's own orientation) with every agent's (10, color, dir) written at its position in index order,
+ * terminated agents included. */
+int mgx_full_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents, uint8_t *out,
+                 void *stream);
+
+/* Vector-env auto-reset (build-defined: the reference has no batching; its caller tests is_done(), base.py:534-539,
+ * and calls reset(), base.py:250-301).  Every env b whose episode is over -- all agents terminated or
+ * step_count >= max_steps -- is re-initialised from a pool of K pre-generated layouts
+ * (pool_grid u8[K,H,W,3], pool_agents u8[K,A,8], pool_target u8[K,4] or NULL):
+ *   layout = (first_env + b + episode[b] * 7919) mod K;  step_count[b] = 0;  episode[b] += 1;  was_reset[b] = 1.
+ * The env's PCG64 stream is left running, as an unseeded reset() does for Empty envs.  `was_reset` may be NULL. */
+int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const uint8_t *pool_grid,
+                   const uint8_t *pool_agents, const uint8_t *pool_target, uint8_t *grid, uint8_t *agents,
+                   int32_t *step_count, uint8_t *target, int32_t *episode, uint8_t *was_reset, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,3 +15,6 @@ from .rllib import RLlibWrapper, to_rllib_env  # noqa: F401,E402
 
 __all__ += ["MultiGridEnv", "CONFIGURATIONS", "BlockedUnlockPickupEnv", "EmptyEnv", "make", "spec_for",
             "RLlibWrapper", "to_rllib_env"]
+from .wrappers import FullyObsWrapper, ImgObsWrapper, OneHotObsWrapper, SingleAgentWrapper  # noqa: F401,E402
+
+__all__ += ["FullyObsWrapper", "ImgObsWrapper", "OneHotObsWrapper", "SingleAgentWrapper"]

@@ -133,6 +133,54 @@ class BatchedMultiGridEnv:
                           self.obs, self.dir, self.reward, self.terminated, self.truncated)
         return self.obs, self.dir, self.reward, self.terminated, self.truncated
 
+    # ------------------------------------------------------------------------------------------ either side of the path
+    def one_hot_obs(self) -> torch.Tensor:
+        """`OneHotObsWrapper` (multigrid/wrappers.py:101-190) applied to the current `obs`: u8[B,A,v,v,21]."""
+        if getattr(self, "_one_hot", None) is None:
+            self._one_hot = torch.zeros(tuple(self.obs.shape[:-1]) + (21,), dtype=torch.uint8, device=self.device)
+        self.backend.one_hot(self.obs, self._one_hot)
+        return self._one_hot
+
+    def full_obs(self) -> torch.Tensor:
+        """`FullyObsWrapper` (multigrid/wrappers.py:17-58): u8[B,W,H,3], the grid in the reference's [x][y]
+        orientation with every agent (terminated or not) drawn at its position."""
+        self._need_state()
+        if getattr(self, "_full", None) is None:
+            self._full = torch.zeros((self.batch, self.spec.width, self.spec.height, 3), dtype=torch.uint8,
+                                     device=self.device)
+        self.backend.full_obs(self.batch, self.grid, self.agents, self._full)
+        return self._full
+
+    def set_layout_pool(self, grids, agents, targets=None):
+        """Pool of K pre-generated episode starts for `reset_done()`: u8[K,H,W,3], u8[K,A,8], u8[K,4] | None."""
+        sp = self.spec
+        g = torch.as_tensor(np.asarray(grids), dtype=torch.uint8)
+        a = torch.as_tensor(np.asarray(agents), dtype=torch.uint8)
+        K = g.shape[0]
+        if tuple(g.shape) != (K, sp.height, sp.width, 3) or tuple(a.shape) != (K, sp.num_agents, 8) or K < 1:
+            raise ValueError("layout pool has the wrong shape")
+        layouts.check_walled(g.numpy())
+        t = None
+        if targets is not None:
+            t = torch.as_tensor(np.asarray(targets), dtype=torch.uint8).to(self.device).contiguous()
+        elif sp.env_kind != "empty":
+            raise ValueError(f"env_kind {sp.env_kind!r} needs per-layout targets")
+        self._pool = (g.to(self.device).contiguous(), a.to(self.device).contiguous(), t)
+        self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
+        self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
+
+    def reset_done(self) -> torch.Tensor:
+        """Vector-env auto-reset (build-defined; the reference leaves `if env.is_done(): env.reset()` to its caller):
+        every finished env (multigrid/base.py:534-539) restarts from the layout pool, its `np_random` stream left
+        running as an unseeded `reset()` does.  Returns was_reset u8[B].  Observations of the restarted envs are
+        produced by the next `gen_obs()` / `step()`."""
+        self._need_state()
+        if getattr(self, "_pool", None) is None:
+            raise RuntimeError("call set_layout_pool() first")
+        self.backend.reset_done(self.batch, self.first_env, self._pool, self.grid, self.agents, self.step_count,
+                                self.target, self.episode, self.was_reset)
+        return self.was_reset
+
     def check_errors(self):
         """Synchronises and raises ValueError if any env met an unknown action since the last check."""
         count, first = (int(v) for v in self.err.cpu())

@@ -13,8 +13,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "mgx_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "mgx_rules.h"), os.path.join(ROOT, "include", "mgx.h")]
+SRCS = [os.path.join(HERE, "csrc", "mgx_kernels.hip"), os.path.join(HERE, "csrc", "mgx_aux.hip")]
+DEPS = SRCS + [os.path.join(HERE, "csrc", "mgx_rules.h"), os.path.join(ROOT, "include", "mgx.h")]
 LIB = os.path.join(HERE, "lib", "libmgx.so")
 ARCH = "gfx950"
 
@@ -38,7 +38,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wall", f"-I{os.path.join(ROOT, 'include')}", SRC, "-o", LIB + ".tmp"]
+           "-Wall", f"-I{os.path.join(ROOT, 'include')}", *SRCS, "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -104,11 +104,49 @@ def _step_impl(grid, agents, rng, step_count, actions, target, err, spec):
     return obs, dirs, reward, terminated, truncated
 
 
+ONE_HOT_DIMS = (11, 6, 4)      # len(Type), len(Color), max(len(State), len(Direction))  (multigrid/wrappers.py:139-140)
+
+
+def _one_hot_into(cells, out, dim_sizes=ONE_HOT_DIMS):
+    ds = (C.c_int32 * 3)(*dim_sizes)
+    with torch.cuda.device(cells.device):
+        rc = _lib.lib().mgx_one_hot(cells.data_ptr(), cells.numel() // 3, ds, out.data_ptr(), _stream(cells.device))
+    _lib.check(rc, "mgx_one_hot")
+
+
+def _one_hot_impl(cells, dim_sizes):
+    _want(cells, "cells", torch.uint8)
+    if cells.shape[-1] != 3 or len(dim_sizes) != 3:
+        raise ValueError("mgx: one_hot expects cells[..., 3] and three dim sizes")
+    out = torch.empty(tuple(cells.shape[:-1]) + (int(sum(dim_sizes)),), dtype=torch.uint8, device=cells.device)
+    _one_hot_into(cells, out, tuple(int(d) for d in dim_sizes))
+    return out
+
+
+def _full_obs_into(sc: MgxSpecC, B, grid, agents, out):
+    with torch.cuda.device(grid.device):
+        rc = _lib.lib().mgx_full_obs(C.byref(sc), B, grid.data_ptr(), agents.data_ptr(), out.data_ptr(),
+                                     _stream(grid.device))
+    _lib.check(rc, "mgx_full_obs")
+
+
+def _full_obs_impl(grid, agents, spec):
+    sc = _spec_from_ints(spec)
+    B = _check_state(sc, grid, agents)
+    out = torch.empty((B, sc.width, sc.height, 3), dtype=torch.uint8, device=grid.device)
+    _full_obs_into(sc, B, grid, agents, out)
+    return out
+
+
 _torch_lib = torch.library.Library("mgx", "DEF")
 _torch_lib.define("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
 _torch_lib.define(
     "step(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
     "Tensor? target, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_torch_lib.define("one_hot(Tensor cells, int[] dim_sizes) -> Tensor")
+_torch_lib.define("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor")
+_torch_lib.impl("one_hot", _one_hot_impl, "CUDA")
+_torch_lib.impl("full_obs", _full_obs_impl, "CUDA")
 _torch_lib.impl("gen_obs", _gen_obs_impl, "CUDA")
 _torch_lib.impl("step", _step_impl, "CUDA")
 
@@ -137,6 +175,22 @@ class HipBackend:
     def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated):
         _step_into(self.sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
                    terminated, truncated)
+
+    def one_hot(self, cells, out):
+        _one_hot_into(cells, out)
+
+    def full_obs(self, B, grid, agents, out):
+        _full_obs_into(self.sc, B, grid, agents, out)
+
+    def reset_done(self, B, first_env, pool, grid, agents, step_count, target, episode, was_reset):
+        pg, pa, pt = pool
+        with torch.cuda.device(grid.device):
+            rc = _lib.lib().mgx_reset_done(
+                C.byref(self.sc), B, first_env, pg.shape[0], pg.data_ptr(), pa.data_ptr(),
+                pt.data_ptr() if pt is not None else None, grid.data_ptr(), agents.data_ptr(), step_count.data_ptr(),
+                target.data_ptr() if pt is not None else None, episode.data_ptr(), was_reset.data_ptr(),
+                _stream(grid.device))
+        _lib.check(rc, "mgx_reset_done")
 
     def launch_info(self, B) -> dict:
         return _lib.launch_info(self.spec, B)

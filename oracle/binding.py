@@ -159,3 +159,22 @@ def gen_obs_batch(spec: dict, grid, agents, nthreads: int = 1):
 
 def max_threads() -> int:
     return int(lib().mgo_max_threads())
+
+
+def one_hot(cells, dim_sizes=(11, 6, 4)) -> np.ndarray:
+    """cells int[..., 3] -> uint8[..., sum(dim_sizes)] (multigrid/wrappers.py:158-190)."""
+    x = np.ascontiguousarray(cells, dtype=np.int64)
+    n = x.size // 3
+    ds = np.array(dim_sizes, dtype=np.int64)
+    out = np.empty((n, int(ds.sum())), dtype=np.uint8)
+    lib().mgo_one_hot(_p(x, C.c_int64), C.c_int64(n), _p(ds, C.c_int64), _p(out, C.c_uint8))
+    return out.reshape(x.shape[:-1] + (int(ds.sum()),))
+
+
+def full_obs(grid_state, agent_state) -> np.ndarray:
+    """Reference-layout single env: (W,H,3), (A,9) -> (W,H,3) int64 (multigrid/wrappers.py:48-58)."""
+    g = np.ascontiguousarray(grid_state, dtype=np.int64)
+    a = np.ascontiguousarray(agent_state, dtype=np.int64)
+    out = np.empty_like(g)
+    lib().mgo_full_obs(_p(g, C.c_int64), _p(a, C.c_int64), g.shape[0], g.shape[1], a.shape[0], _p(out, C.c_int64))
+    return out

@@ -261,6 +261,37 @@ def main():
            edit=key_and_doors, script=script, note="scripted unlock / wrong key / close / reopen")
 
     record_layouts()
+    record_wrappers()
+
+
+def record_wrappers():
+    """OneHotObsWrapper / FullyObsWrapper outputs of the real reference (multigrid/wrappers.py:17-190) along a short
+    rollout with every object type present."""
+    from multigrid.wrappers import FullyObsWrapper, OneHotObsWrapper
+    for fname, kw in (("wrappers_empty8_a3", dict(agents=3)), ("wrappers_empty16_a4_v5", dict(size=16, agents=4, agent_view_size=5))):
+        base = make_env("MultiGrid-Empty-8x8-v0", **kw)
+        base.reset(seed=9)
+        sprinkle(0.3, 21)(base)
+        A = base.num_agents
+        oh, fo = OneHotObsWrapper(base), FullyObsWrapper(base)
+        ar = np.random.default_rng(4)
+        rec = dict(obs=[], one_hot=[], full=[], grid=[], agents=[])
+        for t in range(40):
+            act = {i: int(a) for i, a in enumerate(ar.integers(0, 7, size=A))}
+            base.step(act)
+            raw = base.gen_obs()
+            rec["obs"].append(np.stack([raw[i]["image"] for i in range(A)]))
+            o1 = oh.observation(base.gen_obs())
+            rec["one_hot"].append(np.stack([o1[i]["image"] for i in range(A)]))
+            o2 = fo.observation(base.gen_obs())
+            assert all(o2[i]["image"] is o2[0]["image"] for i in range(A))
+            rec["full"].append(np.array(o2[0]["image"]))
+            rec["grid"].append(base.grid.state.copy()); rec["agents"].append(np.asarray(base.agent_states).copy())
+        out = {k: narrow(np.asarray(v)) for k, v in rec.items()}
+        out["spec_json"] = np.array(json.dumps(spec_of_noreset(base, "empty")))
+        path = os.path.join(OUT, fname + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{fname:34s} one_hot{out['one_hot'].shape} full{out['full'].shape} {os.path.getsize(path) / 1024:.1f} KiB")
 
 
 def record_layouts():

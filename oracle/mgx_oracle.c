@@ -385,6 +385,35 @@ static void pack_env(const MgoSpec *sp, const int64_t *grid_state, const int64_t
     }
 }
 
+/* multigrid/wrappers.py:158-190 OneHotObsWrapper.one_hot: x (h,w,3) int -> out (h,w,sum(dim_sizes)) uint8.
+ * Restated over a flat list of cells (the (h,w) loops only enumerate cells). */
+int mgo_one_hot(const int64_t *x, int64_t n_cells, const int64_t *dim_sizes, uint8_t *out) {
+    const int64_t D = dim_sizes[0] + dim_sizes[1] + dim_sizes[2];
+    memset(out, 0, (size_t)(n_cells * D));
+    int64_t dim_offset = 0;
+    for (int d = 0; d < 3; ++d) {
+        for (int64_t c = 0; c < n_cells; ++c) {
+            int64_t k = dim_offset + x[c * 3 + d];
+            out[c * D + k] = 1;
+        }
+        dim_offset += dim_sizes[d];
+    }
+    return 0;
+}
+
+/* multigrid/wrappers.py:48-58 FullyObsWrapper.observation: img = grid.encode() (grid.py:310-322: state.copy());
+ * for agent in agents: img[agent.state.pos] = agent.encode() (agent.py:135-148).  Reference layout (W,H,3). */
+int mgo_full_obs(const int64_t *grid_state, const int64_t *agent_state, int W, int H, int A, int64_t *img) {
+    memcpy(img, grid_state, sizeof(int64_t) * (size_t)W * H * 3);
+    for (int a = 0; a < A; ++a) {
+        const int64_t *s = agent_state + (size_t)a * AS_DIM;
+        int64_t *c = img + ((size_t)s[AS_X] * H + s[AS_Y]) * 3;
+        c[0] = T_AGENT; c[1] = s[AS_COLOR]; c[2] = s[AS_DIR];
+    }
+    (void)W;
+    return 0;
+}
+
 int mgo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

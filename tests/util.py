@@ -15,10 +15,12 @@ from oracle import binding as ob
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _ALL = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 #: rollout fixtures (state + actions + per-step outputs) and reset/layout fixtures, both written by oracle/gen_golden.py
-GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith("layout_")]
+GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith(("layout_", "wrappers_"))]
 GOLDEN_IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
 LAYOUT_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("layout_")]
 LAYOUT_IDS = [os.path.basename(p)[:-4] for p in LAYOUT_GOLDEN]
+WRAPPER_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("wrappers_")]
+WRAPPER_IDS = [os.path.basename(p)[:-4] for p in WRAPPER_GOLDEN]
 
 
 def load_golden(path):
@@ -115,6 +117,28 @@ class OracleBackend:
             return
         obs.copy_(torch.from_numpy(o)); dirs.copy_(torch.from_numpy(d)); reward.copy_(torch.from_numpy(r))
         terminated.copy_(torch.from_numpy(te)); truncated.copy_(torch.from_numpy(tr))
+
+    def one_hot(self, cells, out):
+        out.copy_(torch.from_numpy(ob.one_hot(cells.numpy())))
+
+    def full_obs(self, B, grid, agents, out):
+        g, a = grid.numpy(), agents.numpy()
+        for b in range(B):
+            out[b] = torch.from_numpy(ob.full_obs(layouts.grid_from_product(g[b]), layouts.unpack_agents(a[b])).astype(np.uint8))
+
+    def reset_done(self, B, first_env, pool, grid, agents, step_count, target, episode, was_reset):
+        pg, pa, pt = pool
+        K = pg.shape[0]
+        for b in range(B):
+            done = bool((agents[b, :, 4] != 0).all()) or int(step_count[b]) >= self.spec.max_steps
+            was_reset[b] = int(done)
+            if done:
+                k = (first_env + b + int(episode[b]) * 7919) % K
+                grid[b] = pg[k]; agents[b] = pa[k]
+                if pt is not None:
+                    target[b] = pt[k]
+                step_count[b] = 0
+                episode[b] += 1
 
     def launch_info(self, B):
         return {}
