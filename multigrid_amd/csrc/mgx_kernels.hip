@@ -49,12 +49,12 @@ struct KernelArgs {
     // per-wavefront LDS slice: stride and carve (byte offsets inside the slice, all 16-byte aligned)
     int32_t wave_lds;
     int32_t off_tile, off_rows, off_rec, off_inb, off_act, off_rng, off_rnd, off_ord, off_rew, off_scnt, off_tgt,
-        off_jump, off_out, off_wall;
+        off_jump, off_out, off_wall, off_woff;
 };
 
 struct LdsPlan {
     int32_t off_tile, off_rows, off_rec, off_inb, off_act, off_rng, off_rnd, off_ord, off_rew, off_scnt, off_tgt,
-        off_jump, off_out, off_wall, total;
+        off_jump, off_out, off_wall, off_woff, total;
 };
 
 inline int align16(int x) { return (x + 15) & ~15; }
@@ -91,6 +91,7 @@ LdsPlan plan_lds(const MgxSpec &sp, int Gw) {
     p.off_jump = o;  o = align16(o + (A + 1) * 32);
     p.off_out = o;   o = align16(o + kRound * V * V * 3 + 16 + 16);               // obs bytes of one round, head skew + pad
     p.off_wall = o;  o = align16(o + 8);                                         // one WALL cell (+ the dword read after it)
+    p.off_woff = o;  o = align16(o + vpw * 4);                                   // cell written by each agent (fast path)
     p.total = o;
     return p;
 }
@@ -104,7 +105,8 @@ int choose_Gw(const MgxSpec &sp, int64_t batch) {
     int Gw = slots_per_wave(sp.view_size) / sp.num_agents;
     if (Gw < 1) Gw = 1;
     while (Gw > 1 && plan_lds(sp, Gw).total > kLdsWaveBudget) --Gw;
-    while (Gw > 1 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;
+    while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
+    while (Gw > 1 && (batch + Gw - 1) / Gw < 512) Gw = (Gw + 1) / 2;       // tiny batches: spread over the chip
     return Gw;
 }
 
@@ -113,9 +115,9 @@ __device__ const JumpTable kJump{};
 // LDS traffic between lanes of ONE wavefront needs no s_barrier (the LDS executes a wave's operations in order);
 // this only stops the compiler from moving LDS accesses across the phase boundary.
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
@@ -268,86 +270,145 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint8_t *tile_raw = L + a.off_tile;                              // holds global bytes [ga, ...)
     const int tile_skew = (int)(g0 - ga);
     uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HW3
-    if (!(a.dbg & 1)) {
-        // 16-byte vectors of [ga, g1): lane-contiguous, all issued before the first is stored (one HBM latency)
-        const uint8_t *gsrc = a.grid + ga;
-        const int len = (int)(g1 - ga);
-        const int avail = (int)min(gtotal - ga, (int64_t)INT_MAX);           // bytes readable from gsrc
-        constexpr int U = 6;
-        for (int base = 16 * lane; base < len; base += 16 * 64 * U) {
-            uint4 v[U];
-            bool ok[U];
+    // Every HBM load of the wavefront is issued here, back to back, into registers; then ONE unconditional
+    // s_waitcnt vmcnt(0); then the LDS stores.  (Waiting under the same lane predicates as the loads makes hipcc's
+    // waitcnt pass believe loads may still be pending and sprinkle vmcnt(0) -- which on CDNA also waits for every
+    // older global STORE -- over the rest of the kernel.)
+    constexpr int U = 8;                                                    // 8 KiB of tile per pass
+    const uint8_t *gsrc = a.grid + ga;
+    const int len = (int)(g1 - ga);
+    const int avail = (int)min(gtotal - ga, (int64_t)INT_MAX);               // bytes readable from gsrc
+    uint4 tv[U];
+    bool tok[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int rel = base + 16 * 64 * u;
-                ok[u] = (rel < len) & (rel + 16 <= avail);
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (ok[u]) v[u] = *reinterpret_cast<const uint4 *>(gsrc + rel);
-            }
+    for (int u = 0; u < U; ++u) {
+        const int rel = 16 * lane + 16 * 64 * u;
+        tok[u] = (rel < len) & (rel + 16 <= avail) & !(a.dbg & 1);
+        tv[u] = make_uint4(0, 0, 0, 0);
+        if (tok[u]) tv[u] = *reinterpret_cast<const uint4 *>(gsrc + rel);
+    }
+    uint64_t in_row = 0, in_rng0 = 0, in_rng1 = 0, in_jump = 0;
+    int32_t in_scnt = 0;
+    uint32_t in_tgt = 0;
+    int8_t in_act = 0;
+    if (lane < NVc) {
+        in_row = reinterpret_cast<const uint64_t *>(a.agents)[v0 + lane];
+        if (DO_STEP) in_act = a.actions[v0 + lane];
+    }
+    if (DO_STEP) {
+        if (A > 1) {
+            if (lane < Gc * 4) in_rng0 = a.rng[e0 * 4 + lane];
+            if (lane + 64 < Gc * 4) in_rng1 = a.rng[e0 * 4 + lane + 64];
+            for (int t = lane; t < (A + 1) * 4; t += 64) jump[t] = kJump.w[0][t];   // A >= 16 only: more than one pass
+        }
+        if (lane < Gc) {
+            in_scnt = a.step_count[e0 + lane];
+            if (a.target) in_tgt = reinterpret_cast<const uint32_t *>(a.target)[e0 + lane];
+        }
+    }
+    (void)in_jump;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (ok[u]) *reinterpret_cast<uint4 *>(tile_raw + base + 16 * 64 * u) = v[u];
-        }
-        if (g1 == gtotal && (gtotal & 15)) {                      // last, partial 16-byte vector of the tensor
-            const int64_t t0 = gtotal & ~(int64_t)15;
-            for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
-        }
+    for (int u = 0; u < U; ++u)
+        if (tok[u]) *reinterpret_cast<uint4 *>(tile_raw + 16 * lane + 16 * 64 * u) = tv[u];
+    for (int rel = 16 * lane + 16 * 64 * U; rel < len; rel += 16 * 64)          // tiles larger than one pass
+        if ((rel + 16 <= avail) & !(a.dbg & 1))
+            *reinterpret_cast<uint4 *>(tile_raw + rel) = *reinterpret_cast<const uint4 *>(gsrc + rel);
+    if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
+        const int64_t t0 = gtotal & ~(int64_t)15;
+        for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
     }
     const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + a.off_wall);
     if (lane == 0) *reinterpret_cast<uint32_t *>(L + a.off_wall) = CELL_WALL;
     const int env_of_lane = lane / A, agent_of_lane = lane - env_of_lane * A;     // slot `lane` = (env, agent)
     if (lane < NVc) {
-        rows[lane] = reinterpret_cast<const uint64_t *>(a.agents)[v0 + lane];
+        rows[lane] = in_row;
         rew[lane] = 0.0;                                                         // base.py:393
-        if (DO_STEP) acts[lane] = a.actions[v0 + lane];
+        if (DO_STEP) acts[lane] = in_act;
     }
     if (DO_STEP) {
         if (A > 1) {
-            for (int t = lane; t < Gc * 4; t += 64) rngs[t] = a.rng[e0 * 4 + t];
-            for (int t = lane; t < (A + 1) * 4; t += 64) jump[t] = kJump.w[0][t];
+            if (lane < Gc * 4) rngs[lane] = in_rng0;
+            if (lane + 64 < Gc * 4) rngs[lane + 64] = in_rng1;
         }
-        if (lane < Gc) {
-            scnt[lane] = a.step_count[e0 + lane];
-            if (a.target) tgt[lane] = reinterpret_cast<const uint32_t *>(a.target)[e0 + lane];
-        }
+        if (lane < Gc) { scnt[lane] = in_scnt; tgt[lane] = in_tgt; }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
     wave_sync();
 
     const StepCfg cf = make_cfg(a.sp);
     if (DO_STEP && !(a.dbg & 2)) {
-        if (A > 1) {
+        const bool in = lane < NVc;
+        if (A > 1 && !(a.dbg & 128)) {
             // -------------------------------------------------------------- P1a: one lane per (env, agent): its draw
-            if (lane < NVc) {
+            if (in) {
                 const int e = env_of_lane, ai = agent_of_lane;
                 uint64_t s_lo, s_hi;
                 rnd[lane] = pcg64_draw_at(rngs + e * 4, jump + (ai + 1) * 4, s_lo, s_hi);   // base.py:399
                 if (ai == A - 1) { a.rng[(e0 + e) * 4 + 0] = s_lo; a.rng[(e0 + e) * 4 + 1] = s_hi; }
             }
-            wave_sync();
-            // -------------------------------------------------------------- P1b: argsort by ranking
-            if (lane < NVc) {
-                const int e = env_of_lane, ai = agent_of_lane;
-                ord[e * A + draw_rank(rnd + e * A, A, ai)] = (uint8_t)ai;
+        }
+        // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
+        // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
+        int32_t *woff = reinterpret_cast<int32_t *>(L + a.off_woff);            // [slot]
+        AgentEval ev{};
+        uint8_t *mytile = tile + env_of_lane * HW3;
+        if (in && !(a.dbg & 64)) {
+            ev = eval_agent(cf, mytile, rows + env_of_lane * A, acts[lane], rows[lane], true);
+            woff[lane] = ev.writes ? ev.off : -1;
+        }
+        wave_sync();
+        const bool conf = in && spec_cell_conflict(woff + env_of_lane * A, A, agent_of_lane, ev);
+        const uint64_t m_event = __builtin_amdgcn_ballot_w64(in && (ev.success | ev.failure | ev.bad));
+        const uint64_t m_conf = __builtin_amdgcn_ballot_w64(conf);
+        const uint64_t m_pres = __builtin_amdgcn_ballot_w64(in && ev.used_presence);
+        const uint64_t m_moved = __builtin_amdgcn_ballot_w64(in && ev.moved);
+        const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+        const uint64_t genv = in ? (amask << (env_of_lane * A)) : 0ull;         // the lanes of this lane's env
+        const bool fb = in && spec_needs_fallback(m_event & genv, m_conf & genv, m_pres & genv, m_moved & genv);
+        if (in && !fb) {                                                         // commit
+            if (ev.go) rows[lane] = ev.nrow;
+            if (ev.writes) {
+                store_cell(mytile + ev.off, ev.ncell);
+                uint8_t *gg = a.grid + (e0 + env_of_lane) * HW3 + ev.off;
+                gg[0] = (uint8_t)ev.ncell; gg[1] = (uint8_t)(ev.ncell >> 8); gg[2] = (uint8_t)(ev.ncell >> 16);
+            }
+        }
+        const uint64_t fbw = __builtin_amdgcn_ballot_w64(fb);                   // envs that need the sequential loop
+        wave_sync();
+        if (fbw != 0) {
+            if (A > 1) {
+                // ---------------------------------------------------------- P1b: argsort by ranking
+                if (in) {
+                    const int e = env_of_lane, ai = agent_of_lane;
+                    ord[e * A + draw_rank(rnd + e * A, A, ai)] = (uint8_t)ai;
+                }
+                wave_sync();
+            }
+            // -------------------------------------------------------------- P1c: one lane per env: the reference's loop
+            const bool mine = lane < Gc && (lane * A < 64) && ((fbw >> (lane * A)) & 1ull);
+            if (mine) {
+                const int e = lane;
+                const int64_t b = e0 + e;
+                uint8_t *etile = tile + e * HW3;
+                uint8_t *ggrid = a.grid + b * HW3;
+                auto dirty = [=](int off) {
+                    ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2];
+                };
+                const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
+                                              scnt[e] + 1, dirty);
+                if (rc != 0 && a.err) { atomicAdd(a.err, 1); atomicMin(a.err + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
             }
             wave_sync();
         }
-        // ------------------------------------------------------------------ P1c: one lane per env, LDS only
+        // ------------------------------------------------------------------ one lane per env: counters, overlay, hook
         if (lane < Gc) {
             const int e = lane;
             const int64_t b = e0 + e;
-            uint8_t *etile = tile + e * HW3;
-            uint64_t *erows = rows + e * A;
-            double *erew = rew + e * A;
             const int32_t sc = scnt[e] + 1;                                      // base.py:333
             a.step_count[b] = sc;
-            uint8_t *ggrid = a.grid + b * HW3;
-            auto dirty = [=](int off) {
-                ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2];
-            };
-            const int rc = handle_actions(cf, etile, erows, acts + e * A, ord + e * A, erew, sc, dirty);
-            if (rc != 0 && a.err) { atomicAdd(a.err, 1); atomicMin(a.err + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
-            overlay_agents(cf, etile, erows);                                    // uses pre-hook `terminated` (Q2)
-            post_step_hook(cf, a.sp.env_kind, erows, reinterpret_cast<const uint8_t *>(tgt + e), sc, erew);
+            if (!(a.dbg & 512)) overlay_agents(cf, tile + e * HW3, rows + e * A);    // uses pre-hook `terminated` (Q2)
+            post_step_hook(cf, a.sp.env_kind, rows + e * A, reinterpret_cast<const uint8_t *>(tgt + e), sc, rew + e * A);
             a.truncated[b] = (uint8_t)(sc >= cf.max_steps);                      // base.py:339
         }
     } else {
@@ -522,7 +583,7 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     ka.off_tile = p.off_tile; ka.off_rows = p.off_rows; ka.off_rec = p.off_rec; ka.off_inb = p.off_inb;
     ka.off_act = p.off_act; ka.off_rng = p.off_rng; ka.off_rnd = p.off_rnd; ka.off_ord = p.off_ord;
     ka.off_rew = p.off_rew; ka.off_scnt = p.off_scnt; ka.off_tgt = p.off_tgt; ka.off_jump = p.off_jump;
-    ka.off_out = p.off_out; ka.off_wall = p.off_wall;
+    ka.off_out = p.off_out; ka.off_wall = p.off_wall; ka.off_woff = p.off_woff;
     int wpb = 4;                                          // wavefronts bundled per workgroup
     while (wpb > 1 && wpb * p.total > 64 * 1024) wpb >>= 1;
     threads = 64 * wpb;

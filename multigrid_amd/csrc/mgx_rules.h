@@ -226,8 +226,82 @@ MGX_HD bool agent_present(const uint64_t *rows, int A, int x, int y) {
     return hit;
 }
 
-// Written as straight-line predicated code (selects instead of early exits): the lanes of a wavefront hold
-// different envs whose agents take different actions, so every branch that ANY lane takes is paid by all.
+// What ONE agent's action does, evaluated against the current tile and agent rows (multigrid/base.py:403-474 for one
+// iteration of the loop).  Written as straight-line predicated code: the lanes of a wavefront hold different agents
+// taking different actions, so every branch that ANY lane takes is paid by all.
+struct AgentEval {
+    uint64_t nrow;        // the agent's row after the action
+    uint32_t ncell;       // the front cell after the action
+    int off;              // byte offset of the front cell in the tile
+    bool go;              // the action is executed (agent present, not terminated, action known)
+    bool bad;             // unknown action value (base.py:473-474)
+    bool reads_cell;      // the outcome depends on the front cell's content
+    bool writes;          // the front cell changes (pickup / drop / toggle)
+    bool moved;           // the agent's position changes
+    bool success;         // it stepped on a goal  (base.py:433-434)
+    bool failure;         // it stepped on lava    (base.py:435-436)
+    bool used_presence;   // the outcome depended on where the other agents stand (base.py:425-429, 453-456)
+};
+
+MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64_t *rows, int action, uint64_t row,
+                            bool alive) {
+    const int A = cf.A;
+    AgentEval ev;
+    // base.py:403-404 absent, 408-409 terminated
+    const bool live = alive & (action >= 0) & !row_term(row);
+    ev.bad = live & (action > ACT_DONE);                                    // base.py:473-474
+    ev.go = live & (action <= ACT_DONE);
+    const int d = row_dir(row), x = row_x(row), y = row_y(row);
+    const int fx = x + dir_dx(d), fy = y + dir_dy(d);                       // agent.py:111-118
+    const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
+    ev.off = inb ? (fy * cf.W + fx) * 3 : 0;
+    const uint32_t cell = load_cell(tile + ev.off);
+    const uint32_t type = cell & 0xff, state = (cell >> 16) & 0xff;
+    const uint32_t carry = row_carry(row), ctype = carry & 0xff;
+    const bool on_cell = ev.go & inb;
+    ev.reads_cell = on_cell & (action >= ACT_FORWARD) & (action <= ACT_TOGGLE);
+    // base.py:412-417 turns
+    const int nd = (action == ACT_LEFT) ? ((d + 3) & 3) : ((action == ACT_RIGHT) ? ((d + 1) & 3) : d);
+    // base.py:420-436 forward; world_object.py:197-201, 287, 314, 339, 452 can_overlap
+    const bool overlap = (type == T_EMPTY) | (type == T_GOAL) | (type == T_FLOOR) | (type == T_LAVA)
+                       | ((type == T_DOOR) & (state == S_OPEN));
+    bool fwd = on_cell & (action == ACT_FORWARD) & overlap;
+    // base.py:449-459 drop
+    bool drop = on_cell & (action == ACT_DROP) & (ctype != T_EMPTY) & (type == T_EMPTY);
+    ev.used_presence = (fwd & !cf.allow_overlap) | drop;
+    if (ev.used_presence) {                                                  // base.py:425-429, 453-456
+        const bool present = agent_present(rows, A, fx, fy);
+        fwd = fwd & (cf.allow_overlap | !present);
+        drop = drop & !present;
+    }
+    // base.py:439-446 pickup; world_object.py:518, 556, 587 can_pickup
+    const bool pick = on_cell & (action == ACT_PICKUP) & (ctype == T_EMPTY)
+                    & ((type == T_KEY) | (type == T_BALL) | (type == T_BOX));
+    // base.py:462-467 toggle; world_object.py:458-474 Door.toggle, 599-605 Box.toggle (contains is None)
+    const bool tog = on_cell & (action == ACT_TOGGLE);
+    const bool unlock = (ctype == T_KEY) & (((carry >> 8) & 0xff) == ((cell >> 8) & 0xff));
+    const uint32_t ns = (state == S_LOCKED) ? (unlock ? (uint32_t)S_OPEN : state)
+                                            : ((state == S_OPEN) ? (uint32_t)S_CLOSED : (uint32_t)S_OPEN);
+    const bool door = tog & (type == T_DOOR) & (ns != state);
+    const bool box = tog & (type == T_BOX);
+
+    uint32_t ncell = cell;
+    ncell = door ? ((cell & 0xffffu) | (ns << 16)) : ncell;
+    ncell = (pick | box) ? CELL_EMPTY : ncell;
+    ncell = drop ? carry : ncell;
+    ev.ncell = ncell;
+    const uint32_t ncarry = pick ? cell : (drop ? CELL_EMPTY : carry);
+    uint64_t nrow = row_set_dir(row, nd);
+    nrow = row_set_pos(nrow, fwd ? fx : x, fwd ? fy : y);
+    ev.nrow = row_set_carry(nrow, ncarry);
+    ev.writes = door | pick | box | drop;
+    ev.moved = fwd;
+    ev.success = fwd & (type == T_GOAL);
+    ev.failure = fwd & (type == T_LAVA);
+    return ev;
+}
+
+// The reference's loop (base.py:402-474): agents act one after the other in `ord`, each seeing the previous ones' effects.
 template <class Dirty>
 MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, const int8_t *act,
                           const uint8_t *ord, double *rew, int32_t step_count, Dirty dirty) {
@@ -235,58 +309,37 @@ MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, cons
     int rc = 0;
     for (int k = 0; k < A; ++k) {
         const int i = (A == 1) ? 0 : ord[k];
-        const int action = act[i];
-        const uint64_t row = rows[i];
-        // base.py:403-404 absent, 408-409 terminated; after an unknown action the reference has raised
-        const bool live = (rc == 0) & (action >= 0) & !row_term(row);
-        if (live & (action > ACT_DONE)) rc = MGX_ERR_UNKNOWN_ACTION;            // base.py:473-474
-        const bool go = live & (action <= ACT_DONE);
-        const int d = row_dir(row), x = row_x(row), y = row_y(row);
-        const int fx = x + dir_dx(d), fy = y + dir_dy(d);                       // agent.py:111-118
-        const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
-        const int off = inb ? (fy * cf.W + fx) * 3 : 0;
-        const uint32_t cell = load_cell(tile + off);
-        const uint32_t type = cell & 0xff, state = (cell >> 16) & 0xff;
-        const uint32_t carry = row_carry(row), ctype = carry & 0xff;
-        const bool on_cell = go & inb;
-        // base.py:412-417 turns
-        const int nd = (action == ACT_LEFT) ? ((d + 3) & 3) : ((action == ACT_RIGHT) ? ((d + 1) & 3) : d);
-        // base.py:420-436 forward; world_object.py:197-201, 287, 314, 339, 452 can_overlap
-        const bool overlap = (type == T_EMPTY) | (type == T_GOAL) | (type == T_FLOOR) | (type == T_LAVA)
-                           | ((type == T_DOOR) & (state == S_OPEN));
-        bool fwd = on_cell & (action == ACT_FORWARD) & overlap;
-        // base.py:449-459 drop
-        bool drop = on_cell & (action == ACT_DROP) & (ctype != T_EMPTY) & (type == T_EMPTY);
-        if ((fwd & !cf.allow_overlap) | drop) {                                  // base.py:425-429, 453-456
-            const bool present = agent_present(rows, A, fx, fy);
-            fwd = fwd & (cf.allow_overlap | !present);
-            drop = drop & !present;
-        }
-        // base.py:439-446 pickup; world_object.py:518, 556, 587 can_pickup
-        const bool pick = on_cell & (action == ACT_PICKUP) & (ctype == T_EMPTY)
-                        & ((type == T_KEY) | (type == T_BALL) | (type == T_BOX));
-        // base.py:462-467 toggle; world_object.py:458-474 Door.toggle, 599-605 Box.toggle (contains is None)
-        const bool tog = on_cell & (action == ACT_TOGGLE);
-        const bool unlock = (ctype == T_KEY) & (((carry >> 8) & 0xff) == ((cell >> 8) & 0xff));
-        const uint32_t ns = (state == S_LOCKED) ? (unlock ? (uint32_t)S_OPEN : state)
-                                                : ((state == S_OPEN) ? (uint32_t)S_CLOSED : (uint32_t)S_OPEN);
-        const bool door = tog & (type == T_DOOR) & (ns != state);
-        const bool box = tog & (type == T_BOX);
-
-        uint32_t ncell = cell;
-        ncell = door ? ((cell & 0xffffu) | (ns << 16)) : ncell;
-        ncell = (pick | box) ? CELL_EMPTY : ncell;
-        ncell = drop ? carry : ncell;
-        const uint32_t ncarry = pick ? cell : (drop ? CELL_EMPTY : carry);
-        uint64_t nrow = row_set_dir(row, nd);
-        nrow = row_set_pos(nrow, fwd ? fx : x, fwd ? fy : y);
-        nrow = row_set_carry(nrow, ncarry);
-        if (go) rows[i] = nrow;
-        if (door | pick | box | drop) { store_cell(tile + off, ncell); dirty(off); }
-        if (fwd & (type == T_GOAL)) on_success(cf, rows, i, step_count, rew);    // base.py:433-434
-        if (fwd & (type == T_LAVA)) set_terminated(rows, A, i, cf.failure_any);  // base.py:435-436, 509-532
+        const AgentEval ev = eval_agent(cf, tile, rows, act[i], rows[i], rc == 0);   // after an unknown action the reference has raised
+        if (ev.bad) rc = MGX_ERR_UNKNOWN_ACTION;
+        if (ev.go) rows[i] = ev.nrow;
+        if (ev.writes) { store_cell(tile + ev.off, ev.ncell); dirty(ev.off); }
+        if (ev.success) on_success(cf, rows, i, step_count, rew);                // base.py:433-434
+        if (ev.failure) set_terminated(rows, A, i, cf.failure_any);              // base.py:435-436, 509-532
     }
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Order-free fast path.  All A agents of an env are evaluated at once against the PRE-step state (one lane per agent).
+// The result equals the sequential loop above, for every visiting order, whenever no agent's inputs could have been
+// changed by another agent's action in the same step.  Sufficient conditions, checked per env:
+//   (1) no agent triggers on_success / on_failure and no action is unknown (these change who is alive, write
+//       rewards, or abort the loop);
+//   (2) no agent writes a cell that another agent's outcome depends on (its front cell, when its action reads it);
+//   (3) no outcome depended on the other agents' positions (drop; forward without agent overlap) while any agent moved.
+// Each agent's own row is only touched by its own action, so with (1)-(3) every agent sees exactly the inputs it would
+// see in the sequential loop.  Envs that fail a condition are simply run through handle_actions() instead.
+// ---------------------------------------------------------------------------------------------------------------
+MGX_HD bool spec_cell_conflict(const int32_t *woff /* [A]: cell written by agent j, or -1 */, int A, int ai,
+                               const AgentEval &ev) {
+    bool c = false;
+    for (int j = 0; j < A; ++j) c |= (j != ai) & (woff[j] == ev.off);
+    return c & ev.reads_cell;
+}
+
+// m_*: bit j = agent j of this env
+MGX_HD bool spec_needs_fallback(uint64_t m_event, uint64_t m_conflict, uint64_t m_presence, uint64_t m_moved) {
+    return (m_event != 0) | (m_conflict != 0) | ((m_presence != 0) & (m_moved != 0));
 }
 
 // envs/blockedunlockpickup.py:166-175, run AFTER the observation inputs are fixed.

@@ -27,7 +27,7 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def step_env(spec, tile, rows8, act, rng4, step_count, target):
+def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=False):
     """tile u8[H,W,3], rows8 u8[A,8], act i8[A], rng4 u64[4], target u8[4]; all updated in place.
     Returns dict(obs, reward, terminated, truncated, order, rc, n_dirty)."""
     sc = spec.to_c()
@@ -39,11 +39,11 @@ def step_env(spec, tile, rows8, act, rng4, step_count, target):
     rc = lib().shim_step_env(C.byref(sc), _p(tile, C.c_uint8), _p(over, C.c_uint8), _p(rows, C.c_uint64),
                              _p(act, C.c_int8), _p(rng4, C.c_uint64), C.byref(scnt), _p(target, C.c_uint8),
                              _p(rew, C.c_double), _p(term, C.c_uint8), _p(trunc, C.c_uint8), _p(order, C.c_uint8),
-                             C.byref(nd))
+                             C.byref(nd), int(force_serial))
     obs = np.empty((A, v, v, 3), np.uint8)
     assert lib().shim_obs_env(C.byref(sc), _p(over, C.c_uint8), _p(rows, C.c_uint64), _p(obs, C.c_uint8)) == 0
     return dict(obs=obs, reward=rew, terminated=term, truncated=int(trunc[0]), order=order, rc=rc,
-                n_dirty=nd.value, step_count=scnt.value)
+                n_dirty=nd.value, step_count=scnt.value, serial=nd.value < 0)
 
 
 def obs_env(spec, tile, rows8):

@@ -21,7 +21,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
                              uint64_t *rows /* A, updated */, const int8_t *act, uint64_t *rng /* 4, updated */,
                              int32_t *step_count, const uint8_t *target, double *rew /* A out */,
                              uint8_t *terminated /* A out */, uint8_t *truncated, uint8_t *order_out,
-                             int32_t *n_dirty) {
+                             int32_t *n_dirty, int force_serial) {
     const StepCfg cf = make_cfg(*sp);
     const int A = cf.A, HW3 = cf.H * cf.W * 3;
     std::vector<uint64_t> rnd(A);
@@ -38,8 +38,31 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
     *step_count = sc;
     int nd = 0;
     auto dirty = [&](int) { ++nd; };
-    const int rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty);
-    *n_dirty = nd;
+    int rc = 0;
+    // the kernel's order-free fast path (P1s), lane by lane; envs that fail its conditions take the sequential loop
+    std::vector<AgentEval> ev(A);
+    std::vector<int32_t> woff(A);
+    uint64_t m_event = 0, m_conf = 0, m_pres = 0, m_moved = 0;
+    for (int ai = 0; ai < A; ++ai) {
+        ev[ai] = eval_agent(cf, tile, rows, act[ai], rows[ai], true);
+        woff[ai] = ev[ai].writes ? ev[ai].off : -1;
+    }
+    for (int ai = 0; ai < A; ++ai) {
+        if (ev[ai].success | ev[ai].failure | ev[ai].bad) m_event |= 1ull << ai;
+        if (spec_cell_conflict(woff.data(), A, ai, ev[ai])) m_conf |= 1ull << ai;
+        if (ev[ai].used_presence) m_pres |= 1ull << ai;
+        if (ev[ai].moved) m_moved |= 1ull << ai;
+    }
+    const bool fallback = spec_needs_fallback(m_event, m_conf, m_pres, m_moved) || force_serial;
+    if (!fallback) {
+        for (int ai = 0; ai < A; ++ai) {
+            if (ev[ai].go) rows[ai] = ev[ai].nrow;
+            if (ev[ai].writes) { store_cell(tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
+        }
+    } else {
+        rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty);
+    }
+    *n_dirty = fallback ? -nd - 1 : nd;          // negative = the sequential loop ran
     std::memcpy(tile_overlaid, tile, HW3);
     overlay_agents(cf, tile_overlaid, rows);
     post_step_hook(cf, sp->env_kind, rows, target, sc, rew);

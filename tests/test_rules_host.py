@@ -24,8 +24,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("force_serial", [False, True], ids=["fastpath", "serial"])
 @pytest.mark.parametrize("spec", CASES, ids=lambda s: f"{s.width}x{s.height}_a{s.num_agents}_v{s.view_size}")
-def test_rules_match_oracle_on_random_states(spec):
+def test_rules_match_oracle_on_random_states(spec, force_serial):
     B, T = 24, 12
     st = util.random_state(spec, B, seed=spec.width * 100 + spec.num_agents)
     ref = {k: v.copy() for k, v in st.items()}
@@ -33,13 +34,15 @@ def test_rules_match_oracle_on_random_states(spec):
     o_ref, _ = ob.gen_obs_batch(sd, ref["grid"], ref["agents"])
     for b in range(B):
         np.testing.assert_array_equal(hostshim.obs_env(spec, st["grid"][b], st["agents"][b]), o_ref[b])
+    n_serial = n_total = 0
     for t in range(T):
         act = util.random_actions(B, spec.num_agents, seed=500 + t)
         o_ref, d_ref, r_ref, te_ref, tr_ref = ob.step_batch(
             sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["target"])
         for b in range(B):
             out = hostshim.step_env(spec, st["grid"][b], st["agents"][b], act[b], st["rng"][b],
-                                    st["step_count"][b], st["target"][b])
+                                    st["step_count"][b], st["target"][b], force_serial)
+            n_serial += out["serial"]; n_total += 1
             st["step_count"][b] = out["step_count"]
             ctx = f"step {t} env {b}"
             assert out["rc"] == 0
@@ -51,6 +54,8 @@ def test_rules_match_oracle_on_random_states(spec):
             assert out["truncated"] == tr_ref[b], ctx
             if spec.num_agents > 1:
                 np.testing.assert_array_equal(st["rng"][b], ref["rng"][b], err_msg=ctx)
+    if not force_serial and spec.num_agents <= 7:
+        assert 0 < n_serial < n_total, (n_serial, n_total)     # both the order-free path and the fallback are exercised
 
 
 @pytest.mark.parametrize("path", util.GOLDEN, ids=util.GOLDEN_IDS)
