@@ -141,6 +141,37 @@ def large_batch_points(spec, device, large_batch):
     return r_step, r_obs
 
 
+def rollout_point(spec, batch, device, steps, first_env, seed):
+    """The same K steps as ONE mgx_rollout launch (env state stays in LDS between steps).  Open-loop actions only."""
+    env = make_env(spec, batch, device, first_env)
+    acts = random_actions(steps, batch, spec.num_agents, device, seed)
+    out = env.rollout(acts[:2].contiguous())                  # warm-up + allocation pattern
+    A, v = spec.num_agents, spec.view_size
+    out = {"obs": torch.empty((steps, batch, A, v, v, 3), dtype=torch.uint8, device=device),
+           "dir": torch.empty((steps, batch, A), dtype=torch.uint8, device=device),
+           "reward": torch.empty((steps, batch, A), dtype=torch.float64, device=device),
+           "terminated": torch.empty((steps, batch, A), dtype=torch.uint8, device=device),
+           "truncated": torch.empty((steps, batch), dtype=torch.uint8, device=device)}
+    stream = torch.cuda.current_stream(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    env.rollout(acts, out)
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    env.check_errors()
+    n = batch * A * steps
+    res = {"value": round(n / wall), "unit": "agent-steps/s", "steps": steps, "launches": 1,
+           "ms_per_step": round(wall * 1e3 / steps, 6), "event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 6),
+           "note": "mgx_rollout: K steps in one launch, bit-identical to K mgx_step calls (tests/test_hip_parity.py); "
+                   "valid for open-loop action sequences such as this benchmark's random actions"}
+    del env, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(spec, batch, budget_s=12.0):
     """Oracle (C port of the reference algorithm, OpenMP over envs) on this host, bounded sample."""
     from oracle import binding as ob
@@ -253,6 +284,7 @@ def main():
             r_step, r_obs = large_batch_points(spec, device, args.large_batch)
             out["roofline_large"] = r_step
             out["gen_obs_large"] = r_obs
+            out["fused_rollout"] = rollout_point(spec, B, device, args.steps, first_env, 1234 + rank)
             out["cpu_baseline"] = cpu_baseline(spec, B)
         print(json.dumps(out), flush=True)
     barrier()

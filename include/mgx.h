@@ -99,6 +99,18 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream);
 
+/* `steps` consecutive mgx_step calls in ONE launch, bit-identical to calling mgx_step `steps` times: every wavefront
+ * keeps its envs' grid tile, agent rows, PCG64 state and step counts in LDS between steps, so the per-step HBM
+ * traffic is just the actions in and the outputs out, and there is no launch or state round trip per step.
+ * For rollouts whose actions do not depend on the observations (scripted / random policies, the benchmark of
+ * BASELINE.json); a policy in the loop needs mgx_step.
+ *   actions i8[steps,B,A]   obs u8[steps,B,A,v,v,3]   dir u8[steps,B,A]   reward f64[steps,B,A]
+ *   terminated u8[steps,B,A]   truncated u8[steps,B]        (state tensors as in mgx_step, updated once at the end) */
+int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+                int32_t *step_count, const int8_t *actions, const uint8_t *target,
+                uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                int32_t *err, void *stream);
+
 /* Geometry the two calls above would use. */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
 

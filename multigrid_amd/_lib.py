@@ -15,7 +15,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -
 
 #: every symbol include/mgx.h declares
 EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
-           "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done")
+           "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout")
 
 
 class MgxLaunchInfo(C.Structure):
@@ -50,6 +50,8 @@ def lib() -> C.CDLL:
     L.mgx_gen_obs.argtypes = [C.POINTER(MgxSpecC), i64, vp, vp, vp, vp, vp]
     L.mgx_step.restype = C.c_int
     L.mgx_step.argtypes = [C.POINTER(MgxSpecC), i64] + [vp] * 13
+    L.mgx_rollout.restype = C.c_int
+    L.mgx_rollout.argtypes = [C.POINTER(MgxSpecC), i64, C.c_int32] + [vp] * 13
     L.mgx_one_hot.restype = C.c_int
     L.mgx_one_hot.argtypes = [vp, i64, C.POINTER(C.c_int32), vp, vp]
     L.mgx_full_obs.restype = C.c_int

@@ -133,6 +133,29 @@ class BatchedMultiGridEnv:
                           self.obs, self.dir, self.reward, self.terminated, self.truncated)
         return self.obs, self.dir, self.reward, self.terminated, self.truncated
 
+    def rollout(self, actions: torch.Tensor, out: dict | None = None) -> dict:
+        """`T` consecutive `step`s in one kernel launch (env state stays in LDS between steps); bit-identical to
+        calling `step(actions[t])` for t = 0..T-1.  For open-loop action sequences (random / scripted policies).
+
+        actions  i8[T,B,A].  Returns {'obs': u8[T,B,A,v,v,3], 'dir', 'reward', 'terminated': [T,B,A],
+        'truncated': u8[T,B]} (pass `out` to reuse buffers).  The env's own `obs`... buffers are not touched."""
+        self._need_state()
+        sp, B = self.spec, self.batch
+        if actions.dtype != torch.int8 or actions.dim() != 3 or tuple(actions.shape[1:]) != (B, sp.num_agents) \
+                or actions.device != self.grid.device or not actions.is_contiguous():
+            raise ValueError(f"actions must be a contiguous int8 tensor of shape (T, {B}, {sp.num_agents}) on {self.grid.device}")
+        T, A, v, dev = actions.shape[0], sp.num_agents, sp.view_size, self.device
+        if out is None:
+            out = {"obs": torch.empty((T, B, A, v, v, 3), dtype=torch.uint8, device=dev),
+                   "dir": torch.empty((T, B, A), dtype=torch.uint8, device=dev),
+                   "reward": torch.empty((T, B, A), dtype=torch.float64, device=dev),
+                   "terminated": torch.empty((T, B, A), dtype=torch.uint8, device=dev),
+                   "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev)}
+        self.backend.rollout(B, T, self.grid, self.agents, self.rng, self.step_count, actions,
+                             self.target if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],
+                             out["reward"], out["terminated"], out["truncated"])
+        return out
+
     # ------------------------------------------------------------------------------------------ either side of the path
     def one_hot_obs(self) -> torch.Tensor:
         """`OneHotObsWrapper` (multigrid/wrappers.py:101-190) applied to the current `obs`: u8[B,A,v,v,21]."""

@@ -46,6 +46,7 @@ struct KernelArgs {
     int32_t *err;
     int32_t Gw;         // envs per wavefront
     int32_t dbg;        // debug: bit p set = skip phase p (profiling only, mgx_debug_skip_phases)
+    int32_t T;          // steps per launch (mgx_rollout), 1 otherwise
     // per-wavefront LDS slice: stride and carve (byte offsets inside the slice, all 16-byte aligned)
     int32_t wave_lds;
     int32_t off_tile, off_rows, off_rec, off_inb, off_act, off_rng, off_rnd, off_ord, off_rew, off_scnt, off_tgt,
@@ -232,8 +233,12 @@ __device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, co
 
 // Every wavefront is autonomous: it owns Gw consecutive envs (<= VPW agent views) and a private LDS slice, and
 // runs all phases for them without any workgroup barrier.  A workgroup is just a bundle of such wavefronts.
-template <int V, bool DO_STEP>
+// MODE 0: gen_obs only.  MODE 1: one step.  MODE 2: a.T consecutive steps with the envs' state kept in LDS between
+// steps (mgx_rollout); per-step outputs go to the [t] slices of the output tensors, the state is written back once.
+template <int V, int MODE>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
+    constexpr bool DO_STEP = MODE != 0;
+    constexpr bool ROLL = MODE == 2;
     constexpr int V2 = V * V;
     constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
     constexpr int VPW = 32;                      // view slots per wavefront (== slots_per_wave)
@@ -336,7 +341,34 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
     wave_sync();
 
+    // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
+    // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
+    LaneConst<V, NW> lc;
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+        const int k = lane + 64 * it;
+        const int j = k / V, i = k - j * V;
+        lc.act[it] = k < V2;
+        lc.la[it] = i - V / 2;
+        lc.fw[it] = V - 1 - j;
+        lc.q3[it] = (i * V + j) * 3;
+        lc.own[it] = (i == V / 2) && (j == V - 1);
+    }
+
     const StepCfg cf = make_cfg(a.sp);
+    const int T = ROLL ? a.T : 1;
+    const int64_t BA = a.batch * A;
+    int8_t next_act = 0;                                                     // ROLL: next step's action, in flight
+    if (ROLL && lane < NVc) next_act = a.actions[v0 + lane];
+    for (int t = 0; t < T; ++t) {
+    const int64_t tv0 = (int64_t)t * BA + v0;                                // this step's (env, agent) output rows
+    if (ROLL) {
+        if (lane < NVc) { acts[lane] = next_act; rew[lane] = 0.0; }
+        if (t + 1 < T && lane < NVc) next_act = a.actions[(int64_t)(t + 1) * BA + v0 + lane];
+        wave_sync();
+    }
+    uint32_t ovl_saved = 0;                                                  // ROLL: clean cell under this agent's overlay
+    int ovl_off = -1;
     if (DO_STEP && !(a.dbg & 2)) {
         const bool in = lane < NVc;
         if (A > 1 && !(a.dbg & 128)) {
@@ -345,7 +377,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 const int e = env_of_lane, ai = agent_of_lane;
                 uint64_t s_lo, s_hi;
                 rnd[lane] = pcg64_draw_at(rngs + e * 4, jump + (ai + 1) * 4, s_lo, s_hi);   // base.py:399
-                if (ai == A - 1) { a.rng[(e0 + e) * 4 + 0] = s_lo; a.rng[(e0 + e) * 4 + 1] = s_hi; }
+                if (ai == A - 1) {                                                // the env's stream after A draws
+                    if (ROLL) { rngs[e * 4 + 0] = s_lo; rngs[e * 4 + 1] = s_hi; }          // (every lane has read it: in-order LDS)
+                    else { a.rng[(e0 + e) * 4 + 0] = s_lo; a.rng[(e0 + e) * 4 + 1] = s_hi; }
+                }
             }
         }
         // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
@@ -370,8 +405,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             if (ev.go) rows[lane] = ev.nrow;
             if (ev.writes) {
                 store_cell(mytile + ev.off, ev.ncell);
-                uint8_t *gg = a.grid + (e0 + env_of_lane) * HW3 + ev.off;
-                gg[0] = (uint8_t)ev.ncell; gg[1] = (uint8_t)(ev.ncell >> 8); gg[2] = (uint8_t)(ev.ncell >> 16);
+                if (!ROLL) {                                                     // ROLL writes the whole tile back at the end
+                    uint8_t *gg = a.grid + (e0 + env_of_lane) * HW3 + ev.off;
+                    gg[0] = (uint8_t)ev.ncell; gg[1] = (uint8_t)(ev.ncell >> 8); gg[2] = (uint8_t)(ev.ncell >> 16);
+                }
             }
         }
         const uint64_t fbw = __builtin_amdgcn_ballot_w64(fb);                   // envs that need the sequential loop
@@ -393,7 +430,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 uint8_t *etile = tile + e * HW3;
                 uint8_t *ggrid = a.grid + b * HW3;
                 auto dirty = [=](int off) {
-                    ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2];
+                    if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
                 };
                 const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
                                               scnt[e] + 1, dirty);
@@ -401,18 +438,27 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             }
             wave_sync();
         }
-        // ------------------------------------------------------------------ one lane per env: counters, overlay, hook
+        // ------------------------------------------------------------------ one lane per agent: overlay for rendering
+        // (obs.py:163-173) with the pre-hook `terminated`; then one lane per env: counters, hook
+        {
+            const int off = (in && !(a.dbg & 512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
+            if (ROLL && off >= 0) ovl_saved = load_cell(mytile + off);
+            ovl_off = off;
+            wave_sync();
+            if (off >= 0) store_cell(mytile + off, (uint32_t)T_AGENT | ((uint32_t)(rows[lane] & 0xffffu) << 8));
+        }
         if (lane < Gc) {
             const int e = lane;
             const int64_t b = e0 + e;
             const int32_t sc = scnt[e] + 1;                                      // base.py:333
-            a.step_count[b] = sc;
-            if (!(a.dbg & 512)) overlay_agents(cf, tile + e * HW3, rows + e * A);    // uses pre-hook `terminated` (Q2)
+            if (ROLL) scnt[e] = sc; else a.step_count[b] = sc;
             post_step_hook(cf, a.sp.env_kind, rows + e * A, reinterpret_cast<const uint8_t *>(tgt + e), sc, rew + e * A);
-            a.truncated[b] = (uint8_t)(sc >= cf.max_steps);                      // base.py:339
+            a.truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
         }
     } else {
-        if (lane < Gc) overlay_agents(cf, tile + lane * HW3, rows + lane * A);
+        const int off = (lane < NVc) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
+        wave_sync();
+        if (off >= 0) store_cell(tile + env_of_lane * HW3 + off, (uint32_t)T_AGENT | ((uint32_t)(rows[lane] & 0xffffu) << 8));
     }
     wave_sync();
 
@@ -431,29 +477,15 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #pragma unroll
         for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = m[k];
         if (DO_STEP) {
-            reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = row;
-            a.reward[v0 + lane] = rew[lane];
-            a.terminated[v0 + lane] = (uint8_t)row_term(row);                    // base.py:338 (+ env hook)
+            if (!ROLL) reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = row;
+            a.reward[tv0 + lane] = rew[lane];
+            a.terminated[tv0 + lane] = (uint8_t)row_term(row);                   // base.py:338 (+ env hook)
         }
-        if (a.dir) a.dir[v0 + lane] = (uint8_t)row_dir(row);                     // base.py:359, 372
+        if (a.dir) a.dir[tv0 + lane] = (uint8_t)row_dir(row);                    // base.py:359, 372
     }
     wave_sync();
 
     // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
-    // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
-    // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
-    LaneConst<V, NW> lc;
-#pragma unroll
-    for (int it = 0; it < NW; ++it) {
-        const int k = lane + 64 * it;
-        const int j = k / V, i = k - j * V;
-        lc.act[it] = k < V2;
-        lc.la[it] = i - V / 2;
-        lc.fw[it] = V - 1 - j;
-        lc.q3[it] = (i * V + j) * 3;
-        lc.own[it] = (i == V / 2) && (j == V - 1);
-    }
-
     uint32_t cell[VPW][NW];                      // registers: every slot's cells, one per lane (and pass)
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
@@ -463,6 +495,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #pragma unroll
         for (int it = 0; it < NW; ++it) cell[s][it] = 0;
     if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+    if (ROLL) {                                                              // take the overlay off again: the tile persists
+        wave_sync();
+        if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
+    }
 
     // ------------------------------------------------------------------ P3: lane s floods the visibility of slot s
     const bool masked = !a.sp.see_through_walls;                                // obs.py:95-100
@@ -480,7 +516,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 
     // ------------------------------------------------------------------ P4/P5 in rounds of kRound slots:
     // P4 masks each cell and transposes it into the obs byte layout in LDS, P5 streams the round to HBM in 16-byte vectors
-    const int64_t o0 = v0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;   // this wave's obs bytes
+    const int64_t o0 = tv0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;  // this wave's obs bytes (of step t)
     const int out_skew = (int)(o0 & 15);                                        // the same for every round
     uint8_t *out_raw = L + a.off_out;                                          // obs bytes [oa_r, ...) of round r
     uint8_t *outb = out_raw + out_skew;
@@ -528,23 +564,43 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             wave_sync();
         }
     }
+    }   // for t
+
+    if (ROLL) {
+        // ------------------------------------------------------------------ state write-back, once per launch
+        for (int rel = 16 * lane; rel < len; rel += 16 * 64) {                  // the tile, as it was loaded
+            const int64_t D = ga + rel;
+            if (D >= g0 && D + 16 <= g1) {
+                *reinterpret_cast<uint4 *>(a.grid + D) = *reinterpret_cast<const uint4 *>(tile_raw + rel);
+            } else {
+                const int64_t lo_b = max(D, g0), hi_b = min(D + 16, g1);
+                for (int64_t B = lo_b; B < hi_b; ++B) a.grid[B] = tile_raw[(int)(B - ga)];
+            }
+        }
+        if (lane < NVc) reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = rows[lane];
+        if (A > 1) {
+            if (lane < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane] = rngs[lane];
+            if (lane + 64 < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane + 64] = rngs[lane + 64];
+        }
+        if (lane < Gc) a.step_count[e0 + lane] = scnt[lane];
+    }
 }
 
 int g_last_hip_error = 0;
 int g_debug_skip = 0;
 int g_debug_G = 0;
 
-template <bool DO_STEP>
+template <int MODE>
 int launch(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
     void (*kern)(const KernelArgs) = nullptr;
     switch (ka.sp.view_size) {
-    case 3:  kern = mgx_fused_kernel<3, DO_STEP>;  break;
-    case 5:  kern = mgx_fused_kernel<5, DO_STEP>;  break;
-    case 7:  kern = mgx_fused_kernel<7, DO_STEP>;  break;
-    case 9:  kern = mgx_fused_kernel<9, DO_STEP>;  break;
-    case 11: kern = mgx_fused_kernel<11, DO_STEP>; break;
-    case 13: kern = mgx_fused_kernel<13, DO_STEP>; break;
-    case 15: kern = mgx_fused_kernel<15, DO_STEP>; break;
+    case 3:  kern = mgx_fused_kernel<3, MODE>;  break;
+    case 5:  kern = mgx_fused_kernel<5, MODE>;  break;
+    case 7:  kern = mgx_fused_kernel<7, MODE>;  break;
+    case 9:  kern = mgx_fused_kernel<9, MODE>;  break;
+    case 11: kern = mgx_fused_kernel<11, MODE>; break;
+    case 13: kern = mgx_fused_kernel<13, MODE>; break;
+    case 15: kern = mgx_fused_kernel<15, MODE>; break;
     default: return MGX_ERR_UNSUPPORTED;
     }
     if (lds_bytes > 64 * 1024) {
@@ -651,7 +707,8 @@ int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const u
     ka.agents = const_cast<uint8_t *>(agents);
     ka.obs = obs;
     ka.dir = dir;
-    return launch<false>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+    ka.T = 1;
+    return launch<0>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
 int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
@@ -675,7 +732,34 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
     ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
     ka.target = target; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
-    return launch<true>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+    ka.T = 1;
+    return launch<1>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+}
+
+int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+                int32_t *step_count, const int8_t *actions, const uint8_t *target,
+                uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                int32_t *err, void *stream) {
+    int rc = check_spec(spec, batch);
+    if (rc) return rc;
+    if (steps < 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (batch == 0 || steps == 0) return MGX_OK;
+    if (!grid || !agents || !step_count || !actions || !obs || !reward || !terminated || !truncated)
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->num_agents > 1 && !rng) return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP && !target) return MGX_ERR_INVALID_ARGUMENT;
+    if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16) || misaligned(rng, 8)
+        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(target, 4))
+        return MGX_ERR_INVALID_ARGUMENT;
+    KernelArgs ka{};
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg);
+    if (rc) return rc;
+    ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
+    ka.target = target; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
+    ka.truncated = truncated; ka.err = err;
+    ka.T = steps;
+    return launch<2>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -363,6 +363,22 @@ MGX_HD void overlay_agents(const StepCfg &cf, uint8_t *tile, const uint64_t *row
     }
 }
 
+// Same overlay, one call per agent (one lane per agent): where several live agents share a cell the reference's
+// ascending loop leaves the highest index visible, so only that agent writes.  Returns the cell's byte offset or -1.
+MGX_HD int overlay_offset(const StepCfg &cf, const uint64_t *rows, int ai) {
+    if (cf.A <= 1) return -1;
+    const uint64_t r = rows[ai];
+    const uint32_t pos = ((uint32_t)r >> 16) & 0xffffu;
+    bool shadowed = false;
+    for (int j = 0; j < cf.A; ++j) {
+        const uint64_t o = rows[j];
+        shadowed |= (j > ai) & !row_term(o) & ((((uint32_t)o >> 16) & 0xffffu) == pos);
+    }
+    const int x = row_x(r), y = row_y(r);
+    if (row_term(r) | shadowed | (x >= cf.W) | (y >= cf.H)) return -1;
+    return (y * cf.W + x) * 3;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // View geometry.  image[i][j] shows world cell  pos + fw*forward + la*right,  fw = V-1-j, la = i - V/2,
 // right = (-dy, dx)  (equivalent to obs.py:182-202 + get_view_exts 275-316).  In tile byte offsets:

@@ -176,6 +176,16 @@ class HipBackend:
         _step_into(self.sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
                    terminated, truncated)
 
+    def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
+                truncated):
+        with torch.cuda.device(grid.device):
+            rc = _lib.lib().mgx_rollout(
+                C.byref(self.sc), B, T, grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
+                actions.data_ptr(), target.data_ptr() if target is not None else None, obs.data_ptr(),
+                dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), err.data_ptr(),
+                _stream(grid.device))
+        _lib.check(rc, "mgx_rollout")
+
     def one_hot(self, cells, out):
         _one_hot_into(cells, out)
 

@@ -64,7 +64,15 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
     }
     *n_dirty = fallback ? -nd - 1 : nd;          // negative = the sequential loop ran
     std::memcpy(tile_overlaid, tile, HW3);
-    overlay_agents(cf, tile_overlaid, rows);
+    {   // the kernel's per-agent overlay (one lane per agent); must equal the ascending loop of overlay_agents()
+        std::vector<uint8_t> ref(tile, tile + HW3);
+        overlay_agents(cf, ref.data(), rows);
+        for (int ai = 0; ai < A; ++ai) {
+            const int off = overlay_offset(cf, rows, ai);
+            if (off >= 0) store_cell(tile_overlaid + off, (uint32_t)T_AGENT | ((uint32_t)(rows[ai] & 0xffffu) << 8));
+        }
+        if (std::memcmp(ref.data(), tile_overlaid, HW3) != 0) return -99;
+    }
     post_step_hook(cf, sp->env_kind, rows, target, sc, rew);
     for (int a = 0; a < A; ++a) terminated[a] = (uint8_t)row_term(rows[a]);
     *truncated = (uint8_t)(sc >= cf.max_steps);

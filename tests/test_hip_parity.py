@@ -258,3 +258,41 @@ def test_reset_done_on_gpu_matches_definition():
         np.testing.assert_array_equal(env.target.cpu().numpy(), pt[k])
         assert int(env.step_count.sum()) == 0
     env.check_errors()
+
+
+ROLL_CASES = [
+    ("C2_empty16_a4", EnvSpec(16, 16, 4, 7, max_steps=1024), 2048, 40, 0.0),
+    ("objects16_a4", EnvSpec(16, 16, 4, 7, max_steps=30), 1500, 40, 0.3),
+    ("bup_a2", EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup"), 3001, 30, 0.25),
+    ("a3_v5_nooverlap_ragged", EnvSpec(9, 7, 3, 5, max_steps=12, allow_agent_overlap=False, failure_termination_mode="any"), 777, 25, 0.3),
+    ("a1_v9", EnvSpec(10, 10, 1, 9, max_steps=20), 333, 20, 0.3),
+    ("a16_v9_64x64", EnvSpec(64, 64, 16, 9, max_steps=100), 48, 8, 0.1),
+]
+
+
+@pytest.mark.parametrize("name,spec,B,T,density", ROLL_CASES, ids=[c[0] for c in ROLL_CASES])
+def test_rollout_equals_repeated_steps(name, spec, B, T, density):
+    """mgx_rollout (T steps in one launch, state kept in LDS) == T x mgx_step, bit for bit, incl. final state."""
+    st = util.random_state(spec, B, seed=zlib.crc32(name.encode()) % 1000, density=density)
+    acts = np.stack([util.random_actions(B, spec.num_agents, seed=300 + t) for t in range(T)])
+    e1 = BatchedMultiGridEnv(spec, B, dev()); e1.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    e2 = BatchedMultiGridEnv(spec, B, dev()); e2.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    a = torch.from_numpy(acts).to(dev())
+    out = e2.rollout(a)
+    for t in range(T):
+        obs, dirs, rew, term, trunc = e1.step(a[t])
+        ctx = f"{name} step {t}"
+        assert torch.equal(out["obs"][t], obs), ctx
+        assert torch.equal(out["dir"][t], dirs), ctx
+        assert torch.equal(out["reward"][t], rew), ctx
+        assert torch.equal(out["terminated"][t], term), ctx
+        assert torch.equal(out["truncated"][t], trunc), ctx
+    for n in ("grid", "agents", "rng", "step_count"):
+        assert torch.equal(getattr(e1, n), getattr(e2, n)), n
+    e1.check_errors(); e2.check_errors()
+    # and a second rollout continues correctly from the written-back state
+    out2 = e2.rollout(a[:3].contiguous())
+    for t in range(3):
+        obs, *_ = e1.step(a[t])
+        assert torch.equal(out2["obs"][t], obs)
+    assert torch.equal(e1.grid, e2.grid)

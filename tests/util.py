@@ -118,6 +118,12 @@ class OracleBackend:
         obs.copy_(torch.from_numpy(o)); dirs.copy_(torch.from_numpy(d)); reward.copy_(torch.from_numpy(r))
         terminated.copy_(torch.from_numpy(te)); truncated.copy_(torch.from_numpy(tr))
 
+    def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
+                truncated):
+        for t in range(T):
+            self.step(B, grid, agents, rng, step_count, actions[t], target, err, obs[t], dirs[t], reward[t],
+                      terminated[t], truncated[t])
+
     def one_hot(self, cells, out):
         out.copy_(torch.from_numpy(ob.one_hot(cells.numpy())))
 
