@@ -343,17 +343,22 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 
     // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
     // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
-    LaneConst<V, NW> lc;
+    auto lane_consts = [&]() {
+        LaneConst<V, NW> c;
 #pragma unroll
-    for (int it = 0; it < NW; ++it) {
-        const int k = lane + 64 * it;
-        const int j = k / V, i = k - j * V;
-        lc.act[it] = k < V2;
-        lc.la[it] = i - V / 2;
-        lc.fw[it] = V - 1 - j;
-        lc.q3[it] = (i * V + j) * 3;
-        lc.own[it] = (i == V / 2) && (j == V - 1);
-    }
+        for (int it = 0; it < NW; ++it) {
+            const int k = lane + 64 * it;
+            const int j = k / V, i = k - j * V;
+            c.act[it] = k < V2;
+            c.la[it] = i - V / 2;
+            c.fw[it] = V - 1 - j;
+            c.q3[it] = (i * V + j) * 3;
+            c.own[it] = (i == V / 2) && (j == V - 1);
+        }
+        return c;
+    };
+    LaneConst<V, NW> lc_roll;
+    if (ROLL) lc_roll = lane_consts();            // hoisted out of the step loop; the one-step kernels make them late
 
     const StepCfg cf = make_cfg(a.sp);
     const int T = ROLL ? a.T : 1;
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     wave_sync();
 
     // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
+    const LaneConst<V, NW> lc = ROLL ? lc_roll : lane_consts();
     uint32_t cell[VPW][NW];                      // registers: every slot's cells, one per lane (and pass)
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll

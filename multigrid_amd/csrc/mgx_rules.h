@@ -72,17 +72,6 @@ MGX_HD uint32_t brev32(uint32_t x) {
 #endif
 }
 
-// 1-D flood of seed bits m through transparent cells s (both v-bit), lighting the first blocker on each side:
-// what the forward sweep (obs.py:257-262) and backward sweep (obs.py:265-271) do to one row.
-template <int V>
-MGX_HD uint32_t flood_row(uint32_t m, uint32_t s) {
-    constexpr uint32_t F = (1u << V) - 1u;
-    const uint32_t up = (m | ((s + (m & s)) ^ s)) & F;          // carry runs up through the transparent run
-    const uint32_t mr = brev32(m) >> (32 - V), sr = brev32(s) >> (32 - V);
-    const uint32_t dn = (mr | ((sr + (mr & sr)) ^ sr)) & F;     // same, towards lower bits
-    return up | (brev32(dn) >> (32 - V));
-}
-
 // bits [pos, pos+V) of a multi-word little-endian bit string
 template <int V, int NW>
 MGX_HD uint32_t get_bits(const uint64_t (&w)[NW], int pos) {
@@ -101,18 +90,28 @@ MGX_HD void or_bits(uint64_t (&w)[NW], int pos, uint32_t bits) {
 
 // sb: see-behind bits of the (unmasked) view, bit j*V + i for image[i][j].  Returns visibility in the same
 // bit order.  The agent sits at (i, j) = (V/2, V-1) (obs.py:252).
+//
+// Both sweep directions of a row are done by ONE carry: a row is kept "mirrored" in a 32-bit word, the row itself in
+// bits [0,V) and its bit-reversal in bits [32-V,32) (x | brev32(x)).  Adding the seed bits to the transparency bits
+// lets the carry run through each transparent run and stop on the first blocker -- upwards in the low copy, which is
+// downwards for the mirrored copy.  brev32 of the result maps each half onto the other, so `u | brev32(u)` completes
+// both copies.  (V <= 15, so the two copies and the carry bit between them never touch.)
 template <int V, int NW>
 MGX_HD void vis_mask(const uint64_t (&sb)[NW], uint64_t (&vis)[NW]) {
     constexpr uint32_t F = (1u << V) - 1u;
+    constexpr uint32_t FC = F | (F << (32 - V));
     for (int k = 0; k < NW; ++k) vis[k] = 0;
     uint32_t init = 1u << (V / 2);
+    init |= brev32(init);
 #pragma unroll
     for (int j = V - 1; j >= 0; --j) {
-        const uint32_t s = get_bits<V, NW>(sb, j * V);
-        const uint32_t m = flood_row<V>(init, s);
-        or_bits<V, NW>(vis, j * V, m);
-        const uint32_t p = m & s;                                  // visible AND transparent
-        init = (p | (p << 1) | (p >> 1)) & F;                      // lights (i-1, i, i+1) of row j-1
+        const uint32_t s0 = get_bits<V, NW>(sb, j * V);
+        const uint32_t s = s0 | brev32(s0);                          // mirrored transparency of row j
+        uint32_t u = (((s + (init & s)) ^ s) | init) & FC;           // flood from the seeds, both directions
+        u |= brev32(u);                                               // each copy gets the other direction's result
+        or_bits<V, NW>(vis, j * V, u & F);
+        const uint32_t p = u & s;                                     // visible AND transparent
+        init = (p | (p << 1) | (p >> 1)) & FC;                        // lights (i-1, i, i+1) of row j-1 (both copies)
     }
 }
 

@@ -11,7 +11,7 @@ lines = []
 
 
 def short(n):
-    return "mgx_fused<step>" if "true>" in n or "Lb1" in n else ("mgx_fused<gen_obs>" if "mgx_fused" in n else n[:40])
+    return "mgx_fused<step>" if ", 1>" in n or "Li1E" in n or "true>" in n else ("mgx_fused<rollout>" if ", 2>" in n or "Li2E" in n else ("mgx_fused<gen_obs>" if "mgx_fused" in n else n[:40]))
 
 
 for f in sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)):

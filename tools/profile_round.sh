@@ -24,6 +24,7 @@ with open(os.path.join(out, "bench_kernel_stats.txt"), "w") as fh:
         fh.write(f"{r['Name'][:90]:90s} calls={r['Calls']:>6s} avg_ns={float(r['AverageNs']):10.1f} total_ns={r['TotalDurationNs']} pct={r['Percentage']}\n")
 print(open(os.path.join(out, "bench_kernel_stats.txt")).read())
 PY
+python tools/traffic_from_pmc.py $OUT $TAG
 cat $OUT/pmc_b4096/summary.txt | grep -i "kernel_stats\|FETCH\|WRITE\|GRBM\|VALU\|SALU\|WAVE_CYCLES\|WAIT_ANY\|TCC"
 echo ----
 cat $OUT/pmc_b1m/summary.txt | grep -i "kernel_stats\|FETCH\|WRITE\|GRBM\|VALU\|SALU\|WAVE_CYCLES\|WAIT_ANY\|TCC"
