@@ -21,9 +21,19 @@
  *   step_count  i32[B]            multigrid/base.py:292, 333
  *   actions     i8 [B, A]         multigrid/core/actions.py:5-15 (0..6); -1 = agent absent from the actions dict
  *                                 (multigrid/base.py:403-404); any other value = MGX_ERR_UNKNOWN_ACTION (base.py:473).
- *   target      u8 [B, 4]         env_kind-specific per-env data.  BlockedUnlockPickup: (type, color, state, 0) of the
- *                                 target box `self.obj` (multigrid/envs/blockedunlockpickup.py:147, 172).  May be NULL
- *                                 for MGX_KIND_EMPTY.
+ *   aux         u8 [B, 16]        the env subclass' own attributes that its step() hook uses (in/out; may be NULL for
+ *                                 MGX_KIND_EMPTY):
+ *                                   BlockedUnlockPickup  [0..2] = encoding of the target box `self.obj`
+ *                                                        (multigrid/envs/blockedunlockpickup.py:147, 172)
+ *                                   RedBlueDoors         [0,1] = blue door (x,y), [2,3] = red door (x,y)
+ *                                                        (multigrid/envs/redbluedoors.py:158-168)
+ *                                   LockedHallway        [0] = number of doors, [1] = bit k set once door k is in
+ *                                                        `self.unlocked_doors` (updated by the step), [2+2k, 3+2k] =
+ *                                                        door k (x,y), [15] = 1 when the last step reported every agent
+ *                                                        terminated (multigrid/envs/locked_hallway.py:203-227)
+ *                                 Door state 3 in `grid` (RedBlueDoors only) = the Door object is closed while
+ *                                 Grid.state still says open (redbluedoors.py:185 closes it without grid.update): the
+ *                                 rules treat it as closed, obs / full_obs show it open.
  *   obs         u8 [B, A, v, v, 3] image[i][j][c] exactly as multigrid/utils/obs.py:65-102 returns it
  *   dir         u8 [B, A]         obs['direction'] (multigrid/base.py:359, 372)
  *   reward      f64[B, A]         multigrid/base.py:393, 503-507, 598-602 (bit-identical Python float arithmetic)
@@ -41,7 +51,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 1
+#define MGX_ABI_VERSION 2
 
 enum {
     MGX_OK = 0,
@@ -51,7 +61,9 @@ enum {
     MGX_ERR_LAUNCH = -4            /* hipLaunchKernel failed; see mgx_last_hip_error() */
 };
 
-enum { MGX_KIND_EMPTY = 0, MGX_KIND_BLOCKEDUNLOCKPICKUP = 1 };
+enum { MGX_KIND_EMPTY = 0, MGX_KIND_BLOCKEDUNLOCKPICKUP = 1, MGX_KIND_REDBLUEDOORS = 2, MGX_KIND_LOCKEDHALLWAY = 3 };
+
+#define MGX_AUX_BYTES 16
 
 #define MGX_MAX_AGENTS 32
 #define MGX_MAX_VIEW 15
@@ -92,10 +104,11 @@ int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const u
 
 /* Replaces MultiGridEnv.step (multigrid/base.py:303-346: step_count += 1, handle_actions 378-476, gen_obs
  * 348-376, terminations, truncations) and the BlockedUnlockPickupEnv.step post-hook
- * (multigrid/envs/blockedunlockpickup.py:166-175), for B envs, in one fused kernel launch.
+ * (multigrid/envs/blockedunlockpickup.py:166-175, redbluedoors.py:170-187, locked_hallway.py:203-227), for B envs, in one
+ * fused kernel launch.
  * grid / agents / rng / step_count are updated in place. */
 int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
-             int32_t *step_count, const int8_t *actions, const uint8_t *target,
+             int32_t *step_count, const int8_t *actions, uint8_t *aux,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream);
 
@@ -107,7 +120,7 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
  *   actions i8[steps,B,A]   obs u8[steps,B,A,v,v,3]   dir u8[steps,B,A]   reward f64[steps,B,A]
  *   terminated u8[steps,B,A]   truncated u8[steps,B]        (state tensors as in mgx_step, updated once at the end) */
 int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
-                int32_t *step_count, const int8_t *actions, const uint8_t *target,
+                int32_t *step_count, const int8_t *actions, uint8_t *aux,
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream);
 
@@ -130,12 +143,12 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const 
 /* Vector-env auto-reset (build-defined: the reference has no batching; its caller tests is_done(), base.py:534-539,
  * and calls reset(), base.py:250-301).  Every env b whose episode is over -- all agents terminated or
  * step_count >= max_steps -- is re-initialised from a pool of K pre-generated layouts
- * (pool_grid u8[K,H,W,3], pool_agents u8[K,A,8], pool_target u8[K,4] or NULL):
+ * (pool_grid u8[K,H,W,3], pool_agents u8[K,A,8], pool_aux u8[K,16] or NULL):
  *   layout = (first_env + b + episode[b] * 7919) mod K;  step_count[b] = 0;  episode[b] += 1;  was_reset[b] = 1.
  * The env's PCG64 stream is left running, as an unseeded reset() does for Empty envs.  `was_reset` may be NULL. */
 int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const uint8_t *pool_grid,
-                   const uint8_t *pool_agents, const uint8_t *pool_target, uint8_t *grid, uint8_t *agents,
-                   int32_t *step_count, uint8_t *target, int32_t *episode, uint8_t *was_reset, void *stream);
+                   const uint8_t *pool_agents, const uint8_t *pool_aux, uint8_t *grid, uint8_t *agents,
+                   int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream);
 
 #ifdef __cplusplus
 }

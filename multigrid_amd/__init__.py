@@ -10,10 +10,12 @@ from .batched import BatchedMultiGridEnv  # noqa: F401
 
 __all__ = ["Action", "Color", "Direction", "State", "Type", "EnvSpec", "BatchedMultiGridEnv"]
 from .env import MultiGridEnv  # noqa: F401,E402
-from .envs import CONFIGURATIONS, BlockedUnlockPickupEnv, EmptyEnv, make, spec_for  # noqa: F401,E402
+from .envs import (CONFIGURATIONS, BlockedUnlockPickupEnv, EmptyEnv, LockedHallwayEnv, PlaygroundEnv,  # noqa: F401,E402
+                   RedBlueDoorsEnv, make, spec_for)
 from .rllib import RLlibWrapper, to_rllib_env  # noqa: F401,E402
 
-__all__ += ["MultiGridEnv", "CONFIGURATIONS", "BlockedUnlockPickupEnv", "EmptyEnv", "make", "spec_for",
+__all__ += ["MultiGridEnv", "CONFIGURATIONS", "BlockedUnlockPickupEnv", "EmptyEnv", "LockedHallwayEnv", "PlaygroundEnv",
+            "RedBlueDoorsEnv", "make", "spec_for",
             "RLlibWrapper", "to_rllib_env"]
 from .wrappers import FullyObsWrapper, ImgObsWrapper, OneHotObsWrapper, SingleAgentWrapper  # noqa: F401,E402
 

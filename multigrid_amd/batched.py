@@ -5,7 +5,7 @@ This is the tensor-level form of `multigrid.base.MultiGridEnv` (multigrid/base.p
 (batch, agent) shape.  The per-env dict API lives in multigrid_amd/env.py on top of this class.
 
 State (device tensors, layouts in include/mgx.h):
-    grid u8[B,H,W,3]   agents u8[B,A,8]   rng i64[B,4] (PCG64 words)   step_count i32[B]   target u8[B,4]
+    grid u8[B,H,W,3]   agents u8[B,A,8]   rng i64[B,4] (PCG64 words)   step_count i32[B]   aux u8[B,16]
 Outputs of `step` (pre-allocated, overwritten by every call -- clone what you keep):
     obs u8[B,A,v,v,3]  dir u8[B,A]  reward f64[B,A]  terminated u8[B,A]  truncated u8[B]
 """
@@ -45,7 +45,7 @@ class BatchedMultiGridEnv:
         self.agents = torch.zeros(spec.agents_shape(B), dtype=torch.uint8, device=dev)
         self.rng = torch.zeros((B, 4), dtype=torch.int64, device=dev)
         self.step_count = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self.target = torch.zeros((B, 4), dtype=torch.uint8, device=dev)
+        self.aux = torch.zeros((B, 16), dtype=torch.uint8, device=dev)       # the env subclass' hook state (include/mgx.h)
         self.err = torch.tensor([0, INT32_MAX], dtype=torch.int32, device=dev)
         self.obs = torch.zeros(spec.obs_shape(B), dtype=torch.uint8, device=dev)
         self.dir = torch.zeros((B, A), dtype=torch.uint8, device=dev)
@@ -55,7 +55,7 @@ class BatchedMultiGridEnv:
         self._loaded = False
 
     # ------------------------------------------------------------------------------------------ state in
-    def load_state(self, grid, agents, rng=None, target=None, step_count=None, validate: bool = True):
+    def load_state(self, grid, agents, rng=None, aux=None, step_count=None, validate: bool = True, target=None):
         """Install an initial state (numpy arrays or tensors in the product layout).  A single env's state
         (no batch dim) is broadcast to the whole batch.  This is also the parity-injection point: the
         reference's `Grid.state` / `AgentState` go through layouts.grid_to_product / pack_agents."""
@@ -83,8 +83,14 @@ class BatchedMultiGridEnv:
             if r.dtype == np.uint64:
                 r = r.view(np.int64)
             self.rng.copy_(prep(r, (B, 4), torch.int64))
-        if target is not None:
-            self.target.copy_(prep(target, (B, 4), torch.uint8))
+        if aux is None and target is not None:                 # BlockedUnlockPickup convenience: (type, color, state[, 0])
+            t = np.zeros(np.asarray(target).shape[:-1] + (16,), dtype=np.uint8)
+            t[..., :min(4, np.asarray(target).shape[-1])] = np.asarray(target)[..., :4]
+            aux = t
+        if aux is not None:
+            self.aux.copy_(prep(aux, (B, 16), torch.uint8))
+        elif self.spec.env_kind != "empty":
+            raise ValueError(f"env_kind {self.spec.env_kind!r} needs `aux` (the env's hook state, include/mgx.h)")
         if step_count is None:
             self.step_count.zero_()
         else:
@@ -129,7 +135,7 @@ class BatchedMultiGridEnv:
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {(self.batch, sp.num_agents)} "
                              f"on {self.grid.device}")
         self.backend.step(self.batch, self.grid, self.agents, self.rng, self.step_count, actions,
-                          self.target if sp.env_kind != "empty" else None, self.err,
+                          self.aux if sp.env_kind != "empty" else None, self.err,
                           self.obs, self.dir, self.reward, self.terminated, self.truncated)
         return self.obs, self.dir, self.reward, self.terminated, self.truncated
 
@@ -152,7 +158,7 @@ class BatchedMultiGridEnv:
                    "terminated": torch.empty((T, B, A), dtype=torch.uint8, device=dev),
                    "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev)}
         self.backend.rollout(B, T, self.grid, self.agents, self.rng, self.step_count, actions,
-                             self.target if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],
+                             self.aux if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],
                              out["reward"], out["terminated"], out["truncated"])
         return out
 
@@ -174,8 +180,8 @@ class BatchedMultiGridEnv:
         self.backend.full_obs(self.batch, self.grid, self.agents, self._full)
         return self._full
 
-    def set_layout_pool(self, grids, agents, targets=None):
-        """Pool of K pre-generated episode starts for `reset_done()`: u8[K,H,W,3], u8[K,A,8], u8[K,4] | None."""
+    def set_layout_pool(self, grids, agents, auxs=None):
+        """Pool of K pre-generated episode starts for `reset_done()`: u8[K,H,W,3], u8[K,A,8], u8[K,16] | None."""
         sp = self.spec
         g = torch.as_tensor(np.asarray(grids), dtype=torch.uint8)
         a = torch.as_tensor(np.asarray(agents), dtype=torch.uint8)
@@ -184,10 +190,13 @@ class BatchedMultiGridEnv:
             raise ValueError("layout pool has the wrong shape")
         layouts.check_walled(g.numpy())
         t = None
-        if targets is not None:
-            t = torch.as_tensor(np.asarray(targets), dtype=torch.uint8).to(self.device).contiguous()
+        if auxs is not None:
+            t = torch.as_tensor(np.asarray(auxs), dtype=torch.uint8)
+            if tuple(t.shape) != (K, 16):
+                raise ValueError("layout pool aux must be u8[K,16]")
+            t = t.to(self.device).contiguous()
         elif sp.env_kind != "empty":
-            raise ValueError(f"env_kind {sp.env_kind!r} needs per-layout targets")
+            raise ValueError(f"env_kind {sp.env_kind!r} needs per-layout aux")
         self._pool = (g.to(self.device).contiguous(), a.to(self.device).contiguous(), t)
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
         self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
@@ -201,7 +210,7 @@ class BatchedMultiGridEnv:
         if getattr(self, "_pool", None) is None:
             raise RuntimeError("call set_layout_pool() first")
         self.backend.reset_done(self.batch, self.first_env, self._pool, self.grid, self.agents, self.step_count,
-                                self.target, self.episode, self.was_reset)
+                                self.aux, self.episode, self.was_reset)
         return self.was_reset
 
     def check_errors(self):
@@ -226,9 +235,9 @@ class BatchedMultiGridEnv:
         return {"spec": self.spec.as_dict(), "first_env": self.first_env,
                 "grid": self.grid.cpu().clone(), "agents": self.agents.cpu().clone(),
                 "rng": self.rng.cpu().clone(), "step_count": self.step_count.cpu().clone(),
-                "target": self.target.cpu().clone()}
+                "aux": self.aux.cpu().clone()}
 
     def load_state_dict(self, sd: dict):
         if EnvSpec.from_dict(sd["spec"]) != self.spec:
             raise ValueError("state_dict was saved for a different EnvSpec")
-        self.load_state(sd["grid"], sd["agents"], sd["rng"], sd["target"], sd["step_count"], validate=False)
+        self.load_state(sd["grid"], sd["agents"], sd["rng"], sd["aux"], sd["step_count"], validate=False)

@@ -76,8 +76,7 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int6
         const uint8_t *g = grid + b * HW * 3;
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {      // i = y*W + x in the product layout
             const int y = i / W, x = i - y * W;
-            uint8_t *d = lds + (x * H + y) * 3;
-            d[0] = g[i * 3]; d[1] = g[i * 3 + 1]; d[2] = g[i * 3 + 2];
+            store_cell(lds + (x * H + y) * 3, grid_view_of(load_cell(g + i * 3)));   // Grid.state (a stale-open door reads open)
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -102,8 +101,8 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int6
 __global__ __launch_bounds__(256) void reset_done_kernel(int HW3, int A, int max_steps, int64_t batch, int64_t first_env,
                                                          int K, const uint8_t *__restrict__ pool_grid,
                                                          const uint8_t *__restrict__ pool_agents,
-                                                         const uint8_t *__restrict__ pool_target, uint8_t *grid,
-                                                         uint8_t *agents, int32_t *step_count, uint8_t *target,
+                                                         const uint8_t *__restrict__ pool_aux, uint8_t *grid,
+                                                         uint8_t *agents, int32_t *step_count, uint8_t *aux,
                                                          int32_t *episode, uint8_t *was_reset) {
     __shared__ int s_done, s_layout;
     for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
@@ -129,7 +128,8 @@ __global__ __launch_bounds__(256) void reset_done_kernel(int HW3, int A, int max
             for (int i = threadIdx.x; i < HW3; i += blockDim.x) dg[i] = sg[i];
             for (int i = threadIdx.x; i < A * MGX_AGENT_STRIDE; i += blockDim.x)
                 agents[b * A * MGX_AGENT_STRIDE + i] = pool_agents[(int64_t)s_layout * A * MGX_AGENT_STRIDE + i];
-            if (target && pool_target && threadIdx.x < 4) target[b * 4 + threadIdx.x] = pool_target[(int64_t)s_layout * 4 + threadIdx.x];
+            if (aux && pool_aux && threadIdx.x < MGX_AUX_BYTES)
+                aux[b * MGX_AUX_BYTES + threadIdx.x] = pool_aux[(int64_t)s_layout * MGX_AUX_BYTES + threadIdx.x];
         }
         __syncthreads();
     }
@@ -175,8 +175,8 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const 
 }
 
 int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const uint8_t *pool_grid,
-                   const uint8_t *pool_agents, const uint8_t *pool_target, uint8_t *grid, uint8_t *agents,
-                   int32_t *step_count, uint8_t *target, int32_t *episode, uint8_t *was_reset, void *stream) {
+                   const uint8_t *pool_agents, const uint8_t *pool_aux, uint8_t *grid, uint8_t *agents,
+                   int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream) {
     if (!spec || batch < 0 || pool_size < 1 || first_env < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (batch == 0) return MGX_OK;
     if (!pool_grid || !pool_agents || !grid || !agents || !step_count || !episode) return MGX_ERR_INVALID_ARGUMENT;
@@ -184,7 +184,7 @@ int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_
     const int64_t blocks = batch < 256 * 32 ? batch : 256 * 32;
     hipLaunchKernelGGL(reset_done_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        spec->width * spec->height * 3, spec->num_agents, spec->max_steps, batch, first_env, pool_size,
-                       pool_grid, pool_agents, pool_target, grid, agents, step_count, target, episode, was_reset);
+                       pool_grid, pool_agents, pool_aux, grid, agents, step_count, aux, episode, was_reset);
     return finish_launch();
 }
 

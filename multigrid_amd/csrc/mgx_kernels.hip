@@ -37,7 +37,7 @@ struct KernelArgs {
     uint64_t *rng;
     int32_t *step_count;
     const int8_t *actions;
-    const uint8_t *target;
+    uint8_t *aux;
     uint8_t *obs;
     uint8_t *dir;
     double *reward;
@@ -88,7 +88,7 @@ LdsPlan plan_lds(const MgxSpec &sp, int Gw) {
     p.off_ord = o;   o = align16(o + vpw);
     p.off_rew = o;   o = align16(o + vpw * 8);
     p.off_scnt = o;  o = align16(o + Gw * 4);
-    p.off_tgt = o;   o = align16(o + Gw * 4);
+    p.off_tgt = o;   o = align16(o + Gw * MGX_AUX_BYTES);
     p.off_jump = o;  o = align16(o + (A + 1) * 32);
     p.off_out = o;   o = align16(o + kRound * V * V * 3 + 16 + 16);               // obs bytes of one round, head skew + pad
     p.off_wall = o;  o = align16(o + 8);                                         // one WALL cell (+ the dword read after it)
@@ -156,7 +156,7 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 // ---- P2 for slots [S0, S0+N): one lane per cell: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
 // own cell -> carried object (obs.py:182-207); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
-template <int V, int NW, int S0, int N, int VPW>
+template <int V, int NW, int S0, int N, int VPW, bool STALE>
 __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
                                              const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                              uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
@@ -192,6 +192,7 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
             const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
             uint32_t c = __builtin_amdgcn_alignbyte(hi[n][it], lo[n][it], sh[n][it]);   // byte 3 is junk from here on
             c = lc.own[it] ? r[n].carry : c;                                // obs.py:207
+            if (STALE) c = grid_view_of(c & 0xffffffu);                     // RedBlueDoors: what Grid.state says (Q9)
             cell[S0 + n][it] = c;
             const uint32_t t = c & 0xffu;                                   // obs.py:46-63 see_behind, as lane masks
             const uint64_t m = __builtin_amdgcn_ballot_w64(t != (uint32_t)T_WALL)
@@ -203,31 +204,31 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
     }
 }
 
-template <int V, int NW, int VPW, int S0, int N>
+template <int V, int NW, int VPW, int S0, int N, bool STALE>
 __device__ __forceinline__ void gather_tail(int NVc, const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
                                             const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                             uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (N < 8 && S0 + N < VPW) {
         if (S0 + N < NVc) {
-            gather_group<V, NW, S0 + N, 1, VPW>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-            gather_tail<V, NW, VPW, S0, N + 1>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+            gather_group<V, NW, S0 + N, 1, VPW, STALE>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+            gather_tail<V, NW, VPW, S0, N + 1, STALE>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
         }
     }
 }
 
 constexpr int kGroup = 8;
 
-template <int V, int NW, int VPW, int S0 = 0>
+template <int V, int NW, int VPW, bool STALE, int S0 = 0>
 __device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         if (S0 + kGroup <= NVc) {
-            gather_group<V, NW, S0, kGroup, VPW>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+            gather_group<V, NW, S0, kGroup, VPW, STALE>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
         } else if (S0 < NVc) {                                               // ragged last group: slot by slot
-            gather_tail<V, NW, VPW, S0, 0>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+            gather_tail<V, NW, VPW, S0, 0, STALE>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
         }
-        gather_all<V, NW, VPW, S0 + kGroup>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, STALE, S0 + kGroup>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
     }
 }
 
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint8_t *ord = L + a.off_ord;                                              // [slot] visiting order per env
     double *rew = reinterpret_cast<double *>(L + a.off_rew);                  // [slot]
     int32_t *scnt = reinterpret_cast<int32_t *>(L + a.off_scnt);              // [env]
-    uint32_t *tgt = reinterpret_cast<uint32_t *>(L + a.off_tgt);              // [env]
+    uint4 *auxl = reinterpret_cast<uint4 *>(L + a.off_tgt);                   // [env] 16-byte hook state (include/mgx.h)
     uint64_t *jump = reinterpret_cast<uint64_t *>(L + a.off_jump);            // [A+1][4]
 
     // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     uint64_t in_row = 0, in_rng0 = 0, in_rng1 = 0, in_jump = 0;
     int32_t in_scnt = 0;
-    uint32_t in_tgt = 0;
+    uint4 in_aux = make_uint4(0, 0, 0, 0);
     int8_t in_act = 0;
     if (lane < NVc) {
         in_row = reinterpret_cast<const uint64_t *>(a.agents)[v0 + lane];
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
         if (lane < Gc) {
             in_scnt = a.step_count[e0 + lane];
-            if (a.target) in_tgt = reinterpret_cast<const uint32_t *>(a.target)[e0 + lane];
+            if (a.aux) in_aux = reinterpret_cast<const uint4 *>(a.aux)[e0 + lane];
         }
     }
     (void)in_jump;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             if (lane < Gc * 4) rngs[lane] = in_rng0;
             if (lane + 64 < Gc * 4) rngs[lane + 64] = in_rng1;
         }
-        if (lane < Gc) { scnt[lane] = in_scnt; tgt[lane] = in_tgt; }
+        if (lane < Gc) { scnt[lane] = in_scnt; auxl[lane] = in_aux; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
     wave_sync();
@@ -443,23 +444,32 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             }
             wave_sync();
         }
-        // ------------------------------------------------------------------ one lane per agent: overlay for rendering
-        // (obs.py:163-173) with the pre-hook `terminated`; then one lane per env: counters, hook
-        {
-            const int off = (in && !(a.dbg & 512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
-            if (ROLL && off >= 0) ovl_saved = load_cell(mytile + off);
-            ovl_off = off;
-            wave_sync();
-            if (off >= 0) store_cell(mytile + off, (uint32_t)T_AGENT | ((uint32_t)(rows[lane] & 0xffffu) << 8));
-        }
+        // ------------------------------------------------------------------ overlay offsets (pre-hook `terminated`, SURVEY
+        // App. C Q2), then one lane per env: counters + the env subclass' hook on the clean tile, then the overlay itself
+        const int ovl = (in && !(a.dbg & 512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
+        wave_sync();
         if (lane < Gc) {
             const int e = lane;
             const int64_t b = e0 + e;
             const int32_t sc = scnt[e] + 1;                                      // base.py:333
             if (ROLL) scnt[e] = sc; else a.step_count[b] = sc;
-            post_step_hook(cf, a.sp.env_kind, rows + e * A, reinterpret_cast<const uint8_t *>(tgt + e), sc, rew + e * A);
+            uint8_t *etile = tile + e * HW3;
+            uint8_t *ggrid = a.grid + b * HW3;
+            auto dirty = [=](int off) {
+                if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
+            };
+            uint8_t *eaux = reinterpret_cast<uint8_t *>(auxl + e);
+            post_step_hook(cf, a.sp.env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
+            if (!ROLL && a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY && a.aux) {
+                a.aux[b * MGX_AUX_BYTES + 1] = eaux[1]; a.aux[b * MGX_AUX_BYTES + 15] = eaux[15];
+            }
             a.truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
         }
+        wave_sync();
+        if (ROLL && ovl >= 0) ovl_saved = load_cell(mytile + ovl);
+        ovl_off = ovl;
+        wave_sync();
+        if (ovl >= 0) store_cell(mytile + ovl, (uint32_t)T_AGENT | ((uint32_t)(rows[lane] & 0xffffu) << 8));
     } else {
         const int off = (lane < NVc) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
         wave_sync();
@@ -484,7 +494,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (DO_STEP) {
             if (!ROLL) reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = row;
             a.reward[tv0 + lane] = rew[lane];
-            a.terminated[tv0 + lane] = (uint8_t)row_term(row);                   // base.py:338 (+ env hook)
+            const bool forced = a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
+            a.terminated[tv0 + lane] = (uint8_t)(row_term(row) | forced);        // base.py:338 (+ env hook)
         }
         if (a.dir) a.dir[tv0 + lane] = (uint8_t)row_dir(row);                    // base.py:359, 372
     }
@@ -500,7 +511,11 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     for (int s = 0; s < VPW; ++s)
 #pragma unroll
         for (int it = 0; it < NW; ++it) cell[s][it] = 0;
-    if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+    if (!(a.dbg & 4)) {
+        // (two instantiations: only RedBlueDoors pays for mapping a stale-open door to what Grid.state says)
+        if (a.sp.env_kind == MGX_KIND_REDBLUEDOORS) gather_all<V, NW, VPW, true>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+        else gather_all<V, NW, VPW, false>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+    }
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
         if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
@@ -588,7 +603,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             if (lane < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane] = rngs[lane];
             if (lane + 64 < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane + 64] = rngs[lane + 64];
         }
-        if (lane < Gc) a.step_count[e0 + lane] = scnt[lane];
+        if (lane < Gc) {
+            a.step_count[e0 + lane] = scnt[lane];
+            if (a.aux && a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
+        }
     }
 }
 
@@ -626,7 +644,7 @@ int check_spec(const MgxSpec *sp, int64_t batch) {
     if (sp->width < 3 || sp->height < 3 || sp->num_agents < 1 || sp->max_steps < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
-    if (sp->env_kind != MGX_KIND_EMPTY && sp->env_kind != MGX_KIND_BLOCKEDUNLOCKPICKUP) return MGX_ERR_UNSUPPORTED;
+    if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_LOCKEDHALLWAY) return MGX_ERR_UNSUPPORTED;
     if (plan_lds(*sp, 1).total > kLdsPerCU) return MGX_ERR_UNSUPPORTED;              // one env must fit one CU's LDS
     return MGX_OK;
 }
@@ -718,7 +736,7 @@ int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const u
 }
 
 int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
-             int32_t *step_count, const int8_t *actions, const uint8_t *target,
+             int32_t *step_count, const int8_t *actions, uint8_t *aux,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream) {
     int rc = check_spec(spec, batch);
@@ -727,23 +745,23 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
     if (!grid || !agents || !step_count || !actions || !obs || !reward || !terminated || !truncated)
         return MGX_ERR_INVALID_ARGUMENT;
     if (spec->num_agents > 1 && !rng) return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP && !target) return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->env_kind != MGX_KIND_EMPTY && !aux) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16) || misaligned(rng, 8)
-        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(target, 4))
+        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(aux, 16))
         return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
     rc = fill_args(ka, spec, batch, threads, lds, nwg);
     if (rc) return rc;
     ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
-    ka.target = target; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
+    ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
     ka.T = 1;
     return launch<1>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
 int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
-                int32_t *step_count, const int8_t *actions, const uint8_t *target,
+                int32_t *step_count, const int8_t *actions, uint8_t *aux,
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream) {
     int rc = check_spec(spec, batch);
@@ -753,16 +771,16 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid
     if (!grid || !agents || !step_count || !actions || !obs || !reward || !terminated || !truncated)
         return MGX_ERR_INVALID_ARGUMENT;
     if (spec->num_agents > 1 && !rng) return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP && !target) return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->env_kind != MGX_KIND_EMPTY && !aux) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16) || misaligned(rng, 8)
-        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(target, 4))
+        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(aux, 16))
         return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
     rc = fill_args(ka, spec, batch, threads, lds, nwg);
     if (rc) return rc;
     ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
-    ka.target = target; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
+    ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
     ka.T = steps;
     return launch<2>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));

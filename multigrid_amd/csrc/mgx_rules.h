@@ -21,7 +21,11 @@ namespace mgx {
 // multigrid/core/constants.py:34-48, 91-97 ; multigrid/core/actions.py:5-15
 enum : int { T_UNSEEN = 0, T_EMPTY = 1, T_WALL = 2, T_FLOOR = 3, T_DOOR = 4, T_KEY = 5, T_BALL = 6, T_BOX = 7,
              T_GOAL = 8, T_LAVA = 9, T_AGENT = 10 };
-enum : int { S_OPEN = 0, S_CLOSED = 1, S_LOCKED = 2 };
+enum : int { S_OPEN = 0, S_CLOSED = 1, S_LOCKED = 2,
+             // RedBlueDoors only (include/mgx.h): the Door OBJECT is closed but Grid.state still says open, because the
+             // env hook closes the object without grid.update (envs/redbluedoors.py:185).  The rules
+             // see a closed door, observations and Grid.state see an open one.
+             S_STALE_OPEN = 3 };
 enum : int { ACT_LEFT = 0, ACT_RIGHT = 1, ACT_FORWARD = 2, ACT_PICKUP = 3, ACT_DROP = 4, ACT_TOGGLE = 5, ACT_DONE = 6 };
 // packed agent row (include/mgx.h)
 enum : int { AG_COLOR = 0, AG_DIR = 1, AG_X = 2, AG_Y = 3, AG_TERM = 4, AG_CARRY = 5 };
@@ -255,7 +259,8 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
     ev.off = inb ? (fy * cf.W + fx) * 3 : 0;
     const uint32_t cell = load_cell(tile + ev.off);
-    const uint32_t type = cell & 0xff, state = (cell >> 16) & 0xff;
+    const uint32_t type = cell & 0xff, gstate = (cell >> 16) & 0xff;
+    const uint32_t state = (gstate == S_STALE_OPEN) ? (uint32_t)S_CLOSED : gstate;   // the WorldObj's own state
     const uint32_t carry = row_carry(row), ctype = carry & 0xff;
     const bool on_cell = ev.go & inb;
     ev.reads_cell = on_cell & (action >= ACT_FORWARD) & (action <= ACT_TOGGLE);
@@ -281,7 +286,7 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     const bool unlock = (ctype == T_KEY) & (((carry >> 8) & 0xff) == ((cell >> 8) & 0xff));
     const uint32_t ns = (state == S_LOCKED) ? (unlock ? (uint32_t)S_OPEN : state)
                                             : ((state == S_OPEN) ? (uint32_t)S_CLOSED : (uint32_t)S_OPEN);
-    const bool door = tog & (type == T_DOOR) & (ns != state);
+    const bool door = tog & (type == T_DOOR) & (ns != gstate);               // Door.toggle ends with grid.update
     const bool box = tog & (type == T_BOX);
 
     uint32_t ncell = cell;
@@ -341,13 +346,65 @@ MGX_HD bool spec_needs_fallback(uint64_t m_event, uint64_t m_conflict, uint64_t 
     return (m_event != 0) | (m_conflict != 0) | ((m_presence != 0) & (m_moved != 0));
 }
 
-// envs/blockedunlockpickup.py:166-175, run AFTER the observation inputs are fixed.
-MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint64_t *rows, const uint8_t *target,
-                           int32_t step_count, double *rew) {
-    if (env_kind != MGX_KIND_BLOCKEDUNLOCKPICKUP) return;
-    const uint32_t want = (uint32_t)target[0] | ((uint32_t)target[1] << 8);
-    for (int a = 0; a < cf.A; ++a)
-        if ((row_carry(rows[a]) & 0xffffu) == want) on_success(cf, rows, a, step_count, rew);
+// What a rendered / exported cell looks like: Grid.state, where a stale-open door still reads "open".
+MGX_HD uint32_t grid_view_of(uint32_t cell) {
+    return (((cell >> 16) & 0xffu) == (uint32_t)S_STALE_OPEN && (cell & 0xffu) == (uint32_t)T_DOOR) ? (cell & 0xffffu) : cell;
+}
+
+// The env subclasses' step() post-hooks, run after the base step on the CLEAN tile (no agent overlay) with the
+// post-step agent rows; `aux` is the env's 16-byte hook state (include/mgx.h).  The observation is not affected (the
+// reference renders before the hook); `terminated` / `reward` outputs are.
+//   BlockedUnlockPickup  envs/blockedunlockpickup.py:166-175
+//   RedBlueDoors         envs/redbluedoors.py:170-187  (agents in ascending index = a dict built in agent order)
+//   LockedHallway        envs/locked_hallway.py:203-227
+template <class Dirty>
+MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint64_t *rows, const int8_t *act,
+                           uint8_t *aux, int32_t step_count, double *rew, Dirty dirty) {
+    const int A = cf.A;
+    if (env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP) {
+        const uint32_t want = (uint32_t)aux[0] | ((uint32_t)aux[1] << 8);
+        for (int a = 0; a < A; ++a)
+            if ((row_carry(rows[a]) & 0xffffu) == want) on_success(cf, rows, a, step_count, rew);
+    } else if (env_kind == MGX_KIND_REDBLUEDOORS) {
+        const int boff = (aux[1] * cf.W + aux[0]) * 3, roff = (aux[3] * cf.W + aux[2]) * 3;
+        for (int a = 0; a < A; ++a) {
+            if (act[a] != ACT_TOGGLE) continue;
+            const uint64_t r = rows[a];
+            const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
+            if (fx != aux[0] || fy != aux[1]) continue;                         // fwd_obj == self.blue_door
+            if (tile[boff + 2] != S_OPEN) continue;                             // ... and self.blue_door.is_open
+            if (tile[roff + 2] == S_OPEN) {
+                on_success(cf, rows, a, step_count, rew);
+            } else {
+                set_terminated(rows, A, a, cf.failure_any);                      // on_failure
+                tile[boff + 2] = S_STALE_OPEN;                                   // blue_door.is_open = False, no grid.update
+                dirty(boff);
+            }
+        }
+    } else if (env_kind == MGX_KIND_LOCKEDHALLWAY) {
+        const int nd = aux[0];
+        for (int a = 0; a < A; ++a) {
+            if (act[a] != ACT_TOGGLE) continue;
+            const uint64_t r = rows[a];
+            const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
+            if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;
+            const uint8_t *c = tile + (fy * cf.W + fx) * 3;
+            if (c[0] != T_DOOR || c[2] == S_LOCKED) continue;                   // isinstance(Door) and not is_locked
+            for (int k = 0; k < nd; ++k) {
+                if (aux[2 + 2 * k] != fx || aux[3 + 2 * k] != fy) continue;
+                if (!((aux[1] >> k) & 1)) {                                      // not yet in self.unlocked_doors
+                    aux[1] = (uint8_t)(aux[1] | (1u << k));
+                    const double rv = reward_value(step_count, cf.max_steps);
+                    if (cf.joint_reward) { for (int b = 0; b < A; ++b) rew[b] += rv; }   // `+=`, not `=`
+                    else rew[a] += rv;
+                }
+                break;
+            }
+        }
+        int cnt = 0;
+        for (int k = 0; k < nd; ++k) cnt += (aux[1] >> k) & 1;
+        aux[15] = (uint8_t)(cnt == nd);          // len(unlocked_doors) == len(rooms): `terminations` only, not agent state
+    }
 }
 
 // obs.py:163-173: overlay every non-terminated agent's (10, color, dir) on the tile, ascending index.

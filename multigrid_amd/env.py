@@ -219,7 +219,7 @@ class MultiGridEnv:
         return layouts.unpack_agents(self._benv.agents[0].cpu().numpy())
 
     def _gen_layout(self, layout_rng: np.random.Generator, np_random: np.random.Generator):
-        """Return (grid u8[H,W,3], agents u8[A,8], target u8[4] | None) for a new episode."""
+        """Return (grid u8[H,W,3], agents u8[A,8], aux u8[16] | None) for a new episode."""
         raise NotImplementedError
 
     def reset(self, seed: int | None = None, **kwargs):
@@ -233,7 +233,7 @@ class MultiGridEnv:
         self.mission = self.mission_space.sample()
         for agent in self.agents:
             agent.mission = self.mission                              # base.py:274-277
-        grid, agents, target = self._gen_layout(self._layout_rng, self._np_random)   # base.py:280
+        grid, agents, aux = self._gen_layout(self._layout_rng, self._np_random)      # base.py:280
         # base.py:283-289: agents placed, not on top of a non-overlappable object
         ag9 = layouts.unpack_agents(agents)
         assert np.all(ag9[:, 3:5] >= 0) and np.all(ag9[:, 2] >= 0)
@@ -241,7 +241,7 @@ class MultiGridEnv:
             t, s = grid[a[4], a[3], 0], grid[a[4], a[3], 2]
             assert t in (Type.empty, Type.goal, Type.floor, Type.lava) or (t == Type.door and s == 0)
         words = rnglib.words_from_bitgen_state(self._np_random.bit_generator.state)
-        self._benv.load_state(grid, agents, rng=words, target=target)       # step_count = 0 (base.py:292)
+        self._benv.load_state(grid, agents, rng=words, aux=aux)             # step_count = 0 (base.py:292)
         self._rng_on_device = True
         obs, dirs = self._benv.gen_obs()                                     # base.py:295
         return self._obs_dict(obs[0].cpu().numpy(), dirs[0].cpu().numpy()), defaultdict(dict)

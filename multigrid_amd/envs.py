@@ -54,10 +54,66 @@ class BlockedUnlockPickupEnv(MultiGridEnv):
                                                                   np_random)
         # blockedunlockpickup.py:164 (the agents' obs keep the sampled mission)
         self.mission = f"pick up the {Color(int(target[1])).name} {Type(int(target[0])).name}"
-        return grid, agents, target
+        return grid, agents, layouts.make_aux("blockedunlockpickup", grid, target)
 
 
-#: multigrid/envs/__init__.py:38-52, restricted to the env classes in scope
+class RedBlueDoorsEnv(MultiGridEnv):
+    """multigrid/envs/redbluedoors.py:13-187"""
+    env_kind = "redbluedoors"
+
+    def __init__(self, size: int = 8, max_steps: int | None = None, joint_reward: bool = True,
+                 success_termination_mode: str = "any", failure_termination_mode: str = "any", **kwargs):
+        self.size = size
+        super().__init__(mission_space=MissionSpace.from_string("open the red door then the blue door"),
+                         width=2 * size, height=size, max_steps=max_steps or (20 * size ** 2),      # redbluedoors.py:134
+                         joint_reward=joint_reward, success_termination_mode=success_termination_mode,
+                         failure_termination_mode=failure_termination_mode, **kwargs)
+
+    def _gen_layout(self, layout_rng, np_random):
+        grid, agents = layouts.redbluedoors_layout(self.size, self.num_agents, layout_rng)
+        return grid, agents, layouts.make_aux("redbluedoors", grid)
+
+
+class LockedHallwayEnv(MultiGridEnv):
+    """multigrid/envs/locked_hallway.py:16-227"""
+    env_kind = "lockedhallway"
+
+    def __init__(self, num_rooms: int = 6, room_size: int = 5, max_hallway_keys: int = 1, max_keys_per_room: int = 2,
+                 max_steps: int | None = None, joint_reward: bool = True, **kwargs):
+        assert room_size >= 4
+        assert num_rooms % 2 == 0
+        if num_rooms > 6:
+            raise ValueError("multigrid_amd: LockedHallway supports at most 6 rooms (the shipped configurations)")
+        self.num_rooms, self.room_size = num_rooms, room_size
+        self.max_hallway_keys, self.max_keys_per_room = max_hallway_keys, max_keys_per_room
+        if max_steps is None:
+            max_steps = 8 * num_rooms * room_size ** 2
+        super().__init__(mission_space=MissionSpace.from_string("unlock all the doors"),
+                         width=(room_size - 1) * 3 + 1, height=(room_size - 1) * (num_rooms // 2) + 1,
+                         max_steps=max_steps, joint_reward=joint_reward, **kwargs)
+
+    def _gen_layout(self, layout_rng, np_random):
+        grid, agents = layouts.lockedhallway_layout(self.num_rooms, self.room_size, self.max_hallway_keys,
+                                                    self.max_keys_per_room, self.num_agents, layout_rng, np_random)
+        return grid, agents, layouts.make_aux("lockedhallway", grid)
+
+
+class PlaygroundEnv(MultiGridEnv):
+    """multigrid/envs/playground.py:9-137 (no step hook: the base rules only)"""
+    env_kind = "empty"
+
+    def __init__(self, room_size: int = 7, num_rows: int = 3, num_cols: int = 3, max_steps: int = 100, **kwargs):
+        self.room_size, self.num_rows, self.num_cols = room_size, num_rows, num_cols
+        super().__init__(mission_space=MissionSpace.from_string(""), width=(room_size - 1) * num_cols + 1,
+                         height=(room_size - 1) * num_rows + 1, max_steps=max_steps, **kwargs)
+
+    def _gen_layout(self, layout_rng, np_random):
+        grid, agents = layouts.playground_layout(self.room_size, self.num_rows, self.num_cols, self.num_agents,
+                                                 layout_rng, np_random)
+        return grid, agents, None
+
+
+#: multigrid/envs/__init__.py:38-52
 CONFIGURATIONS = {
     "MultiGrid-BlockedUnlockPickup-v0": (BlockedUnlockPickupEnv, {}),
     "MultiGrid-Empty-5x5-v0": (EmptyEnv, {"size": 5}),
@@ -66,6 +122,12 @@ CONFIGURATIONS = {
     "MultiGrid-Empty-Random-6x6-v0": (EmptyEnv, {"size": 6, "agent_start_pos": None}),
     "MultiGrid-Empty-8x8-v0": (EmptyEnv, {}),
     "MultiGrid-Empty-16x16-v0": (EmptyEnv, {"size": 16}),
+    "MultiGrid-LockedHallway-2Rooms-v0": (LockedHallwayEnv, {"num_rooms": 2}),
+    "MultiGrid-LockedHallway-4Rooms-v0": (LockedHallwayEnv, {"num_rooms": 4}),
+    "MultiGrid-LockedHallway-6Rooms-v0": (LockedHallwayEnv, {"num_rooms": 6}),
+    "MultiGrid-Playground-v0": (PlaygroundEnv, {}),
+    "MultiGrid-RedBlueDoors-6x6-v0": (RedBlueDoorsEnv, {"size": 6}),
+    "MultiGrid-RedBlueDoors-8x8-v0": (RedBlueDoorsEnv, {"size": 8}),
 }
 
 
@@ -93,6 +155,22 @@ def spec_for(env_id: str, agents: int = 1, **kwargs) -> EnvSpec:
                        joint_reward=kw.get("joint_reward", False),
                        success_termination_mode=kw.get("success_termination_mode", "any"),
                        env_kind="empty", **common)
+    if cls is RedBlueDoorsEnv:
+        size = kw.get("size", 8)
+        common["failure_termination_mode"] = kw.get("failure_termination_mode", "any")
+        return EnvSpec(width=2 * size, height=size, max_steps=kw.get("max_steps") or 20 * size ** 2,
+                       joint_reward=kw.get("joint_reward", True),
+                       success_termination_mode=kw.get("success_termination_mode", "any"), env_kind="redbluedoors", **common)
+    if cls is LockedHallwayEnv:
+        n, rs = kw.get("num_rooms", 6), kw.get("room_size", 5)
+        return EnvSpec(width=(rs - 1) * 3 + 1, height=(rs - 1) * (n // 2) + 1,
+                       max_steps=kw.get("max_steps") or 8 * n * rs ** 2, joint_reward=kw.get("joint_reward", True),
+                       success_termination_mode=kw.get("success_termination_mode", "any"), env_kind="lockedhallway", **common)
+    if cls is PlaygroundEnv:
+        rs, nr, nc = kw.get("room_size", 7), kw.get("num_rows", 3), kw.get("num_cols", 3)
+        return EnvSpec(width=(rs - 1) * nc + 1, height=(rs - 1) * nr + 1, max_steps=kw.get("max_steps", 100),
+                       joint_reward=kw.get("joint_reward", False),
+                       success_termination_mode=kw.get("success_termination_mode", "any"), env_kind="empty", **common)
     rs = kw.get("room_size", 6)
     return EnvSpec(width=(rs - 1) * 2 + 1, height=rs, max_steps=kw.get("max_steps") or 16 * rs ** 2,
                    joint_reward=kw.get("joint_reward", True), success_termination_mode="any",

@@ -94,7 +94,11 @@ def grid_to_product(state_whc: np.ndarray) -> np.ndarray:
 
 
 def grid_from_product(grid_hwc: np.ndarray) -> np.ndarray:
-    return np.ascontiguousarray(np.swapaxes(np.asarray(grid_hwc), -3, -2)).astype(np.int64)
+    """Product grid u8[...,H,W,3] -> what the reference's Grid.state (...,W,H,3) holds.  A RedBlueDoors door in the
+    internal state 3 (object closed, grid.state stale; include/mgx.h) reads "open" there, as in the reference."""
+    g = np.ascontiguousarray(np.swapaxes(np.asarray(grid_hwc), -3, -2)).astype(np.int64)
+    g[(g[..., 0] == Type.door) & (g[..., 2] == 3), 2] = 0
+    return g
 
 
 # ---- multigrid/base.py:604-697 -------------------------------------------------------------------------
@@ -196,6 +200,228 @@ def blockedunlockpickup_layout(room_size: int, num_agents: int, layout_rng, np_r
                 break
     target = np.array([box[0], box[1], box[2], 0], dtype=np.uint8)
     return grid.to_product(), pack_agents(ag), target
+
+
+# ---- multigrid/core/roomgrid.py:53-495 (Room, RoomGrid) restated over a _Grid -------------------------------------
+class _Room:
+    def __init__(self, top, size):
+        self.top, self.size = top, size
+        self.doors = {d: None for d in range(4)}          # None | True (wall removed) | door cell tuple
+        self.door_pos = {d: None for d in range(4)}
+        self.neighbors = {d: None for d in range(4)}
+        self.objs = []
+
+    @property
+    def locked(self) -> bool:                              # roomgrid.py:84-88
+        return any(isinstance(door, tuple) and door[2] == State.locked for door in self.doors.values())
+
+    def set_door_pos(self, d, random=None):                # roomgrid.py:90-128
+        left, top = self.top
+        right, bottom = left + self.size[0] - 1, top + self.size[1] - 1
+        if d == 0:
+            pos = (right, int(random.integers(top + 1, bottom))) if random is not None else (right, (top + bottom) // 2)
+        elif d == 1:
+            pos = (int(random.integers(left + 1, right)), bottom) if random is not None else ((left + right) // 2, bottom)
+        elif d == 2:
+            pos = (left, int(random.integers(top + 1, bottom))) if random is not None else (left, (top + bottom) // 2)
+        else:
+            pos = (int(random.integers(left + 1, right)), top) if random is not None else ((left + right) // 2, top)
+        self.door_pos[d] = pos
+        return pos
+
+
+class _RoomGrid:
+    """RoomGrid._gen_grid and helpers (roomgrid.py:203-463); `rng` = construction-time generator, `np_random` = seeded."""
+
+    def __init__(self, room_size, num_rows, num_cols, num_agents, rng, np_random):
+        self.rs, self.num_rows, self.num_cols = room_size, num_rows, num_cols
+        self.rng, self.np_random = rng, np_random
+        self.width, self.height = (room_size - 1) * num_cols + 1, (room_size - 1) * num_rows + 1
+        self.grid = _Grid(self.width, self.height)
+        self.ag = _fresh_agents(num_agents)
+        self.room_grid = [[None] * num_cols for _ in range(num_rows)]
+        for row in range(num_rows):                                    # roomgrid.py:209-218
+            for col in range(num_cols):
+                room = _Room((col * (room_size - 1), row * (room_size - 1)), (room_size, room_size))
+                self.room_grid[row][col] = room
+                self.grid.wall_rect(*room.top, *room.size)
+        for row in range(num_rows):                                    # roomgrid.py:220-231
+            for col in range(num_cols):
+                room = self.room_grid[row][col]
+                if col < num_cols - 1:
+                    room.neighbors[0] = self.room_grid[row][col + 1]
+                if row < num_rows - 1:
+                    room.neighbors[1] = self.room_grid[row + 1][col]
+                if col > 0:
+                    room.neighbors[2] = self.room_grid[row][col - 1]
+                if row > 0:
+                    room.neighbors[3] = self.room_grid[row - 1][col]
+        self.ag[:, 2] = 0                                              # roomgrid.py:232-236
+        self.ag[:, 3] = (num_cols // 2) * (room_size - 1) + room_size // 2
+        self.ag[:, 4] = (num_rows // 2) * (room_size - 1) + room_size // 2
+
+    def get_room(self, col, row):
+        return self.room_grid[row][col]
+
+    def rand_int(self, lo, hi):
+        return int(self.rng.integers(lo, hi))
+
+    def rand_color(self):
+        return self.rand_int(0, len(Color))
+
+    def place_in_room(self, col, row, cell):                           # roomgrid.py:238-259
+        room = self.get_room(col, row)
+        pos = _place_obj(self.grid, self.ag, self.rng, cell, room.top, room.size, reject_fn=_reject_next_to, max_tries=1000)
+        room.objs.append(cell)
+        return pos
+
+    def add_object(self, col, row, kind=None, color=None):             # roomgrid.py:261-283
+        kind = kind if kind is not None else [Type.key, Type.ball, Type.box][self.rand_int(0, 3)]
+        color = color if color is not None else self.rand_color()
+        cell = (int(kind), int(color), 0)
+        return cell, self.place_in_room(col, row, cell)
+
+    def add_door(self, col, row, d, color=None, locked=None, rand_pos=True):    # roomgrid.py:285-331
+        room = self.get_room(col, row)
+        assert room.neighbors[d] is not None, "no neighbor in this direction"
+        assert room.doors[d] is None, "door already exists"
+        color = color if color is not None else self.rand_color()
+        locked = locked if locked is not None else (self.rand_int(0, 2) == 0)
+        door = (int(Type.door), int(color), int(State.locked if locked else State.closed))
+        pos = room.set_door_pos(d, random=self.np_random if rand_pos else None)
+        self.grid.set(*pos, door)
+        room.doors[d] = door
+        room.neighbors[d].doors[(d + 2) % 4] = door
+        return door, pos
+
+    def remove_wall(self, col, row, d):                                 # roomgrid.py:333-374
+        room = self.get_room(col, row)
+        assert room.doors[d] is None and room.neighbors[d]
+        tx, ty = room.top
+        w, h = room.size
+        for i in range(1, (h if d in (0, 2) else w) - 1):
+            x, y = {0: (tx + w - 1, ty + i), 1: (tx + i, ty + h - 1), 2: (tx, ty + i), 3: (tx + i, ty)}[d]
+            self.grid.set(x, y, None)
+        room.doors[d] = True
+        room.neighbors[d].doors[(d + 2) % 4] = True
+
+    def place_agent(self, i, col=None, row=None, rand_dir=True):        # roomgrid.py:376-404
+        col = col if col is not None else self.rand_int(0, self.num_cols)
+        row = row if row is not None else self.rand_int(0, self.num_rows)
+        room = self.get_room(col, row)
+        while True:
+            _place_agent(self.grid, self.ag, i, self.rng, room.top, room.size, rand_dir, max_tries=1000)
+            fx, fy = self.ag[i, 3:5] + DIR_TO_VEC[self.ag[i, 2]]
+            if self.grid.is_empty(fx, fy) or self.grid.state[fx, fy, 0] == Type.wall:
+                break
+
+    def connect_all(self, door_colors=None, max_itrs=5000):             # roomgrid.py:406-452
+        door_colors = list(range(len(Color))) if door_colors is None else door_colors
+        start = self.get_room(0, 0)
+        for _ in range(max_itrs):
+            seen, queue = set(), [start]                                # bfs, roomgrid.py:20-43
+            while queue:
+                node = queue.pop(0)
+                if id(node) not in seen:
+                    seen.add(id(node))
+                    queue.extend(node.neighbors[d] for d in range(4) if node.doors[d] is not None)
+            if len(seen) == self.num_rows * self.num_cols:
+                return
+            col, row, d = self.rand_int(0, self.num_cols), self.rand_int(0, self.num_rows), self.rand_int(0, 4)
+            room = self.get_room(col, row)
+            if not room.neighbors[d] or room.doors[d]:
+                continue
+            if room.locked or room.neighbors[d].locked:
+                continue
+            color = door_colors[self.rand_int(0, len(door_colors))]
+            self.add_door(col, row, d, color=color, locked=False)
+        raise RecursionError("connect_all() failed")
+
+    def result(self):
+        return self.grid.to_product(), pack_agents(self.ag)
+
+
+def make_aux(kind: str, grid_hwc: np.ndarray, target=None) -> np.ndarray:
+    """The 16-byte hook state of include/mgx.h for a freshly generated layout."""
+    aux = np.zeros(16, dtype=np.uint8)
+    g = np.asarray(grid_hwc)
+    if kind == "blockedunlockpickup":
+        aux[:3] = target[:3]
+    elif kind == "redbluedoors":
+        (by, bx), = np.argwhere((g[..., 0] == Type.door) & (g[..., 1] == Color.blue))
+        (ry, rx), = np.argwhere((g[..., 0] == Type.door) & (g[..., 1] == Color.red))
+        aux[:4] = (bx, by, rx, ry)
+    elif kind == "lockedhallway":
+        doors = sorted((int(x), int(y)) for y, x in np.argwhere(g[..., 0] == Type.door))
+        assert len(doors) <= 6
+        aux[0] = len(doors)
+        for k, (x, y) in enumerate(doors):
+            aux[2 + 2 * k], aux[3 + 2 * k] = x, y
+    return aux
+
+
+# ---- multigrid/envs/playground.py:122-137 -----------------------------------------------------------------------------
+def playground_layout(room_size, num_rows, num_cols, num_agents, layout_rng, np_random):
+    rg = _RoomGrid(room_size, num_rows, num_cols, num_agents, layout_rng, np_random)
+    rg.connect_all()
+    for _ in range(12):
+        col, row = rg.rand_int(0, num_cols), rg.rand_int(0, num_rows)
+        rg.add_object(col, row)
+    for i in range(num_agents):
+        rg.place_agent(i)
+    return rg.result()
+
+
+# ---- multigrid/envs/redbluedoors.py:142-168 -----------------------------------------------------------------------------
+def redbluedoors_layout(size, num_agents, layout_rng):
+    width, height = 2 * size, size
+    grid = _Grid(width, height)
+    ag = _fresh_agents(num_agents)
+    room_top, room_size = (width // 4, 0), (width // 2, height)
+    grid.wall_rect(0, 0, width, height)
+    grid.wall_rect(*room_top, *room_size)
+    for i in range(num_agents):
+        _place_agent(grid, ag, i, layout_rng, top=room_top, size=room_size)
+    grid.set(room_top[0], int(layout_rng.integers(1, height - 1)), (int(Type.door), int(Color.red), int(State.closed)))
+    grid.set(room_top[0] + room_size[0] - 1, int(layout_rng.integers(1, height - 1)),
+             (int(Type.door), int(Color.blue), int(State.closed)))
+    return grid.to_product(), pack_agents(ag)
+
+
+# ---- multigrid/envs/locked_hallway.py:155-201 ---------------------------------------------------------------------------
+def lockedhallway_layout(num_rooms, room_size, max_hallway_keys, max_keys_per_room, num_agents, layout_rng, np_random):
+    from math import ceil
+    num_rows = num_rooms // 2
+    rg = _RoomGrid(room_size, num_rows, 3, num_agents, layout_rng, np_random)
+    LEFT, HALLWAY, RIGHT = range(3)
+    color_sequence = list(range(len(Color))) * ceil(num_rooms / len(Color))
+    layout_rng.shuffle(color_sequence)                                   # _rand_perm, random.py:75-83
+    color_sequence = color_sequence[:num_rooms]
+    for row in range(num_rows - 1):
+        rg.remove_wall(HALLWAY, row, 1)
+    rooms = {}
+    door_colors = list(color_sequence)
+    layout_rng.shuffle(door_colors)
+    for row in range(num_rows):
+        for col, d in ((LEFT, 0), (RIGHT, 2)):
+            color = door_colors.pop()
+            rooms[color] = rg.get_room(col, row)
+            rg.add_door(col, row, d, color=color, locked=True, rand_pos=False)
+    num_hallway_keys = rg.rand_int(1, max_hallway_keys + 1)
+    hallway_top = rg.get_room(HALLWAY, 0).top
+    hallway_size = (rg.get_room(HALLWAY, 0).size[0], rg.height)
+    for key_color in color_sequence[:num_hallway_keys]:
+        _place_obj(rg.grid, rg.ag, layout_rng, (int(Type.key), key_color, 0), hallway_top, hallway_size)
+    key_index = num_hallway_keys
+    while key_index < len(color_sequence):
+        room = rooms[color_sequence[key_index - 1]]
+        num_room_keys = rg.rand_int(1, max_keys_per_room + 1)
+        for key_color in color_sequence[key_index:key_index + num_room_keys]:
+            _place_obj(rg.grid, rg.ag, layout_rng, (int(Type.key), key_color, 0), room.top, room.size)
+            key_index += 1
+    for i in range(num_agents):
+        _place_agent(rg.grid, rg.ag, i, layout_rng, top=hallway_top, size=hallway_size)
+    return rg.result()
 
 
 def check_walled(grid_hwc: np.ndarray):

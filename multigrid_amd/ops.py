@@ -93,7 +93,7 @@ def _step_impl(grid, agents, rng, step_count, actions, target, err, spec):
     _want(actions, "actions", torch.int8, (B, A))
     _want(err, "err", torch.int32, (2,))
     if target is not None:
-        _want(target, "target", torch.uint8, (B, 4))
+        _want(target, "aux", torch.uint8, (B, 16))
     dev = grid.device
     obs = torch.empty((B, A, v, v, 3), dtype=torch.uint8, device=dev)
     dirs = torch.empty((B, A), dtype=torch.uint8, device=dev)
@@ -142,7 +142,7 @@ _torch_lib = torch.library.Library("mgx", "DEF")
 _torch_lib.define("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
 _torch_lib.define(
     "step(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
-    "Tensor? target, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+    "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 _torch_lib.define("one_hot(Tensor cells, int[] dim_sizes) -> Tensor")
 _torch_lib.define("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor")
 _torch_lib.impl("one_hot", _one_hot_impl, "CUDA")

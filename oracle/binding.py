@@ -14,7 +14,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmgx_oracle.so")
 
-KIND = {"empty": 0, "blockedunlockpickup": 1}
+KIND = {"empty": 0, "blockedunlockpickup": 1, "redbluedoors": 2, "lockedhallway": 3}
+AUX = 16
 ERR_UNKNOWN_ACTION = -2
 
 
@@ -90,7 +91,8 @@ class RefEnv:
         self.agent_state = np.ascontiguousarray(agent_state, dtype=np.int64).copy()
         self.rng = np.ascontiguousarray(rng_lohi, dtype=np.uint64).copy()
         self.step_count = np.array([step_count], dtype=np.int64)
-        self.target = np.array(list(target) if target is not None else [0, 0, 0], dtype=np.int64)
+        t = list(target) if target is not None else []
+        self.target = np.array(t + [0] * (AUX - len(t)), dtype=np.int64)          # the env subclass' hook state (aux)
 
     def gen_obs(self):
         return gen_obs_ref(self.grid_state, self.agent_state, self.spec.view_size,
@@ -118,8 +120,8 @@ class RefEnv:
 
 
 def step_batch(spec: dict, grid, agents, rng, step_count, actions, target=None, nthreads: int = 1):
-    """Product-layout batched step on numpy arrays (modified in place).  Returns (obs, dir, reward,
-    terminated, truncated)."""
+    """Product-layout batched step on numpy arrays (modified in place; `target` = aux u8[B,16], include/mgx.h).
+    Returns (obs, dir, reward, terminated, truncated)."""
     sp = make_spec(spec)
     B = grid.shape[0]
     A, v = sp.num_agents, sp.view_size

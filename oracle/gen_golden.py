@@ -96,8 +96,20 @@ def spec_of(env, kind, extra=None):
     )
     if kind == "blockedunlockpickup":
         d["target"] = [int(v) for v in np.asarray(env.obj)]
+    if kind == "redbluedoors":
+        d["blue_door"] = [int(v) for v in env.blue_door.cur_pos or door_pos(env, "blue")]
+        d["red_door"] = [int(v) for v in env.red_door.cur_pos or door_pos(env, "red")]
+    if kind == "lockedhallway":
+        d["doors"] = sorted([int(x), int(y)] for x, y in np.argwhere(env.grid.state[..., 0] == 4))
     d.update(extra or {})
     return d
+
+
+def door_pos(env, color):
+    ci = ["red", "green", "blue", "purple", "yellow", "grey"].index(color)
+    st = env.grid.state
+    (x, y), = np.argwhere((st[..., 0] == 4) & (st[..., 1] == ci))
+    return int(x), int(y)
 
 
 def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, script=None, note=""):
@@ -262,6 +274,65 @@ def main():
 
     record_layouts()
     record_wrappers()
+    record_hook_envs()
+
+
+def face(env, i, target_xy, carrying=None):
+    """Teleport agent i next to `target_xy`, facing it (first free side)."""
+    tx, ty = target_xy
+    for d, (dx, dy) in enumerate([(1, 0), (0, 1), (-1, 0), (0, -1)]):
+        x, y = tx - dx, ty - dy
+        if 0 < x < env.width - 1 and 0 < y < env.height - 1 and env.grid.get(x, y) is None:
+            env.agents[i].state.pos = (x, y)
+            env.agents[i].state.dir = d
+            if carrying is not None:
+                env.agents[i].state.carrying = carrying
+            return
+    raise RuntimeError("no free side")
+
+
+def record_hook_envs():
+    """Section 8f-4: RedBlueDoors (envs/redbluedoors.py:170-187, incl. the stale-grid quirk Q9), LockedHallway
+    (envs/locked_hallway.py:203-227) and Playground (no hook; RoomGrid layout) -- rollouts of the real reference."""
+    from multigrid.core.world_object import Key
+    T, L, R, F, P, D, G, N = 5, 0, 1, 2, 3, 4, 5, 6   # toggle, left, right, forward, pickup, drop, toggle(again), done
+
+    def rbd_success(env):
+        face(env, 0, door_pos(env, "red")); face(env, 1, door_pos(env, "blue"))
+    record("rbd_a2_success", make_env("MultiGrid-RedBlueDoors-8x8-v0", agents=2), "redbluedoors", 71, None, None,
+           edit=rbd_success, script=[[T, N], [N, T], [N, T], [T, T], [F, F], [N, T]],
+           note="red then blue: success; hook keeps firing for terminated agents")
+
+    def rbd_failure(env):
+        face(env, 1, door_pos(env, "blue"))
+        bx, by = door_pos(env, "blue")
+        env.agents[0].state.pos = (bx - 1, by); env.agents[0].state.dir = 0
+    for mode in ("any", "all"):
+        record(f"rbd_a2_failure_{mode}",
+               make_env("MultiGrid-RedBlueDoors-8x8-v0", agents=2, failure_termination_mode=mode), "redbluedoors", 72,
+               None, None, edit=rbd_failure,
+               script=[[N, T], [F, N], [T, N], [F, T], [T, N], [F, F], [T, T], [F, F], [L, T], [T, N]],
+               note="blue first: failure; the blue door object closes while grid.state keeps saying open (Q9)")
+    record("rbd_a3_random", make_env("MultiGrid-RedBlueDoors-6x6-v0", agents=3, failure_termination_mode="all"),
+           "redbluedoors", 73, 400, np.random.default_rng(373), p_missing=0.05, note="random rollout")
+
+    def lh_unlock(env):
+        doors = sorted((int(x), int(y)) for x, y in np.argwhere(env.grid.state[..., 0] == 4))
+        colors = ["red", "green", "blue", "purple", "yellow", "grey"]
+        for i, (x, y) in enumerate(doors[:env.num_agents]):
+            face(env, i, (x, y), carrying=Key(colors[int(env.grid.state[x, y, 1])]))
+    for name, A, jr in (("MultiGrid-LockedHallway-2Rooms-v0", 2, True), ("MultiGrid-LockedHallway-2Rooms-v0", 2, False),
+                        ("MultiGrid-LockedHallway-6Rooms-v0", 3, True)):
+        rooms = name.split("-")[2]
+        record(f"lh_{rooms.lower()}_a{A}_{'joint' if jr else 'own'}", make_env(name, agents=A, joint_reward=jr),
+               "lockedhallway", 74 + A, None, None, edit=lh_unlock,
+               script=[[N] * A, [T] + [N] * (A - 1), [T] * A, [T] * A, [F] * A, [T] * A, [L] * A, [T] * A] +
+                      np.random.default_rng(5).integers(0, 7, size=(30, A)).tolist(),
+               note="unlock with key: reward accumulates; all doors unlocked -> returned terminations only")
+    record("lh_4rooms_a2_random", make_env("MultiGrid-LockedHallway-4Rooms-v0", agents=2), "lockedhallway", 77, 300,
+           np.random.default_rng(377), p_missing=0.05, note="random rollout")
+    record("playground_a3", make_env("MultiGrid-Playground-v0", agents=3), "empty", 78, 100,
+           np.random.default_rng(378), p_missing=0.05, note="Playground: no hook, 19x19 RoomGrid layout, max_steps 100")
 
 
 def record_wrappers():
@@ -303,6 +374,9 @@ def record_layouts():
         ("layout_bup_a3", "MultiGrid-BlockedUnlockPickup-v0", dict(agents=3), "blockedunlockpickup"),
         ("layout_emptyrandom6_a3", "MultiGrid-Empty-Random-6x6-v0", dict(agents=3), "empty"),
         ("layout_empty8_a2", "MultiGrid-Empty-8x8-v0", dict(agents=2), "empty"),
+        ("layout_rbd8_a2", "MultiGrid-RedBlueDoors-8x8-v0", dict(agents=2), "redbluedoors"),
+        ("layout_lh4_a2", "MultiGrid-LockedHallway-4Rooms-v0", dict(agents=2), "lockedhallway"),
+        ("layout_playground_a2", "MultiGrid-Playground-v0", dict(agents=2), "empty"),
     ]
     for fname, name, kw, kind in cases:
         env = make_env(name, **kw)

@@ -43,7 +43,16 @@ static const int64_t WALL_ENCODING[3] = { T_WALL, C_GREY, 0 };
 static const int64_t UNSEEN_ENCODING[3] = { T_UNSEEN, 0, 0 };
 static const int64_t EMPTY_ENCODING[3] = { T_EMPTY, 0, 0 }; /* world_object.py:131-137 */
 
-enum { KIND_EMPTY = 0, KIND_BLOCKEDUNLOCKPICKUP = 1 };
+enum { KIND_EMPTY = 0, KIND_BLOCKEDUNLOCKPICKUP = 1, KIND_REDBLUEDOORS = 2, KIND_LOCKEDHALLWAY = 3 };
+
+/* Per-env hook state `aux` (int64[16]), mirroring the attributes the env subclasses keep:
+ *   BlockedUnlockPickup  [0..2] = self.obj encoding                        (envs/blockedunlockpickup.py:147)
+ *   RedBlueDoors         [0,1] = blue door (x,y), [2,3] = red door (x,y),  (envs/redbluedoors.py:158-168)
+ *                        [4]   = 1 while the blue Door OBJECT is closed but grid.state still says open: the hook
+ *                                closes the object without grid.update (redbluedoors.py:185)
+ *   LockedHallway        [0] = number of doors, [1] = bit mask of doors already in self.unlocked_doors,
+ *                        [2+2i, 3+2i] = door i (x,y), [15] = 1 if the hook reported all agents terminated  */
+#define MGO_AUX 16
 
 typedef struct {
     int32_t width, height, num_agents, view_size, max_steps;
@@ -253,7 +262,7 @@ static int agent_present(const int64_t *agent_state, int A, int64_t x, int64_t y
  * Returns 0, or MGO_ERR_UNKNOWN_ACTION at the first invalid action in visiting order (base.py:473-474;
  * earlier agents in the order have already acted, exactly as when the reference raises mid-loop). */
 static int handle_actions(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, uint64_t rng[4],
-                          int64_t step_count, const int8_t *actions, double *rewards, int *order_out) {
+                          int64_t step_count, const int8_t *actions, double *rewards, int *order_out, int64_t *aux) {
     const int W = sp->width, H = sp->height, A = sp->num_agents;
     int order[MGO_MAX_AGENTS];
     for (int a = 0; a < A; ++a) rewards[a] = 0.0;                     /* base.py:393 */
@@ -270,11 +279,16 @@ static int handle_actions(const MgoSpec *sp, int64_t *grid_state, int64_t *agent
         if (s[AS_DIR] >= 0 && s[AS_DIR] < 4) { fx += DIR_TO_VEC[s[AS_DIR]][0]; fy += DIR_TO_VEC[s[AS_DIR]][1]; }
         int in_bounds = fx >= 0 && fx < W && fy >= 0 && fy < H;       /* shipped envs are walled: always true */
         int64_t *cell = in_bounds ? grid_state + ((size_t)fx * H + fy) * 3 : NULL;
+        /* The rules below act on the WorldObj the grid holds (Grid.get, grid.py:102-117).  Its state equals
+         * grid.state except for the RedBlueDoors blue door after the hook closed the object only (Q9). */
+        const int stale = sp->env_kind == KIND_REDBLUEDOORS && aux && aux[4] && cell && fx == aux[0] && fy == aux[1];
+        int64_t obj[3] = {0, 0, 0};
+        if (cell) { obj[0] = cell[0]; obj[1] = cell[1]; obj[2] = stale ? S_CLOSED : cell[2]; }
         switch (action) {
         case A_LEFT:  s[AS_DIR] = (s[AS_DIR] + 3) % 4; break;          /* base.py:412-413 */
         case A_RIGHT: s[AS_DIR] = (s[AS_DIR] + 1) % 4; break;          /* base.py:416-417 */
         case A_FORWARD:                                                /* base.py:420-436 */
-            if (cell && can_overlap(cell)) {
+            if (cell && can_overlap(obj)) {
                 if (!sp->allow_agent_overlap && agent_present(agent_state, A, fx, fy)) break;
                 s[AS_X] = fx; s[AS_Y] = fy;
                 if (cell[0] == T_GOAL) on_success(sp, agent_state, i, step_count, rewards);
@@ -297,10 +311,11 @@ static int handle_actions(const MgoSpec *sp, int64_t *grid_state, int64_t *agent
         case A_TOGGLE:                                                 /* base.py:462-467 */
             if (!cell) break;
             if (cell[0] == T_DOOR) {                                   /* world_object.py:458-474 Door.toggle */
-                if (cell[2] == S_LOCKED) {
+                if (obj[2] == S_LOCKED) {
                     if (s[AS_CARRY] == T_KEY && s[AS_CARRY + 1] == cell[1]) cell[2] = S_OPEN;
                 } else {
-                    cell[2] = (cell[2] == S_OPEN) ? S_CLOSED : S_OPEN;
+                    cell[2] = (obj[2] == S_OPEN) ? S_CLOSED : S_OPEN;      /* grid.update: state := object */
+                    if (stale) aux[4] = 0;
                 }
             } else if (cell[0] == T_BOX) {                             /* world_object.py:599-605 Box.toggle */
                 memcpy(cell, EMPTY_ENCODING, 3 * sizeof(int64_t));    /* contains is None in scope */
@@ -316,13 +331,13 @@ static int handle_actions(const MgoSpec *sp, int64_t *grid_state, int64_t *agent
 /* base.py:303-346 step (+ envs/blockedunlockpickup.py:166-175 post-step hook).  Single env, reference
  * layout.  target: (3,) encoding of the BlockedUnlockPickup target box (ignored for KIND_EMPTY). */
 int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, uint64_t rng[4],
-                 int64_t *step_count, const int8_t *actions, const int64_t *target,
+                 int64_t *step_count, const int8_t *actions, int64_t *target /* aux[MGO_AUX] */,
                  int64_t *obs, int64_t *direction, double *rewards, uint8_t *terminated, uint8_t *truncated,
                  int *order_out) {
     const int A = sp->num_agents;
     if (A < 1 || A > MGO_MAX_AGENTS) return -1;
     *step_count += 1;                                                  /* base.py:333 */
-    int rc = handle_actions(sp, grid_state, agent_state, rng, *step_count, actions, rewards, order_out);
+    int rc = handle_actions(sp, grid_state, agent_state, rng, *step_count, actions, rewards, order_out, target);
     if (rc) return rc;
     rc = mgo_gen_obs_ref(grid_state, agent_state, sp->width, sp->height, A, sp->view_size,   /* base.py:337 */
                          sp->see_through_walls, obs);
@@ -345,6 +360,57 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
             }
         }
     }
+    if (sp->env_kind == KIND_REDBLUEDOORS) {                           /* redbluedoors.py:170-187 */
+        int64_t *aux = target;
+        const int W = sp->width, H = sp->height;
+        for (int a = 0; a < A; ++a) {                                  /* `for agent_id, action in actions.items()` */
+            if (actions[a] != A_TOGGLE) continue;                      /* absent (-1) or another action */
+            const int64_t *s = agent_state + (size_t)a * AS_DIM;
+            int64_t fx = s[AS_X], fy = s[AS_Y];
+            if (s[AS_DIR] >= 0 && s[AS_DIR] < 4) { fx += DIR_TO_VEC[s[AS_DIR]][0]; fy += DIR_TO_VEC[s[AS_DIR]][1]; }
+            if (fx != aux[0] || fy != aux[1]) continue;                /* fwd_obj == self.blue_door */
+            int64_t *blue = grid_state + ((size_t)aux[0] * H + aux[1]) * 3;
+            const int64_t *red = grid_state + ((size_t)aux[2] * H + aux[3]) * 3;
+            const int blue_open = !aux[4] && blue[2] == S_OPEN;        /* the OBJECT's state */
+            if (!blue_open) continue;
+            if (red[2] == S_OPEN) {
+                on_success(sp, agent_state, a, *step_count, rewards);
+                if (sp->success_any) { for (int b = 0; b < A; ++b) terminated[b] = 1; } else terminated[a] = 1;
+            } else {
+                on_failure(sp, agent_state, a);
+                if (sp->failure_any) { for (int b = 0; b < A; ++b) terminated[b] = 1; } else terminated[a] = 1;
+                aux[4] = 1;                                            /* blue_door.is_open = False, no grid.update */
+            }
+        }
+        (void)W;
+    }
+    if (sp->env_kind == KIND_LOCKEDHALLWAY) {                          /* locked_hallway.py:203-227 */
+        int64_t *aux = target;
+        const int H = sp->height;
+        const int nd = (int)aux[0];
+        for (int a = 0; a < A; ++a) {
+            if (actions[a] != A_TOGGLE) continue;
+            const int64_t *s = agent_state + (size_t)a * AS_DIM;
+            int64_t fx = s[AS_X], fy = s[AS_Y];
+            if (s[AS_DIR] >= 0 && s[AS_DIR] < 4) { fx += DIR_TO_VEC[s[AS_DIR]][0]; fy += DIR_TO_VEC[s[AS_DIR]][1]; }
+            if (fx < 0 || fx >= sp->width || fy < 0 || fy >= H) continue;
+            const int64_t *c = grid_state + ((size_t)fx * H + fy) * 3;
+            if (c[0] != T_DOOR || c[2] == S_LOCKED) continue;          /* isinstance(Door) and not is_locked */
+            for (int d = 0; d < nd; ++d) {
+                if (aux[2 + 2 * d] != fx || aux[3 + 2 * d] != fy) continue;
+                if (aux[1] & (1 << d)) break;                          /* already in self.unlocked_doors */
+                aux[1] |= (1 << d);
+                const double r = reward_value(*step_count, sp->max_steps);
+                if (sp->joint_reward) { for (int b = 0; b < A; ++b) rewards[b] += r; }   /* `+=`, not `=` */
+                else rewards[a] += r;
+                break;
+            }
+        }
+        int cnt = 0;
+        for (int d = 0; d < nd; ++d) cnt += (int)((aux[1] >> d) & 1);
+        aux[15] = (cnt == nd);                                         /* len(unlocked_doors) == len(rooms) */
+        if (aux[15]) for (int b = 0; b < A; ++b) terminated[b] = 1;    /* the returned dict only, not agent state */
+    }
     return 0;
 }
 
@@ -352,7 +418,7 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
  * Batched wrappers over the product's packed layout (include/mgx.h):
  *   grid u8[B,H,W,3] ([y][x]); agents u8[B,A,8] = [color,dir,x,y,terminated,carry_type,carry_color,
  *   carry_state]; rng u64[B,4] = [state_lo,state_hi,inc_lo,inc_hi]; step_count i32[B]; actions i8[B,A];
- *   target u8[B,4]; obs u8[B,A,v,v,3]; dir u8[B,A]; reward f64[B,A]; terminated u8[B,A]; truncated u8[B].
+ *   aux u8[B,16] (include/mgx.h); obs u8[B,A,v,v,3]; dir u8[B,A]; reward f64[B,A]; terminated u8[B,A]; truncated u8[B].
  * ---------------------------------------------------------------------------------------------- */
 static void unpack_env(const MgoSpec *sp, const uint8_t *grid, const uint8_t *agents,
                        int64_t *grid_state, int64_t *agent_state) {
@@ -437,16 +503,26 @@ int mgo_step_batch(const MgoSpec *sp, int64_t B, uint8_t *grid, uint8_t *agents,
         int64_t *gs = (int64_t *)malloc(sizeof(int64_t) * gsz);
         int64_t *as = (int64_t *)malloc(sizeof(int64_t) * (size_t)A * AS_DIM);
         int64_t *ob = (int64_t *)malloc(sizeof(int64_t) * osz);
-        int64_t dirs[MGO_MAX_AGENTS], tgt[3];
+        int64_t dirs[MGO_MAX_AGENTS], tgt[MGO_AUX];
 #pragma omp for schedule(static)
         for (int64_t b = 0; b < B; ++b) {
             unpack_env(sp, grid + b * gsz, agents + (size_t)b * A * 8, gs, as);
             int64_t sc = step_count[b];
-            tgt[0] = target ? target[b * 4] : 0; tgt[1] = target ? target[b * 4 + 1] : 0; tgt[2] = 0;
+            for (int k = 0; k < MGO_AUX; ++k) tgt[k] = target ? target[b * MGO_AUX + k] : 0;
+            if (sp->env_kind == KIND_REDBLUEDOORS) {               /* product encoding: state 3 = object closed, grid says open */
+                int64_t *blue = gs + ((size_t)tgt[0] * H + tgt[1]) * 3;
+                tgt[4] = (blue[2] == 3);
+                if (tgt[4]) blue[2] = S_OPEN;
+            }
             int rc = mgo_step_ref(sp, gs, as, rng + b * 4, &sc, actions + (size_t)b * A, tgt, ob, dirs,
                                   reward + (size_t)b * A, terminated + (size_t)b * A, truncated + b, NULL);
             step_count[b] = (int32_t)sc;
+            if (sp->env_kind == KIND_REDBLUEDOORS && tgt[4]) gs[((size_t)tgt[0] * H + tgt[1]) * 3 + 2] = 3;
             pack_env(sp, gs, as, grid + b * gsz, agents + (size_t)b * A * 8);
+            if (sp->env_kind == KIND_LOCKEDHALLWAY && target) {
+                ((uint8_t *)target)[b * MGO_AUX + 1] = (uint8_t)tgt[1];
+                ((uint8_t *)target)[b * MGO_AUX + 15] = (uint8_t)tgt[15];
+            }
             if (rc) {
 #pragma omp critical
                 { if (bad < 0 || b < bad) bad = b; }

@@ -28,7 +28,7 @@ def _p(a, t):
 
 
 def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=False):
-    """tile u8[H,W,3], rows8 u8[A,8], act i8[A], rng4 u64[4], target u8[4]; all updated in place.
+    """tile u8[H,W,3], rows8 u8[A,8], act i8[A], rng4 u64[4], target = aux u8[16]; all updated in place.
     Returns dict(obs, reward, terminated, truncated, order, rc, n_dirty)."""
     sc = spec.to_c()
     A, v = spec.num_agents, spec.view_size

@@ -19,7 +19,7 @@ static const JumpTable kJump{};
 extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated, NOT overlaid */,
                              uint8_t *tile_overlaid /* out: tile with agent overlay (render input) */,
                              uint64_t *rows /* A, updated */, const int8_t *act, uint64_t *rng /* 4, updated */,
-                             int32_t *step_count, const uint8_t *target, double *rew /* A out */,
+                             int32_t *step_count, uint8_t *aux /* 16, updated */, double *rew /* A out */,
                              uint8_t *terminated /* A out */, uint8_t *truncated, uint8_t *order_out,
                              int32_t *n_dirty, int force_serial) {
     const StepCfg cf = make_cfg(*sp);
@@ -63,18 +63,23 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
         rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty);
     }
     *n_dirty = fallback ? -nd - 1 : nd;          // negative = the sequential loop ran
+    // the kernel's per-agent overlay (one lane per agent): offsets from the PRE-hook rows, cells written after the hook
+    std::vector<int> ovl(A);
+    std::vector<uint64_t> pre_rows(rows, rows + A);
+    for (int ai = 0; ai < A; ++ai) ovl[ai] = overlay_offset(cf, rows, ai);
+
+    for (int a = 0; a < A; ++a) terminated[a] = 0;
+    post_step_hook(cf, sp->env_kind, tile, rows, act, aux, sc, rew, dirty);       // on the clean tile, like the kernel
+    const bool forced = sp->env_kind == MGX_KIND_LOCKEDHALLWAY && aux[15];
+    for (int a = 0; a < A; ++a) terminated[a] = (uint8_t)(row_term(rows[a]) | forced);
     std::memcpy(tile_overlaid, tile, HW3);
-    {   // the kernel's per-agent overlay (one lane per agent); must equal the ascending loop of overlay_agents()
+    for (int ai = 0; ai < A; ++ai)
+        if (ovl[ai] >= 0) store_cell(tile_overlaid + ovl[ai], (uint32_t)T_AGENT | ((uint32_t)(rows[ai] & 0xffffu) << 8));
+    {   // must equal the reference's ascending loop (overlay_agents) run on the pre-hook rows
         std::vector<uint8_t> ref(tile, tile + HW3);
-        overlay_agents(cf, ref.data(), rows);
-        for (int ai = 0; ai < A; ++ai) {
-            const int off = overlay_offset(cf, rows, ai);
-            if (off >= 0) store_cell(tile_overlaid + off, (uint32_t)T_AGENT | ((uint32_t)(rows[ai] & 0xffffu) << 8));
-        }
+        overlay_agents(cf, ref.data(), pre_rows.data());
         if (std::memcmp(ref.data(), tile_overlaid, HW3) != 0) return -99;
     }
-    post_step_hook(cf, sp->env_kind, rows, target, sc, rew);
-    for (int a = 0; a < A; ++a) terminated[a] = (uint8_t)row_term(rows[a]);
     *truncated = (uint8_t)(sc >= cf.max_steps);
     return rc;
 }
@@ -96,6 +101,7 @@ static void obs_env(const MgxSpec *sp, const uint8_t *tile, const uint64_t *rows
             uint32_t c = CELL_WALL;
             if (in) c = load_cell(tile + g.origin + fw * g.stepF + la * g.stepL);
             if (i == V / 2 && j == V - 1) c = row_carry(row);
+            if (sp->env_kind == MGX_KIND_REDBLUEDOORS) c = grid_view_of(c);
             if (see_behind(c)) sb[k >> 6] |= 1ull << (k & 63);
             cells[i * V + j] = c;
         }

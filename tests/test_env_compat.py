@@ -22,9 +22,7 @@ def make(env_id, **kw):
 @pytest.mark.parametrize("path", util.LAYOUT_GOLDEN, ids=util.LAYOUT_IDS)
 def test_reset_sequence_matches_reference(path):
     z = np.load(path)
-    name = {"layout_bup_a2": "MultiGrid-BlockedUnlockPickup-v0", "layout_bup_a3": "MultiGrid-BlockedUnlockPickup-v0",
-            "layout_emptyrandom6_a3": "MultiGrid-Empty-Random-6x6-v0",
-            "layout_empty8_a2": "MultiGrid-Empty-8x8-v0"}[path.split("/")[-1][:-4]]
+    name = util.LAYOUT_ENV_IDS[path.split("/")[-1][:-4]]
     A = z["agents0"].shape[1]
     env = make(name, agents=A, layout_seed=int(z["construct_seed"]))
     for k, sd in enumerate(z["reset_seeds"]):
@@ -41,7 +39,7 @@ def test_reset_sequence_matches_reference(path):
                 assert str(obs[i]["mission"]) == str(z["missions"][k]), ctx
         assert env.step_count == 0
         if "bup" in path:
-            np.testing.assert_array_equal(env._benv.target[0].numpy()[:3], z["targets"][k], err_msg=ctx)
+            np.testing.assert_array_equal(env._benv.aux[0].numpy()[:3], z["targets"][k], err_msg=ctx)
         for t in range(5):
             env.step({i: int(z["actions"][k][t, i]) for i in range(A)})
 

@@ -25,7 +25,7 @@ def test_golden_replay(path, replicas):
     z, d, spec = util.load_golden(path)
     env = BatchedMultiGridEnv(spec, replicas, dev())
     env.load_state(layouts.grid_to_product(z["grid0"]), layouts.pack_agents(z["agents0"]),
-                   rng=util.rng_words_lohi(z["rng0"]), target=util.golden_target(d))
+                   rng=util.rng_words_lohi(z["rng0"]), aux=util.golden_aux(d))
     obs, dirs = env.gen_obs()
     for b in range(replicas):
         np.testing.assert_array_equal(obs[b].cpu().numpy(), z["obs0"])
@@ -130,9 +130,7 @@ def test_dict_api_reset_sequence_on_gpu(path):
     """multigrid_amd.make(...) on the HIP backend reproduces the reference's reset()/step() sequence."""
     import multigrid_amd as mg
     z = np.load(path)
-    name = {"layout_bup_a2": "MultiGrid-BlockedUnlockPickup-v0", "layout_bup_a3": "MultiGrid-BlockedUnlockPickup-v0",
-            "layout_emptyrandom6_a3": "MultiGrid-Empty-Random-6x6-v0",
-            "layout_empty8_a2": "MultiGrid-Empty-8x8-v0"}[path.split("/")[-1][:-4]]
+    name = util.LAYOUT_ENV_IDS[path.split("/")[-1][:-4]]
     A = z["agents0"].shape[1]
     env = mg.make(name, agents=A, layout_seed=int(z["construct_seed"]), device=dev())
     for k, sd in enumerate(z["reset_seeds"]):
@@ -242,7 +240,8 @@ def test_reset_done_on_gpu_matches_definition():
     pool = [layouts.blockedunlockpickup_layout(6, 2, r, r) for _ in range(K)]
     pg, pa, pt = (np.stack([p[i] for p in pool]) for i in range(3))
     env = BatchedMultiGridEnv(spec, B, dev(), first_env=first)
-    env.load_state(pg[0], pa[0], target=pt[0]); env.seed_synthetic(2)
+    pt = np.stack([layouts.make_aux("blockedunlockpickup", pg[k], pt[k]) for k in range(K)])
+    env.load_state(pg[0], pa[0], aux=pt[0]); env.seed_synthetic(2)
     env.set_layout_pool(pg, pa, pt)
     g = torch.Generator(device=dev()); g.manual_seed(1)
     for ep in range(3):
@@ -255,7 +254,7 @@ def test_reset_done_on_gpu_matches_definition():
         k = (first + np.arange(B) + np.maximum(env.episode.cpu().numpy() - 1, 0) * 7919) % K
         np.testing.assert_array_equal(env.grid.cpu().numpy(), pg[k])
         np.testing.assert_array_equal(env.agents.cpu().numpy(), pa[k])
-        np.testing.assert_array_equal(env.target.cpu().numpy(), pt[k])
+        np.testing.assert_array_equal(env.aux.cpu().numpy(), pt[k])
         assert int(env.step_count.sum()) == 0
     env.check_errors()
 
@@ -296,3 +295,62 @@ def test_rollout_equals_repeated_steps(name, spec, B, T, density):
         obs, *_ = e1.step(a[t])
         assert torch.equal(out2["obs"][t], obs)
     assert torch.equal(e1.grid, e2.grid)
+
+
+HOOK_CASES = [
+    ("redbluedoors6_a3", "MultiGrid-RedBlueDoors-6x6-v0", dict(agents=3, failure_termination_mode="all"), 600, 80),
+    ("redbluedoors8_a2", "MultiGrid-RedBlueDoors-8x8-v0", dict(agents=2), 400, 60),
+    ("lockedhallway4_a2", "MultiGrid-LockedHallway-4Rooms-v0", dict(agents=2), 300, 60),
+    ("playground_a3", "MultiGrid-Playground-v0", dict(agents=3), 200, 60),
+]
+
+
+@pytest.mark.parametrize("name,env_id,kw,B,T", HOOK_CASES, ids=[c[0] for c in HOOK_CASES])
+def test_hook_envs_random_rollouts_vs_oracle(name, env_id, kw, B, T):
+    """Section 8f-4 envs: B different generated layouts, random actions, every step vs the oracle; also as one rollout."""
+    import multigrid_amd as mg
+    from multigrid_amd import envs as E
+    spec = mg.spec_for(env_id, **kw)
+    cls, cfg = mg.CONFIGURATIONS[env_id]
+    r = np.random.default_rng(zlib.crc32(name.encode()))
+    grids, agents, auxs = [], [], []
+    for b in range(B):
+        if cls is E.RedBlueDoorsEnv:
+            g, a = layouts.redbluedoors_layout(cfg["size"], spec.num_agents, r)
+        elif cls is E.LockedHallwayEnv:
+            g, a = layouts.lockedhallway_layout(cfg["num_rooms"], 5, 1, 2, spec.num_agents, r, r)
+            # hand every agent a key so that doors actually get unlocked by the random walk
+            a[:, 5] = 5; a[:, 6] = r.integers(0, 6, size=spec.num_agents)
+        else:
+            g, a = layouts.playground_layout(7, 3, 3, spec.num_agents, r, r)
+        grids.append(g); agents.append(a); auxs.append(layouts.make_aux(spec.env_kind, g))
+    st = dict(grid=np.stack(grids), agents=np.stack(agents), aux=np.stack(auxs),
+              rng=np.random.default_rng(1).integers(0, 2 ** 63, size=(B, 4), dtype=np.int64).astype(np.uint64) | np.uint64(1),
+              step_count=np.zeros(B, np.int32))
+    acts = np.stack([np.random.default_rng(50 + t).choice([0, 1, 2, 2, 2, 3, 4, 5, 5, 5, 6], size=(B, spec.num_agents)).astype(np.int8)
+                     for t in range(T)])
+    env = BatchedMultiGridEnv(spec, B, dev()); env.load_state(st["grid"], st["agents"], st["rng"], st["aux"])
+    roll = BatchedMultiGridEnv(spec, B, dev()); roll.load_state(st["grid"], st["agents"], st["rng"], st["aux"])
+    out = roll.rollout(torch.from_numpy(acts).to(dev()))
+    ref = {k: v.copy() for k, v in st.items()}
+    sd = spec.as_dict()
+    events = 0
+    for t in range(T):
+        o_ref, d_ref, r_ref, te_ref, tr_ref = ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"],
+                                                            acts[t], ref["aux"], nthreads=8)
+        obs, dirs, rew, term, trunc = env.step(torch.from_numpy(acts[t]).to(dev()))
+        ctx = f"{name} step {t}"
+        np.testing.assert_array_equal(env.grid.cpu().numpy(), ref["grid"], err_msg=ctx)
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"], err_msg=ctx)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_ref, err_msg=ctx)
+        assert rew.cpu().numpy().tobytes() == r_ref.tobytes(), ctx
+        np.testing.assert_array_equal(term.cpu().numpy(), te_ref, err_msg=ctx)
+        np.testing.assert_array_equal(trunc.cpu().numpy(), tr_ref, err_msg=ctx)
+        if spec.env_kind == "lockedhallway":
+            np.testing.assert_array_equal(env.aux.cpu().numpy()[:, [1, 15]], ref["aux"][:, [1, 15]], err_msg=ctx)
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew) and torch.equal(out["terminated"][t], term), ctx
+        events += int((r_ref > 0).any()) + int(te_ref.any())
+    assert torch.equal(env.grid, roll.grid) and torch.equal(env.aux, roll.aux) and torch.equal(env.rng, roll.rng)
+    if spec.env_kind != "empty":
+        assert events > 0, "the rollout never reached a hook event"
+    env.check_errors()

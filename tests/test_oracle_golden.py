@@ -35,7 +35,8 @@ def test_fixtures_present():
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_oracle_replays_reference(path):
     z, spec = load(path)
-    env = ob.RefEnv(spec, z["grid0"], z["agents0"], rng_lohi(z["rng0"]), target=spec.get("target"))
+    from tests import util
+    env = ob.RefEnv(spec, z["grid0"], z["agents0"], rng_lohi(z["rng0"]), target=[int(v) for v in util.golden_aux(spec)])
     np.testing.assert_array_equal(env.gen_obs(), z["obs0"].astype(np.int64))
     T = z["actions"].shape[0]
     for t in range(T):

@@ -19,6 +19,10 @@ GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith(("layout_", "wra
 GOLDEN_IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
 LAYOUT_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("layout_")]
 LAYOUT_IDS = [os.path.basename(p)[:-4] for p in LAYOUT_GOLDEN]
+LAYOUT_ENV_IDS = {"layout_bup_a2": "MultiGrid-BlockedUnlockPickup-v0", "layout_bup_a3": "MultiGrid-BlockedUnlockPickup-v0",
+                  "layout_emptyrandom6_a3": "MultiGrid-Empty-Random-6x6-v0", "layout_empty8_a2": "MultiGrid-Empty-8x8-v0",
+                  "layout_rbd8_a2": "MultiGrid-RedBlueDoors-8x8-v0", "layout_lh4_a2": "MultiGrid-LockedHallway-4Rooms-v0",
+                  "layout_playground_a2": "MultiGrid-Playground-v0"}
 WRAPPER_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("wrappers_")]
 WRAPPER_IDS = [os.path.basename(p)[:-4] for p in WRAPPER_GOLDEN]
 
@@ -35,9 +39,23 @@ def rng_words_lohi(words_hilo) -> np.ndarray:
     return np.array([ls, hs, li, hi], dtype=np.uint64)
 
 
-def golden_target(d: dict) -> np.ndarray:
-    t = d.get("target", [0, 0, 0])
-    return np.array([t[0], t[1], t[2], 0], dtype=np.uint8)
+def golden_aux(d: dict) -> np.ndarray:
+    """The env subclass' hook state for a golden fixture, as the product's aux u8[16] (include/mgx.h)."""
+    a = np.zeros(16, dtype=np.uint8)
+    kind = d.get("env_kind", "empty")
+    if kind == "blockedunlockpickup":
+        a[:3] = d["target"]
+    elif kind == "redbluedoors":
+        a[0:2] = d["blue_door"]; a[2:4] = d["red_door"]
+    elif kind == "lockedhallway":
+        doors = d["doors"]
+        a[0] = len(doors)
+        for i, (x, y) in enumerate(doors):
+            a[2 + 2 * i], a[3 + 2 * i] = x, y
+    return a
+
+
+golden_target = golden_aux
 
 
 def random_state(spec: EnvSpec, B: int, seed: int, density: float = 0.25, terminated_p: float = 0.05,
@@ -78,7 +96,7 @@ def random_state(spec: EnvSpec, B: int, seed: int, density: float = 0.25, termin
     rng = np.random.default_rng(seed + 1).integers(0, 2 ** 63, size=(B, 4), dtype=np.int64).astype(np.uint64)
     rng[:, 2] |= np.uint64(1)
     step_count = r.integers(0, max(1, spec.max_steps), size=B).astype(np.int32)
-    target = np.zeros((B, 4), dtype=np.uint8)
+    target = np.zeros((B, 16), dtype=np.uint8)               # aux (include/mgx.h); BlockedUnlockPickup: the target box
     target[:, 0] = 7
     target[:, 1] = r.integers(0, 6, size=B)
     return dict(grid=grid, agents=agents, rng=rng, step_count=step_count, target=target)
@@ -142,7 +160,7 @@ class OracleBackend:
                 k = (first_env + b + int(episode[b]) * 7919) % K
                 grid[b] = pg[k]; agents[b] = pa[k]
                 if pt is not None:
-                    target[b] = pt[k]
+                    target[b] = pt[k]          # aux
                 step_count[b] = 0
                 episode[b] += 1
 
