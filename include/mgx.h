@@ -26,14 +26,16 @@
  *                                   BlockedUnlockPickup  [0..2] = encoding of the target box `self.obj`
  *                                                        (multigrid/envs/blockedunlockpickup.py:147, 172)
  *                                   RedBlueDoors         [0,1] = blue door (x,y), [2,3] = red door (x,y)
- *                                                        (multigrid/envs/redbluedoors.py:158-168)
+ *                                                        (multigrid/envs/redbluedoors.py:158-168); [4] = 1 while the blue
+ *                                                        Door OBJECT is closed although Grid.state (= `grid`) still says
+ *                                                        open: the hook closes it without grid.update
+ *                                                        (redbluedoors.py:185).  The rules act on the object, obs on
+ *                                                        `grid`; updated by the step
  *                                   LockedHallway        [0] = number of doors, [1] = bit k set once door k is in
  *                                                        `self.unlocked_doors` (updated by the step), [2+2k, 3+2k] =
  *                                                        door k (x,y), [15] = 1 when the last step reported every agent
  *                                                        terminated (multigrid/envs/locked_hallway.py:203-227)
- *                                 Door state 3 in `grid` (RedBlueDoors only) = the Door object is closed while
- *                                 Grid.state still says open (redbluedoors.py:185 closes it without grid.update): the
- *                                 rules treat it as closed, obs / full_obs show it open.
+
  *   obs         u8 [B, A, v, v, 3] image[i][j][c] exactly as multigrid/utils/obs.py:65-102 returns it
  *   dir         u8 [B, A]         obs['direction'] (multigrid/base.py:359, 372)
  *   reward      f64[B, A]         multigrid/base.py:393, 503-507, 598-602 (bit-identical Python float arithmetic)

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int6
         const uint8_t *g = grid + b * HW * 3;
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {      // i = y*W + x in the product layout
             const int y = i / W, x = i - y * W;
-            store_cell(lds + (x * H + y) * 3, grid_view_of(load_cell(g + i * 3)));   // Grid.state (a stale-open door reads open)
+            uint8_t *d = lds + (x * H + y) * 3;
+            d[0] = g[i * 3]; d[1] = g[i * 3 + 1]; d[2] = g[i * 3 + 2];
         }
         __syncthreads();
         if (threadIdx.x == 0) {

@@ -156,7 +156,7 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 // ---- P2 for slots [S0, S0+N): one lane per cell: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
 // own cell -> carried object (obs.py:182-207); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
-template <int V, int NW, int S0, int N, int VPW, bool STALE>
+template <int V, int NW, int S0, int N, int VPW>
 __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
                                              const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                              uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
@@ -192,7 +192,6 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
             const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
             uint32_t c = __builtin_amdgcn_alignbyte(hi[n][it], lo[n][it], sh[n][it]);   // byte 3 is junk from here on
             c = lc.own[it] ? r[n].carry : c;                                // obs.py:207
-            if (STALE) c = grid_view_of(c & 0xffffffu);                     // RedBlueDoors: what Grid.state says (Q9)
             cell[S0 + n][it] = c;
             const uint32_t t = c & 0xffu;                                   // obs.py:46-63 see_behind, as lane masks
             const uint64_t m = __builtin_amdgcn_ballot_w64(t != (uint32_t)T_WALL)
@@ -204,31 +203,16 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
     }
 }
 
-template <int V, int NW, int VPW, int S0, int N, bool STALE>
-__device__ __forceinline__ void gather_tail(int NVc, const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
-                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
-                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
-    if constexpr (N < 8 && S0 + N < VPW) {
-        if (S0 + N < NVc) {
-            gather_group<V, NW, S0 + N, 1, VPW, STALE>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-            gather_tail<V, NW, VPW, S0, N + 1, STALE>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-        }
-    }
-}
-
 constexpr int kGroup = 8;
 
-template <int V, int NW, int VPW, bool STALE, int S0 = 0>
+template <int V, int NW, int VPW, int S0 = 0>
 __device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
-        if (S0 + kGroup <= NVc) {
-            gather_group<V, NW, S0, kGroup, VPW, STALE>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-        } else if (S0 < NVc) {                                               // ragged last group: slot by slot
-            gather_tail<V, NW, VPW, S0, 0, STALE>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-        }
-        gather_all<V, NW, VPW, STALE, S0 + kGroup>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+        // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
+        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, S0 + kGroup>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
     }
 }
 
@@ -395,7 +379,9 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         AgentEval ev{};
         uint8_t *mytile = tile + env_of_lane * HW3;
         if (in && !(a.dbg & 64)) {
-            ev = eval_agent(cf, mytile, rows + env_of_lane * A, acts[lane], rows[lane], true);
+            const int so = (a.sp.env_kind == MGX_KIND_REDBLUEDOORS)
+                               ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), a.sp.env_kind) : -1;
+            ev = eval_agent(cf, mytile, rows + env_of_lane * A, acts[lane], rows[lane], true, so);
             woff[lane] = ev.writes ? ev.off : -1;
         }
         wave_sync();
@@ -409,6 +395,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         const bool fb = in && spec_needs_fallback(m_event & genv, m_conf & genv, m_pres & genv, m_moved & genv);
         if (in && !fb) {                                                         // commit
             if (ev.go) rows[lane] = ev.nrow;
+            if (ev.unstale) reinterpret_cast<uint8_t *>(auxl + env_of_lane)[4] = 0;
             if (ev.writes) {
                 store_cell(mytile + ev.off, ev.ncell);
                 if (!ROLL) {                                                     // ROLL writes the whole tile back at the end
@@ -439,7 +426,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                     if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
                 };
                 const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
-                                              scnt[e] + 1, dirty);
+                                              scnt[e] + 1, dirty, reinterpret_cast<uint8_t *>(auxl + e), a.sp.env_kind);
                 if (rc != 0 && a.err) { atomicAdd(a.err, 1); atomicMin(a.err + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
             }
             wave_sync();
@@ -460,8 +447,9 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             };
             uint8_t *eaux = reinterpret_cast<uint8_t *>(auxl + e);
             post_step_hook(cf, a.sp.env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
-            if (!ROLL && a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY && a.aux) {
-                a.aux[b * MGX_AUX_BYTES + 1] = eaux[1]; a.aux[b * MGX_AUX_BYTES + 15] = eaux[15];
+            if (!ROLL && a.aux) {                                                // the hook state the step may change
+                if (a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY) { a.aux[b * MGX_AUX_BYTES + 1] = eaux[1]; a.aux[b * MGX_AUX_BYTES + 15] = eaux[15]; }
+                if (a.sp.env_kind == MGX_KIND_REDBLUEDOORS) a.aux[b * MGX_AUX_BYTES + 4] = eaux[4];
             }
             a.truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
         }
@@ -498,6 +486,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             a.terminated[tv0 + lane] = (uint8_t)(row_term(row) | forced);        // base.py:338 (+ env hook)
         }
         if (a.dir) a.dir[tv0 + lane] = (uint8_t)row_dir(row);                    // base.py:359, 372
+    } else if (lane < ((NVc + kGroup - 1) & ~(kGroup - 1))) {                // padding slots of the last gather group
+        ViewRec r;
+        r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = CELL_WALL;
+        rec[lane] = r;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = 0;
     }
     wave_sync();
 
@@ -511,11 +505,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     for (int s = 0; s < VPW; ++s)
 #pragma unroll
         for (int it = 0; it < NW; ++it) cell[s][it] = 0;
-    if (!(a.dbg & 4)) {
-        // (two instantiations: only RedBlueDoors pays for mapping a stale-open door to what Grid.state says)
-        if (a.sp.env_kind == MGX_KIND_REDBLUEDOORS) gather_all<V, NW, VPW, true>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-        else gather_all<V, NW, VPW, false>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-    }
+    if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
         if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
@@ -605,7 +595,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
         if (lane < Gc) {
             a.step_count[e0 + lane] = scnt[lane];
-            if (a.aux && a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
+            if (a.aux && a.sp.env_kind >= MGX_KIND_REDBLUEDOORS) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
         }
     }
 }

@@ -21,11 +21,7 @@ namespace mgx {
 // multigrid/core/constants.py:34-48, 91-97 ; multigrid/core/actions.py:5-15
 enum : int { T_UNSEEN = 0, T_EMPTY = 1, T_WALL = 2, T_FLOOR = 3, T_DOOR = 4, T_KEY = 5, T_BALL = 6, T_BOX = 7,
              T_GOAL = 8, T_LAVA = 9, T_AGENT = 10 };
-enum : int { S_OPEN = 0, S_CLOSED = 1, S_LOCKED = 2,
-             // RedBlueDoors only (include/mgx.h): the Door OBJECT is closed but Grid.state still says open, because the
-             // env hook closes the object without grid.update (envs/redbluedoors.py:185).  The rules
-             // see a closed door, observations and Grid.state see an open one.
-             S_STALE_OPEN = 3 };
+enum : int { S_OPEN = 0, S_CLOSED = 1, S_LOCKED = 2 };
 enum : int { ACT_LEFT = 0, ACT_RIGHT = 1, ACT_FORWARD = 2, ACT_PICKUP = 3, ACT_DROP = 4, ACT_TOGGLE = 5, ACT_DONE = 6 };
 // packed agent row (include/mgx.h)
 enum : int { AG_COLOR = 0, AG_DIR = 1, AG_X = 2, AG_Y = 3, AG_TERM = 4, AG_CARRY = 5 };
@@ -244,10 +240,14 @@ struct AgentEval {
     bool success;         // it stepped on a goal  (base.py:433-434)
     bool failure;         // it stepped on lava    (base.py:435-436)
     bool used_presence;   // the outcome depended on where the other agents stand (base.py:425-429, 453-456)
+    bool unstale;         // it toggled the RedBlueDoors blue door whose object state had diverged from Grid.state
 };
 
+// `stale_off`: byte offset of a door whose WorldObj is CLOSED although Grid.state (the tile) says open, or -1.  Only
+// RedBlueDoors produces one: its hook closes the blue door object without grid.update (envs/redbluedoors.py:185,
+// SURVEY App. C Q9); the rules act on the object (Grid.get), observations on Grid.state.
 MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64_t *rows, int action, uint64_t row,
-                            bool alive) {
+                            bool alive, int stale_off = -1) {
     const int A = cf.A;
     AgentEval ev;
     // base.py:403-404 absent, 408-409 terminated
@@ -260,7 +260,8 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     ev.off = inb ? (fy * cf.W + fx) * 3 : 0;
     const uint32_t cell = load_cell(tile + ev.off);
     const uint32_t type = cell & 0xff, gstate = (cell >> 16) & 0xff;
-    const uint32_t state = (gstate == S_STALE_OPEN) ? (uint32_t)S_CLOSED : gstate;   // the WorldObj's own state
+    const bool stale = inb & (ev.off == stale_off);
+    const uint32_t state = stale ? (uint32_t)S_CLOSED : gstate;             // the WorldObj's own state
     const uint32_t carry = row_carry(row), ctype = carry & 0xff;
     const bool on_cell = ev.go & inb;
     ev.reads_cell = on_cell & (action >= ACT_FORWARD) & (action <= ACT_TOGGLE);
@@ -298,7 +299,8 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     uint64_t nrow = row_set_dir(row, nd);
     nrow = row_set_pos(nrow, fwd ? fx : x, fwd ? fy : y);
     ev.nrow = row_set_carry(nrow, ncarry);
-    ev.writes = door | pick | box | drop;
+    ev.unstale = tog & stale;                                               // Door.toggle + grid.update: object == grid again
+    ev.writes = door | pick | box | drop | ev.unstale;                      // (an unstale 'writes' the cell's meaning)
     ev.moved = fwd;
     ev.success = fwd & (type == T_GOAL);
     ev.failure = fwd & (type == T_LAVA);
@@ -306,16 +308,24 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
 }
 
 // The reference's loop (base.py:402-474): agents act one after the other in `ord`, each seeing the previous ones' effects.
+// `stale` points at the env's stale-door flag (aux[4] of a RedBlueDoors env) or is NULL.
+MGX_HD int stale_offset(const StepCfg &cf, const uint8_t *aux, int env_kind) {
+    return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.W + aux[0]) * 3 : -1;
+}
+
 template <class Dirty>
 MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, const int8_t *act,
-                          const uint8_t *ord, double *rew, int32_t step_count, Dirty dirty) {
+                          const uint8_t *ord, double *rew, int32_t step_count, Dirty dirty,
+                          uint8_t *aux = nullptr, int env_kind = MGX_KIND_EMPTY) {
     const int A = cf.A;
     int rc = 0;
     for (int k = 0; k < A; ++k) {
         const int i = (A == 1) ? 0 : ord[k];
-        const AgentEval ev = eval_agent(cf, tile, rows, act[i], rows[i], rc == 0);   // after an unknown action the reference has raised
+        const int so = aux ? stale_offset(cf, aux, env_kind) : -1;
+        const AgentEval ev = eval_agent(cf, tile, rows, act[i], rows[i], rc == 0, so);   // after an unknown action the reference has raised
         if (ev.bad) rc = MGX_ERR_UNKNOWN_ACTION;
         if (ev.go) rows[i] = ev.nrow;
+        if (ev.unstale) aux[4] = 0;
         if (ev.writes) { store_cell(tile + ev.off, ev.ncell); dirty(ev.off); }
         if (ev.success) on_success(cf, rows, i, step_count, rew);                // base.py:433-434
         if (ev.failure) set_terminated(rows, A, i, cf.failure_any);              // base.py:435-436, 509-532
@@ -346,11 +356,6 @@ MGX_HD bool spec_needs_fallback(uint64_t m_event, uint64_t m_conflict, uint64_t 
     return (m_event != 0) | (m_conflict != 0) | ((m_presence != 0) & (m_moved != 0));
 }
 
-// What a rendered / exported cell looks like: Grid.state, where a stale-open door still reads "open".
-MGX_HD uint32_t grid_view_of(uint32_t cell) {
-    return (((cell >> 16) & 0xffu) == (uint32_t)S_STALE_OPEN && (cell & 0xffu) == (uint32_t)T_DOOR) ? (cell & 0xffffu) : cell;
-}
-
 // The env subclasses' step() post-hooks, run after the base step on the CLEAN tile (no agent overlay) with the
 // post-step agent rows; `aux` is the env's 16-byte hook state (include/mgx.h).  The observation is not affected (the
 // reference renders before the hook); `terminated` / `reward` outputs are.
@@ -372,13 +377,12 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if (fx != aux[0] || fy != aux[1]) continue;                         // fwd_obj == self.blue_door
-            if (tile[boff + 2] != S_OPEN) continue;                             // ... and self.blue_door.is_open
+            if (tile[boff + 2] != S_OPEN || aux[4]) continue;                   // ... and self.blue_door.is_open (the OBJECT)
             if (tile[roff + 2] == S_OPEN) {
                 on_success(cf, rows, a, step_count, rew);
             } else {
                 set_terminated(rows, A, a, cf.failure_any);                      // on_failure
-                tile[boff + 2] = S_STALE_OPEN;                                   // blue_door.is_open = False, no grid.update
-                dirty(boff);
+                aux[4] = 1;                              // blue_door.is_open = False, no grid.update: Grid.state stays open
             }
         }
     } else if (env_kind == MGX_KIND_LOCKEDHALLWAY) {

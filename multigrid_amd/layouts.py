@@ -94,11 +94,8 @@ def grid_to_product(state_whc: np.ndarray) -> np.ndarray:
 
 
 def grid_from_product(grid_hwc: np.ndarray) -> np.ndarray:
-    """Product grid u8[...,H,W,3] -> what the reference's Grid.state (...,W,H,3) holds.  A RedBlueDoors door in the
-    internal state 3 (object closed, grid.state stale; include/mgx.h) reads "open" there, as in the reference."""
-    g = np.ascontiguousarray(np.swapaxes(np.asarray(grid_hwc), -3, -2)).astype(np.int64)
-    g[(g[..., 0] == Type.door) & (g[..., 2] == 3), 2] = 0
-    return g
+    """Product grid u8[...,H,W,3] -> the reference's Grid.state (...,W,H,3)."""
+    return np.ascontiguousarray(np.swapaxes(np.asarray(grid_hwc), -3, -2)).astype(np.int64)
 
 
 # ---- multigrid/base.py:604-697 -------------------------------------------------------------------------

@@ -509,20 +509,15 @@ int mgo_step_batch(const MgoSpec *sp, int64_t B, uint8_t *grid, uint8_t *agents,
             unpack_env(sp, grid + b * gsz, agents + (size_t)b * A * 8, gs, as);
             int64_t sc = step_count[b];
             for (int k = 0; k < MGO_AUX; ++k) tgt[k] = target ? target[b * MGO_AUX + k] : 0;
-            if (sp->env_kind == KIND_REDBLUEDOORS) {               /* product encoding: state 3 = object closed, grid says open */
-                int64_t *blue = gs + ((size_t)tgt[0] * H + tgt[1]) * 3;
-                tgt[4] = (blue[2] == 3);
-                if (tgt[4]) blue[2] = S_OPEN;
-            }
             int rc = mgo_step_ref(sp, gs, as, rng + b * 4, &sc, actions + (size_t)b * A, tgt, ob, dirs,
                                   reward + (size_t)b * A, terminated + (size_t)b * A, truncated + b, NULL);
             step_count[b] = (int32_t)sc;
-            if (sp->env_kind == KIND_REDBLUEDOORS && tgt[4]) gs[((size_t)tgt[0] * H + tgt[1]) * 3 + 2] = 3;
             pack_env(sp, gs, as, grid + b * gsz, agents + (size_t)b * A * 8);
             if (sp->env_kind == KIND_LOCKEDHALLWAY && target) {
                 ((uint8_t *)target)[b * MGO_AUX + 1] = (uint8_t)tgt[1];
                 ((uint8_t *)target)[b * MGO_AUX + 15] = (uint8_t)tgt[15];
             }
+            if (sp->env_kind == KIND_REDBLUEDOORS && target) ((uint8_t *)target)[b * MGO_AUX + 4] = (uint8_t)tgt[4];
             if (rc) {
 #pragma omp critical
                 { if (bad < 0 || b < bad) bad = b; }

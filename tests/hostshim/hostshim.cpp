@@ -44,7 +44,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
     std::vector<int32_t> woff(A);
     uint64_t m_event = 0, m_conf = 0, m_pres = 0, m_moved = 0;
     for (int ai = 0; ai < A; ++ai) {
-        ev[ai] = eval_agent(cf, tile, rows, act[ai], rows[ai], true);
+        ev[ai] = eval_agent(cf, tile, rows, act[ai], rows[ai], true, stale_offset(cf, aux, sp->env_kind));
         woff[ai] = ev[ai].writes ? ev[ai].off : -1;
     }
     for (int ai = 0; ai < A; ++ai) {
@@ -57,10 +57,11 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
     if (!fallback) {
         for (int ai = 0; ai < A; ++ai) {
             if (ev[ai].go) rows[ai] = ev[ai].nrow;
+            if (ev[ai].unstale) aux[4] = 0;
             if (ev[ai].writes) { store_cell(tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
         }
     } else {
-        rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty);
+        rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty, aux, sp->env_kind);
     }
     *n_dirty = fallback ? -nd - 1 : nd;          // negative = the sequential loop ran
     // the kernel's per-agent overlay (one lane per agent): offsets from the PRE-hook rows, cells written after the hook
@@ -101,7 +102,6 @@ static void obs_env(const MgxSpec *sp, const uint8_t *tile, const uint64_t *rows
             uint32_t c = CELL_WALL;
             if (in) c = load_cell(tile + g.origin + fw * g.stepF + la * g.stepL);
             if (i == V / 2 && j == V - 1) c = row_carry(row);
-            if (sp->env_kind == MGX_KIND_REDBLUEDOORS) c = grid_view_of(c);
             if (see_behind(c)) sb[k >> 6] |= 1ull << (k & 63);
             cells[i * V + j] = c;
         }
