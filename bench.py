@@ -152,6 +152,8 @@ def rollout_point(spec, batch, device, steps, first_env, seed):
            "reward": torch.empty((steps, batch, A), dtype=torch.float64, device=device),
            "terminated": torch.empty((steps, batch, A), dtype=torch.uint8, device=device),
            "truncated": torch.empty((steps, batch), dtype=torch.uint8, device=device)}
+    for v in out.values():
+        v.zero_()                                              # first touch of the fresh allocations, outside the timing
     stream = torch.cuda.current_stream(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)

@@ -47,18 +47,10 @@ struct KernelArgs {
     int32_t Gw;         // envs per wavefront
     int32_t dbg;        // debug: bit p set = skip phase p (profiling only, mgx_debug_skip_phases)
     int32_t T;          // steps per launch (mgx_rollout), 1 otherwise
-    // per-wavefront LDS slice: stride and carve (byte offsets inside the slice, all 16-byte aligned)
+    // per-wavefront LDS slice: its stride and the slot count its carve is derived from (LdsCarve below)
     int32_t wave_lds;
-    int32_t off_tile, off_rows, off_rec, off_inb, off_act, off_rng, off_rnd, off_ord, off_rew, off_scnt, off_tgt,
-        off_jump, off_out, off_wall, off_woff;
+    int32_t vpw;
 };
-
-struct LdsPlan {
-    int32_t off_tile, off_rows, off_rec, off_inb, off_act, off_rng, off_rnd, off_ord, off_rew, off_scnt, off_tgt,
-        off_jump, off_out, off_wall, off_woff, total;
-};
-
-inline int align16(int x) { return (x + 15) & ~15; }
 
 // per-view record written by P1d and read (broadcast) by the wavefront in P2
 struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
@@ -70,31 +62,40 @@ constexpr int kRound = 16;        // view slots whose obs bytes are staged in LD
 // View slots per wavefront = cell registers per lane (x passes per view).
 inline int slots_per_wave(int view_size) { return 32; (void)view_size; }
 
-// LDS slice of ONE wavefront holding Gw envs
-LdsPlan plan_lds(const MgxSpec &sp, int Gw) {
-    const int V = sp.view_size, A = sp.num_agents;
-    const int nw = (V * V + 63) / 64;
-    int vpw = (Gw * A + 15) & ~15;                 // slots in use (the kernel is compiled for slots_per_wave(V))
-    if (vpw > slots_per_wave(V)) vpw = slots_per_wave(V);
-    LdsPlan p;
-    int o = 0;
-    p.off_tile = o;  o = align16(o + Gw * sp.height * sp.width * 3 + 16 + 16);   // head skew + over-read
-    p.off_rows = o;  o = align16(o + vpw * MGX_AGENT_STRIDE);
-    p.off_rec = o;   o = align16(o + vpw * (int)sizeof(ViewRec));
-    p.off_inb = o;   o = align16(o + vpw * nw * 8);
-    p.off_act = o;   o = align16(o + vpw);
-    p.off_rng = o;   o = align16(o + Gw * 32);
-    p.off_rnd = o;   o = align16(o + vpw * 8);
-    p.off_ord = o;   o = align16(o + vpw);
-    p.off_rew = o;   o = align16(o + vpw * 8);
-    p.off_scnt = o;  o = align16(o + Gw * 4);
-    p.off_tgt = o;   o = align16(o + Gw * MGX_AUX_BYTES);
-    p.off_jump = o;  o = align16(o + (A + 1) * 32);
-    p.off_out = o;   o = align16(o + kRound * V * V * 3 + 16 + 16);               // obs bytes of one round, head skew + pad
-    p.off_wall = o;  o = align16(o + 8);                                         // one WALL cell (+ the dword read after it)
-    p.off_woff = o;  o = align16(o + vpw * 4);                                   // cell written by each agent (fast path)
-    p.total = o;
-    return p;
+// Carve of ONE wavefront's LDS slice (byte offsets, all multiples of 16).  Everything is a closed form of
+// (vpw, nw, Gw, A, tile bytes, round bytes) so the kernel recomputes an offset where it needs it instead of carrying
+// fifteen of them in SGPRs from the kernel arguments.  Per-slot arrays first (vpw = slots in use, a multiple of 16).
+struct LdsCarve {
+    int vpw, nw, Gw, A, tile_bytes, round_bytes;
+    __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
+    __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]
+    __host__ __device__ int rnd() const { return 24 * vpw; }                         // u64  [vpw]
+    __host__ __device__ int rew() const { return 32 * vpw; }                         // f64  [vpw]
+    __host__ __device__ int inb() const { return 40 * vpw; }                         // u64  [vpw][nw]
+    __host__ __device__ int woff() const { return (40 + 8 * nw) * vpw; }             // i32  [vpw]
+    __host__ __device__ int act() const { return (44 + 8 * nw) * vpw; }              // i8   [vpw]
+    __host__ __device__ int ord() const { return (45 + 8 * nw) * vpw; }              // u8   [vpw]
+    __host__ __device__ int rng() const { return (46 + 8 * nw) * vpw; }              // u64  [Gw][4]
+    __host__ __device__ int scnt() const { return rng() + 32 * Gw; }                 // i32  [Gw]
+    __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]
+    __host__ __device__ int jump() const { return aux() + 16 * Gw; }                 // u64  [A+1][4]
+    __host__ __device__ int wall() const { return jump() + 32 * (A + 1); }           // one WALL cell + the dword after it
+    __host__ __device__ int out() const { return wall() + 16; }                      // obs bytes of one round, skew + pad
+    __host__ __device__ int tile() const { return out() + round_bytes + 32; }        // grid bytes, head skew + over-read
+    __host__ __device__ int total() const { return (tile() + tile_bytes + 32 + 15) & ~15; }
+};
+
+__host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw) {
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * 3, kRound * V * V * 3};
+}
+
+inline int slots_in_use(const MgxSpec &sp, int Gw) {
+    int vpw = (Gw * sp.num_agents + 15) & ~15;     // (the kernel is compiled for slots_per_wave(V) slots)
+    return vpw > slots_per_wave(sp.view_size) ? slots_per_wave(sp.view_size) : vpw;
+}
+
+inline int wave_lds_bytes(const MgxSpec &sp, int Gw) {
+    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw)).total();
 }
 
 constexpr int kLdsPerCU = 160 * 1024;
@@ -105,7 +106,7 @@ constexpr int kLdsWaveBudget = 12 * 1024;     // keeps >= 12 wavefronts per CU r
 int choose_Gw(const MgxSpec &sp, int64_t batch) {
     int Gw = slots_per_wave(sp.view_size) / sp.num_agents;
     if (Gw < 1) Gw = 1;
-    while (Gw > 1 && plan_lds(sp, Gw).total > kLdsWaveBudget) --Gw;
+    while (Gw > 1 && wave_lds_bytes(sp, Gw) > kLdsWaveBudget) --Gw;
     while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
     while (Gw > 1 && (batch + Gw - 1) / Gw < 512) Gw = (Gw + 1) / 2;       // tiny batches: spread over the chip
     return Gw;
@@ -241,23 +242,24 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const int64_t v0 = e0 * A;                                // first (env, agent) row
 
     uint8_t *L = lds + wave * a.wave_lds;
-    uint64_t *rows = reinterpret_cast<uint64_t *>(L + a.off_rows);            // [slot] packed agent rows
-    ViewRec *rec = reinterpret_cast<ViewRec *>(L + a.off_rec);                // [slot]
-    uint64_t *inbw = reinterpret_cast<uint64_t *>(L + a.off_inb);             // [slot][NW] in-bounds lanes
-    int8_t *acts = reinterpret_cast<int8_t *>(L + a.off_act);                 // [slot]
-    uint64_t *rngs = reinterpret_cast<uint64_t *>(L + a.off_rng);             // [env][4]
-    uint64_t *rnd = reinterpret_cast<uint64_t *>(L + a.off_rnd);              // [slot] 53-bit draws
-    uint8_t *ord = L + a.off_ord;                                              // [slot] visiting order per env
-    double *rew = reinterpret_cast<double *>(L + a.off_rew);                  // [slot]
-    int32_t *scnt = reinterpret_cast<int32_t *>(L + a.off_scnt);              // [env]
-    uint4 *auxl = reinterpret_cast<uint4 *>(L + a.off_tgt);                   // [env] 16-byte hook state (include/mgx.h)
-    uint64_t *jump = reinterpret_cast<uint64_t *>(L + a.off_jump);            // [A+1][4]
+    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw);
+    uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
+    ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
+    uint64_t *inbw = reinterpret_cast<uint64_t *>(L + cv.inb());              // [slot][NW] in-bounds lanes
+    int8_t *acts = reinterpret_cast<int8_t *>(L + cv.act());                  // [slot]
+    uint64_t *rngs = reinterpret_cast<uint64_t *>(L + cv.rng());              // [env][4]
+    uint64_t *rnd = reinterpret_cast<uint64_t *>(L + cv.rnd());               // [slot] 53-bit draws
+    uint8_t *ord = L + cv.ord();                                               // [slot] visiting order per env
+    double *rew = reinterpret_cast<double *>(L + cv.rew());                   // [slot]
+    int32_t *scnt = reinterpret_cast<int32_t *>(L + cv.scnt());               // [env]
+    uint4 *auxl = reinterpret_cast<uint4 *>(L + cv.aux());                    // [env] 16-byte hook state (include/mgx.h)
+    uint64_t *jump = reinterpret_cast<uint64_t *>(L + cv.jump());             // [A+1][4]
 
     // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
     const int64_t g0 = e0 * HW3, g1 = g0 + (int64_t)Gc * HW3;       // byte range of these envs in `grid`
     const int64_t gtotal = a.batch * (int64_t)HW3;
     const int64_t ga = g0 & ~(int64_t)15;
-    uint8_t *tile_raw = L + a.off_tile;                              // holds global bytes [ga, ...)
+    uint8_t *tile_raw = L + cv.tile();                              // holds global bytes [ga, ...)
     const int tile_skew = (int)(g0 - ga);
     uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HW3
     // Every HBM load of the wavefront is issued here, back to back, into registers; then ONE unconditional
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         const int64_t t0 = gtotal & ~(int64_t)15;
         for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
     }
-    const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + a.off_wall);
-    if (lane == 0) *reinterpret_cast<uint32_t *>(L + a.off_wall) = CELL_WALL;
+    const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + cv.wall());
+    if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL_WALL;
     const int env_of_lane = lane / A, agent_of_lane = lane - env_of_lane * A;     // slot `lane` = (env, agent)
     if (lane < NVc) {
         rows[lane] = in_row;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
         // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
         // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
-        int32_t *woff = reinterpret_cast<int32_t *>(L + a.off_woff);            // [slot]
+        int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
         AgentEval ev{};
         uint8_t *mytile = tile + env_of_lane * HW3;
         if (in && !(a.dbg & 64)) {
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     wave_sync();
 
     // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
-    const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + a.off_tile + tile_skew);   // LDS address of env 0 cell 0
+    const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + cv.tile() + tile_skew);   // LDS address of env 0 cell 0
     if (lane < NVc) {
         const int e = env_of_lane;
         const uint64_t row = rows[lane];
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     // P4 masks each cell and transposes it into the obs byte layout in LDS, P5 streams the round to HBM in 16-byte vectors
     const int64_t o0 = tv0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;  // this wave's obs bytes (of step t)
     const int out_skew = (int)(o0 & 15);                                        // the same for every round
-    uint8_t *out_raw = L + a.off_out;                                          // obs bytes [oa_r, ...) of round r
+    uint8_t *out_raw = L + cv.out();                                          // obs bytes [oa_r, ...) of round r
     uint8_t *outb = out_raw + out_skew;
     constexpr int kRoundBytes = kRound * V2 * 3;                                // multiple of 16
 #pragma unroll
@@ -635,7 +637,7 @@ int check_spec(const MgxSpec *sp, int64_t batch) {
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
     if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_LOCKEDHALLWAY) return MGX_ERR_UNSUPPORTED;
-    if (plan_lds(*sp, 1).total > kLdsPerCU) return MGX_ERR_UNSUPPORTED;              // one env must fit one CU's LDS
+    if (wave_lds_bytes(*sp, 1) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;              // one env must fit one CU's LDS
     return MGX_OK;
 }
 
@@ -646,14 +648,11 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     const int max_gw = slots_per_wave(sp->view_size) / sp->num_agents;
     if (ka.Gw > max_gw) ka.Gw = max_gw;
     if (ka.Gw < 1) ka.Gw = 1;
-    while (ka.Gw > 1 && plan_lds(*sp, ka.Gw).total > kLdsPerCU) --ka.Gw;
+    while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
-    const LdsPlan p = plan_lds(*sp, ka.Gw);
-    ka.wave_lds = p.total;
-    ka.off_tile = p.off_tile; ka.off_rows = p.off_rows; ka.off_rec = p.off_rec; ka.off_inb = p.off_inb;
-    ka.off_act = p.off_act; ka.off_rng = p.off_rng; ka.off_rnd = p.off_rnd; ka.off_ord = p.off_ord;
-    ka.off_rew = p.off_rew; ka.off_scnt = p.off_scnt; ka.off_tgt = p.off_tgt; ka.off_jump = p.off_jump;
-    ka.off_out = p.off_out; ka.off_wall = p.off_wall; ka.off_woff = p.off_woff;
+    ka.vpw = slots_in_use(*sp, ka.Gw);
+    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw);
+    struct { int total; } p{ka.wave_lds};
     int wpb = 4;                                          // wavefronts bundled per workgroup
     while (wpb > 1 && wpb * p.total > 64 * 1024) wpb >>= 1;
     threads = 64 * wpb;
