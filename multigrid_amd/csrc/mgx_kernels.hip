@@ -57,10 +57,14 @@ struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 byte
 
 typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
 
+#ifndef MGX_SLOTS_SMALL_VIEW
+#define MGX_SLOTS_SMALL_VIEW 32
+#endif
+constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 constexpr int kRound = 16;        // view slots whose obs bytes are staged in LDS at a time (P4/P5)
 
 // View slots per wavefront = cell registers per lane (x passes per view).
-inline int slots_per_wave(int view_size) { return 32; (void)view_size; }
+inline int slots_per_wave(int view_size) { return view_size <= 7 ? kSlotsSmallView : 32; }
 
 // Carve of ONE wavefront's LDS slice (byte offsets, all multiples of 16).  Everything is a closed form of
 // (vpw, nw, Gw, A, tile bytes, round bytes) so the kernel recomputes an offset where it needs it instead of carrying
@@ -68,20 +72,24 @@ inline int slots_per_wave(int view_size) { return 32; (void)view_size; }
 struct LdsCarve {
     int vpw, nw, Gw, A, tile_bytes, round_bytes;
     __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
+    // -- per-step temporaries, all dead once P2 has gathered the cells; `out` (P4/P5 staging) reuses their space --
     __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]
     __host__ __device__ int rnd() const { return 24 * vpw; }                         // u64  [vpw]
     __host__ __device__ int rew() const { return 32 * vpw; }                         // f64  [vpw]
     __host__ __device__ int inb() const { return 40 * vpw; }                         // u64  [vpw][nw]
     __host__ __device__ int woff() const { return (40 + 8 * nw) * vpw; }             // i32  [vpw]
-    __host__ __device__ int act() const { return (44 + 8 * nw) * vpw; }              // i8   [vpw]
-    __host__ __device__ int ord() const { return (45 + 8 * nw) * vpw; }              // u8   [vpw]
-    __host__ __device__ int rng() const { return (46 + 8 * nw) * vpw; }              // u64  [Gw][4]
+    __host__ __device__ int temps_end() const { return (44 + 8 * nw) * vpw; }
+    __host__ __device__ int out() const { return rec(); }                            // obs bytes of one round, skew + pad
+    __host__ __device__ int out_end() const { return (out() + round_bytes + 32 + 15) & ~15; }
+    // -- state that lives across phases / steps --
+    __host__ __device__ int act() const { return temps_end() > out_end() ? temps_end() : out_end(); }   // i8 [vpw]
+    __host__ __device__ int ord() const { return act() + vpw; }                      // u8   [vpw]
+    __host__ __device__ int rng() const { return ord() + vpw; }                      // u64  [Gw][4]
     __host__ __device__ int scnt() const { return rng() + 32 * Gw; }                 // i32  [Gw]
     __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]
     __host__ __device__ int jump() const { return aux() + 16 * Gw; }                 // u64  [A+1][4]
     __host__ __device__ int wall() const { return jump() + 32 * (A + 1); }           // one WALL cell + the dword after it
-    __host__ __device__ int out() const { return wall() + 16; }                      // obs bytes of one round, skew + pad
-    __host__ __device__ int tile() const { return out() + round_bytes + 32; }        // grid bytes, head skew + over-read
+    __host__ __device__ int tile() const { return wall() + 16; }                     // grid bytes, head skew + over-read
     __host__ __device__ int total() const { return (tile() + tile_bytes + 32 + 15) & ~15; }
 };
 
@@ -99,7 +107,10 @@ inline int wave_lds_bytes(const MgxSpec &sp, int Gw) {
 }
 
 constexpr int kLdsPerCU = 160 * 1024;
-constexpr int kLdsWaveBudget = 12 * 1024;     // keeps >= 12 wavefronts per CU resident
+#ifndef MGX_LDS_WAVE_BUDGET
+#define MGX_LDS_WAVE_BUDGET (12 * 1024)
+#endif
+constexpr int kLdsWaveBudget = MGX_LDS_WAVE_BUDGET;     // keeps >= 12 wavefronts per CU resident
 
 // Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
 // to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     constexpr bool ROLL = MODE == 2;
     constexpr int V2 = V * V;
     constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
-    constexpr int VPW = 32;                      // view slots per wavefront (== slots_per_wave)
+    constexpr int VPW = V <= 7 ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave)
     extern __shared__ __align__(16) uint8_t lds[];
 
     const int lane = threadIdx.x & 63;

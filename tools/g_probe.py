@@ -13,7 +13,7 @@ for B in [int(x) for x in sys.argv[1:]] or [1 << 20]:
     i = [0]
     def step():
         env.step(acts[i[0] & 3]); i[0] += 1
-    for G in (4, 8):
+    for G in (4, 8, 16):
         _lib.lib().mgx_debug_set_envs_per_wavefront(G)
         t = bench.kernel_time_ms(step, 30, dev) * 1e3
         o = bench.kernel_time_ms(env.gen_obs, 30, dev) * 1e3
