@@ -92,7 +92,7 @@ def timed_rollout(env, actions, mode, dist_barrier):
 def kernel_time_ms(fn, iters, device):
     """Average duration of `fn`'s single kernel launch: `iters` back-to-back launches between two HIP events."""
     stream = torch.cuda.current_stream(device)
-    for _ in range(3):
+    for _ in range(max(3, iters // 2)):          # also lets the clocks settle
         fn()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
@@ -127,8 +127,8 @@ def large_batch_points(spec, device, large_batch):
 
     def step():
         env.step(acts[i[0] & 3]); i[0] += 1
-    ms_step = kernel_time_ms(step, 20, device)
-    ms_obs = kernel_time_ms(env.gen_obs, 20, device)
+    ms_step = kernel_time_ms(step, 60, device)
+    ms_obs = kernel_time_ms(env.gen_obs, 60, device)
     n = large_batch * spec.num_agents
     r_step = roofline(n * spec.bytes_step(), ms_step, pmc_traffic("step", large_batch))
     r_step.update(batch=large_batch, kernel="mgx_fused_kernel<7,step>", ms_per_launch=round(ms_step, 4),

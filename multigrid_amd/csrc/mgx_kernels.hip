@@ -71,30 +71,38 @@ inline int slots_per_wave(int view_size) { return view_size <= 7 ? kSlotsSmallVi
 // fifteen of them in SGPRs from the kernel arguments.  Per-slot arrays first (vpw = slots in use, a multiple of 16).
 struct LdsCarve {
     int vpw, nw, Gw, A, tile_bytes, round_bytes;
+    bool roll;      // mgx_rollout: tile and PCG64 state live across steps (no aliasing of the tile, rng kept in LDS)
+    bool has_aux;   // env kinds with hook state
     __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
-    // -- per-step temporaries, all dead once P2 has gathered the cells; `out` (P4/P5 staging) reuses their space --
+    // -- per-step temporaries, all dead once P2 has gathered the cells --
     __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]
     __host__ __device__ int rnd() const { return 24 * vpw; }                         // u64  [vpw]
     __host__ __device__ int rew() const { return 32 * vpw; }                         // f64  [vpw]
     __host__ __device__ int inb() const { return 40 * vpw; }                         // u64  [vpw][nw]
     __host__ __device__ int woff() const { return (40 + 8 * nw) * vpw; }             // i32  [vpw]
     __host__ __device__ int temps_end() const { return (44 + 8 * nw) * vpw; }
-    __host__ __device__ int out() const { return rec(); }                            // obs bytes of one round, skew + pad
-    __host__ __device__ int out_end() const { return (out() + round_bytes + 32 + 15) & ~15; }
     // -- state that lives across phases / steps --
-    __host__ __device__ int act() const { return temps_end() > out_end() ? temps_end() : out_end(); }   // i8 [vpw]
+    __host__ __device__ int act() const { return temps_end(); }                      // i8   [vpw]
     __host__ __device__ int ord() const { return act() + vpw; }                      // u8   [vpw]
-    __host__ __device__ int rng() const { return ord() + vpw; }                      // u64  [Gw][4]
-    __host__ __device__ int scnt() const { return rng() + 32 * Gw; }                 // i32  [Gw]
-    __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]
-    __host__ __device__ int jump() const { return aux() + 16 * Gw; }                 // u64  [A+1][4]
-    __host__ __device__ int wall() const { return jump() + 32 * (A + 1); }           // one WALL cell + the dword after it
-    __host__ __device__ int tile() const { return wall() + 16; }                     // grid bytes, head skew + over-read
-    __host__ __device__ int total() const { return (tile() + tile_bytes + 32 + 15) & ~15; }
+    __host__ __device__ int rng() const { return ord() + vpw; }                      // u64  [Gw][4]   (rollout only)
+    __host__ __device__ int scnt() const { return rng() + (roll ? 32 * Gw : 0); }    // i32  [Gw]
+    __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
+    __host__ __device__ int jump() const { return aux() + (has_aux ? 16 * Gw : 0); } // u64  [A][4]: k = 1..A
+    __host__ __device__ int wall() const { return jump() + 32 * A; }                 // one WALL cell + the dword after it
+    // P4/P5 staging of one round's obs bytes (skew + pad).  One-step kernels put it over the tile, which is dead once
+    // P2 has gathered the cells; the rollout keeps the tile and uses the (equally dead) temporaries' space + its own.
+    __host__ __device__ int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
+    __host__ __device__ int own_out() const { return wall() + 16; }
+    __host__ __device__ int tile() const { return roll ? own_out() + out_bytes() : own_out(); }   // grid bytes, skew + over-read
+    __host__ __device__ int out() const { return roll ? own_out() : tile(); }
+    __host__ __device__ int total() const {
+        const int t = tile_bytes + 32 > out_bytes() || roll ? tile_bytes + 32 : out_bytes();
+        return (tile() + t + 15) & ~15;
+    }
 };
 
-__host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw) {
-    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * 3, kRound * V * V * 3};
+__host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux) {
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * 3, kRound * V * V * 3, roll, has_aux};
 }
 
 inline int slots_in_use(const MgxSpec &sp, int Gw) {
@@ -102,8 +110,9 @@ inline int slots_in_use(const MgxSpec &sp, int Gw) {
     return vpw > slots_per_wave(sp.view_size) ? slots_per_wave(sp.view_size) : vpw;
 }
 
-inline int wave_lds_bytes(const MgxSpec &sp, int Gw) {
-    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw)).total();
+inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false) {
+    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw), roll,
+                      sp.env_kind != MGX_KIND_EMPTY).total();
 }
 
 constexpr int kLdsPerCU = 160 * 1024;
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const int64_t v0 = e0 * A;                                // first (env, agent) row
 
     uint8_t *L = lds + wave * a.wave_lds;
-    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw);
+    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, a.sp.env_kind != MGX_KIND_EMPTY);
     uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
     ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
     uint64_t *inbw = reinterpret_cast<uint64_t *>(L + cv.inb());              // [slot][NW] in-bounds lanes
@@ -290,7 +299,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         tv[u] = make_uint4(0, 0, 0, 0);
         if (tok[u]) tv[u] = *reinterpret_cast<const uint4 *>(gsrc + rel);
     }
-    uint64_t in_row = 0, in_rng0 = 0, in_rng1 = 0, in_jump = 0;
+    uint64_t in_row = 0, in_rng0 = 0, in_rng1 = 0;
+    uint64_t my_rng[4] = {0, 0, 0, 0};                                       // one-step kernels: this lane's env's PCG64 words
     int32_t in_scnt = 0;
     uint4 in_aux = make_uint4(0, 0, 0, 0);
     int8_t in_act = 0;
@@ -300,16 +310,20 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     if (DO_STEP) {
         if (A > 1) {
-            if (lane < Gc * 4) in_rng0 = a.rng[e0 * 4 + lane];
-            if (lane + 64 < Gc * 4) in_rng1 = a.rng[e0 * 4 + lane + 64];
-            for (int t = lane; t < (A + 1) * 4; t += 64) jump[t] = kJump.w[0][t];   // A >= 16 only: more than one pass
+            if (ROLL) {
+                if (lane < Gc * 4) in_rng0 = a.rng[e0 * 4 + lane];
+                if (lane + 64 < Gc * 4) in_rng1 = a.rng[e0 * 4 + lane + 64];
+            } else if (lane < NVc) {                                             // same address for the A lanes of an env
+                const uint64_t *src = a.rng + (e0 + lane / A) * 4;
+                my_rng[0] = src[0]; my_rng[1] = src[1]; my_rng[2] = src[2]; my_rng[3] = src[3];
+            }
+            for (int t = lane; t < A * 4; t += 64) jump[t] = kJump.w[1][t];          // constants for k = 1..A
         }
         if (lane < Gc) {
             in_scnt = a.step_count[e0 + lane];
             if (a.aux) in_aux = reinterpret_cast<const uint4 *>(a.aux)[e0 + lane];
         }
     }
-    (void)in_jump;
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -331,10 +345,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     if (DO_STEP) {
         if (A > 1) {
-            if (lane < Gc * 4) rngs[lane] = in_rng0;
-            if (lane + 64 < Gc * 4) rngs[lane + 64] = in_rng1;
+            if (ROLL) {
+                if (lane < Gc * 4) rngs[lane] = in_rng0;
+                if (lane + 64 < Gc * 4) rngs[lane + 64] = in_rng1;
+            }
         }
-        if (lane < Gc) { scnt[lane] = in_scnt; auxl[lane] = in_aux; }
+        if (lane < Gc) { scnt[lane] = in_scnt; if (cv.has_aux) auxl[lane] = in_aux; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
     wave_sync();
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             if (in) {
                 const int e = env_of_lane, ai = agent_of_lane;
                 uint64_t s_lo, s_hi;
-                rnd[lane] = pcg64_draw_at(rngs + e * 4, jump + (ai + 1) * 4, s_lo, s_hi);   // base.py:399
+                rnd[lane] = pcg64_draw_at(ROLL ? rngs + e * 4 : my_rng, jump + ai * 4, s_lo, s_hi);   // base.py:399
                 if (ai == A - 1) {                                                // the env's stream after A draws
                     if (ROLL) { rngs[e * 4 + 0] = s_lo; rngs[e * 4 + 1] = s_hi; }          // (every lane has read it: in-order LDS)
                     else { a.rng[(e0 + e) * 4 + 0] = s_lo; a.rng[(e0 + e) * 4 + 1] = s_hi; }
@@ -616,6 +632,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 int g_last_hip_error = 0;
 int g_debug_skip = 0;
 int g_debug_G = 0;
+int g_debug_wpb = 0;
 
 template <int MODE>
 int launch(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
@@ -652,7 +669,8 @@ int check_spec(const MgxSpec *sp, int64_t batch) {
     return MGX_OK;
 }
 
-int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg) {
+int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg,
+              bool roll = false) {
     ka.sp = *sp;
     ka.batch = batch;
     ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch);
@@ -662,10 +680,13 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
     ka.vpw = slots_in_use(*sp, ka.Gw);
-    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw);
+    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll);
     struct { int total; } p{ka.wave_lds};
-    int wpb = 4;                                          // wavefronts bundled per workgroup
+    // wavefronts bundled per workgroup: 2 packs a CU's 160 KiB of LDS tighter than 4 once the chip is full (measured
+    // 403 vs 425 us at 1M envs); below that, fewer and larger workgroups launch faster (9.9 vs 10.5 us at 4096 envs)
+    int wpb = ((batch + ka.Gw - 1) / ka.Gw >= 16384) ? 2 : 4;
     while (wpb > 1 && wpb * p.total > 64 * 1024) wpb >>= 1;
+    if (g_debug_wpb > 0) wpb = g_debug_wpb;
     threads = 64 * wpb;
     lds_bytes = wpb * p.total;
     const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
@@ -699,6 +720,7 @@ int mgx_last_hip_error(void) { return g_last_hip_error; }
 // then meaningless; tools/phase_probe.py uses it to attribute kernel time to phases.
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
+void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
 
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     int rc = check_spec(spec, batch);
@@ -777,7 +799,7 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid
         return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, /*roll=*/true);
     if (rc) return rc;
     ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
     ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
