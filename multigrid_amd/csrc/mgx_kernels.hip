@@ -50,12 +50,47 @@ struct KernelArgs {
     // per-wavefront LDS slice: its stride and the slot count its carve is derived from (LdsCarve below)
     int32_t wave_lds;
     int32_t vpw;
+    int32_t inv_A;      // ceil(2^16 / A): (lane * inv_A) >> 16 == lane / A for lane < 64
 };
+
+// gfx950's LDS does take a dword / short access at any byte address (hipcc emits one ds_read_b32 for an align-1 load),
+// but measured it is far slower than the aligned pair + v_alignbyte: 1M envs, fused step 371 us aligned, 581 us with
+// unaligned reads in P2, 602 us with unaligned 16-bit writes in P4, 882 us with both.  Kept for the record only.
+#ifndef MGX_UA_READ
+#define MGX_UA_READ 0
+#endif
+#ifndef MGX_UA_WRITE
+#define MGX_UA_WRITE 0
+#endif
+#ifndef MGX_LATE_ARGS
+#define MGX_LATE_ARGS 1
+#endif
+#ifndef MGX_BUF_STORE
+#define MGX_BUF_STORE 1
+#endif
+
+// A kernel argument fetched where it is used (s_load from the kernarg segment) instead of living in SGPRs from the
+// kernel's first instruction on: the fused kernel is short of SGPRs, and every spilled one costs VALU
+// v_writelane / v_readlane instructions on a VALU-bound kernel.  Only for the fields used late and rarely.
+template <typename T>
+__device__ __forceinline__ T kernarg_at(size_t offset) {
+    typedef const char __attribute__((address_space(4))) *cptr;
+    typedef const T __attribute__((address_space(4))) *tptr;
+    return *(tptr)((cptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+#if MGX_LATE_ARGS
+#define MGX_LATE(field) kernarg_at<decltype(KernelArgs::field)>(offsetof(KernelArgs, field))
+#else
+#define MGX_LATE(field) (a.field)
+#endif
 
 // per-view record written by P1d and read (broadcast) by the wavefront in P2
 struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
 
 typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef const u32_unaligned __attribute__((address_space(3))) *lds_u32_ua_ptr;
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 
 #ifndef MGX_SLOTS_SMALL_VIEW
 #define MGX_SLOTS_SMALL_VIEW 32
@@ -134,6 +169,13 @@ int choose_Gw(const MgxSpec &sp, int64_t batch) {
 
 __device__ const JumpTable kJump{};
 
+// -DMGX_MARKERS=1 (tools/isa_phase_count.py): comment lines in the assembly that delimit the phases
+#if MGX_MARKERS
+#define MGX_MARK(name) asm volatile("; MGX_MARK " name ::: "memory")
+#else
+#define MGX_MARK(name) ((void)0)
+#endif
+
 // LDS traffic between lanes of ONE wavefront needs no s_barrier (the LDS executes a wave's operations in order);
 // this only stops the compiler from moving LDS accesses across the phase boundary.
 __device__ __forceinline__ void wave_sync() {
@@ -168,14 +210,23 @@ __device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t sval, const 
 #endif
 }
 
+// Raw buffer resource over `bytes` bytes at `base` (wave-uniform).  Lanes whose offset falls outside read zeros and
+// their stores are dropped, so the bulk copies need neither per-lane predicates nor 64-bit VALU address arithmetic.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
 template <int V, int NIT>
 struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V + i
     int la[NIT], fw[NIT], q3[NIT];
     bool act[NIT], own[NIT];
 };
 
-// ---- P2 for slots [S0, S0+N): one lane per cell: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
-// own cell -> carried object (obs.py:182-207); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.
+// ---- P2 for slots [S0, S0+N): one lane per cell: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall
+// (obs.py:182-202); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.  The agent's own cell still
+// shows the grid here; lane s patches the carried object in afterwards (P3: its see-behind bit, P4: its bytes).
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
 template <int V, int NW, int S0, int N, int VPW>
 __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
@@ -190,7 +241,10 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
 #pragma unroll
         for (int it = 0; it < NW; ++it) inbm[n][it] = inbw[(S0 + n) * NW + it];
     }
+    uint32_t raw[N][NW];
+#if !MGX_UA_READ
     uint32_t lo[N][NW], hi[N][NW], sh[N][NW];
+#endif
     bool inb[N][NW];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -201,8 +255,12 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
             // wavefront's WALL cell instead (obs.py:199-202)
             const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
             const uint32_t addr = inb[n][it] ? (uint32_t)off : wall_addr;
-            const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(addr & ~3u);             // LDS byte address -> its dword pair
+#if MGX_UA_READ
+            raw[n][it] = *(lds_u32_ua_ptr)(uintptr_t)addr;                  // one unaligned ds_read_b32: cell + a junk byte
+#else
+            const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(addr & ~3u);     // LDS byte address -> its dword pair
             lo[n][it] = p[0]; hi[n][it] = p[1]; sh[n][it] = addr & 3u;
+#endif
         }
     }
 #pragma unroll
@@ -211,13 +269,15 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
         for (int it = 0; it < NW; ++it) {
             constexpr uint64_t kAll = ~0ull;
             const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
-            uint32_t c = __builtin_amdgcn_alignbyte(hi[n][it], lo[n][it], sh[n][it]);   // byte 3 is junk from here on
-            c = lc.own[it] ? r[n].carry : c;                                // obs.py:207
+#if !MGX_UA_READ
+            raw[n][it] = __builtin_amdgcn_alignbyte(hi[n][it], lo[n][it], sh[n][it]);
+#endif
+            const uint32_t c = raw[n][it];                                  // (byte 3 is junk from here on)
             cell[S0 + n][it] = c;
-            const uint32_t t = c & 0xffu;                                   // obs.py:46-63 see_behind, as lane masks
+            const uint32_t t = c & 0xffu, st = (c >> 16) & 0xffu;           // obs.py:46-63 see_behind, as lane masks
             const uint64_t m = __builtin_amdgcn_ballot_w64(t != (uint32_t)T_WALL)
                              & (__builtin_amdgcn_ballot_w64(t != (uint32_t)T_DOOR)
-                                | __builtin_amdgcn_ballot_w64((c & 0xff0000u) == 0)) & act_mask;
+                                | __builtin_amdgcn_ballot_w64(st == 0)) & act_mask;
             sbLo[it] = set_lane(sbLo[it], (uint32_t)m, S0 + n);
             sbHi[it] = set_lane(sbHi[it], (uint32_t)(m >> 32), S0 + n);
         }
@@ -275,6 +335,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint4 *auxl = reinterpret_cast<uint4 *>(L + cv.aux());                    // [env] 16-byte hook state (include/mgx.h)
     uint64_t *jump = reinterpret_cast<uint64_t *>(L + cv.jump());             // [A+1][4]
 
+    MGX_MARK("P0");
     // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
     const int64_t g0 = e0 * HW3, g1 = g0 + (int64_t)Gc * HW3;       // byte range of these envs in `grid`
     const int64_t gtotal = a.batch * (int64_t)HW3;
@@ -290,71 +351,63 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const uint8_t *gsrc = a.grid + ga;
     const int len = (int)(g1 - ga);
     const int avail = (int)min(gtotal - ga, (int64_t)INT_MAX);               // bytes readable from gsrc
-    uint4 tv[U];
-    bool tok[U];
+    const int grec = (a.dbg & 1) ? 0 : min((len + 15) & ~15, avail);
+    const __amdgpu_buffer_rsrc_t grsrc = make_rsrc(gsrc, grec);
+    const int lane16 = 16 * lane;
+    u32x4 tv[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int rel = 16 * lane + 16 * 64 * u;
-        tok[u] = (rel < len) & (rel + 16 <= avail) & !(a.dbg & 1);
-        tv[u] = make_uint4(0, 0, 0, 0);
-        if (tok[u]) tv[u] = *reinterpret_cast<const uint4 *>(gsrc + rel);
-    }
-    uint64_t in_row = 0, in_rng0 = 0, in_rng1 = 0;
-    uint64_t my_rng[4] = {0, 0, 0, 0};                                       // one-step kernels: this lane's env's PCG64 words
-    int32_t in_scnt = 0;
-    uint4 in_aux = make_uint4(0, 0, 0, 0);
-    int8_t in_act = 0;
-    if (lane < NVc) {
-        in_row = reinterpret_cast<const uint64_t *>(a.agents)[v0 + lane];
-        if (DO_STEP) in_act = a.actions[v0 + lane];
-    }
+    for (int u = 0; u < U; ++u)
+        tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
+    const int env_of_lane = (lane * a.inv_A) >> 16, agent_of_lane = lane - env_of_lane * A;   // slot `lane` = (env, agent)
+    u32x2 in_row = {0, 0};
+    u32x4 in_rngA = {0, 0, 0, 0}, in_rngB = {0, 0, 0, 0};                    // this lane's env's PCG64 words (ROLL: two envs' halves)
+    uint32_t in_scnt = 0;
+    u32x4 in_aux = {0, 0, 0, 0};
+    uint8_t in_act = 0;
+    in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
     if (DO_STEP) {
+        in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0, 0);
         if (A > 1) {
-            if (ROLL) {
-                if (lane < Gc * 4) in_rng0 = a.rng[e0 * 4 + lane];
-                if (lane + 64 < Gc * 4) in_rng1 = a.rng[e0 * 4 + lane + 64];
-            } else if (lane < NVc) {                                             // same address for the A lanes of an env
-                const uint64_t *src = a.rng + (e0 + lane / A) * 4;
-                my_rng[0] = src[0]; my_rng[1] = src[1]; my_rng[2] = src[2]; my_rng[3] = src[3];
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.rng + e0 * 4, Gc * 32);
+            if (ROLL) {                                                          // env-major copy: lane l holds words 2l, 2l+1
+                in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, lane16, 0, 0);
+            } else {                                                             // same address for the A lanes of an env
+                in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32, 0, 0);
+                in_rngB = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32 + 16, 0, 0);
             }
             for (int t = lane; t < A * 4; t += 64) jump[t] = kJump.w[1][t];          // constants for k = 1..A
         }
-        if (lane < Gc) {
-            in_scnt = a.step_count[e0 + lane];
-            if (a.aux) in_aux = reinterpret_cast<const uint4 *>(a.aux)[e0 + lane];
-        }
+        in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0, 0);
+        if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (tok[u]) *reinterpret_cast<uint4 *>(tile_raw + 16 * lane + 16 * 64 * u) = tv[u];
-    for (int rel = 16 * lane + 16 * 64 * U; rel < len; rel += 16 * 64)          // tiles larger than one pass
-        if ((rel + 16 <= avail) & !(a.dbg & 1))
-            *reinterpret_cast<uint4 *>(tile_raw + rel) = *reinterpret_cast<const uint4 *>(gsrc + rel);
+        if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
+    for (int rel = lane16 + 1024 * U; rel < len; rel += 1024)                   // tiles larger than one pass
+        *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, 0);
     if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
         const int64_t t0 = gtotal & ~(int64_t)15;
         for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
     }
     const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + cv.wall());
     if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL_WALL;
-    const int env_of_lane = lane / A, agent_of_lane = lane - env_of_lane * A;     // slot `lane` = (env, agent)
+    uint64_t my_rng[4];                                                      // one-step kernels: PCG64 words in registers
+    my_rng[0] = ((uint64_t)in_rngA.y << 32) | in_rngA.x; my_rng[1] = ((uint64_t)in_rngA.w << 32) | in_rngA.z;
+    my_rng[2] = ((uint64_t)in_rngB.y << 32) | in_rngB.x; my_rng[3] = ((uint64_t)in_rngB.w << 32) | in_rngB.z;
     if (lane < NVc) {
-        rows[lane] = in_row;
+        reinterpret_cast<u32x2 *>(rows)[lane] = in_row;
         rew[lane] = 0.0;                                                         // base.py:393
-        if (DO_STEP) acts[lane] = in_act;
+        if (DO_STEP) acts[lane] = (int8_t)in_act;
     }
     if (DO_STEP) {
-        if (A > 1) {
-            if (ROLL) {
-                if (lane < Gc * 4) rngs[lane] = in_rng0;
-                if (lane + 64 < Gc * 4) rngs[lane + 64] = in_rng1;
-            }
-        }
-        if (lane < Gc) { scnt[lane] = in_scnt; if (cv.has_aux) auxl[lane] = in_aux; }
+        if (A > 1 && ROLL && lane < Gc * 2) reinterpret_cast<u32x4 *>(rngs)[lane] = in_rngA;
+        if (lane < Gc) { scnt[lane] = (int32_t)in_scnt; if (cv.has_aux) reinterpret_cast<u32x4 *>(auxl)[lane] = in_aux; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
     wave_sync();
 
+    MGX_MARK("P0end");
     // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
     // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
     auto lane_consts = [&]() {
@@ -391,6 +444,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     if (DO_STEP && !(a.dbg & 2)) {
         const bool in = lane < NVc;
         if (A > 1 && !(a.dbg & 128)) {
+            MGX_MARK("P1a");
             // -------------------------------------------------------------- P1a: one lane per (env, agent): its draw
             if (in) {
                 const int e = env_of_lane, ai = agent_of_lane;
@@ -398,10 +452,11 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 rnd[lane] = pcg64_draw_at(ROLL ? rngs + e * 4 : my_rng, jump + ai * 4, s_lo, s_hi);   // base.py:399
                 if (ai == A - 1) {                                                // the env's stream after A draws
                     if (ROLL) { rngs[e * 4 + 0] = s_lo; rngs[e * 4 + 1] = s_hi; }          // (every lane has read it: in-order LDS)
-                    else { a.rng[(e0 + e) * 4 + 0] = s_lo; a.rng[(e0 + e) * 4 + 1] = s_hi; }
+                    else { uint64_t *dst = MGX_LATE(rng) + (e0 + e) * 4; dst[0] = s_lo; dst[1] = s_hi; }
                 }
             }
         }
+        MGX_MARK("P1s");
         // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
         // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
         int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
@@ -428,11 +483,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             if (ev.writes) {
                 store_cell(mytile + ev.off, ev.ncell);
                 if (!ROLL) {                                                     // ROLL writes the whole tile back at the end
-                    uint8_t *gg = a.grid + (e0 + env_of_lane) * HW3 + ev.off;
+                    uint8_t *gg = MGX_LATE(grid) + (e0 + env_of_lane) * HW3 + ev.off;
                     gg[0] = (uint8_t)ev.ncell; gg[1] = (uint8_t)(ev.ncell >> 8); gg[2] = (uint8_t)(ev.ncell >> 16);
                 }
             }
         }
+        MGX_MARK("P1s_end");
         const uint64_t fbw = __builtin_amdgcn_ballot_w64(fb);                   // envs that need the sequential loop
         wave_sync();
         if (fbw != 0) {
@@ -450,16 +506,18 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 const int e = lane;
                 const int64_t b = e0 + e;
                 uint8_t *etile = tile + e * HW3;
-                uint8_t *ggrid = a.grid + b * HW3;
+                uint8_t *ggrid = MGX_LATE(grid) + b * HW3;
                 auto dirty = [=](int off) {
                     if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
                 };
                 const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
                                               scnt[e] + 1, dirty, reinterpret_cast<uint8_t *>(auxl + e), a.sp.env_kind);
-                if (rc != 0 && a.err) { atomicAdd(a.err, 1); atomicMin(a.err + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
+                int32_t *errp = MGX_LATE(err);
+                if (rc != 0 && errp) { atomicAdd(errp, 1); atomicMin(errp + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
             }
             wave_sync();
         }
+        MGX_MARK("P1hook");
         // ------------------------------------------------------------------ overlay offsets (pre-hook `terminated`, SURVEY
         // App. C Q2), then one lane per env: counters + the env subclass' hook on the clean tile, then the overlay itself
         const int ovl = (in && !(a.dbg & 512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
@@ -468,19 +526,20 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             const int e = lane;
             const int64_t b = e0 + e;
             const int32_t sc = scnt[e] + 1;                                      // base.py:333
-            if (ROLL) scnt[e] = sc; else a.step_count[b] = sc;
+            if (ROLL) scnt[e] = sc; else MGX_LATE(step_count)[b] = sc;
             uint8_t *etile = tile + e * HW3;
-            uint8_t *ggrid = a.grid + b * HW3;
+            uint8_t *ggrid = MGX_LATE(grid) + b * HW3;
             auto dirty = [=](int off) {
                 if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
             };
             uint8_t *eaux = reinterpret_cast<uint8_t *>(auxl + e);
             post_step_hook(cf, a.sp.env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
-            if (!ROLL && a.aux) {                                                // the hook state the step may change
-                if (a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY) { a.aux[b * MGX_AUX_BYTES + 1] = eaux[1]; a.aux[b * MGX_AUX_BYTES + 15] = eaux[15]; }
-                if (a.sp.env_kind == MGX_KIND_REDBLUEDOORS) a.aux[b * MGX_AUX_BYTES + 4] = eaux[4];
+            if (!ROLL && cv.has_aux) {                                           // the hook state the step may change
+                uint8_t *gaux = MGX_LATE(aux) + b * MGX_AUX_BYTES;
+                if (a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[15] = eaux[15]; }
+                if (a.sp.env_kind == MGX_KIND_REDBLUEDOORS) gaux[4] = eaux[4];
             }
-            a.truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
+            MGX_LATE(truncated)[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
         }
         wave_sync();
         if (ROLL && ovl >= 0) ovl_saved = load_cell(mytile + ovl);
@@ -494,52 +553,59 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     wave_sync();
 
+    MGX_MARK("P1d");
     // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
     const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + cv.tile() + tile_skew);   // LDS address of env 0 cell 0
+    uint32_t my_carry = 0;                                                   // slot `lane`: what its agent carries
     if (lane < NVc) {
         const int e = env_of_lane;
         const uint64_t row = rows[lane];
         const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
         ViewRec r;
         r.origin = (int32_t)tile_addr + e * HW3 + g.origin;
-        r.stepF = g.stepF; r.stepL = g.stepL; r.carry = row_carry(row);
+        r.stepF = g.stepF; r.stepL = g.stepL; r.carry = 0;
+        my_carry = row_carry(row);
         rec[lane] = r;
         uint64_t m[NW];
         inbounds_mask<V, NW>(g, m);
 #pragma unroll
         for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = m[k];
         if (DO_STEP) {
-            if (!ROLL) reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = row;
-            a.reward[tv0 + lane] = rew[lane];
+            const u32x2 rowv = {(uint32_t)row, (uint32_t)(row >> 32)};
+            if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(MGX_LATE(agents) + v0 * 8, NVc * 8), lane * 8, 0, 0);
+            const uint64_t rbits = __builtin_bit_cast(uint64_t, rew[lane]);
+            const u32x2 rewv = {(uint32_t)rbits, (uint32_t)(rbits >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(MGX_LATE(reward) + tv0, NVc * 8), lane * 8, 0, 0);
             const bool forced = a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
-            a.terminated[tv0 + lane] = (uint8_t)(row_term(row) | forced);        // base.py:338 (+ env hook)
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row_term(row) | forced),                    // base.py:338 (+ env hook)
+                                                 make_rsrc(MGX_LATE(terminated) + tv0, NVc), lane, 0, 0);
         }
-        if (a.dir) a.dir[tv0 + lane] = (uint8_t)row_dir(row);                    // base.py:359, 372
+        uint8_t *dirp = MGX_LATE(dir);
+        if (dirp) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)row_dir(row), make_rsrc(dirp + tv0, NVc), lane, 0, 0);   // base.py:359, 372
     } else if (lane < ((NVc + kGroup - 1) & ~(kGroup - 1))) {                // padding slots of the last gather group
         ViewRec r;
-        r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = CELL_WALL;
+        r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = 0;
         rec[lane] = r;
 #pragma unroll
         for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = 0;
     }
     wave_sync();
 
+    MGX_MARK("P2");
     // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
     const LaneConst<V, NW> lc = ROLL ? lc_roll : lane_consts();
-    uint32_t cell[VPW][NW];                      // registers: every slot's cells, one per lane (and pass)
+    uint32_t cell[VPW][NW];                      // registers: every slot's cells, one per lane (and pass); P4 reads
+                                                 // only the gathered ones (s < NVc)
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
     for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
-#pragma unroll
-    for (int s = 0; s < VPW; ++s)
-#pragma unroll
-        for (int it = 0; it < NW; ++it) cell[s][it] = 0;
     if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
         if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
     }
 
+    MGX_MARK("P3");
     // ------------------------------------------------------------------ P3: lane s floods the visibility of slot s
     const bool masked = !a.sp.see_through_walls;                                // obs.py:95-100
     uint32_t visLo[NW], visHi[NW];
@@ -549,11 +615,15 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         uint64_t sb[NW], vis[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) sb[k] = ((uint64_t)sbHi[k] << 32) | sbLo[k];
+        constexpr int kOwn = (V - 1) * V + V / 2;                               // the agent's own cell: image[V/2][V-1]
+        sb[kOwn >> 6] = (sb[kOwn >> 6] & ~(1ull << (kOwn & 63)))              // ... shows what it carries (obs.py:207)
+                      | ((uint64_t)see_behind(my_carry) << (kOwn & 63));
         vis_mask<V, NW>(sb, vis);
 #pragma unroll
         for (int k = 0; k < NW; ++k) { visLo[k] = (uint32_t)vis[k]; visHi[k] = (uint32_t)(vis[k] >> 32); }
     }
 
+    MGX_MARK("P4");
     // ------------------------------------------------------------------ P4/P5 in rounds of kRound slots:
     // P4 masks each cell and transposes it into the obs byte layout in LDS, P5 streams the round to HBM in 16-byte vectors
     const int64_t o0 = tv0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;  // this wave's obs bytes (of step t)
@@ -580,28 +650,47 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     c = __builtin_amdgcn_inverse_ballot_w64(m) ? c : CELL_UNSEEN;
                                 }
                                 uint8_t *d = d0 + sl * (V2 * 3);
+#if MGX_UA_WRITE
+                                *reinterpret_cast<u16_unaligned *>(d) = (uint16_t)c;        // ds_write_b16 at any byte address
+                                d[2] = (uint8_t)(c >> 16);                                  // ds_write_b8_d16_hi
+#else
                                 d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+#endif
                             }
                         }
                     }
                 }
+                wave_sync();
+                // lane r0+sl: its agent's own cell shows the carried object (obs.py:207; always visible, obs.py:252)
+                if (lane >= r0 && lane < r0 + kRound && lane < NVc)
+                    store_cell(outb + (lane - r0) * (V2 * 3) + ((V / 2) * V + (V - 1)) * 3, my_carry);
             }
             wave_sync();
+            MGX_MARK("P5");
             if (!(a.dbg & 32)) {
                 const int64_t ro0 = o0 + (int64_t)r0 * (V2 * 3);                // this round's obs bytes [ro0, ro1)
-                const int64_t ro1 = min(ro0 + kRoundBytes, o1);
-                const int64_t roa = ro0 - out_skew;
-                for (int64_t D = roa + 16 * lane; D < ro1; D += 16 * 64) {
-                    const uint8_t *src = out_raw + (int)(D - roa);
-                    if (D >= ro0 && D + 16 <= ro1) {
-                        *reinterpret_cast<uint4 *>(a.obs + D) = *reinterpret_cast<const uint4 *>(src);
-                    } else {
-                        const int64_t lo_b = max(D, ro0), hi_b = min(D + 16, ro1);
-                        for (int64_t B = lo_b; B < hi_b; ++B) a.obs[B] = src[(int)(B - D)];
+                const int rlen = out_skew + (int)min((int64_t)kRoundBytes, o1 - ro0);   // staged bytes, from the aligned start
+                uint8_t *gdst = MGX_LATE(obs) + (ro0 - out_skew);
+                const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(gdst, rlen);
+                constexpr int kPasses = (kRoundBytes + 15 + 1023) / 1024;
+#pragma unroll
+                for (int k = 0; k < kPasses; ++k) {
+                    const int rel = lane16 + 1024 * k;
+                    if ((rel + 16 <= rlen) & (rel >= out_skew)) {
+#if MGX_BUF_STORE
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), orsrc, rel, 0, 0);
+#else
+                        *reinterpret_cast<u32x4 *>(gdst + rel) = *reinterpret_cast<const u32x4 *>(out_raw + rel);
+#endif
+                    } else if (rel < rlen) {                                    // ragged head / tail of the wave's bytes
+                        const int lo_b = max(rel, out_skew), hi_b = min(rel + 16, rlen);
+#pragma clang loop vectorize(disable) unroll(disable)
+                        for (int B = lo_b; B < hi_b; ++B) gdst[B] = out_raw[B];
                     }
                 }
             }
             wave_sync();
+            MGX_MARK("P5end");
         }
     }
     }   // for t
@@ -680,6 +769,7 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
     ka.vpw = slots_in_use(*sp, ka.Gw);
+    ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll);
     struct { int total; } p{ka.wave_lds};
     // wavefronts bundled per workgroup: 2 packs a CU's 160 KiB of LDS tighter than 4 once the chip is full (measured

@@ -11,6 +11,9 @@ import bench  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda", 0)
+if os.environ.get("MGX_SKIP"):                      # profiling: skip phases (results are then garbage)
+    from multigrid_amd import _lib
+    _lib.lib().mgx_debug_skip_phases(int(os.environ["MGX_SKIP"]))
 spec = bench.workload_spec()
 env = bench.make_env(spec, B, dev, 0)
 acts = bench.random_actions(4, B, spec.num_agents, dev, 7)
@@ -19,5 +22,6 @@ for t in range(N):
 for t in range(N):
     env.gen_obs()
 torch.cuda.synchronize()
-env.check_errors()
+if not os.environ.get("MGX_SKIP"):
+    env.check_errors()
 print("ok", B, N)
