@@ -259,7 +259,8 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
             raw[n][it] = *(lds_u32_ua_ptr)(uintptr_t)addr;                  // one unaligned ds_read_b32: cell + a junk byte
 #else
             const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(addr & ~3u);     // LDS byte address -> its dword pair
-            lo[n][it] = p[0]; hi[n][it] = p[1]; sh[n][it] = addr & 3u;
+            lo[n][it] = p[0]; hi[n][it] = p[1]; sh[n][it] = addr;           // v_alignbyte_b32 only looks at bits [1:0]
+                                                                            // (probed on gfx950: tools/hwprobe/alignbyte.hip)
 #endif
         }
     }
