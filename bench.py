@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="envs per GPU (BASELINE.json configs[1]: 4096)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: the K timed steps are one hipGraph replay; eager: K Python-level env.step calls")
+    ap.add_argument("--settle-steps", type=int, default=3000,
+                    help="untimed launches on a scratch env before the timed region (clock ramp); 0 disables")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / cpu_baseline legs")
     ap.add_argument("--skip-phases", type=int, default=0,
@@ -253,6 +255,13 @@ def main():
     acts = random_actions(args.steps, B, A, device, 1234 + rank)
     for t in range(args.warmup):
         env.step(warm[t])
+    if args.settle_steps > 0:
+        # The timed region is ~10 ms; the GPU needs longer than the W warm-up steps to reach its steady clocks.  More
+        # untimed launches of the same kernel, on a scratch copy so that the measured envs' state is exactly "W steps in".
+        scratch = make_env(spec, B, device, first_env=first_env)
+        for t in range(args.settle_steps):
+            scratch.step(warm[t % warm.shape[0]])
+        del scratch
     torch.cuda.synchronize(device)
     wall_s, ev_ms = timed_rollout(env, acts, args.mode, barrier)
     if not args.skip_phases:
@@ -272,7 +281,8 @@ def main():
                                f"(BASELINE.json configs[1]), uniform random actions 0..6",
                    "batch_per_gpu": B, "global_batch": world * B, "agents": A, "grid": "16x16", "view_size": 7,
                    "mode": args.mode, "parallelism": f"env-sharded x{world}, no collective",
-                   "launch": env.backend.launch_info(B), "auto_reset": False},
+                   "launch": env.backend.launch_info(B), "auto_reset": False,
+                   "clock_settle": f"{args.settle_steps} untimed steps on a scratch env before the timed region"},
     }
     if rank == 0:
         ms_launch = ev_ms / args.steps

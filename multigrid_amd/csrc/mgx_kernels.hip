@@ -170,8 +170,17 @@ int choose_Gw(const MgxSpec &sp, int64_t batch) {
 __device__ const JumpTable kJump{};
 
 // -DMGX_MARKERS=1 (tools/isa_phase_count.py): comment lines in the assembly that delimit the phases
+// -DMGX_TIMESTAMPS=1 (tools/stamp_probe.py): wavefront `g_stamp_wave` records the shader clock at every marker
 #if MGX_MARKERS
 #define MGX_MARK(name) asm volatile("; MGX_MARK " name ::: "memory")
+#elif MGX_TIMESTAMPS
+__device__ unsigned long long g_stamps[64];
+__device__ long long g_stamp_wave = 0;
+#define MGX_MARK(name)                                                                                   \
+    do {                                                                                                 \
+        if (wid == g_stamp_wave && lane == 0 && stamp_i < 64) g_stamps[stamp_i] = __builtin_readcyclecounter(); \
+        ++stamp_i;                                                                                       \
+    } while (0)
 #else
 #define MGX_MARK(name) ((void)0)
 #endif
@@ -323,6 +332,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const int64_t v0 = e0 * A;                                // first (env, agent) row
 
     uint8_t *L = lds + wave * a.wave_lds;
+#if MGX_TIMESTAMPS
+    int stamp_i = 0;
+    MGX_MARK("start");
+#endif
     const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, a.sp.env_kind != MGX_KIND_EMPTY);
     uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
     ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
@@ -558,6 +571,11 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
     const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + cv.tile() + tile_skew);   // LDS address of env 0 cell 0
     uint32_t my_carry = 0;                                                   // slot `lane`: what its agent carries
+    // (the output pointers are fetched first so that the s_load latency hides behind the geometry arithmetic)
+    uint8_t *const p_dir = MGX_LATE(dir);
+    uint8_t *const p_agents = DO_STEP ? MGX_LATE(agents) : nullptr;
+    double *const p_reward = DO_STEP ? MGX_LATE(reward) : nullptr;
+    uint8_t *const p_term = DO_STEP ? MGX_LATE(terminated) : nullptr;
     if (lane < NVc) {
         const int e = env_of_lane;
         const uint64_t row = rows[lane];
@@ -573,16 +591,15 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = m[k];
         if (DO_STEP) {
             const u32x2 rowv = {(uint32_t)row, (uint32_t)(row >> 32)};
-            if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(MGX_LATE(agents) + v0 * 8, NVc * 8), lane * 8, 0, 0);
+            if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(p_agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
             const uint64_t rbits = __builtin_bit_cast(uint64_t, rew[lane]);
             const u32x2 rewv = {(uint32_t)rbits, (uint32_t)(rbits >> 32)};
-            __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(MGX_LATE(reward) + tv0, NVc * 8), lane * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(p_reward + tv0, NVc * 8), lane * 8, 0, 0);
             const bool forced = a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row_term(row) | forced),                    // base.py:338 (+ env hook)
-                                                 make_rsrc(MGX_LATE(terminated) + tv0, NVc), lane, 0, 0);
+                                                 make_rsrc(p_term + tv0, NVc), lane, 0, 0);
         }
-        uint8_t *dirp = MGX_LATE(dir);
-        if (dirp) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)row_dir(row), make_rsrc(dirp + tv0, NVc), lane, 0, 0);   // base.py:359, 372
+        if (p_dir) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)row_dir(row), make_rsrc(p_dir + tv0, NVc), lane, 0, 0);   // base.py:359, 372
     } else if (lane < ((NVc + kGroup - 1) & ~(kGroup - 1))) {                // padding slots of the last gather group
         ViewRec r;
         r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = 0;
@@ -640,23 +657,26 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 for (int it = 0; it < NW; ++it) {
                     if (lc.act[it]) {
                         uint8_t *d0 = outb + lc.q3[it];
+                        // whole groups of kGroup slots, like P2 (padding slots write junk into staging space that P5
+                        // never copies): straight-line code whose readlane -> select -> write chains overlap
 #pragma unroll
-                        for (int sl = 0; sl < kRound; ++sl) {
-                            const int s = r0 + sl;
-                            if (s < NVc) {
-                                uint32_t c = cell[s][it];
-                                if (masked) {
+                        for (int g0 = 0; g0 < kRound; g0 += kGroup) {
+                            if (r0 + g0 < NVc) {
+#pragma unroll
+                                for (int sl = g0; sl < g0 + kGroup; ++sl) {
+                                    const int s = r0 + sl;
+                                    // (see_through_walls: the masks are all ones -- no branch, it would fence the schedule)
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
-                                    c = __builtin_amdgcn_inverse_ballot_w64(m) ? c : CELL_UNSEEN;
-                                }
-                                uint8_t *d = d0 + sl * (V2 * 3);
+                                    const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
+                                    uint8_t *d = d0 + sl * (V2 * 3);
 #if MGX_UA_WRITE
-                                *reinterpret_cast<u16_unaligned *>(d) = (uint16_t)c;        // ds_write_b16 at any byte address
-                                d[2] = (uint8_t)(c >> 16);                                  // ds_write_b8_d16_hi
+                                    *reinterpret_cast<u16_unaligned *>(d) = (uint16_t)c;    // ds_write_b16 at any byte address
+                                    d[2] = (uint8_t)(c >> 16);                              // ds_write_b8_d16_hi
 #else
-                                d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+                                    d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
 #endif
+                                }
                             }
                         }
                     }
@@ -696,6 +716,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     }   // for t
 
+#if MGX_TIMESTAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    MGX_MARK("end");
+#endif
     if (ROLL) {
         // ------------------------------------------------------------------ state write-back, once per launch
         for (int rel = 16 * lane; rel < len; rel += 16 * 64) {                  // the tile, as it was loaded
@@ -812,6 +836,14 @@ int mgx_last_hip_error(void) { return g_last_hip_error; }
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
+#if MGX_TIMESTAMPS
+int mgx_debug_read_stamps(unsigned long long *out64, long long wave) {   // reads the last launch's stamps, selects the next wave
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    unsigned long long zero[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_wave), &wave, sizeof wave) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     int rc = check_spec(spec, batch);

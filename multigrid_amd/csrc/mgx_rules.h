@@ -454,11 +454,11 @@ MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d) {
     g.origin = (y * W + x) * 3;
     g.stepF = (dy * W + dx) * 3;
     g.stepL = (dx * W - dy) * 3;
-    int lmin, lmax;
-    if (d == 0)      { g.fmax = W - 1 - x; lmin = -y;          lmax = H - 1 - y; }
-    else if (d == 1) { g.fmax = H - 1 - y; lmin = x - (W - 1); lmax = x; }
-    else if (d == 2) { g.fmax = x;         lmin = y - (H - 1); lmax = y; }
-    else             { g.fmax = y;         lmin = -x;          lmax = W - 1 - x; }
+    // room ahead and to both sides, as selects (one lane per view: the lanes hold all four directions)
+    const bool d0 = d == 0, d1 = d == 1, d2 = d == 2;
+    g.fmax = d0 ? W - 1 - x : (d1 ? H - 1 - y : (d2 ? x : y));
+    const int lmin = d0 ? -y : (d1 ? x - (W - 1) : (d2 ? y - (H - 1) : -x));
+    const int lmax = d0 ? H - 1 - y : (d1 ? x : (d2 ? y : W - 1 - x));
     g.imin = lmin + h < 0 ? 0 : lmin + h;
     g.imax = lmax + h > V - 1 ? V - 1 : lmax + h;
     return g;
@@ -467,13 +467,23 @@ MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d) {
 // in-bounds bit mask in lane order k = j*V + i
 template <int V, int NW>
 MGX_HD void inbounds_mask(const ViewGeom &g, uint64_t (&m)[NW]) {
-    for (int k = 0; k < NW; ++k) m[k] = 0;
-    if (g.imax < g.imin) return;
-    const uint32_t cols = ((2u << g.imax) - 1u) & ~((1u << g.imin) - 1u);
+    const bool any = g.imax >= g.imin;
+    const uint32_t cols = any ? (((2u << g.imax) - 1u) & ~((1u << g.imin) - 1u)) : 0u;
     const int jmin = (V - 1 - g.fmax) < 0 ? 0 : (V - 1 - g.fmax);
+    if constexpr (NW == 1) {
+        // the column pattern repeated in every row by doubling, then the rows nearer than jmin cut off
+        uint64_t r = cols;
+        r |= r << V;
+        r |= r << (2 * V);
+        if (V > 4) r |= r << (4 * V);
+        constexpr uint64_t kAll = (V * V >= 64) ? ~0ull : ((1ull << ((V * V) & 63)) - 1ull);
+        m[0] = (jmin >= V) ? 0ull : (r & kAll & (~0ull << (jmin * V)));
+    } else {
+        for (int k = 0; k < NW; ++k) m[k] = 0;
 #pragma unroll
-    for (int j = 0; j < V; ++j)
-        if (j >= jmin) or_bits<V, NW>(m, j * V, cols);
+        for (int j = 0; j < V; ++j)
+            if (j >= jmin) or_bits<V, NW>(m, j * V, cols);
+    }
 }
 
 }  // namespace mgx

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-phase latency of ONE wavefront of the fused step kernel from in-kernel shader-clock stamps (profiling aid).
+Needs a library built with -DMGX_TIMESTAMPS=1 in place of multigrid_amd/lib/libmgx.so (tools/altlib_sweep.sh style).
+Usage (GPU box): python tools/stamp_probe.py [batch ...]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from multigrid_amd import _lib  # noqa: E402
+
+lib = _lib.lib()
+if not hasattr(lib, "mgx_debug_read_stamps"):
+    sys.exit("library was not built with -DMGX_TIMESTAMPS=1")
+lib.mgx_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_longlong]
+dev = torch.device("cuda", 0)
+spec = bench.workload_spec()
+names = ["start", "P0", "P0end", "P1a", "P1s", "P1s_end", "P1hook", "P1d", "P2", "P3", "P4", "P5", "P5end", "P5'", "P5end'", "end"]
+for B in [int(x) for x in sys.argv[1:]] or [4096]:
+    env = bench.make_env(spec, B, dev, 0)
+    acts = bench.random_actions(64, B, spec.num_agents, dev, 7)
+    li = env.backend.launch_info(B)
+    nw = (B + li["envs_per_wavefront"] - 1) // li["envs_per_wavefront"]
+    for t in range(20):
+        env.step(acts[t])
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 64)()
+    print(f"B={B} launch {li}")
+    for wave in (0, nw // 2, nw - 1):
+        lib.mgx_debug_read_stamps(buf, wave)          # select the wave (and clear)
+        acc = None
+        reps = 20
+        for r in range(reps):
+            env.step(acts[20 + r])
+            torch.cuda.synchronize()
+            lib.mgx_debug_read_stamps(buf, wave)
+            st = [int(x) for x in buf if x]
+            d = [st[i + 1] - st[i] for i in range(len(st) - 1)]
+            acc = d if acc is None else [min(x, y) for x, y in zip(acc, d)]     # min over launches: least disturbed
+        labels = names[:len(acc)] if len(acc) + 1 != 14 else names[:12] + ["P5end"]
+        tot = sum(acc)
+        print(f"  wave {wave}: total {tot} clk  " + "  ".join(f"{labels[i]}>{acc[i]}" for i in range(len(acc))))
+    del env
