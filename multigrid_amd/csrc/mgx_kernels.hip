@@ -110,20 +110,22 @@ struct LdsCarve {
     bool has_aux;   // env kinds with hook state
     __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
     // -- per-step temporaries, all dead once P2 has gathered the cells --
-    __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]
-    __host__ __device__ int rnd() const { return 24 * vpw; }                         // u64  [vpw]
-    __host__ __device__ int rew() const { return 32 * vpw; }                         // f64  [vpw]
-    __host__ __device__ int inb() const { return 40 * vpw; }                         // u64  [vpw][nw]
-    __host__ __device__ int woff() const { return (40 + 8 * nw) * vpw; }             // i32  [vpw]
-    __host__ __device__ int temps_end() const { return (44 + 8 * nw) * vpw; }
+    __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]  (P1d -> P2)
+    __host__ __device__ int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
+    __host__ __device__ int rew() const { return 24 * vpw; }                         // f64  [vpw]
+    __host__ __device__ int woff() const { return 32 * vpw; }                        // i32  [vpw]     (P1s)
+    // one-step kernels: the jump-ahead constants (P1a only) share woff's space; the rollout re-reads them every step
+    __host__ __device__ int woff_bytes() const { return (!roll && 32 * A > 4 * vpw) ? 32 * A : 4 * vpw; }
+    __host__ __device__ int temps_end() const { return woff() + woff_bytes(); }
     // -- state that lives across phases / steps --
     __host__ __device__ int act() const { return temps_end(); }                      // i8   [vpw]
     __host__ __device__ int ord() const { return act() + vpw; }                      // u8   [vpw]
     __host__ __device__ int rng() const { return ord() + vpw; }                      // u64  [Gw][4]   (rollout only)
     __host__ __device__ int scnt() const { return rng() + (roll ? 32 * Gw : 0); }    // i32  [Gw]
     __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
-    __host__ __device__ int jump() const { return aux() + (has_aux ? 16 * Gw : 0); } // u64  [A][4]: k = 1..A
-    __host__ __device__ int wall() const { return jump() + 32 * A; }                 // one WALL cell + the dword after it
+    __host__ __device__ int own_jump() const { return aux() + (has_aux ? 16 * Gw : 0); }
+    __host__ __device__ int jump() const { return roll ? own_jump() : woff(); }      // u64  [A][4]: k = 1..A
+    __host__ __device__ int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one WALL cell + the dword after it
     // P4/P5 staging of one round's obs bytes (skew + pad).  One-step kernels put it over the tile, which is dead once
     // P2 has gathered the cells; the rollout keeps the tile and uses the (equally dead) temporaries' space + its own.
     __host__ __device__ int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
@@ -227,6 +229,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
 
+// lanes whose cell has state byte (bits 16..23) == 0, in one VALU instruction (hipcc does the type compares with an
+// SDWA byte select but spends an extra v_and_b32 on this one)
+__device__ __forceinline__ uint64_t state_is_open(uint32_t c) {
+    uint64_t m;
+    asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(m) : "v"(c), "v"(0u));
+    return m;
+}
+
 template <int V, int NIT>
 struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V + i
     int la[NIT], fw[NIT], q3[NIT];
@@ -238,7 +248,8 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 // shows the grid here; lane s patches the carried object in afterwards (P3: its see-behind bit, P4: its bytes).
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
 template <int V, int NW, int S0, int N, int VPW>
-__device__ __forceinline__ void gather_group(const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
+__device__ __forceinline__ void gather_group(const uint32_t wall_addr, const ViewRec *rec,
+                                             const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
                                              const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                              uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     constexpr int V2 = V * V;
@@ -248,7 +259,9 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
     for (int n = 0; n < N; ++n) {
         r[n] = rec[S0 + n];                                                  // broadcast reads
 #pragma unroll
-        for (int it = 0; it < NW; ++it) inbm[n][it] = inbw[(S0 + n) * NW + it];
+        for (int it = 0; it < NW; ++it)                                      // lane S0+n made this slot's mask in P1d
+            inbm[n][it] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbHi[it], S0 + n) << 32)
+                        | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbLo[it], S0 + n);
     }
     uint32_t raw[N][NW];
 #if !MGX_UA_READ
@@ -259,7 +272,7 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
     for (int n = 0; n < N; ++n) {
 #pragma unroll
         for (int it = 0; it < NW; ++it) {
-            inb[n][it] = __builtin_amdgcn_inverse_ballot_w64(uniform64(inbm[n][it]));
+            inb[n][it] = __builtin_amdgcn_inverse_ballot_w64(inbm[n][it]);
             // world cell seen at image[i][j]: pos + fw*forward + la*right; lanes looking outside the grid read the
             // wavefront's WALL cell instead (obs.py:199-202)
             const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
@@ -284,10 +297,9 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
 #endif
             const uint32_t c = raw[n][it];                                  // (byte 3 is junk from here on)
             cell[S0 + n][it] = c;
-            const uint32_t t = c & 0xffu, st = (c >> 16) & 0xffu;           // obs.py:46-63 see_behind, as lane masks
+            const uint32_t t = c & 0xffu;                                   // obs.py:46-63 see_behind, as lane masks
             const uint64_t m = __builtin_amdgcn_ballot_w64(t != (uint32_t)T_WALL)
-                             & (__builtin_amdgcn_ballot_w64(t != (uint32_t)T_DOOR)
-                                | __builtin_amdgcn_ballot_w64(st == 0)) & act_mask;
+                             & (__builtin_amdgcn_ballot_w64(t != (uint32_t)T_DOOR) | state_is_open(c)) & act_mask;
             sbLo[it] = set_lane(sbLo[it], (uint32_t)m, S0 + n);
             sbHi[it] = set_lane(sbHi[it], (uint32_t)(m >> 32), S0 + n);
         }
@@ -297,13 +309,14 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
 constexpr int kGroup = 8;
 
 template <int V, int NW, int VPW, int S0 = 0>
-__device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, const ViewRec *rec, const uint64_t *inbw,
+__device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, const ViewRec *rec,
+                                           const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
-        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW>(wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
-        gather_all<V, NW, VPW, S0 + kGroup>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW>(wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, S0 + kGroup>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     }
 }
 
@@ -339,7 +352,6 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, a.sp.env_kind != MGX_KIND_EMPTY);
     uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
     ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
-    uint64_t *inbw = reinterpret_cast<uint64_t *>(L + cv.inb());              // [slot][NW] in-bounds lanes
     int8_t *acts = reinterpret_cast<int8_t *>(L + cv.act());                  // [slot]
     uint64_t *rngs = reinterpret_cast<uint64_t *>(L + cv.rng());              // [env][4]
     uint64_t *rnd = reinterpret_cast<uint64_t *>(L + cv.rnd());               // [slot] 53-bit draws
@@ -471,6 +483,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             }
         }
         MGX_MARK("P1s");
+        wave_sync();                                                            // (woff below reuses the jump constants' space)
         // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
         // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
         int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
@@ -571,6 +584,9 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
     const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + cv.tile() + tile_skew);   // LDS address of env 0 cell 0
     uint32_t my_carry = 0;                                                   // slot `lane`: what its agent carries
+    uint32_t inbLo[NW], inbHi[NW];                                           // slot `lane`: its in-bounds lanes (P2 reads them
+#pragma unroll                                                               // with v_readlane; padding slots: none in bounds)
+    for (int k = 0; k < NW; ++k) { inbLo[k] = 0; inbHi[k] = 0; }
     // (the output pointers are fetched first so that the s_load latency hides behind the geometry arithmetic)
     uint8_t *const p_dir = MGX_LATE(dir);
     uint8_t *const p_agents = DO_STEP ? MGX_LATE(agents) : nullptr;
@@ -588,7 +604,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         uint64_t m[NW];
         inbounds_mask<V, NW>(g, m);
 #pragma unroll
-        for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = m[k];
+        for (int k = 0; k < NW; ++k) { inbLo[k] = (uint32_t)m[k]; inbHi[k] = (uint32_t)(m[k] >> 32); }
         if (DO_STEP) {
             const u32x2 rowv = {(uint32_t)row, (uint32_t)(row >> 32)};
             if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(p_agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
@@ -604,8 +620,6 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         ViewRec r;
         r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = 0;
         rec[lane] = r;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) inbw[lane * NW + k] = 0;
     }
     wave_sync();
 
@@ -617,7 +631,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
     for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
-    if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbw, lc, cell, sbLo, sbHi);
+    if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
         if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
