@@ -1,22 +1,29 @@
 // mgx_kernels.hip -- gfx950 (MI355X, CDNA4, wave64) kernels + the C ABI of libmgx.so (include/mgx.h).
 //
-// One fused kernel does a whole MultiGridEnv.step for a chunk of G environments per 256-thread workgroup:
+// One fused kernel does a whole MultiGridEnv.step for the batch.  Every WAVEFRONT is autonomous: it owns Gw consecutive
+// envs (<= 32 agent views, "slots") and a private LDS slice and runs all phases for them without a workgroup barrier:
 //
-//   P0  coalesced 16-byte loads of the chunk's (G,H,W,3) uint8 grid bytes and packed agent rows into LDS
-//   P1  one lane per env: step_count += 1, PCG64 visiting order, handle_actions on the LDS tile (dirty cells
-//       are written straight back to HBM, 3 bytes each), agent overlay for rendering, env post-step hook,
-//       reward / terminated / truncated / rng / step_count written out          (multigrid/base.py:303-476)
-//   P2  one WAVEFRONT per agent view, one lane per view cell: rotate-to-facing gather from the LDS tile,
-//       out-of-bounds -> wall, own cell -> carried object, see-behind bit per lane, __ballot -> 64-bit row
-//       masks, cells staged in LDS in image order                              (multigrid/utils/obs.py:130-233)
-//   P3  one lane per view: bit-parallel line-of-sight flood on the ballot masks (carry-propagation closed
-//       form of the sequential sweeps)                                         (multigrid/utils/obs.py:235-273)
-//   P4  wavefront per view again: cells whose visibility bit is clear become UNSEEN (obs.py:95-100)
-//   P5  flat, dword-coalesced store of the chunk's (G,A,v,v,3) observation bytes, agent rows and directions
+//   P0   buffer_load_dwordx4 of the wave's (Gw,H,W,3) uint8 grid bytes, packed agent rows, actions, PCG64 words and
+//        step counts; one s_waitcnt; LDS stores
+//   P1a  lane = (env, agent): that agent's PCG64 draw by jump-ahead                            (multigrid/base.py:396-399)
+//   P1s  lane = (env, agent): order-free evaluation of every action against the pre-step state, committed when the
+//        env's agents cannot have influenced each other; otherwise P1b (rank argsort of the draws) + P1c (lane = env:
+//        the reference's sequential handle_actions loop on the LDS tile)                       (base.py:378-476)
+//        then the agent overlay offsets, the env subclass' post-step hook, step_count / truncated
+//   P1d  lane = view: view geometry record, in-bounds lane mask, stores of agent rows / reward / terminated / dir
+//   P2   lane = view CELL, slots unrolled x8: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
+//        see-behind ballot -> 64-bit row mask deposited in lane s; cells stay in registers  (multigrid/utils/obs.py:130-233)
+//   P3   lane = view: bit-parallel line-of-sight flood on the ballot masks (closed form of the sequential sweeps,
+//        obs.py:235-273); own cell := carried object (obs.py:207)
+//   P4   lane = cell: cells whose visibility bit is clear become UNSEEN (obs.py:95-100); 3 bytes each into the obs
+//        byte layout in LDS (the rotate/transpose)
+//   P5   ds_read_b128 -> buffer_store_dwordx4 of the (Gw,A,v,v,3) observation bytes
 //
-// Pure integer / byte work: no MFMA.  The bound is HBM bytes, so the design goals are: every HBM
-// byte touched once, 16-byte loads, 4-byte coalesced stores, and as few VALU instructions per view cell as
-// possible.  Workgroups touch disjoint memory, so the blockIdx -> XCD mapping needs no swizzle.
+// Pure integer / byte work: no MFMA.  The roof is HBM bytes; what the kernel is actually bound by is the number of
+// VALU instructions per view, so the rules of the house are: every HBM byte touched once, 16-byte
+// loads and stores through buffer resources (no per-lane predicates, no 64-bit VALU addressing), per-view data to the
+// cell lanes as LDS broadcasts or SGPR masks, and as few VALU instructions per slot as possible.  Workgroups touch
+// disjoint memory, so the blockIdx -> XCD mapping needs no swizzle.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
