@@ -292,7 +292,7 @@ def main():
                   traffic_unit="bytes per launch (rocprofv3 PMC, profiles/traffic.json)",
                   note="working set fits the 256 MiB Infinity Cache at this batch: latency-bound, see roofline_large")
         out["roofline"] = rf
-        if not args.no_extras:
+        if not args.no_extras and world == 1:                  # the large-batch / rollout / CPU legs: N=1 only
             r_step, r_obs = large_batch_points(spec, device, args.large_batch)
             out["roofline_large"] = r_step
             out["gen_obs_large"] = r_obs
