@@ -331,9 +331,12 @@ __device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, co
 // runs all phases for them without any workgroup barrier.  A workgroup is just a bundle of such wavefronts.
 // MODE 0: gen_obs only.  MODE 1: one step.  MODE 2: a.T consecutive steps with the envs' state kept in LDS between
 // steps (mgx_rollout); per-step outputs go to the [t] slices of the output tensors, the state is written back once.
-template <int V, int MODE>
+// HOOKS: the env kind has a post-step hook and 16 bytes of hook state (every kind but EMPTY).  The EMPTY instantiation
+// drops that code and its SGPRs.
+template <int V, int MODE, bool HOOKS>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
     constexpr bool DO_STEP = MODE != 0;
+    const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
     constexpr bool ROLL = MODE == 2;
     constexpr int V2 = V * V;
     constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     int stamp_i = 0;
     MGX_MARK("start");
 #endif
-    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, a.sp.env_kind != MGX_KIND_EMPTY);
+    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, HOOKS);
     uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
     ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
     int8_t *acts = reinterpret_cast<int8_t *>(L + cv.act());                  // [slot]
@@ -497,8 +500,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         AgentEval ev{};
         uint8_t *mytile = tile + env_of_lane * HW3;
         if (in && !(a.dbg & 64)) {
-            const int so = (a.sp.env_kind == MGX_KIND_REDBLUEDOORS)
-                               ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), a.sp.env_kind) : -1;
+            const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
+                               ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
             ev = eval_agent(cf, mytile, rows + env_of_lane * A, acts[lane], rows[lane], true, so);
             woff[lane] = ev.writes ? ev.off : -1;
         }
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                     if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
                 };
                 const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
-                                              scnt[e] + 1, dirty, reinterpret_cast<uint8_t *>(auxl + e), a.sp.env_kind);
+                                              scnt[e] + 1, dirty, reinterpret_cast<uint8_t *>(auxl + e), env_kind);
                 int32_t *errp = MGX_LATE(err);
                 if (rc != 0 && errp) { atomicAdd(errp, 1); atomicMin(errp + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
             }
@@ -567,11 +570,11 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
             };
             uint8_t *eaux = reinterpret_cast<uint8_t *>(auxl + e);
-            post_step_hook(cf, a.sp.env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
+            post_step_hook(cf, env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
             if (!ROLL && cv.has_aux) {                                           // the hook state the step may change
                 uint8_t *gaux = MGX_LATE(aux) + b * MGX_AUX_BYTES;
-                if (a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[15] = eaux[15]; }
-                if (a.sp.env_kind == MGX_KIND_REDBLUEDOORS) gaux[4] = eaux[4];
+                if (env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[15] = eaux[15]; }
+                if (env_kind == MGX_KIND_REDBLUEDOORS) gaux[4] = eaux[4];
             }
             MGX_LATE(truncated)[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
         }
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             const uint64_t rbits = __builtin_bit_cast(uint64_t, rew[lane]);
             const u32x2 rewv = {(uint32_t)rbits, (uint32_t)(rbits >> 32)};
             __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(p_reward + tv0, NVc * 8), lane * 8, 0, 0);
-            const bool forced = a.sp.env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
+            const bool forced = env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row_term(row) | forced),                    // base.py:338 (+ env hook)
                                                  make_rsrc(p_term + tv0, NVc), lane, 0, 0);
         }
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
         if (lane < Gc) {
             a.step_count[e0 + lane] = scnt[lane];
-            if (a.aux && a.sp.env_kind >= MGX_KIND_REDBLUEDOORS) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
+            if (HOOKS && env_kind >= MGX_KIND_REDBLUEDOORS) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
         }
     }
 }
@@ -772,16 +775,19 @@ int g_debug_wpb = 0;
 template <int MODE>
 int launch(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
     void (*kern)(const KernelArgs) = nullptr;
+    const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
+#define MGX_PICK(V) kern = hooks ? mgx_fused_kernel<V, MODE, (MODE != 0)> : mgx_fused_kernel<V, MODE, false>
     switch (ka.sp.view_size) {
-    case 3:  kern = mgx_fused_kernel<3, MODE>;  break;
-    case 5:  kern = mgx_fused_kernel<5, MODE>;  break;
-    case 7:  kern = mgx_fused_kernel<7, MODE>;  break;
-    case 9:  kern = mgx_fused_kernel<9, MODE>;  break;
-    case 11: kern = mgx_fused_kernel<11, MODE>; break;
-    case 13: kern = mgx_fused_kernel<13, MODE>; break;
-    case 15: kern = mgx_fused_kernel<15, MODE>; break;
+    case 3:  MGX_PICK(3);  break;
+    case 5:  MGX_PICK(5);  break;
+    case 7:  MGX_PICK(7);  break;
+    case 9:  MGX_PICK(9);  break;
+    case 11: MGX_PICK(11); break;
+    case 13: MGX_PICK(13); break;
+    case 15: MGX_PICK(15); break;
     default: return MGX_ERR_UNSUPPORTED;
     }
+#undef MGX_PICK
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction counts per phase of the fused kernel (profiling aid).
 Compiles mgx_kernels.hip with -DMGX_MARKERS=1 to assembly and counts VALU / SALU / LDS / VMEM instructions between the
-phase markers of one kernel instantiation.  Usage: python tools/isa_phase_count.py [V] [MODE]   (default 7 1)"""
+phase markers of one kernel instantiation.  Usage: python tools/isa_phase_count.py [V] [MODE] [HOOKS]   (default 7 1 0)"""
 import collections
 import os
 import re
@@ -12,12 +12,13 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 V = sys.argv[1] if len(sys.argv) > 1 else "7"
 MODE = sys.argv[2] if len(sys.argv) > 2 else "1"
-extra = sys.argv[3:]
+HOOKS = sys.argv[3] if len(sys.argv) > 3 else "0"
+extra = sys.argv[4:]
 out = os.path.join(tempfile.gettempdir(), "mgx_markers.s")
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DMGX_MARKERS=1",
                        f"-I{ROOT}/include", "-S", "--cuda-device-only", *extra,
                        f"{ROOT}/multigrid_amd/csrc/mgx_kernels.hip", "-o", out])
-want = f"mgx_fused_kernelILi{V}ELi{MODE}E"
+want = f"mgx_fused_kernelILi{V}ELi{MODE}ELb{HOOKS}E"
 cur = None
 phase = "pre"
 counts = collections.OrderedDict()
