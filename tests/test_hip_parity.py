@@ -194,6 +194,36 @@ def test_full_size_properties_c4_shape():
     whole.check_errors(); rep.check_errors()
 
 
+def test_tensors_beyond_4gib_address_correctly():
+    """7.5 M envs of the C2 shape: obs is 4.4 GB and grid 5.8 GB, so byte offsets leave 32 bits.  The first and the last
+    2048 envs (with an odd, ragged tail) must come out exactly as when those envs are stepped on their own -- env-local
+    results cannot depend on where the env sits in the batch."""
+    spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
+    B, n = 7_500_003, 2048
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * (1 << 30):
+        pytest.skip("needs ~14 GB of free HBM")
+    grid, agents = layouts.empty_layout(16, 4)
+    big = BatchedMultiGridEnv(spec, B, dev()); big.load_state(grid, agents); big.seed_synthetic(11)
+    head = BatchedMultiGridEnv(spec, n, dev(), first_env=0); head.load_state(grid, agents); head.seed_synthetic(11)
+    tail = BatchedMultiGridEnv(spec, n, dev(), first_env=B - n); tail.load_state(grid, agents); tail.seed_synthetic(11)
+    assert big.obs.numel() > (1 << 32) and big.grid.numel() > (1 << 32)
+    g = torch.Generator(device=dev()); g.manual_seed(3)
+    for t in range(6):
+        act = torch.randint(0, 7, (B, 4), dtype=torch.int8, device=dev(), generator=g)
+        ob_ = big.step(act)
+        oh = head.step(act[:n].contiguous()); ot = tail.step(act[B - n:].contiguous())
+        for w, a, b in zip(ob_, oh, ot):
+            assert torch.equal(w[:n], a) and torch.equal(w[B - n:], b)
+    assert torch.equal(big.grid[B - n:], tail.grid) and torch.equal(big.agents[B - n:], tail.agents)
+    assert torch.equal(big.rng[B - n:], tail.rng) and torch.equal(big.step_count[B - n:], tail.step_count)
+    o1, _ = big.gen_obs()
+    assert torch.equal(o1[B - n:], tail.obs) and torch.equal(o1[:n], head.obs)
+    big.check_errors()
+    del big, head, tail
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("path", util.WRAPPER_GOLDEN, ids=util.WRAPPER_IDS)
 def test_wrapper_kernels_vs_reference_goldens(path):
     import json
