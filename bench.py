@@ -141,6 +141,49 @@ def large_batch_points(spec, device, large_batch):
     return r_step, r_obs
 
 
+def aux_kernel_points(device, batch=1 << 20):
+    """Bandwidth of the kernels either side of the fused step at an HBM-resident size."""
+    spec = workload_spec()
+    A, V, H, W = spec.num_agents, spec.view_size, spec.height, spec.width
+    env = make_env(spec, batch, device, 0)
+    acts = random_actions(4, batch, A, device, 7)
+    for t in range(4):
+        env.step(acts[t])
+    out = {}
+    # one-hot of the step's observations: 3 B in, 21 B out per view cell (wrappers.py:158-190)
+    cells = batch * A * V * V
+    t = kernel_time_ms(env.one_hot_obs, 30, device)
+    by = cells * (3 + 21)
+    out["one_hot"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
+                      "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    # fully observable encode: grid in, transposed grid out, agent rows in
+    t = kernel_time_ms(env.full_obs, 30, device)
+    by = batch * (2 * H * W * 3 + A * 8)
+    out["full_obs"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
+                       "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    # auto-reset with every env done: agent rows + step counts in, layout out
+    grid, agents = layouts.empty_layout(W, A)
+    K = 64
+    env.set_layout_pool(np.broadcast_to(grid, (K,) + grid.shape).copy(), np.broadcast_to(agents, (K,) + agents.shape).copy())
+
+    def reset_all():
+        env.step_count.fill_(spec.max_steps)          # every env truncated -> every env is reset
+        env.reset_done()
+    def fill_only():
+        env.step_count.fill_(spec.max_steps)
+    t = kernel_time_ms(reset_all, 30, device) - kernel_time_ms(fill_only, 30, device)
+    by = batch * (H * W * 3 + 2 * A * 8 + 4 + 4 + 4 + 1)
+    out["reset_done_all"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
+                             "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    env.step_count.zero_()
+    t = kernel_time_ms(env.reset_done, 30, device)     # nobody done: the scan only
+    by = batch * (A * 8 + 4 + 1)
+    out["reset_done_none"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
+                              "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+
 def rollout_point(spec, batch, device, steps, first_env, seed):
     """The same K steps as ONE mgx_rollout launch (env state stays in LDS between steps).  Open-loop actions only."""
     env = make_env(spec, batch, device, first_env)
@@ -297,6 +340,7 @@ def main():
             out["roofline_large"] = r_step
             out["gen_obs_large"] = r_obs
             out["fused_rollout"] = rollout_point(spec, B, device, args.steps, first_env, 1234 + rank)
+            out["aux_kernels"] = aux_kernel_points(device)
             out["cpu_baseline"] = cpu_baseline(spec, B)
         print(json.dumps(out), flush=True)
     barrier()

@@ -4,6 +4,8 @@
 //   mgx_full_obs    FullyObsWrapper.observation     multigrid/wrappers.py:48-58     (grid transpose-copy + agent overlay)
 //   mgx_reset_done  vector-env auto-reset from a pool of pre-generated layouts (build-defined; the reference has no
 //                   batching: its user calls reset() when is_done(), multigrid/base.py:250-301, 534-539)
+//
+// All three are streaming kernels: 16-byte loads and stores, the byte shuffling in between goes through LDS.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
@@ -16,124 +18,239 @@ using namespace mgx;
 
 int g_aux_hip_error = 0;
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void wave_sync() {          // LDS traffic inside ONE wavefront is in order: compiler fence only
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// one_hot: out[cell][d0 + d1 + d2] = 1 at {x0, d0 + x1, d0 + d1 + x2}.  One thread per 16 output bytes (a vector never
-// spans more than two cells when the channel count is >= 16; the general path handles any count).
+// one_hot: out[cell][d0 + d1 + d2] = 1 at {x0, d0 + x1, d0 + d1 + x2}.
+// A workgroup takes chunks of 1024 cells: (1) each thread loads 12 bytes = 4 cells and leaves their D-bit one-hot masks
+// in LDS, (2) each thread assembles 16 output bytes at a time from the masks of the 1-2 cells they span (any D works)
+// and stores them as one vector.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t cell_bits(const uint8_t *x, int64_t cell, int64_t n_cells, int d0, int d1, int d2) {
-    if (cell >= n_cells) return 0;
-    const uint8_t *p = x + cell * 3;
+constexpr int kOhCells = 1024;
+
+__device__ __forceinline__ uint32_t one_hot_mask(uint32_t c, int d0, int d1, int d2) {
+    const uint32_t p0 = c & 0xffu, p1 = (c >> 8) & 0xffu, p2 = (c >> 16) & 0xffu;
     uint32_t m = 0;
-    if (p[0] < d0) m |= 1u << p[0];
-    if (p[1] < d1) m |= 1u << (d0 + p[1]);
-    if (p[2] < d2) m |= 1u << (d0 + d1 + p[2]);
+    m |= (p0 < (uint32_t)d0) ? (1u << p0) : 0u;
+    m |= (p1 < (uint32_t)d1) ? (1u << (d0 + p1)) : 0u;
+    m |= (p2 < (uint32_t)d2) ? (1u << (d0 + d1 + p2)) : 0u;
     return m;
 }
 
 __global__ __launch_bounds__(256) void one_hot_kernel(const uint8_t *__restrict__ x, int64_t n_cells, int d0, int d1, int d2,
-                                                      uint8_t *__restrict__ out) {
-    const int D = d0 + d1 + d2;                                   // <= 32
-    const int64_t total = n_cells * D;
-    for (int64_t o = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; o < total;
-         o += (int64_t)gridDim.x * blockDim.x * 16) {
-        const int64_t c0 = o / D;
-        const int k0 = (int)(o - c0 * D);
-        // the bits of up to 16 consecutive output bytes, gathered from consecutive cells
-        uint32_t bits = 0;
-        int have = 0;
-        int64_t c = c0;
-        int k = k0;
-        while (have < 16) {
-            const uint32_t m = cell_bits(x, c, n_cells, d0, d1, d2) >> k;
-            bits |= (m << have) & 0xffffu;
-            have += D - k;
-            k = 0;
-            ++c;
-        }
-        uint4 v;                                                  // spread 4 bits -> 4 bytes of 0/1
-        v.x = (((bits >> 0) & 0xfu) * 0x00204081u) & 0x01010101u;
-        v.y = (((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
-        v.z = (((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
-        v.w = (((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
-        if (o + 16 <= total) {
-            *reinterpret_cast<uint4 *>(out + o) = v;
+                                                      uint32_t inv_D, uint8_t *__restrict__ out) {
+    __shared__ __align__(16) uint32_t masks[kOhCells + 32];
+    const int D = d0 + d1 + d2;                                   // 3 <= D <= 32;  inv_D = ceil(2^32 / D)
+    const int64_t nchunks = (n_cells + kOhCells - 1) / kOhCells;
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 3) == 0;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t c_base = chunk * kOhCells;
+        const int ncell = (int)min((int64_t)kOhCells, n_cells - c_base);
+        const uint8_t *src = x + c_base * 3;
+        uint32_t c0, c1, c2, c3;
+        if (aligned) {                                            // 12 bytes per thread; past the end reads zeros
+            // (the range is rounded up to the aligned dword that holds the last valid byte: the check is per dword)
+            const u32x3 w = __builtin_amdgcn_raw_buffer_load_b96(make_rsrc(src, (ncell * 3 + 3) & ~3), threadIdx.x * 12, 0, 0);
+            c0 = w.x; c1 = (w.x >> 24) | (w.y << 8); c2 = (w.y >> 16) | (w.z << 16); c3 = w.z >> 8;
         } else {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            for (int b = 0; o + b < total; ++b) out[o + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+            uint32_t c[4];
+            for (int k = 0; k < 4; ++k) {
+                const int i = threadIdx.x * 4 + k;
+                c[k] = i < ncell ? load_cell(src + i * 3) : 0u;
+            }
+            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
         }
+        u32x4 m;
+        m.x = one_hot_mask(c0, d0, d1, d2); m.y = one_hot_mask(c1, d0, d1, d2);
+        m.z = one_hot_mask(c2, d0, d1, d2); m.w = one_hot_mask(c3, d0, d1, d2);
+        reinterpret_cast<u32x4 *>(masks)[threadIdx.x] = m;
+        __syncthreads();
+        const int total = ncell * D;                              // output bytes of this chunk
+        uint8_t *dst = out + c_base * D;                          // 16-byte aligned: c_base is a multiple of 1024
+        for (int o = threadIdx.x * 16; o < total; o += 256 * 16) {
+            const int cq = (int)__umulhi((uint32_t)o, inv_D);     // o / D, exact for o < 2^20
+            const int k0 = o - cq * D;
+            uint32_t bits = masks[cq] >> k0;                      // bits of up to 16 consecutive output bytes
+            int have = D - k0, c = cq + 1;
+            while (have < 16) { bits |= masks[c] << have; have += D; ++c; }
+            u32x4 v;                                              // spread 4 bits -> 4 bytes of 0/1
+            v.x = (((bits >> 0) & 0xfu) * 0x00204081u) & 0x01010101u;
+            v.y = (((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+            v.z = (((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+            v.w = (((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+            if (o + 16 <= total) {
+                *reinterpret_cast<u32x4 *>(dst + o) = v;
+            } else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (int b = 0; o + b < total; ++b) dst[o + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // full_obs: img = grid.encode() (a copy of Grid.state, (W,H,3) indexed [x][y]); img[agent.pos] = agent.encode() for
-// every agent in index order, terminated or not (wrappers.py:52-54).  One workgroup per env: transpose through LDS.
+// every agent in index order, terminated or not (wrappers.py:52-54).
+// Every wavefront is autonomous (as in the fused kernel): it takes G consecutive envs, loads their [y][x] tiles into LDS
+// with 16-byte vectors, writes each cell to its [x][y] place in a second LDS buffer (one lane per cell), overlays the
+// agents there, and streams that buffer out with 16-byte vectors.  Input and output of an env have the same size, so the
+// two buffers share one 16-byte skew.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int64_t batch, const uint8_t *__restrict__ grid,
+__global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int G, int wave_lds, uint32_t inv_W,
+                                                       uint32_t inv_HW, int64_t batch, const uint8_t *__restrict__ grid,
                                                        const uint8_t *__restrict__ agents, uint8_t *__restrict__ out) {
-    extern __shared__ __align__(16) uint8_t lds[];               // W*H*3 bytes in OUTPUT order [x][y][c]
-    const int HW = H * W;
-    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
-        const uint8_t *g = grid + b * HW * 3;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {      // i = y*W + x in the product layout
-            const int y = i / W, x = i - y * W;
-            uint8_t *d = lds + (x * H + y) * 3;
-            d[0] = g[i * 3]; d[1] = g[i * 3 + 1]; d[2] = g[i * 3 + 2];
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t e0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * G;
+    if (e0 >= batch) return;
+    const int Gc = (int)min((int64_t)G, batch - e0);
+    const int HW = H * W, HW3 = HW * 3;
+    const int64_t g0 = e0 * HW3, gtotal = batch * (int64_t)HW3;
+    const int64_t ga = g0 & ~(int64_t)15;
+    const int skew = (int)(g0 - ga);
+    const int len = skew + Gc * HW3;                               // staged bytes, from the aligned start
+    const int buf = (G * HW3 + 15 + 16 + 15) & ~15;                // one buffer: skew + over-read pad
+    uint8_t *in_raw = lds + wave * wave_lds, *out_raw = in_raw + buf;
+    const int lane16 = lane * 16;
+    // (1) tile -> LDS; lanes past the end of the tensor read zeros (never used)
+    // (range rounded up to the aligned 16 bytes that hold the tensor's last byte: the range check is per dword)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(grid + ga, (int)min((gtotal - ga + 15) & ~(int64_t)15, (int64_t)INT_MAX & ~15));
+    for (int rel = lane16; rel < len; rel += 1024 * 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, rel + 1024 * u, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (rel + 1024 * u < len) *reinterpret_cast<u32x4 *>(in_raw + rel + 1024 * u) = v[u];
+    }
+    wave_sync();
+    // (2) one lane per cell: [y][x] -> [x][y]
+    const uint32_t in_addr = (uint32_t)(uintptr_t)(lds_u32_ptr)(in_raw + skew);
+    uint8_t *out_cells = out_raw + skew;
+    const int ncell = Gc * HW;
+    for (int i = lane; i < ncell; i += 64) {
+        const int e = (int)__umulhi((uint32_t)i, inv_HW);                                    // i / HW  (i < 2^16)
+        const int r = i - e * HW;
+        const int y = (int)__umulhi((uint32_t)r, inv_W), xx = r - y * W;                    // r / W
+        const uint32_t a = in_addr + (uint32_t)i * 3u;
+        const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(a & ~3u);
+        const uint32_t c = __builtin_amdgcn_alignbyte(p[1], p[0], a);                       // 3-byte cell (+1 junk byte)
+        uint8_t *d = out_cells + e * HW3 + (xx * H + y) * 3;
+        d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+    }
+    wave_sync();
+    // (3) agents, index order: a later agent overwrites an earlier one on the same cell, so only the last one writes
+    const uint64_t *rows = reinterpret_cast<const uint64_t *>(agents) + e0 * A;
+    for (int s = lane; s < Gc * A; s += 64) {
+        const int e = s / A, ai = s - e * A;
+        const uint64_t r = rows[s];
+        const uint32_t pos = ((uint32_t)r >> 16) & 0xffffu;
+        bool shadowed = false;
+        for (int j = ai + 1; j < A; ++j) shadowed |= ((((uint32_t)rows[e * A + j]) >> 16) & 0xffffu) == pos;
+        const int x = row_x(r), y = row_y(r);
+        if (!shadowed && x < W && y < H)
+            store_cell(out_cells + e * HW3 + (x * H + y) * 3, (uint32_t)T_AGENT | ((uint32_t)(r & 0xffffu) << 8));
+    }
+    wave_sync();
+    // (4) stream out
+    uint8_t *gdst = out + ga;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(gdst, len);
+    for (int rel = lane16; rel < len; rel += 1024) {
+        if ((rel >= skew) & (rel + 16 <= len)) {
+            __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), ro, rel, 0, 0);
+        } else {
+            const int lo_b = max(rel, skew), hi_b = min(rel + 16, len);
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int B = lo_b; B < hi_b; ++B) gdst[B] = out_raw[B];
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint64_t *rows = reinterpret_cast<const uint64_t *>(agents) + b * A;
-            for (int a = 0; a < A; ++a) {
-                const uint64_t r = rows[a];
-                const int x = row_x(r), y = row_y(r);
-                if (x < W && y < H) store_cell(lds + (x * H + y) * 3, (uint32_t)T_AGENT | ((uint32_t)(r & 0xffffu) << 8));
-            }
-        }
-        __syncthreads();
-        uint8_t *o = out + b * HW * 3;
-        for (int i = threadIdx.x; i < HW * 3; i += blockDim.x) o[i] = lds[i];
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // reset_done: every env whose episode is over (all agents terminated, or step_count >= max_steps: base.py:534-539)
 // is re-initialised from layout pool[(global_env + episode * stride) mod K]; step_count := 0, episode += 1.
+// One lane per env decides; the wavefront then copies the layouts of its finished envs with all 64 lanes, in the widest
+// unit the layout size allows.
 // ---------------------------------------------------------------------------------------------------------------
+template <typename VecT>
+__device__ __forceinline__ void copy_layouts(int n, int units, uint32_t inv_units, int64_t e0, int64_t env_bytes,
+                                             const int *l_env, const int *l_lay, const uint8_t *pool, uint8_t *dstbase,
+                                             int lane) {
+    if (units >= 64) {                                            // big layouts: env by env, lanes over its vectors
+        for (int j = 0; j < n; ++j) {
+            const VecT *s = reinterpret_cast<const VecT *>(pool + (int64_t)l_lay[j] * env_bytes);
+            VecT *d = reinterpret_cast<VecT *>(dstbase + (e0 + l_env[j]) * env_bytes);
+            for (int v = lane; v < units; v += 64) d[v] = s[v];
+        }
+    } else {                                                      // small layouts: (env, vector) pairs flattened over the lanes
+        const int total = n * units;
+        for (int k = lane; k < total; k += 64) {
+            const int j = (int)__umulhi((uint32_t)k, inv_units), v = k - j * units;      // k / units, k < 4096
+            const VecT *s = reinterpret_cast<const VecT *>(pool + (int64_t)l_lay[j] * env_bytes);
+            VecT *d = reinterpret_cast<VecT *>(dstbase + (e0 + l_env[j]) * env_bytes);
+            d[v] = s[v];
+        }
+    }
+}
+
+template <typename VecT>
 __global__ __launch_bounds__(256) void reset_done_kernel(int HW3, int A, int max_steps, int64_t batch, int64_t first_env,
-                                                         int K, const uint8_t *__restrict__ pool_grid,
+                                                         int K, uint32_t inv_units, uint32_t inv_A,
+                                                         const uint8_t *__restrict__ pool_grid,
                                                          const uint8_t *__restrict__ pool_agents,
                                                          const uint8_t *__restrict__ pool_aux, uint8_t *grid,
                                                          uint8_t *agents, int32_t *step_count, uint8_t *aux,
                                                          int32_t *episode, uint8_t *was_reset) {
-    __shared__ int s_done, s_layout;
-    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
-        if (threadIdx.x == 0) {
-            const uint64_t *rows = reinterpret_cast<const uint64_t *>(agents) + b * A;
-            bool all_term = true;
-            for (int a = 0; a < A; ++a) all_term &= row_term(rows[a]);
-            const int done = all_term || step_count[b] >= max_steps;
-            s_done = done;
-            if (done) {
-                const int ep = episode[b];
-                // a fixed odd stride walks the whole pool before repeating; depends only on the GLOBAL env index
-                s_layout = (int)((uint64_t)(first_env + b + (int64_t)ep * 7919) % (uint64_t)K);
-                episode[b] = ep + 1;
-                step_count[b] = 0;
-            }
-            if (was_reset) was_reset[b] = (uint8_t)done;
+    __shared__ int s_env[4][64], s_lay[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (e0 >= batch) return;
+    const int64_t b = e0 + lane;
+    bool done = false;
+    int layout = 0;
+    if (b < batch) {
+        const uint64_t *rows = reinterpret_cast<const uint64_t *>(agents) + b * A;
+        bool all_term = true;
+        for (int a = 0; a < A; ++a) all_term &= row_term(rows[a]);
+        done = all_term || step_count[b] >= max_steps;
+        if (done) {
+            const int ep = episode[b];
+            // a fixed odd stride walks the whole pool before repeating; depends only on the GLOBAL env index
+            layout = (int)((uint64_t)(first_env + b + (int64_t)ep * 7919) % (uint64_t)K);
+            episode[b] = ep + 1;
+            step_count[b] = 0;
         }
-        __syncthreads();
-        if (s_done) {
-            const uint8_t *sg = pool_grid + (int64_t)s_layout * HW3;
-            uint8_t *dg = grid + b * HW3;
-            for (int i = threadIdx.x; i < HW3; i += blockDim.x) dg[i] = sg[i];
-            for (int i = threadIdx.x; i < A * MGX_AGENT_STRIDE; i += blockDim.x)
-                agents[b * A * MGX_AGENT_STRIDE + i] = pool_agents[(int64_t)s_layout * A * MGX_AGENT_STRIDE + i];
-            if (aux && pool_aux && threadIdx.x < MGX_AUX_BYTES)
-                aux[b * MGX_AUX_BYTES + threadIdx.x] = pool_aux[(int64_t)s_layout * MGX_AUX_BYTES + threadIdx.x];
-        }
-        __syncthreads();
+        if (was_reset) was_reset[b] = (uint8_t)done;
     }
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(done);
+    if (mask == 0) return;
+    const int n = __builtin_popcountll(mask);
+    if (done) {
+        const int pos = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        s_env[wave][pos] = lane; s_lay[wave][pos] = layout;
+    }
+    wave_sync();
+    const int *l_env = s_env[wave], *l_lay = s_lay[wave];
+    copy_layouts<VecT>(n, HW3 / (int)sizeof(VecT), inv_units, e0, HW3, l_env, l_lay, pool_grid, grid, lane);
+    copy_layouts<uint64_t>(n, A, inv_A, e0, (int64_t)A * MGX_AGENT_STRIDE, l_env, l_lay, pool_agents, agents, lane);   // 8-byte rows
+    if (aux && pool_aux)
+        for (int j = lane; j < n; j += 64)
+            reinterpret_cast<uint4 *>(aux)[e0 + l_env[j]] = reinterpret_cast<const uint4 *>(pool_aux)[l_lay[j]];
 }
 
 int finish_launch() {
@@ -141,6 +258,8 @@ int finish_launch() {
     if (e != hipSuccess) { g_aux_hip_error = (int)e; return MGX_ERR_LAUNCH; }
     return MGX_OK;
 }
+
+inline bool misaligned(const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
 
 }  // namespace
 
@@ -150,14 +269,15 @@ int mgx_one_hot(const uint8_t *cells, int64_t n_cells, const int32_t *dim_sizes,
     if (n_cells < 0 || !dim_sizes) return MGX_ERR_INVALID_ARGUMENT;
     const int d0 = dim_sizes[0], d1 = dim_sizes[1], d2 = dim_sizes[2];
     if (d0 < 1 || d1 < 1 || d2 < 1) return MGX_ERR_INVALID_ARGUMENT;
-    if (d0 + d1 + d2 > 32) return MGX_ERR_UNSUPPORTED;
+    const int D = d0 + d1 + d2;
+    if (D > 32) return MGX_ERR_UNSUPPORTED;
     if (n_cells == 0) return MGX_OK;
-    if (!cells || !out || (reinterpret_cast<uintptr_t>(out) & 15)) return MGX_ERR_INVALID_ARGUMENT;
-    const int64_t vectors = (n_cells * (d0 + d1 + d2) + 15) / 16;
-    int64_t blocks = (vectors + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (!cells || !out || misaligned(out, 16)) return MGX_ERR_INVALID_ARGUMENT;
+    const int64_t chunks = (n_cells + kOhCells - 1) / kOhCells;
+    const int64_t blocks = chunks < 256 * 16 ? chunks : 256 * 16;
+    const uint32_t inv_D = (uint32_t)(((1ull << 32) + D - 1) / D);
     hipLaunchKernelGGL(one_hot_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells,
-                       n_cells, d0, d1, d2, out);
+                       n_cells, d0, d1, d2, inv_D, out);
     return finish_launch();
 }
 
@@ -165,13 +285,29 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const 
                  void *stream) {
     if (!spec || batch < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->width < 3 || spec->height < 3 || spec->num_agents < 1) return MGX_ERR_INVALID_ARGUMENT;
-    const int lds = spec->width * spec->height * 3;
-    if (lds > 64 * 1024) return MGX_ERR_UNSUPPORTED;
+    if (spec->width > 255 || spec->height > 255) return MGX_ERR_UNSUPPORTED;
+    const int HW3 = spec->width * spec->height * 3;
+    if (2 * (HW3 + 48) > 64 * 1024) return MGX_ERR_UNSUPPORTED;
     if (batch == 0) return MGX_OK;
-    if (!grid || !agents || !out || (reinterpret_cast<uintptr_t>(agents) & 7)) return MGX_ERR_INVALID_ARGUMENT;
-    const int64_t blocks = batch < 256 * 16 ? batch : 256 * 16;
-    hipLaunchKernelGGL(full_obs_kernel, dim3((unsigned)blocks), dim3(256), (size_t)lds, static_cast<hipStream_t>(stream),
-                       spec->width, spec->height, spec->num_agents, batch, grid, agents, out);
+    if (!grid || !agents || !out || misaligned(agents, 8) || misaligned(grid, 16) || misaligned(out, 16))
+        return MGX_ERR_INVALID_ARGUMENT;
+    int G = (6 * 1024) / HW3;                                     // ~12 KiB of LDS per wavefront
+    if (G < 1) G = 1;
+    if (G * spec->width * spec->height > 65535) G = 65535 / (spec->width * spec->height);
+    while (G > 1 && (batch + G - 1) / G < 4096) G = (G + 1) / 2;  // small batches: spread over the chip
+    const int buf = (G * HW3 + 15 + 16 + 15) & ~15;
+    const int wave_lds = 2 * buf;
+    int wpb = 4;
+    while (wpb > 1 && wpb * wave_lds > 64 * 1024) wpb >>= 1;
+    const int64_t nwaves = (batch + G - 1) / G;
+    const int64_t blocks = (nwaves + wpb - 1) / wpb;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    const uint32_t inv_W = (uint32_t)(((1ull << 32) + spec->width - 1) / spec->width);
+    const uint32_t hw = (uint32_t)(spec->width * spec->height);
+    const uint32_t inv_HW = (uint32_t)(((1ull << 32) + hw - 1) / hw);
+    hipLaunchKernelGGL(full_obs_kernel, dim3((unsigned)blocks), dim3(64 * wpb), (size_t)(wpb * wave_lds),
+                       static_cast<hipStream_t>(stream), spec->width, spec->height, spec->num_agents, G, wave_lds, inv_W,
+                       inv_HW, batch, grid, agents, out);
     return finish_launch();
 }
 
@@ -181,11 +317,30 @@ int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_
     if (!spec || batch < 0 || pool_size < 1 || first_env < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (batch == 0) return MGX_OK;
     if (!pool_grid || !pool_agents || !grid || !agents || !step_count || !episode) return MGX_ERR_INVALID_ARGUMENT;
-    if (reinterpret_cast<uintptr_t>(agents) & 7) return MGX_ERR_INVALID_ARGUMENT;
-    const int64_t blocks = batch < 256 * 32 ? batch : 256 * 32;
-    hipLaunchKernelGGL(reset_done_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       spec->width * spec->height * 3, spec->num_agents, spec->max_steps, batch, first_env, pool_size,
-                       pool_grid, pool_agents, pool_aux, grid, agents, step_count, aux, episode, was_reset);
+    if (misaligned(agents, 8) || misaligned(pool_agents, 8) || misaligned(aux, 16) || misaligned(pool_aux, 16))
+        return MGX_ERR_INVALID_ARGUMENT;
+    const int HW3 = spec->width * spec->height * 3;
+    const int64_t blocks = (batch + 255) / 256;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    // widest copy unit that divides the layout size and the base addresses
+    int unit = 16;
+    while (unit > 1 && (HW3 % unit || misaligned(grid, unit) || misaligned(pool_grid, unit))) unit >>= 1;
+    const int units = HW3 / unit;
+    const uint32_t inv_units = (uint32_t)(((1ull << 32) + units - 1) / units);
+    const uint32_t inv_A = (uint32_t)(((1ull << 32) + spec->num_agents - 1) / spec->num_agents);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define MGX_RESET(T)                                                                                                   \
+    hipLaunchKernelGGL(reset_done_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, HW3, spec->num_agents,           \
+                       spec->max_steps, batch, first_env, pool_size, inv_units, inv_A, pool_grid, pool_agents, pool_aux, grid, \
+                       agents, step_count, aux, episode, was_reset)
+    switch (unit) {
+    case 16: MGX_RESET(uint4); break;
+    case 8:  MGX_RESET(uint64_t); break;
+    case 4:  MGX_RESET(uint32_t); break;
+    case 2:  MGX_RESET(uint16_t); break;
+    default: MGX_RESET(uint8_t); break;
+    }
+#undef MGX_RESET
     return finish_launch();
 }
 

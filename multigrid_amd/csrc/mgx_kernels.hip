@@ -202,11 +202,6 @@ __device__ __forceinline__ void wave_sync() {
     asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32)
-         | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-}
-
 // a*b + c on the full-rate 24-bit multiplier (hipcc turns the C expression into quarter-rate v_mul_lo_u32 /
 // v_mad_u64_u32 here)
 __device__ __forceinline__ int mad24(int a, int b, int c) {

@@ -263,6 +263,40 @@ def test_one_hot_and_full_obs_vs_oracle_at_scale():
     assert torch.equal(got, env.full_obs())
 
 
+AUX_SHAPES = [(5, 5, 3, 7), (9, 7, 2, 1000), (11, 6, 2, 4097), (16, 16, 4, 513), (64, 64, 16, 37), (100, 90, 5, 9)]
+
+
+@pytest.mark.parametrize("W,H,A,B", AUX_SHAPES, ids=[f"{w}x{h}_a{a}_b{b}" for w, h, a, b in AUX_SHAPES])
+def test_full_obs_and_reset_done_odd_shapes(W, H, A, B):
+    """Layout sizes that are not multiples of 16 / 4 / 2 bytes, ragged batches, tiles larger than one LDS pass."""
+    spec = EnvSpec(W, H, A, 7, max_steps=9)
+    st = util.random_state(spec, B, seed=W * 1000 + H, terminated_p=0.3)
+    env = BatchedMultiGridEnv(spec, B, dev(), first_env=5)
+    env.load_state(st["grid"], st["agents"], st["rng"])
+    full = env.full_obs().cpu().numpy()
+    for b in sorted(set(list(range(0, B, max(1, B // 23))) + [B - 1])):
+        np.testing.assert_array_equal(full[b], ob.full_obs(layouts.grid_from_product(st["grid"][b]),
+                                                           layouts.unpack_agents(st["agents"][b])))
+    # auto-reset: a random subset is over (truncated or all agents terminated), the rest must stay untouched
+    K = 7
+    pool = util.random_state(spec, K, seed=99, terminated_p=0.0)
+    env.set_layout_pool(pool["grid"], pool["agents"])
+    r = np.random.default_rng(B)
+    sc = np.where(r.random(B) < 0.4, spec.max_steps, r.integers(0, spec.max_steps, size=B)).astype(np.int32)
+    env.step_count.copy_(torch.from_numpy(sc))
+    all_term = st["agents"][:, :, 4].min(axis=1) > 0
+    done = all_term | (sc >= spec.max_steps)
+    was = env.reset_done().cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(was, done)
+    k = (5 + np.arange(B)) % K
+    want_grid = np.where(done[:, None, None, None], pool["grid"][k], st["grid"])
+    want_agents = np.where(done[:, None, None], pool["agents"][k], st["agents"])
+    np.testing.assert_array_equal(env.grid.cpu().numpy(), want_grid)
+    np.testing.assert_array_equal(env.agents.cpu().numpy(), want_agents)
+    np.testing.assert_array_equal(env.step_count.cpu().numpy(), np.where(done, 0, sc))
+    np.testing.assert_array_equal(env.episode.cpu().numpy(), done.astype(np.int32))
+
+
 def test_reset_done_on_gpu_matches_definition():
     spec = EnvSpec(11, 6, 2, 7, max_steps=6, joint_reward=True, env_kind="blockedunlockpickup")
     B, K, first = 1000, 17, 12345
