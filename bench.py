@@ -41,12 +41,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 
 def workload_spec() -> EnvSpec:
     # MultiGrid-Empty-16x16-v0: multigrid/envs/__init__.py:46, empty.py:145 (max_steps = 4*size^2)
+    if os.environ.get("MGX_WORKLOAD", "c2") == "c5":      # profiling tools only: BASELINE.json configs[4] (64x64, 16 agents, v=9)
+        return EnvSpec(width=64, height=64, num_agents=16, view_size=9, max_steps=4 * 64 * 64, env_kind="empty")
     return EnvSpec(width=16, height=16, num_agents=4, view_size=7, max_steps=4 * 16 * 16, env_kind="empty")
 
 
 def make_env(spec, batch, device, first_env, seed=1234):
     env = BatchedMultiGridEnv(spec, batch, device, first_env=first_env)
     grid, agents = layouts.empty_layout(spec.width, spec.num_agents)      # agents at (1,1) facing right
+    if spec.width == 64:                                                  # C5: random interior starts (host default_rng(5))
+        r = np.random.default_rng(5)
+        agents = np.broadcast_to(agents, (batch,) + agents.shape).copy()
+        agents[..., 2] = r.integers(1, 63, size=agents.shape[:2]); agents[..., 3] = r.integers(1, 63, size=agents.shape[:2])
+        agents[..., 1] = r.integers(0, 4, size=agents.shape[:2])
+        grid = np.broadcast_to(grid, (batch,) + grid.shape)
     env.load_state(grid, agents)
     env.seed_synthetic(seed)
     return env

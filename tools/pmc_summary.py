@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 CSVs written by tools/pmc_probe.sh: per-kernel average duration and counter means."""
 import csv
+import re
 import glob
 import os
 import sys
@@ -11,7 +12,10 @@ lines = []
 
 
 def short(n):
-    return "mgx_fused<step>" if ", 1>" in n or "Li1E" in n or "true>" in n else ("mgx_fused<rollout>" if ", 2>" in n or "Li2E" in n else ("mgx_fused<gen_obs>" if "mgx_fused" in n else n[:40]))
+    m = re.search(r"mgx_fused_kernel<\d+, (\d)", n) or re.search(r"mgx_fused_kernelILi\d+ELi(\d)E", n)
+    if m:
+        return {"0": "mgx_fused<gen_obs>", "1": "mgx_fused<step>", "2": "mgx_fused<rollout>"}[m.group(1)]
+    return n[:40]
 
 
 for f in sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)):

@@ -9,14 +9,15 @@ for M in 0 1 2 4 8 16 32 64 128 63; do
   MGX_SKIP=$M rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv \
       -d $OUT/m$M -o p -- python tools/large_step.py $B 4 > $OUT/m$M.log 2>&1 || echo "mask $M failed"
   python - "$OUT/m$M" "$M" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 d, m = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "mgx_fused" not in k: continue
-        name = "step" if ", 1>" in k else "gen_obs" if ", 0>" in k else "roll"
+        mode = re.search(r"mgx_fused_kernel<\d+, (\d)", k).group(1)
+        name = {"0": "gen_obs", "1": "step", "2": "roll"}[mode]
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, c in acc.items():
     w = sum(c["SQ_WAVES"]) / len(c["SQ_WAVES"])
