@@ -472,8 +472,14 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     uint32_t ovl_saved = 0;                                                  // ROLL: clean cell under this agent's overlay
     int ovl_off = -1;
+    // this lane's agent row, carried in registers through the step (one-step kernels have it from P0); re-read from LDS
+    // only after something else may have changed it (the sequential fallback, an env hook)
+    uint64_t cur_row = ROLL ? (lane < NVc ? rows[lane] : 0ull) : (((uint64_t)in_row.y << 32) | in_row.x);
     if (DO_STEP && !(a.dbg & 2)) {
         const bool in = lane < NVc;
+        // (fetched now so that the s_load latency hides behind P1a / P1s)
+        int32_t *const p_step_count = ROLL ? nullptr : MGX_LATE(step_count);
+        uint8_t *const p_truncated = MGX_LATE(truncated);
         if (A > 1 && !(a.dbg & 128)) {
             MGX_MARK("P1a");
             // -------------------------------------------------------------- P1a: one lane per (env, agent): its draw
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (in && !(a.dbg & 64)) {
             const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
                                ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
-            ev = eval_agent(cf, mytile, rows + env_of_lane * A, acts[lane], rows[lane], true, so);
+            ev = eval_agent(cf, mytile, rows + env_of_lane * A, ROLL ? (int)acts[lane] : (int)(int8_t)in_act, cur_row, true, so);
             woff[lane] = ev.writes ? ev.off : -1;
         }
         wave_sync();
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         const uint64_t genv = in ? (amask << (env_of_lane * A)) : 0ull;         // the lanes of this lane's env
         const bool fb = in && spec_needs_fallback(m_event & genv, m_conf & genv, m_pres & genv, m_moved & genv);
         if (in && !fb) {                                                         // commit
-            if (ev.go) rows[lane] = ev.nrow;
+            if (ev.go) { rows[lane] = ev.nrow; cur_row = ev.nrow; }
             if (ev.unstale) reinterpret_cast<uint8_t *>(auxl + env_of_lane)[4] = 0;
             if (ev.writes) {
                 store_cell(mytile + ev.off, ev.ncell);
@@ -557,8 +563,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (lane < Gc) {
             const int e = lane;
             const int64_t b = e0 + e;
-            const int32_t sc = scnt[e] + 1;                                      // base.py:333
-            if (ROLL) scnt[e] = sc; else MGX_LATE(step_count)[b] = sc;
+            const int32_t sc = (ROLL ? scnt[e] : (int32_t)in_scnt) + 1;          // base.py:333
+            if (ROLL) scnt[e] = sc; else p_step_count[b] = sc;
             uint8_t *etile = tile + e * HW3;
             uint8_t *ggrid = MGX_LATE(grid) + b * HW3;
             auto dirty = [=](int off) {
@@ -571,17 +577,18 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 if (env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[15] = eaux[15]; }
                 if (env_kind == MGX_KIND_REDBLUEDOORS) gaux[4] = eaux[4];
             }
-            MGX_LATE(truncated)[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
+            p_truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
         }
         wave_sync();
+        if ((HOOKS || fbw != 0) && in) cur_row = rows[lane];                     // (a hook / the fallback may have terminated it)
         if (ROLL && ovl >= 0) ovl_saved = load_cell(mytile + ovl);
         ovl_off = ovl;
         wave_sync();
-        if (ovl >= 0) store_cell(mytile + ovl, (uint32_t)T_AGENT | ((uint32_t)(rows[lane] & 0xffffu) << 8));
+        if (ovl >= 0) store_cell(mytile + ovl, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
     } else {
         const int off = (lane < NVc) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
         wave_sync();
-        if (off >= 0) store_cell(tile + env_of_lane * HW3 + off, (uint32_t)T_AGENT | ((uint32_t)(rows[lane] & 0xffffu) << 8));
+        if (off >= 0) store_cell(tile + env_of_lane * HW3 + off, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
     }
     wave_sync();
 
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint8_t *const p_term = DO_STEP ? MGX_LATE(terminated) : nullptr;
     if (lane < NVc) {
         const int e = env_of_lane;
-        const uint64_t row = rows[lane];
+        const uint64_t row = cur_row;
         const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
         ViewRec r;
         r.origin = (int32_t)tile_addr + e * HW3 + g.origin;
