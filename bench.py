@@ -37,6 +37,7 @@ from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts  # noqa: E402
 from multigrid_amd.sharding import shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+AUTO_RESET = True              # finished envs (all terminated / truncated) restart; fused into the step launch
 
 
 def workload_spec() -> EnvSpec:
@@ -57,6 +58,9 @@ def make_env(spec, batch, device, first_env, seed=1234):
         grid = np.broadcast_to(grid, (batch,) + grid.shape)
     env.load_state(grid, agents)
     env.seed_synthetic(seed)
+    if AUTO_RESET:                                                        # the reference's reset() of this env class is one
+        g1, a1 = layouts.empty_layout(spec.width, spec.num_agents)         # fixed layout (empty.py:151-170): a pool of K = 1
+        env.set_layout_pool(g1[None], a1[None])
     return env
 
 
@@ -78,7 +82,7 @@ def timed_rollout(env, actions, mode, dist_barrier):
         with torch.cuda.stream(s):
             with torch.cuda.graph(graph, stream=s):
                 for t in range(K):
-                    env.step(actions[t])
+                    env.step(actions[t], auto_reset=AUTO_RESET)
         stream.wait_stream(s)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     dist_barrier()
@@ -89,7 +93,7 @@ def timed_rollout(env, actions, mode, dist_barrier):
         graph.replay()
     else:
         for t in range(K):
-            env.step(actions[t])
+            env.step(actions[t], auto_reset=AUTO_RESET)
     ev1.record(stream)
     torch.cuda.synchronize(env.device)
     t1 = time.perf_counter()
@@ -134,7 +138,7 @@ def large_batch_points(spec, device, large_batch):
     i = [0]
 
     def step():
-        env.step(acts[i[0] & 3]); i[0] += 1
+        env.step(acts[i[0] & 3], auto_reset=AUTO_RESET); i[0] += 1
     ms_step = kernel_time_ms(step, 60, device)
     ms_obs = kernel_time_ms(env.gen_obs, 60, device)
     n = large_batch * spec.num_agents
@@ -196,13 +200,14 @@ def rollout_point(spec, batch, device, steps, first_env, seed):
     """The same K steps as ONE mgx_rollout launch (env state stays in LDS between steps).  Open-loop actions only."""
     env = make_env(spec, batch, device, first_env)
     acts = random_actions(steps, batch, spec.num_agents, device, seed)
-    out = env.rollout(acts[:2].contiguous())                  # warm-up + allocation pattern
+    out = env.rollout(acts[:2].contiguous(), auto_reset=AUTO_RESET)   # warm-up + allocation pattern
     A, v = spec.num_agents, spec.view_size
     out = {"obs": torch.empty((steps, batch, A, v, v, 3), dtype=torch.uint8, device=device),
            "dir": torch.empty((steps, batch, A), dtype=torch.uint8, device=device),
            "reward": torch.empty((steps, batch, A), dtype=torch.float64, device=device),
            "terminated": torch.empty((steps, batch, A), dtype=torch.uint8, device=device),
-           "truncated": torch.empty((steps, batch), dtype=torch.uint8, device=device)}
+           "truncated": torch.empty((steps, batch), dtype=torch.uint8, device=device),
+           "was_reset": torch.empty((steps, batch), dtype=torch.uint8, device=device)}
     for v in out.values():
         v.zero_()                                              # first touch of the fresh allocations, outside the timing
     stream = torch.cuda.current_stream(device)
@@ -210,7 +215,7 @@ def rollout_point(spec, batch, device, steps, first_env, seed):
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     ev0.record(stream)
-    env.rollout(acts, out)
+    env.rollout(acts, out, auto_reset=AUTO_RESET)
     ev1.record(stream)
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
@@ -261,6 +266,7 @@ def main():
                     help="graph: the K timed steps are one hipGraph replay; eager: K Python-level env.step calls")
     ap.add_argument("--settle-steps", type=int, default=3000,
                     help="untimed launches on a scratch env before the timed region (clock ramp); 0 disables")
+    ap.add_argument("--no-auto-reset", action="store_true", help="step finished envs on as the reference does (base.py:408-409)")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / cpu_baseline legs")
     ap.add_argument("--skip-phases", type=int, default=0,
@@ -268,6 +274,8 @@ def main():
     ap.add_argument("--envs-per-wavefront", type=int, default=0,
                     help="tuning probe: override the launcher's choice of envs per wavefront (0 = automatic)")
     args = ap.parse_args()
+    global AUTO_RESET
+    AUTO_RESET = not args.no_auto_reset
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -305,13 +313,13 @@ def main():
     warm = random_actions(max(args.warmup, 1), B, A, device, 1000 + rank)
     acts = random_actions(args.steps, B, A, device, 1234 + rank)
     for t in range(args.warmup):
-        env.step(warm[t])
+        env.step(warm[t], auto_reset=AUTO_RESET)
     if args.settle_steps > 0:
         # The timed region is ~10 ms; the GPU needs longer than the W warm-up steps to reach its steady clocks.  More
         # untimed launches of the same kernel, on a scratch copy so that the measured envs' state is exactly "W steps in".
         scratch = make_env(spec, B, device, first_env=first_env)
         for t in range(args.settle_steps):
-            scratch.step(warm[t % warm.shape[0]])
+            scratch.step(warm[t % warm.shape[0]], auto_reset=AUTO_RESET)
         del scratch
     torch.cuda.synchronize(device)
     wall_s, ev_ms = timed_rollout(env, acts, args.mode, barrier)
@@ -332,7 +340,9 @@ def main():
                                f"(BASELINE.json configs[1]), uniform random actions 0..6",
                    "batch_per_gpu": B, "global_batch": world * B, "agents": A, "grid": "16x16", "view_size": 7,
                    "mode": args.mode, "parallelism": f"env-sharded x{world}, no collective",
-                   "launch": env.backend.launch_info(B), "auto_reset": False,
+                   "launch": env.backend.launch_info(B),
+                   "auto_reset": ("fused into the step launch (mgx_step_autoreset): envs that are done restart from the "
+                                  "env class' fixed reset layout before the next step") if AUTO_RESET else False,
                    "clock_settle": f"{args.settle_steps} untimed steps on a scratch env before the timed region"},
     }
     if rank == 0:

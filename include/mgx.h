@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 2
+#define MGX_ABI_VERSION 3
 
 enum {
     MGX_OK = 0,
@@ -151,6 +151,31 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const 
 int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const uint8_t *pool_grid,
                    const uint8_t *pool_agents, const uint8_t *pool_aux, uint8_t *grid, uint8_t *agents,
                    int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream);
+
+/* The two calls below fuse mgx_reset_done into the step: an env whose episode ended with the PREVIOUS step (all agents
+ * terminated or step_count >= max_steps, base.py:534-539) is first re-initialised from the layout pool exactly as
+ * mgx_reset_done defines, then the step is applied to the fresh state -- bit-identical to mgx_reset_done followed by
+ * mgx_step, without the second launch.  `was_reset` (u8[B], or u8[steps,B] for the rollout; may be NULL) reports which envs
+ * restarted before each step. */
+typedef struct MgxAutoReset {
+    int64_t first_env;            /* global index of env 0 of this shard */
+    int32_t pool_size;            /* K >= 1 */
+    const uint8_t *pool_grid;     /* u8[K,H,W,3] */
+    const uint8_t *pool_agents;   /* u8[K,A,8] */
+    const uint8_t *pool_aux;      /* u8[K,16]; NULL for MGX_KIND_EMPTY */
+    int32_t *episode;             /* i32[B], in/out */
+    uint8_t *was_reset;           /* out, may be NULL */
+} MgxAutoReset;
+
+int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+                       uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                       uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                       int32_t *err, void *stream);
+
+int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar, uint8_t *grid,
+                          uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                          uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                          int32_t *err, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,17 +10,24 @@ from .spec import MgxSpecC
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmgx.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
 EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
-           "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout")
+           "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout", "mgx_step_autoreset",
+           "mgx_rollout_autoreset")
 
 
 class MgxLaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("envs_per_wavefront", "envs_per_workgroup", "threads_per_workgroup", "workgroups",
                                           "lds_bytes")]
+
+
+class MgxAutoReset(C.Structure):
+    """include/mgx.h: struct MgxAutoReset."""
+    _fields_ = [("first_env", C.c_int64), ("pool_size", C.c_int32), ("pool_grid", C.c_void_p),
+                ("pool_agents", C.c_void_p), ("pool_aux", C.c_void_p), ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
 
 
 class MgxError(RuntimeError):
@@ -52,6 +59,10 @@ def lib() -> C.CDLL:
     L.mgx_step.argtypes = [C.POINTER(MgxSpecC), i64] + [vp] * 13
     L.mgx_rollout.restype = C.c_int
     L.mgx_rollout.argtypes = [C.POINTER(MgxSpecC), i64, C.c_int32] + [vp] * 13
+    L.mgx_step_autoreset.restype = C.c_int
+    L.mgx_step_autoreset.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxAutoReset)] + [vp] * 13
+    L.mgx_rollout_autoreset.restype = C.c_int
+    L.mgx_rollout_autoreset.argtypes = [C.POINTER(MgxSpecC), i64, C.c_int32, C.POINTER(MgxAutoReset)] + [vp] * 13
     L.mgx_one_hot.restype = C.c_int
     L.mgx_one_hot.argtypes = [vp, i64, C.POINTER(C.c_int32), vp, vp]
     L.mgx_full_obs.restype = C.c_int

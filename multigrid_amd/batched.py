@@ -119,8 +119,19 @@ class BatchedMultiGridEnv:
         self.backend.gen_obs(self.batch, self.grid, self.agents, self.obs, self.dir)
         return self.obs, self.dir
 
-    def step(self, actions: torch.Tensor):
+    def _auto_reset_args(self, auto_reset, was_reset):
+        if not auto_reset:
+            return None
+        if getattr(self, "_pool", None) is None:
+            raise RuntimeError("auto_reset needs set_layout_pool() first")
+        return (self.first_env, self._pool, self.episode, was_reset)
+
+    def step(self, actions: torch.Tensor, auto_reset: bool = False):
         """multigrid/base.py:303-346 for every env.
+
+        auto_reset=True fuses `reset_done()` into the launch (build-defined, include/mgx.h mgx_step_autoreset): an env
+        whose episode ended with the previous step first restarts from the layout pool, then takes this step's
+        actions; `was_reset` tells which ones did.  Bit-identical to `reset_done(); step(actions)`.
 
         actions  i8[B,A] on the env's device; `Action` values 0..6, NO_ACTION (-1) = agent not acting
                  (its key absent from the reference's actions dict, base.py:403-404).
@@ -134,17 +145,21 @@ class BatchedMultiGridEnv:
                 or actions.device != self.grid.device or not actions.is_contiguous():
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {(self.batch, sp.num_agents)} "
                              f"on {self.grid.device}")
+        ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
         self.backend.step(self.batch, self.grid, self.agents, self.rng, self.step_count, actions,
                           self.aux if sp.env_kind != "empty" else None, self.err,
-                          self.obs, self.dir, self.reward, self.terminated, self.truncated)
+                          self.obs, self.dir, self.reward, self.terminated, self.truncated,
+                          **({"auto_reset": ar} if ar is not None else {}))
         return self.obs, self.dir, self.reward, self.terminated, self.truncated
 
-    def rollout(self, actions: torch.Tensor, out: dict | None = None) -> dict:
+    def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False) -> dict:
         """`T` consecutive `step`s in one kernel launch (env state stays in LDS between steps); bit-identical to
         calling `step(actions[t])` for t = 0..T-1.  For open-loop action sequences (random / scripted policies).
 
         actions  i8[T,B,A].  Returns {'obs': u8[T,B,A,v,v,3], 'dir', 'reward', 'terminated': [T,B,A],
-        'truncated': u8[T,B]} (pass `out` to reuse buffers).  The env's own `obs`... buffers are not touched."""
+        'truncated': u8[T,B]} (pass `out` to reuse buffers).  The env's own `obs`... buffers are not touched.
+        auto_reset=True: finished envs restart from the layout pool before each step (as `step(auto_reset=True)`);
+        the result then also holds 'was_reset': u8[T,B]."""
         self._need_state()
         sp, B = self.spec, self.batch
         if actions.dtype != torch.int8 or actions.dim() != 3 or tuple(actions.shape[1:]) != (B, sp.num_agents) \
@@ -157,9 +172,13 @@ class BatchedMultiGridEnv:
                    "reward": torch.empty((T, B, A), dtype=torch.float64, device=dev),
                    "terminated": torch.empty((T, B, A), dtype=torch.uint8, device=dev),
                    "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev)}
+        if auto_reset and "was_reset" not in out:
+            out["was_reset"] = torch.empty((T, B), dtype=torch.uint8, device=dev)
+        ar = self._auto_reset_args(auto_reset, out.get("was_reset"))
         self.backend.rollout(B, T, self.grid, self.agents, self.rng, self.step_count, actions,
                              self.aux if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],
-                             out["reward"], out["terminated"], out["truncated"])
+                             out["reward"], out["terminated"], out["truncated"],
+                             **({"auto_reset": ar} if ar is not None else {}))
         return out
 
     # ------------------------------------------------------------------------------------------ either side of the path

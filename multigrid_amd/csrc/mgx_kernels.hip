@@ -58,6 +58,14 @@ struct KernelArgs {
     int32_t wave_lds;
     int32_t vpw;
     int32_t inv_A;      // ceil(2^16 / A): (lane * inv_A) >> 16 == lane / A for lane < 64
+    // fused auto-reset (mgx_step_autoreset / mgx_rollout_autoreset; include/mgx.h: MgxAutoReset)
+    int32_t pool_size;
+    int64_t first_env;
+    const uint8_t *pool_grid;
+    const uint8_t *pool_agents;
+    const uint8_t *pool_aux;
+    int32_t *episode;
+    uint8_t *was_reset;
 };
 
 // gfx950's LDS does take a dword / short access at any byte address (hipcc emits one ds_read_b32 for an align-1 load),
@@ -328,7 +336,9 @@ __device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, co
 // steps (mgx_rollout); per-step outputs go to the [t] slices of the output tensors, the state is written back once.
 // HOOKS: the env kind has a post-step hook and 16 bytes of hook state (every kind but EMPTY).  The EMPTY instantiation
 // drops that code and its SGPRs.
-template <int V, int MODE, bool HOOKS>
+// AR: fused auto-reset -- an env whose episode ended with the previous step restarts from the layout pool before this
+// step's actions are applied (== mgx_reset_done followed by the step, in one launch).
+template <int V, int MODE, bool HOOKS, bool AR>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
     constexpr bool DO_STEP = MODE != 0;
     const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
@@ -473,8 +483,55 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint32_t ovl_saved = 0;                                                  // ROLL: clean cell under this agent's overlay
     int ovl_off = -1;
     // this lane's agent row, carried in registers through the step (one-step kernels have it from P0); re-read from LDS
-    // only after something else may have changed it (the sequential fallback, an env hook)
+    // only after something else may have changed it (a reset, the sequential fallback, an env hook)
     uint64_t cur_row = ROLL ? (lane < NVc ? rows[lane] : 0ull) : (((uint64_t)in_row.y << 32) | in_row.x);
+    uint64_t reset_mask = 0;                                                 // AR: envs (bit = env of the wave) restarted now
+    if (AR && DO_STEP) {
+        // -------------------------------------------------------------- auto-reset (build-defined, include/mgx.h): one lane
+        // per env tests base.py:534-539 on the state the previous step left; a finished env takes the pool layout
+        // (first_env + b + episode * 7919) mod K, step_count 0, episode + 1 -- the definition mgx_reset_done implements
+        const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(cur_row));   // bit = (env, agent) slot
+        bool done = false;
+        if (lane < Gc) {
+            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+            const bool all_term = ((alive >> (lane * A)) & amask) == 0;
+            done = all_term | ((ROLL ? scnt[lane] : (int32_t)in_scnt) >= cf.max_steps);
+            if (a.was_reset) a.was_reset[(int64_t)t * a.batch + e0 + lane] = (uint8_t)done;
+        }
+        reset_mask = __builtin_amdgcn_ballot_w64(done);
+        if (reset_mask != 0) {                                                   // rare: a few envs per thousand steps
+            for (uint64_t m = reset_mask; m != 0; m &= m - 1) {
+                const int e = __builtin_ctzll(m);                                // wave-uniform
+                const int64_t b = e0 + e;
+                int32_t *p_ep = MGX_LATE(episode);
+                const int32_t ep = p_ep[b];
+                const int lay = (int)((uint64_t)(MGX_LATE(first_env) + b + (int64_t)ep * 7919) % (uint64_t)MGX_LATE(pool_size));
+                wave_sync();
+                if (lane == 0) p_ep[b] = ep + 1;
+                const uint8_t *sg = MGX_LATE(pool_grid) + (int64_t)lay * HW3;
+                uint8_t *etile = tile + e * HW3;
+                uint8_t *gg = MGX_LATE(grid) + b * HW3;
+                for (int i = lane; i < HW3; i += 64) {                           // bytes: layouts have any size / alignment
+                    const uint8_t v = sg[i];
+                    etile[i] = v;
+                    if (!ROLL) gg[i] = v;                                        // (the rollout writes its tile back at the end)
+                }
+                const uint64_t *sa = reinterpret_cast<const uint64_t *>(MGX_LATE(pool_agents)) + (int64_t)lay * A;
+                for (int j = lane; j < A; j += 64) rows[e * A + j] = sa[j];
+                if (lane == 0) {
+                    scnt[e] = 0;
+                    if (HOOKS) {
+                        const uint4 x = reinterpret_cast<const uint4 *>(MGX_LATE(pool_aux))[lay];
+                        auxl[e] = x;
+                        if (!ROLL) reinterpret_cast<uint4 *>(MGX_LATE(aux))[b] = x;
+                    }
+                }
+            }
+            wave_sync();
+            if (!ROLL && lane < Gc && ((reset_mask >> lane) & 1ull)) in_scnt = 0;
+        }
+    }
+    if (AR && reset_mask != 0 && lane < NVc) cur_row = rows[lane];
     if (DO_STEP && !(a.dbg & 2)) {
         const bool in = lane < NVc;
         // (fetched now so that the s_load latency hides behind P1a / P1s)
@@ -764,7 +821,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
         if (lane < Gc) {
             a.step_count[e0 + lane] = scnt[lane];
-            if (HOOKS && env_kind >= MGX_KIND_REDBLUEDOORS) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
+            if (HOOKS && (AR || env_kind >= MGX_KIND_REDBLUEDOORS)) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
         }
     }
 }
@@ -778,7 +835,11 @@ template <int MODE>
 int launch(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
     void (*kern)(const KernelArgs) = nullptr;
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
-#define MGX_PICK(V) kern = hooks ? mgx_fused_kernel<V, MODE, (MODE != 0)> : mgx_fused_kernel<V, MODE, false>
+    const bool ar = MODE != 0 && ka.pool_grid != nullptr;
+    constexpr bool S = MODE != 0;
+#define MGX_PICK(V)                                                                                       \
+    kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S> : mgx_fused_kernel<V, MODE, S, false>)            \
+                 : (ar ? mgx_fused_kernel<V, MODE, false, S> : mgx_fused_kernel<V, MODE, false, false>)
     switch (ka.sp.view_size) {
     case 3:  MGX_PICK(3);  break;
     case 5:  MGX_PICK(5);  break;
@@ -909,35 +970,10 @@ int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const u
     return launch<0>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
-int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
-             int32_t *step_count, const int8_t *actions, uint8_t *aux,
-             uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
-             int32_t *err, void *stream) {
-    int rc = check_spec(spec, batch);
-    if (rc) return rc;
-    if (batch == 0) return MGX_OK;
-    if (!grid || !agents || !step_count || !actions || !obs || !reward || !terminated || !truncated)
-        return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->num_agents > 1 && !rng) return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->env_kind != MGX_KIND_EMPTY && !aux) return MGX_ERR_INVALID_ARGUMENT;
-    if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16) || misaligned(rng, 8)
-        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(aux, 16))
-        return MGX_ERR_INVALID_ARGUMENT;
-    KernelArgs ka{};
-    int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg);
-    if (rc) return rc;
-    ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
-    ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
-    ka.truncated = truncated; ka.err = err;
-    ka.T = 1;
-    return launch<1>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
-}
-
-int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
-                int32_t *step_count, const int8_t *actions, uint8_t *aux,
-                uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
-                int32_t *err, void *stream) {
+static int step_common(bool roll, const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar,
+                       uint8_t *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
+                       uint8_t *aux, uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated,
+                       uint8_t *truncated, int32_t *err, void *stream) {
     int rc = check_spec(spec, batch);
     if (rc) return rc;
     if (steps < 0) return MGX_ERR_INVALID_ARGUMENT;
@@ -950,14 +986,59 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid
         || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(aux, 16))
         return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
+    if (ar) {
+        if (ar->pool_size < 1 || ar->first_env < 0 || !ar->pool_grid || !ar->pool_agents || !ar->episode)
+            return MGX_ERR_INVALID_ARGUMENT;
+        if (spec->env_kind != MGX_KIND_EMPTY && !ar->pool_aux) return MGX_ERR_INVALID_ARGUMENT;
+        if (misaligned(ar->pool_agents, 8) || misaligned(ar->pool_aux, 16) || misaligned(ar->episode, 4))
+            return MGX_ERR_INVALID_ARGUMENT;
+        ka.pool_size = ar->pool_size; ka.first_env = ar->first_env; ka.pool_grid = ar->pool_grid;
+        ka.pool_agents = ar->pool_agents; ka.pool_aux = ar->pool_aux; ka.episode = ar->episode;
+        ka.was_reset = ar->was_reset;
+    }
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg, /*roll=*/true);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, roll);
     if (rc) return rc;
     ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
     ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
-    ka.T = steps;
-    return launch<2>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+    ka.T = roll ? steps : 1;
+    return roll ? launch<2>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream))
+                : launch<1>(ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+}
+
+int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+             int32_t *step_count, const int8_t *actions, uint8_t *aux,
+             uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+             int32_t *err, void *stream) {
+    return step_common(false, spec, batch, 1, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+                       terminated, truncated, err, stream);
+}
+
+int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+                int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                int32_t *err, void *stream) {
+    return step_common(true, spec, batch, steps, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+                       terminated, truncated, err, stream);
+}
+
+int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+                       uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                       uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                       int32_t *err, void *stream) {
+    if (!ar) return MGX_ERR_INVALID_ARGUMENT;
+    return step_common(false, spec, batch, 1, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+                       terminated, truncated, err, stream);
+}
+
+int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar, uint8_t *grid,
+                          uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                          uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                          int32_t *err, void *stream) {
+    if (!ar) return MGX_ERR_INVALID_ARGUMENT;
+    return step_common(true, spec, batch, steps, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+                       terminated, truncated, err, stream);
 }
 
 }  // extern "C"

@@ -172,18 +172,42 @@ class HipBackend:
     def gen_obs(self, B, grid, agents, obs, dirs):
         _gen_obs_into(self.sc, B, grid, agents, obs, dirs)
 
-    def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated):
-        _step_into(self.sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
-                   terminated, truncated)
+    @staticmethod
+    def _auto_reset_struct(auto_reset):
+        """auto_reset = (first_env, (pool_grid, pool_agents, pool_aux | None), episode, was_reset | None)"""
+        first_env, (pg, pa, pt), episode, was_reset = auto_reset
+        return _lib.MgxAutoReset(first_env, pg.shape[0], pg.data_ptr(), pa.data_ptr(),
+                                 pt.data_ptr() if pt is not None else None, episode.data_ptr(),
+                                 was_reset.data_ptr() if was_reset is not None else None)
+
+    def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated,
+             auto_reset=None):
+        if auto_reset is None:
+            _step_into(self.sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
+                       terminated, truncated)
+            return
+        ar = self._auto_reset_struct(auto_reset)
+        with torch.cuda.device(grid.device):
+            rc = _lib.lib().mgx_step_autoreset(
+                C.byref(self.sc), B, C.byref(ar), grid.data_ptr(), agents.data_ptr(),
+                rng.data_ptr() if rng is not None else None, step_count.data_ptr(), actions.data_ptr(),
+                target.data_ptr() if target is not None else None, obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(),
+                terminated.data_ptr(), truncated.data_ptr(), err.data_ptr() if err is not None else None,
+                _stream(grid.device))
+        _lib.check(rc, "mgx_step_autoreset")
 
     def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
-                truncated):
-        with torch.cuda.device(grid.device):
-            rc = _lib.lib().mgx_rollout(
-                C.byref(self.sc), B, T, grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
+                truncated, auto_reset=None):
+        args = (grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
                 actions.data_ptr(), target.data_ptr() if target is not None else None, obs.data_ptr(),
                 dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(), truncated.data_ptr(), err.data_ptr(),
                 _stream(grid.device))
+        with torch.cuda.device(grid.device):
+            if auto_reset is None:
+                rc = _lib.lib().mgx_rollout(C.byref(self.sc), B, T, *args)
+            else:
+                ar = self._auto_reset_struct(auto_reset)
+                rc = _lib.lib().mgx_rollout_autoreset(C.byref(self.sc), B, T, C.byref(ar), *args)
         _lib.check(rc, "mgx_rollout")
 
     def one_hot(self, cells, out):

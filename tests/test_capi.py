@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     L = _lib.lib()
     for n in names:
         assert getattr(L, n) is not None
-    assert L.mgx_abi_version() == _lib.ABI_VERSION == 2
+    assert L.mgx_abi_version() == _lib.ABI_VERSION == 3
     assert _lib.error_string(0) == "ok" and "action" in _lib.error_string(-2)
 
 
@@ -55,6 +55,9 @@ def test_argument_validation_codes():
     # NULL tensors are rejected before anything is launched
     assert L.mgx_gen_obs(C.byref(ok), 8, None, None, None, None, None) == _lib.ERR_INVALID_ARGUMENT
     assert L.mgx_step(C.byref(ok), 8, *([None] * 13)) == _lib.ERR_INVALID_ARGUMENT
+    assert L.mgx_step_autoreset(C.byref(ok), 8, None, *([None] * 13)) == _lib.ERR_INVALID_ARGUMENT
+    ar = _lib.MgxAutoReset(0, 0, None, None, None, None, None)
+    assert L.mgx_rollout_autoreset(C.byref(ok), 8, 4, C.byref(ar), *([None] * 13)) == _lib.ERR_INVALID_ARGUMENT
     # an empty batch is a no-op
     assert L.mgx_gen_obs(C.byref(ok), 0, None, None, None, None, None) == _lib.OK
     with pytest.raises(_lib.MgxError):

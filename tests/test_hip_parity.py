@@ -323,6 +323,64 @@ def test_reset_done_on_gpu_matches_definition():
     env.check_errors()
 
 
+AR_CASES = [
+    ("empty8_a2", EnvSpec(8, 8, 2, 7, max_steps=7), 777, 40),
+    ("empty16_a4_ragged", EnvSpec(16, 16, 4, 7, max_steps=5), 4099, 24),
+    ("odd_9x7_a3_v5", EnvSpec(9, 7, 3, 5, max_steps=6, failure_termination_mode="any"), 515, 30),
+    ("bup_a2", EnvSpec(11, 6, 2, 7, max_steps=9, joint_reward=True, env_kind="blockedunlockpickup"), 1500, 40),
+    ("a16_v9_64x64", EnvSpec(64, 64, 16, 9, max_steps=4), 40, 10),
+]
+
+
+def _ar_env(spec, B, seed):
+    """Env + layout pool: random walled states (objects, lava, goals -> early terminations) for the plain kinds, real
+    BlockedUnlockPickup layouts for the hook kind."""
+    K = 5
+    if spec.env_kind == "blockedunlockpickup":
+        r = np.random.default_rng(seed)
+        pool = [layouts.blockedunlockpickup_layout(6, 2, r, r) for _ in range(K)]
+        pg, pa = np.stack([p[0] for p in pool]), np.stack([p[1] for p in pool])
+        pt = np.stack([layouts.make_aux("blockedunlockpickup", p[0], p[2]) for p in pool])
+    else:
+        st = util.random_state(spec, K, seed=seed, terminated_p=0.0, density=0.3)
+        pg, pa, pt = st["grid"], st["agents"], None
+    idx = (np.arange(B) * 3) % K
+    env = BatchedMultiGridEnv(spec, B, dev(), first_env=11)
+    env.load_state(pg[idx], pa[idx], aux=None if pt is None else pt[idx])
+    env.seed_synthetic(seed)
+    env.set_layout_pool(pg, pa, pt)
+    return env
+
+
+@pytest.mark.parametrize("name,spec,B,T", AR_CASES, ids=[c[0] for c in AR_CASES])
+def test_fused_auto_reset_equals_reset_then_step(name, spec, B, T):
+    """mgx_step_autoreset == mgx_reset_done followed by mgx_step, every step, on every output and on the state; and
+    mgx_rollout_autoreset == the same sequence in one launch."""
+    A = spec.num_agents
+    fused, split, roll = _ar_env(spec, B, 21), _ar_env(spec, B, 21), _ar_env(spec, B, 21)
+    g = torch.Generator(device=dev()); g.manual_seed(9)
+    acts = torch.randint(0, 7, (T, B, A), dtype=torch.int8, device=dev(), generator=g)
+    acts[:, ::7, 0] = -1                                            # some agents absent
+    r = roll.rollout(acts, auto_reset=True)
+    n_reset = 0
+    for t in range(T):
+        was = split.reset_done().clone()
+        want = [x.clone() for x in split.step(acts[t])]
+        got = fused.step(acts[t], auto_reset=True)
+        assert torch.equal(fused.was_reset, was), f"step {t}: was_reset"
+        for k, (gx, wx) in enumerate(zip(got, want)):
+            assert torch.equal(gx, wx), f"step {t}: output {k}"
+        for k, key in enumerate(("obs", "dir", "reward", "terminated", "truncated")):
+            assert torch.equal(r[key][t], want[k]), f"rollout step {t}: {key}"
+        assert torch.equal(r["was_reset"][t], was)
+        n_reset += int(was.sum())
+    for e in (fused, roll):
+        for f in ("grid", "agents", "rng", "step_count", "aux", "episode"):
+            assert torch.equal(getattr(e, f), getattr(split, f)), f
+    assert n_reset > B                                              # every env restarted more than once on average
+    fused.check_errors(); split.check_errors(); roll.check_errors()
+
+
 ROLL_CASES = [
     ("C2_empty16_a4", EnvSpec(16, 16, 4, 7, max_steps=1024), 2048, 40, 0.0),
     ("objects16_a4", EnvSpec(16, 16, 4, 7, max_steps=30), 1500, 40, 0.3),

@@ -18,7 +18,7 @@ spec = bench.workload_spec()
 env = bench.make_env(spec, B, dev, 0)
 acts = bench.random_actions(4, B, spec.num_agents, dev, 7)
 for t in range(N):
-    env.step(acts[t & 3])
+    env.step(acts[t & 3], auto_reset=bench.AUTO_RESET)
 for t in range(N):
     env.gen_obs()
 torch.cuda.synchronize()
