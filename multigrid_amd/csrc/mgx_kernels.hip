@@ -421,7 +421,9 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0, 0);
         if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
     }
+    const int32_t max_steps_s = a.sp.max_steps;                             // (AR: fetched under the load wait, not after it)
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
+    if (AR) asm volatile("" ::"s"(max_steps_s));
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     // this lane's agent row, carried in registers through the step (one-step kernels have it from P0); re-read from LDS
     // only after something else may have changed it (a reset, the sequential fallback, an env hook)
     uint64_t cur_row = ROLL ? (lane < NVc ? rows[lane] : 0ull) : (((uint64_t)in_row.y << 32) | in_row.x);
+    MGX_MARK("AR");
     uint64_t reset_mask = 0;                                                 // AR: envs (bit = env of the wave) restarted now
     if (AR && DO_STEP) {
         // -------------------------------------------------------------- auto-reset (build-defined, include/mgx.h): one lane
@@ -494,8 +497,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         bool done = false;
         if (lane < Gc) {
             const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-            const bool all_term = ((alive >> (lane * A)) & amask) == 0;
-            done = all_term | ((ROLL ? scnt[lane] : (int32_t)in_scnt) >= cf.max_steps);
+            const bool all_term = ((alive >> mad24(lane, A, 0)) & amask) == 0;
+            done = all_term | ((ROLL ? scnt[lane] : (int32_t)in_scnt) >= max_steps_s);
             if (a.was_reset) a.was_reset[(int64_t)t * a.batch + e0 + lane] = (uint8_t)done;
         }
         reset_mask = __builtin_amdgcn_ballot_w64(done);

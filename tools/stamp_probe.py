@@ -18,14 +18,14 @@ if not hasattr(lib, "mgx_debug_read_stamps"):
 lib.mgx_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_longlong]
 dev = torch.device("cuda", 0)
 spec = bench.workload_spec()
-names = ["start", "P0", "P0end", "P1a", "P1s", "P1s_end", "P1hook", "P1d", "P2", "P3", "P4", "P5", "P5end", "P5'", "P5end'", "end"]
+names = ["start", "P0", "P0end", "AR", "P1a", "P1s", "P1s_end", "P1hook", "P1d", "P2", "P3", "P4", "P5", "P5end", "P5'", "P5end'", "end"]
 for B in [int(x) for x in sys.argv[1:]] or [4096]:
     env = bench.make_env(spec, B, dev, 0)
     acts = bench.random_actions(64, B, spec.num_agents, dev, 7)
     li = env.backend.launch_info(B)
     nw = (B + li["envs_per_wavefront"] - 1) // li["envs_per_wavefront"]
     for t in range(20):
-        env.step(acts[t])
+        env.step(acts[t], auto_reset=bench.AUTO_RESET)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     print(f"B={B} launch {li}")
@@ -34,13 +34,13 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
         acc = None
         reps = 20
         for r in range(reps):
-            env.step(acts[20 + r])
+            env.step(acts[20 + r], auto_reset=bench.AUTO_RESET)
             torch.cuda.synchronize()
             lib.mgx_debug_read_stamps(buf, wave)
             st = [int(x) for x in buf if x]
             d = [st[i + 1] - st[i] for i in range(len(st) - 1)]
             acc = d if acc is None else [min(x, y) for x, y in zip(acc, d)]     # min over launches: least disturbed
-        labels = names[:len(acc)] if len(acc) + 1 != 14 else names[:12] + ["P5end"]
+        labels = names[:len(acc)]
         tot = sum(acc)
         print(f"  wave {wave}: total {tot} clk  " + "  ".join(f"{labels[i]}>{acc[i]}" for i in range(len(acc))))
     del env
