@@ -287,17 +287,26 @@ def main():
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to benchmark")
-    device = torch.device("cuda", local_rank)
+    # MGX_BENCH_ONE_GPU=1 (validation only): every rank on device 0 with gloo, to exercise the multi-rank code path on
+    # a single-GPU box; the numbers of such a run mean nothing.
+    one_gpu_check = os.environ.get("MGX_BENCH_ONE_GPU") == "1"
+    device = torch.device("cuda", 0 if one_gpu_check else local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_gpu_check:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if one_gpu_check:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     if args.skip_phases:
         from multigrid_amd import _lib
@@ -326,7 +335,7 @@ def main():
     if not args.skip_phases:
         env.check_errors()
 
-    t = torch.tensor([wall_s], dtype=torch.float64, device=device)
+    t = torch.tensor([wall_s], dtype=torch.float64, device="cpu" if one_gpu_check else device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
