@@ -129,9 +129,7 @@ struct LdsCarve {
     __host__ __device__ int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
     __host__ __device__ int rew() const { return 24 * vpw; }                         // f64  [vpw]
     __host__ __device__ int woff() const { return 32 * vpw; }                        // i32  [vpw]     (P1s)
-    // one-step kernels: the jump-ahead constants (P1a only) share woff's space; the rollout re-reads them every step
-    __host__ __device__ int woff_bytes() const { return (!roll && 32 * A > 4 * vpw) ? 32 * A : 4 * vpw; }
-    __host__ __device__ int temps_end() const { return woff() + woff_bytes(); }
+    __host__ __device__ int temps_end() const { return woff() + 4 * vpw; }
     // -- state that lives across phases / steps --
     __host__ __device__ int act() const { return temps_end(); }                      // i8   [vpw]
     __host__ __device__ int ord() const { return act() + vpw; }                      // u8   [vpw]
@@ -139,8 +137,9 @@ struct LdsCarve {
     __host__ __device__ int scnt() const { return rng() + (roll ? 32 * Gw : 0); }    // i32  [Gw]
     __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
     __host__ __device__ int own_jump() const { return aux() + (has_aux ? 16 * Gw : 0); }
-    __host__ __device__ int jump() const { return roll ? own_jump() : woff(); }      // u64  [A][4]: k = 1..A
-    __host__ __device__ int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one WALL cell + the dword after it
+    __host__ __device__ int jump() const { return own_jump(); }                      // u64  [A][4]: k = 1..A   (rollout only: the
+    __host__ __device__ int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one-step kernels keep them in registers)
+                                                                                     // wall: one WALL cell + the dword after it
     // P4/P5 staging of one round's obs bytes (skew + pad).  One-step kernels put it over the tile, which is dead once
     // P2 has gathered the cells; the rollout keeps the tile and uses the (equally dead) temporaries' space + its own.
     __host__ __device__ int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
@@ -395,31 +394,50 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const int grec = (a.dbg & 1) ? 0 : min((len + 15) & ~15, avail);
     const __amdgpu_buffer_rsrc_t grsrc = make_rsrc(gsrc, grec);
     const int lane16 = 16 * lane;
+    const int env_of_lane = (lane * a.inv_A) >> 16, agent_of_lane = lane - env_of_lane * A;   // slot `lane` = (env, agent)
+    // (1) what the draws (P1a) need goes out first: this lane's env's PCG64 words and its agent's jump-ahead constants
+    u32x4 in_rngA = {0, 0, 0, 0}, in_rngB = {0, 0, 0, 0};                    // (ROLL: two envs' halves, copied to LDS)
+    u32x4 in_jmpA = {0, 0, 0, 0}, in_jmpB = {0, 0, 0, 0};
+    if (DO_STEP && A > 1) {
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.rng + e0 * 4, Gc * 32);
+        if (ROLL) {                                                              // env-major copy: lane l holds words 2l, 2l+1
+            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, lane16, 0, 0);
+            for (int t = lane; t < A * 4; t += 64) jump[t] = kJump.w[1][t];          // constants for k = 1..A, re-read every step
+        } else {                                                                 // same address for the A lanes of an env
+            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32, 0, 0);
+            in_rngB = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32 + 16, 0, 0);
+            const u32x4 *jk = reinterpret_cast<const u32x4 *>(&kJump.w[1 + agent_of_lane][0]);   // agent k draws k+1 ahead
+            in_jmpA = jk[0]; in_jmpB = jk[1];
+        }
+    }
+    // (2) the tile and the rest
     u32x4 tv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
         tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
-    const int env_of_lane = (lane * a.inv_A) >> 16, agent_of_lane = lane - env_of_lane * A;   // slot `lane` = (env, agent)
     u32x2 in_row = {0, 0};
-    u32x4 in_rngA = {0, 0, 0, 0}, in_rngB = {0, 0, 0, 0};                    // this lane's env's PCG64 words (ROLL: two envs' halves)
     uint32_t in_scnt = 0;
     u32x4 in_aux = {0, 0, 0, 0};
     uint8_t in_act = 0;
     in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
     if (DO_STEP) {
         in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0, 0);
-        if (A > 1) {
-            const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.rng + e0 * 4, Gc * 32);
-            if (ROLL) {                                                          // env-major copy: lane l holds words 2l, 2l+1
-                in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, lane16, 0, 0);
-            } else {                                                             // same address for the A lanes of an env
-                in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32, 0, 0);
-                in_rngB = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32 + 16, 0, 0);
-            }
-            for (int t = lane; t < A * 4; t += 64) jump[t] = kJump.w[1][t];          // constants for k = 1..A
-        }
         in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0, 0);
         if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
+    }
+    // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
+    // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
+    uint64_t my_rng[4];
+    my_rng[0] = ((uint64_t)in_rngA.y << 32) | in_rngA.x; my_rng[1] = ((uint64_t)in_rngA.w << 32) | in_rngA.z;
+    my_rng[2] = ((uint64_t)in_rngB.y << 32) | in_rngB.x; my_rng[3] = ((uint64_t)in_rngB.w << 32) | in_rngB.z;
+    uint64_t my_draw = 0;
+    if (DO_STEP && !ROLL && A > 1 && !(a.dbg & (2 | 128)) && lane < NVc) {
+        uint64_t jk[4];
+        jk[0] = ((uint64_t)in_jmpA.y << 32) | in_jmpA.x; jk[1] = ((uint64_t)in_jmpA.w << 32) | in_jmpA.z;
+        jk[2] = ((uint64_t)in_jmpB.y << 32) | in_jmpB.x; jk[3] = ((uint64_t)in_jmpB.w << 32) | in_jmpB.z;
+        uint64_t s_lo, s_hi;
+        my_draw = pcg64_draw_at(my_rng, jk, s_lo, s_hi);
+        if (agent_of_lane == A - 1) { uint64_t *dst = a.rng + (e0 + env_of_lane) * 4; dst[0] = s_lo; dst[1] = s_hi; }
     }
     const int32_t max_steps_s = a.sp.max_steps;                             // (AR: fetched under the load wait, not after it)
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
@@ -435,10 +453,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + cv.wall());
     if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL_WALL;
-    uint64_t my_rng[4];                                                      // one-step kernels: PCG64 words in registers
-    my_rng[0] = ((uint64_t)in_rngA.y << 32) | in_rngA.x; my_rng[1] = ((uint64_t)in_rngA.w << 32) | in_rngA.z;
-    my_rng[2] = ((uint64_t)in_rngB.y << 32) | in_rngB.x; my_rng[3] = ((uint64_t)in_rngB.w << 32) | in_rngB.z;
     if (lane < NVc) {
+        if (DO_STEP && !ROLL && A > 1) rnd[lane] = my_draw;                      // (only the sequential fallback reads the draws)
         reinterpret_cast<u32x2 *>(rows)[lane] = in_row;
         rew[lane] = 0.0;                                                         // base.py:393
         if (DO_STEP) acts[lane] = (int8_t)in_act;
@@ -540,21 +556,18 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         // (fetched now so that the s_load latency hides behind P1a / P1s)
         int32_t *const p_step_count = ROLL ? nullptr : MGX_LATE(step_count);
         uint8_t *const p_truncated = MGX_LATE(truncated);
-        if (A > 1 && !(a.dbg & 128)) {
-            MGX_MARK("P1a");
-            // -------------------------------------------------------------- P1a: one lane per (env, agent): its draw
+        MGX_MARK("P1a");
+        if (ROLL && A > 1 && !(a.dbg & 128)) {
+            // -------------------------------------------------------------- P1a (rollout; the one-step kernels did it in P0):
+            // one lane per (env, agent): its draw
             if (in) {
                 const int e = env_of_lane, ai = agent_of_lane;
                 uint64_t s_lo, s_hi;
-                rnd[lane] = pcg64_draw_at(ROLL ? rngs + e * 4 : my_rng, jump + ai * 4, s_lo, s_hi);   // base.py:399
-                if (ai == A - 1) {                                                // the env's stream after A draws
-                    if (ROLL) { rngs[e * 4 + 0] = s_lo; rngs[e * 4 + 1] = s_hi; }          // (every lane has read it: in-order LDS)
-                    else { uint64_t *dst = MGX_LATE(rng) + (e0 + e) * 4; dst[0] = s_lo; dst[1] = s_hi; }
-                }
+                rnd[lane] = pcg64_draw_at(rngs + e * 4, jump + ai * 4, s_lo, s_hi);         // base.py:399
+                if (ai == A - 1) { rngs[e * 4 + 0] = s_lo; rngs[e * 4 + 1] = s_hi; }        // (every lane has read it: in-order LDS)
             }
         }
         MGX_MARK("P1s");
-        wave_sync();                                                            // (woff below reuses the jump constants' space)
         // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
         // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
         int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
