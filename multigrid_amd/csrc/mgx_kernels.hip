@@ -410,21 +410,21 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             in_jmpA = jk[0]; in_jmpB = jk[1];
         }
     }
-    // (2) the tile and the rest
-    u32x4 tv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
     u32x2 in_row = {0, 0};
     uint32_t in_scnt = 0;
     u32x4 in_aux = {0, 0, 0, 0};
     uint8_t in_act = 0;
     in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
     if (DO_STEP) {
-        in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0, 0);
         in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0, 0);
+        in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0, 0);
         if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
     }
+    // (2) the tile
+    u32x4 tv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
     // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
     // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
     uint64_t my_rng[4];
@@ -439,9 +439,21 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         my_draw = pcg64_draw_at(my_rng, jk, s_lo, s_hi);
         if (agent_of_lane == A - 1) { uint64_t *dst = a.rng + (e0 + env_of_lane) * 4; dst[0] = s_lo; dst[1] = s_hi; }
     }
-    const int32_t max_steps_s = a.sp.max_steps;                             // (AR: fetched under the load wait, not after it)
+    // (4) auto-reset test of the one-step kernels, also under the wait (build-defined, include/mgx.h): one lane per env
+    // tests base.py:534-539 on the state the previous step left
+    uint64_t reset_mask0 = 0;
+    if (AR && DO_STEP && !ROLL) {
+        const uint64_t row0 = ((uint64_t)in_row.y << 32) | in_row.x;
+        const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(row0));     // bit = (env, agent) slot
+        bool done = false;
+        if (lane < Gc) {
+            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+            done = (((alive >> mad24(lane, A, 0)) & amask) == 0) | ((int32_t)in_scnt >= a.sp.max_steps);
+            if (a.was_reset) a.was_reset[e0 + lane] = (uint8_t)done;
+        }
+        reset_mask0 = __builtin_amdgcn_ballot_w64(done);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
-    if (AR) asm volatile("" ::"s"(max_steps_s));
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
@@ -506,18 +518,20 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     MGX_MARK("AR");
     uint64_t reset_mask = 0;                                                 // AR: envs (bit = env of the wave) restarted now
     if (AR && DO_STEP) {
-        // -------------------------------------------------------------- auto-reset (build-defined, include/mgx.h): one lane
-        // per env tests base.py:534-539 on the state the previous step left; a finished env takes the pool layout
+        // -------------------------------------------------------------- auto-reset: a finished env takes the pool layout
         // (first_env + b + episode * 7919) mod K, step_count 0, episode + 1 -- the definition mgx_reset_done implements
-        const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(cur_row));   // bit = (env, agent) slot
-        bool done = false;
-        if (lane < Gc) {
-            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-            const bool all_term = ((alive >> mad24(lane, A, 0)) & amask) == 0;
-            done = all_term | ((ROLL ? scnt[lane] : (int32_t)in_scnt) >= max_steps_s);
-            if (a.was_reset) a.was_reset[(int64_t)t * a.batch + e0 + lane] = (uint8_t)done;
+        if (ROLL) {
+            const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(cur_row));   // bit = (env, agent) slot
+            bool done = false;
+            if (lane < Gc) {
+                const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+                done = (((alive >> mad24(lane, A, 0)) & amask) == 0) | (scnt[lane] >= cf.max_steps);
+                if (a.was_reset) a.was_reset[(int64_t)t * a.batch + e0 + lane] = (uint8_t)done;
+            }
+            reset_mask = __builtin_amdgcn_ballot_w64(done);
+        } else {
+            reset_mask = reset_mask0;                                            // (tested in P0, under the load wait)
         }
-        reset_mask = __builtin_amdgcn_ballot_w64(done);
         if (reset_mask != 0) {                                                   // rare: a few envs per thousand steps
             for (uint64_t m = reset_mask; m != 0; m &= m - 1) {
                 const int e = __builtin_ctzll(m);                                // wave-uniform
