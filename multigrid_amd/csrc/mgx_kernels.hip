@@ -453,16 +453,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
         reset_mask0 = __builtin_amdgcn_ballot_w64(done);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
-    for (int rel = lane16 + 1024 * U; rel < len; rel += 1024)                   // tiles larger than one pass
-        *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, 0);
-    if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
-        const int64_t t0 = gtotal & ~(int64_t)15;
-        for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
-    }
+    // (5) the small inputs are here long before the tile: their LDS stores go first
     const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + cv.wall());
     if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL_WALL;
     if (lane < NVc) {
@@ -474,6 +465,16 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     if (DO_STEP) {
         if (A > 1 && ROLL && lane < Gc * 2) reinterpret_cast<u32x4 *>(rngs)[lane] = in_rngA;
         if (lane < Gc) { scnt[lane] = (int32_t)in_scnt; if (cv.has_aux) reinterpret_cast<u32x4 *>(auxl)[lane] = in_aux; }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
+    for (int rel = lane16 + 1024 * U; rel < len; rel += 1024)                   // tiles larger than one pass
+        *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, 0);
+    if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
+        const int64_t t0 = gtotal & ~(int64_t)15;
+        for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
     wave_sync();
