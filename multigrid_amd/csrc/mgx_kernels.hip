@@ -315,7 +315,10 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
     }
 }
 
-constexpr int kGroup = 8;
+#ifndef MGX_GROUP
+#define MGX_GROUP 16
+#endif
+constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as one straight-line block
 
 template <int V, int NW, int VPW, int S0 = 0>
 __device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, const ViewRec *rec,
