@@ -424,10 +424,16 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
     }
     // (2) the tile
-    u32x4 tv[U];
+    u32x4 tv[U], tv2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
         tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
+    const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env: a second burst, same wait
+    if (big_tile) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            tv2[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 1024 * U + 4096 * (u >> 2), 0);
+    }
     // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
     // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
     uint64_t my_rng[4];
@@ -473,8 +479,13 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
-    for (int rel = lane16 + 1024 * U; rel < len; rel += 1024)                   // tiles larger than one pass
-        *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, 0);
+    if (big_tile) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lane16 + 1024 * (U + u) < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * (U + u)) = tv2[u];
+        for (int rel = lane16 + 2048 * U; rel < len; rel += 1024)               // tiles larger than two bursts (16 KiB)
+            *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, 0);
+    }
     if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
         const int64_t t0 = gtotal & ~(int64_t)15;
         for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
