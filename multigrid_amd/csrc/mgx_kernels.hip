@@ -428,12 +428,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #pragma unroll
     for (int u = 0; u < U; ++u)
         tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
-    const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env: a second burst, same wait
-    if (big_tile) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            tv2[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 1024 * U + 4096 * (u >> 2), 0);
-    }
+    const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env per wavefront
     // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
     // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
     uint64_t my_rng[4];
@@ -447,6 +442,13 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         uint64_t s_lo, s_hi;
         my_draw = pcg64_draw_at(my_rng, jk, s_lo, s_hi);
         if (agent_of_lane == A - 1) { uint64_t *dst = a.rng + (e0 + env_of_lane) * 4; dst[0] = s_lo; dst[1] = s_hi; }
+    }
+    // (3b) big tiles: a second burst under the same wait (requested here, once the draws' inputs are dead, so that the
+    // register peak of P0 stays below that of the gather)
+    if (big_tile) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            tv2[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 1024 * U + 4096 * (u >> 2), 0);
     }
     // (4) auto-reset test of the one-step kernels, also under the wait (build-defined, include/mgx.h): one lane per env
     // tests base.py:534-539 on the state the previous step left
