@@ -476,3 +476,12 @@ def test_hook_envs_random_rollouts_vs_oracle(name, env_id, kw, B, T):
     if spec.env_kind != "empty":
         assert events > 0, "the rollout never reached a hook event"
     env.check_errors()
+
+
+def test_random_specs_soak():
+    """A few seconds of tools/fuzz_parity.py: random specs / shapes / states, step and rollout vs the oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "10", "12345"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
