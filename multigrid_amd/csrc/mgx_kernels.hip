@@ -612,14 +612,28 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
         wave_sync();
         const bool conf = in && spec_cell_conflict(woff + env_of_lane * A, A, agent_of_lane, ev);
-        const uint64_t m_event = __builtin_amdgcn_ballot_w64(in && (ev.success | ev.failure | ev.bad));
+        const uint64_t m_bad = __builtin_amdgcn_ballot_w64(in && ev.bad);
         const uint64_t m_conf = __builtin_amdgcn_ballot_w64(conf);
         const uint64_t m_pres = __builtin_amdgcn_ballot_w64(in && ev.used_presence);
         const uint64_t m_moved = __builtin_amdgcn_ballot_w64(in && ev.moved);
+        const uint64_t m_ends = __builtin_amdgcn_ballot_w64(in && event_ends_all(cf, ev));
+        const uint64_t m_evt = __builtin_amdgcn_ballot_w64(in && (ev.success | ev.failure));
         const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
         const uint64_t genv = in ? (amask << (env_of_lane * A)) : 0ull;         // the lanes of this lane's env
-        const bool fb = in && spec_needs_fallback(m_event & genv, m_conf & genv, m_pres & genv, m_moved & genv);
-        if (in && !fb) {                                                         // commit
+        const bool fb = in && spec_needs_fallback(m_bad & genv, m_conf & genv, m_pres & genv, m_moved & genv);
+        // an event that ends the episode for every agent: only the agents visited up to it act (mgx_rules.h)
+        bool does_act = in && !fb;
+        if (A > 1 && m_ends != 0) {                                              // rare, wave-uniform
+            int my_rank = 0;
+            if (in) {
+                my_rank = draw_rank(rnd + env_of_lane * A, A, agent_of_lane);
+                ord[env_of_lane * A + my_rank] = (uint8_t)agent_of_lane;
+            }
+            wave_sync();
+            if (in && (m_ends & genv) != 0)
+                does_act = does_act && my_rank <= event_cutoff(ord + env_of_lane * A, (m_ends & genv) >> (env_of_lane * A), A);
+        }
+        if (does_act) {                                                              // commit
             if (ev.go) { rows[lane] = ev.nrow; cur_row = ev.nrow; }
             if (ev.unstale) reinterpret_cast<uint8_t *>(auxl + env_of_lane)[4] = 0;
             if (ev.writes) {
@@ -627,6 +641,17 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 if (!ROLL) {                                                     // ROLL writes the whole tile back at the end
                     uint8_t *gg = MGX_LATE(grid) + (e0 + env_of_lane) * HW3 + ev.off;
                     gg[0] = (uint8_t)ev.ncell; gg[1] = (uint8_t)(ev.ncell >> 8); gg[2] = (uint8_t)(ev.ncell >> 16);
+                }
+            }
+        }
+        if (m_evt != 0) {                                                        // on_success / on_failure of the agents that acted
+            const uint64_t m_succ = __builtin_amdgcn_ballot_w64(does_act && ev.success);
+            if (in && !fb) {
+                if (cf.joint_reward ? (m_succ & genv) != 0 : (does_act && ev.success))
+                    rew[lane] = reward_value(scnt[env_of_lane] + 1, cf.max_steps);       // base.py:500-507, 598-602
+                if ((does_act && event_ends_self(cf, ev)) || (m_ends & genv) != 0) {          // base.py:478-498, 509-532
+                    cur_row |= 1ull << 32;
+                    rows[lane] = cur_row;
                 }
             }
         }

@@ -335,15 +335,36 @@ MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, cons
 
 // ---------------------------------------------------------------------------------------------------------------
 // Order-free fast path.  All A agents of an env are evaluated at once against the PRE-step state (one lane per agent).
-// The result equals the sequential loop above, for every visiting order, whenever no agent's inputs could have been
-// changed by another agent's action in the same step.  Sufficient conditions, checked per env:
-//   (1) no agent triggers on_success / on_failure and no action is unknown (these change who is alive, write
-//       rewards, or abort the loop);
+// The result equals the sequential loop above whenever no agent's inputs could have been changed by another agent's
+// action in the same step.  Sufficient conditions, checked per env:
+//   (1) no action is unknown (the reference aborts the loop there);
 //   (2) no agent writes a cell that another agent's outcome depends on (its front cell, when its action reads it);
 //   (3) no outcome depended on the other agents' positions (drop; forward without agent overlap) while any agent moved.
 // Each agent's own row is only touched by its own action, so with (1)-(3) every agent sees exactly the inputs it would
 // see in the sequential loop.  Envs that fail a condition are simply run through handle_actions() instead.
+//
+// on_success / on_failure stay inside the path.  An event that terminates only its own agent (mode 'all') changes
+// nobody else's inputs.  An event that terminates EVERY agent (mode 'any') is where the visiting order matters: agents
+// visited after it find themselves terminated and do nothing (base.py:408-409).  So the agents' ranks in the visiting
+// order are computed for such an env, the first episode-ending event in that order is the cutoff, agents up to and
+// including it act as evaluated, the later ones only receive the terminated flag.  Rewards are assignments of one value
+// (base.py:500-507), so they commute.
 // ---------------------------------------------------------------------------------------------------------------
+MGX_HD bool event_ends_all(const StepCfg &cf, const AgentEval &ev) {
+    return (ev.success & cf.success_any) | (ev.failure & cf.failure_any);
+}
+MGX_HD bool event_ends_self(const StepCfg &cf, const AgentEval &ev) {
+    return (ev.success & !cf.success_any) | (ev.failure & !cf.failure_any);
+}
+
+// Position in the visiting order of the first agent whose event ends the episode for all (A if there is none).
+// `ord` = the visiting order (ord[k] = agent visited k-th), m_ends_all: bit j = agent j has such an event.
+MGX_HD int event_cutoff(const uint8_t *ord, uint64_t m_ends_all, int A) {
+    int cut = A;
+    for (int k = A - 1; k >= 0; --k) cut = ((m_ends_all >> ord[k]) & 1ull) ? k : cut;
+    return cut;
+}
+
 MGX_HD bool spec_cell_conflict(const int32_t *woff /* [A]: cell written by agent j, or -1 */, int A, int ai,
                                const AgentEval &ev) {
     bool c = false;
@@ -352,8 +373,8 @@ MGX_HD bool spec_cell_conflict(const int32_t *woff /* [A]: cell written by agent
 }
 
 // m_*: bit j = agent j of this env
-MGX_HD bool spec_needs_fallback(uint64_t m_event, uint64_t m_conflict, uint64_t m_presence, uint64_t m_moved) {
-    return (m_event != 0) | (m_conflict != 0) | ((m_presence != 0) & (m_moved != 0));
+MGX_HD bool spec_needs_fallback(uint64_t m_bad, uint64_t m_conflict, uint64_t m_presence, uint64_t m_moved) {
+    return (m_bad != 0) | (m_conflict != 0) | ((m_presence != 0) & (m_moved != 0));
 }
 
 // The env subclasses' step() post-hooks, run after the base step on the CLEAN tile (no agent overlay) with the

@@ -42,23 +42,39 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
     // the kernel's order-free fast path (P1s), lane by lane; envs that fail its conditions take the sequential loop
     std::vector<AgentEval> ev(A);
     std::vector<int32_t> woff(A);
-    uint64_t m_event = 0, m_conf = 0, m_pres = 0, m_moved = 0;
+    uint64_t m_bad = 0, m_conf = 0, m_pres = 0, m_moved = 0, m_ends_all = 0;
     for (int ai = 0; ai < A; ++ai) {
         ev[ai] = eval_agent(cf, tile, rows, act[ai], rows[ai], true, stale_offset(cf, aux, sp->env_kind));
         woff[ai] = ev[ai].writes ? ev[ai].off : -1;
     }
     for (int ai = 0; ai < A; ++ai) {
-        if (ev[ai].success | ev[ai].failure | ev[ai].bad) m_event |= 1ull << ai;
+        if (ev[ai].bad) m_bad |= 1ull << ai;
+        if (event_ends_all(cf, ev[ai])) m_ends_all |= 1ull << ai;
         if (spec_cell_conflict(woff.data(), A, ai, ev[ai])) m_conf |= 1ull << ai;
         if (ev[ai].used_presence) m_pres |= 1ull << ai;
         if (ev[ai].moved) m_moved |= 1ull << ai;
     }
-    const bool fallback = spec_needs_fallback(m_event, m_conf, m_pres, m_moved) || force_serial;
+    const bool fallback = spec_needs_fallback(m_bad, m_conf, m_pres, m_moved) || force_serial;
     if (!fallback) {
+        // lane by lane, as the kernel: who acts (rank <= cutoff), commit, then the events of the agents that acted
+        const int cut = (m_ends_all != 0 && A > 1) ? event_cutoff(ord.data(), m_ends_all, A) : A;
+        std::vector<bool> acts(A);
+        bool joint_success = false;
         for (int ai = 0; ai < A; ++ai) {
-            if (ev[ai].go) rows[ai] = ev[ai].nrow;
-            if (ev[ai].unstale) aux[4] = 0;
-            if (ev[ai].writes) { store_cell(tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
+            const int rank = (A > 1) ? draw_rank(rnd.data(), A, ai) : 0;
+            acts[ai] = rank <= cut;
+            joint_success |= acts[ai] & ev[ai].success;
+        }
+        const double r = reward_value(sc, cf.max_steps);
+        for (int ai = 0; ai < A; ++ai) {
+            if (acts[ai]) {
+                if (ev[ai].go) rows[ai] = ev[ai].nrow;
+                if (ev[ai].unstale) aux[4] = 0;
+                if (ev[ai].writes) { store_cell(tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
+            }
+            if (cf.joint_reward ? joint_success : (acts[ai] & ev[ai].success)) rew[ai] = r;
+            if ((acts[ai] & event_ends_self(cf, ev[ai])) | (m_ends_all != 0))
+                reinterpret_cast<uint8_t *>(rows)[ai * MGX_AGENT_STRIDE + AG_TERM] = 1;
         }
     } else {
         rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty, aux, sp->env_kind);

@@ -29,7 +29,7 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     print(f"B={B} launch {li}")
-    for wave in (0, nw // 2, nw - 1):
+    for wave in (0, nw // 4, nw // 2, (3 * nw) // 4, nw - 1):
         lib.mgx_debug_read_stamps(buf, wave)          # select the wave (and clear)
         acc = None
         reps = 20
