@@ -418,7 +418,9 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     u32x4 in_aux = {0, 0, 0, 0};
     uint8_t in_act = 0;
     in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
+    uint32_t in_ep = 0;                                                      // AR: env `lane`'s episode count
     if (DO_STEP) {
+        if (AR && !ROLL) in_ep = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.episode + e0, Gc * 4), lane * 4, 0, 0);
         in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0, 0);
         in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0, 0);
         if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
@@ -554,17 +556,29 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 const int e = __builtin_ctzll(m);                                // wave-uniform
                 const int64_t b = e0 + e;
                 int32_t *p_ep = MGX_LATE(episode);
-                const int32_t ep = p_ep[b];
-                const int lay = (int)((uint64_t)(MGX_LATE(first_env) + b + (int64_t)ep * 7919) % (uint64_t)MGX_LATE(pool_size));
+                const int32_t K = MGX_LATE(pool_size);
+                // (one-step kernels fetched the episode counts in P0: no dependent load in front of the copy)
+                const int32_t ep = ROLL ? p_ep[b] : (int32_t)__builtin_amdgcn_readlane(in_ep, e);
+                const int lay = (K == 1) ? 0 : (int)((uint64_t)(MGX_LATE(first_env) + b + (int64_t)ep * 7919) % (uint64_t)K);
                 wave_sync();
                 if (lane == 0) p_ep[b] = ep + 1;
                 const uint8_t *sg = MGX_LATE(pool_grid) + (int64_t)lay * HW3;
                 uint8_t *etile = tile + e * HW3;
                 uint8_t *gg = MGX_LATE(grid) + b * HW3;
-                for (int i = lane; i < HW3; i += 64) {                           // bytes: layouts have any size / alignment
-                    const uint8_t v = sg[i];
-                    etile[i] = v;
-                    if (!ROLL) gg[i] = v;                                        // (the rollout writes its tile back at the end)
+                const uint32_t etile_addr = (uint32_t)(uintptr_t)(lds_u32_ptr)etile;
+                if (((HW3 | etile_addr | (uint32_t)reinterpret_cast<uintptr_t>(sg) | (uint32_t)reinterpret_cast<uintptr_t>(gg)) & 3u) == 0) {
+#pragma unroll 4
+                    for (int i = lane; i < HW3 / 4; i += 64) {                   // dwords: several loads in flight per lane
+                        const uint32_t v = reinterpret_cast<const uint32_t *>(sg)[i];
+                        reinterpret_cast<uint32_t *>(etile)[i] = v;
+                        if (!ROLL) reinterpret_cast<uint32_t *>(gg)[i] = v;      // (the rollout writes its tile back at the end)
+                    }
+                } else {
+                    for (int i = lane; i < HW3; i += 64) {                       // bytes: layouts of any size / alignment
+                        const uint8_t v = sg[i];
+                        etile[i] = v;
+                        if (!ROLL) gg[i] = v;
+                    }
                 }
                 const uint64_t *sa = reinterpret_cast<const uint64_t *>(MGX_LATE(pool_agents)) + (int64_t)lay * A;
                 for (int j = lane; j < A; j += 64) rows[e * A + j] = sa[j];
