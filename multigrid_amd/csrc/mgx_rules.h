@@ -182,6 +182,7 @@ MGX_HD uint64_t pcg64_draw_at(const uint64_t *rng, const uint64_t *jump_k, uint6
 MGX_HD int draw_rank(const uint64_t *rnd, int A, int a) {
     const uint64_t ra = rnd[a];
     int rank = 0;
+#pragma unroll 4                                                            // (4 LDS reads in flight instead of a round trip each)
     for (int b = 0; b < A; ++b) { const uint64_t rb = rnd[b]; rank += (rb < ra) | ((rb == ra) & (b < a)); }
     return rank;
 }
@@ -221,6 +222,7 @@ MGX_HD void on_success(const StepCfg &cf, uint64_t *rows, int i, int32_t step_co
 MGX_HD bool agent_present(const uint64_t *rows, int A, int x, int y) {
     const uint32_t want = (uint32_t)x | ((uint32_t)y << 8);
     bool hit = false;
+#pragma unroll 4
     for (int a = 0; a < A; ++a) hit |= (((uint32_t)rows[a] >> 16) & 0xffffu) == want;
     return hit;
 }
@@ -368,6 +370,7 @@ MGX_HD int event_cutoff(const uint8_t *ord, uint64_t m_ends_all, int A) {
 MGX_HD bool spec_cell_conflict(const int32_t *woff /* [A]: cell written by agent j, or -1 */, int A, int ai,
                                const AgentEval &ev) {
     bool c = false;
+#pragma unroll 4
     for (int j = 0; j < A; ++j) c |= (j != ai) & (woff[j] == ev.off);
     return c & ev.reads_cell;
 }
@@ -451,6 +454,7 @@ MGX_HD int overlay_offset(const StepCfg &cf, const uint64_t *rows, int ai) {
     const uint64_t r = rows[ai];
     const uint32_t pos = ((uint32_t)r >> 16) & 0xffffu;
     bool shadowed = false;
+#pragma unroll 4
     for (int j = 0; j < cf.A; ++j) {
         const uint64_t o = rows[j];
         shadowed |= (j > ai) & !row_term(o) & ((((uint32_t)o >> 16) & 0xffffu) == pos);
