@@ -622,30 +622,39 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
                                ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
             ev = eval_agent(cf, mytile, rows + env_of_lane * A, ROLL ? (int)acts[lane] : (int)(int8_t)in_act, cur_row, true, so);
-            woff[lane] = ev.writes ? ev.off : -1;
         }
-        wave_sync();
-        const bool conf = in && spec_cell_conflict(woff + env_of_lane * A, A, agent_of_lane, ev);
-        const uint64_t m_bad = __builtin_amdgcn_ballot_w64(in && ev.bad);
-        const uint64_t m_conf = __builtin_amdgcn_ballot_w64(conf);
-        const uint64_t m_pres = __builtin_amdgcn_ballot_w64(in && ev.used_presence);
-        const uint64_t m_moved = __builtin_amdgcn_ballot_w64(in && ev.moved);
-        const uint64_t m_ends = __builtin_amdgcn_ballot_w64(in && event_ends_all(cf, ev));
-        const uint64_t m_evt = __builtin_amdgcn_ballot_w64(in && (ev.success | ev.failure));
-        const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-        const uint64_t genv = in ? (amask << (env_of_lane * A)) : 0ull;         // the lanes of this lane's env
-        const bool fb = in && spec_needs_fallback(m_bad & genv, m_conf & genv, m_pres & genv, m_moved & genv);
-        // an event that ends the episode for every agent: only the agents visited up to it act (mgx_rules.h)
-        bool does_act = in && !fb;
-        if (A > 1 && m_ends != 0) {                                              // rare, wave-uniform
-            int my_rank = 0;
-            if (in) {
-                my_rank = draw_rank(rnd + env_of_lane * A, A, agent_of_lane);
-                ord[env_of_lane * A + my_rank] = (uint8_t)agent_of_lane;
-            }
+        // condition (2) needs the cells the other agents write: exchanged through LDS only when somebody writes at all
+        bool conf = false;
+        if (__builtin_amdgcn_ballot_w64(in && ev.writes) != 0) {
+            if (in) woff[lane] = ev.writes ? ev.off : -1;
             wave_sync();
-            if (in && (m_ends & genv) != 0)
-                does_act = does_act && my_rank <= event_cutoff(ord + env_of_lane * A, (m_ends & genv) >> (env_of_lane * A), A);
+            conf = in && spec_cell_conflict(woff + env_of_lane * A, A, agent_of_lane, ev);
+        }
+        // the common step has none of this in the whole wavefront: one ballot decides whether the masks are needed at all
+        bool fb = false, does_act = in;
+        uint64_t m_ends = 0, m_evt = 0, genv = 0;
+        if (__builtin_amdgcn_ballot_w64(in && (ev.bad | conf | ev.used_presence | ev.success | ev.failure)) != 0) {
+            const uint64_t m_bad = __builtin_amdgcn_ballot_w64(in && ev.bad);
+            const uint64_t m_conf = __builtin_amdgcn_ballot_w64(conf);
+            const uint64_t m_pres = __builtin_amdgcn_ballot_w64(in && ev.used_presence);
+            const uint64_t m_moved = __builtin_amdgcn_ballot_w64(in && ev.moved);
+            m_ends = __builtin_amdgcn_ballot_w64(in && event_ends_all(cf, ev));
+            m_evt = __builtin_amdgcn_ballot_w64(in && (ev.success | ev.failure));
+            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+            genv = in ? (amask << (env_of_lane * A)) : 0ull;                     // the lanes of this lane's env
+            fb = in && spec_needs_fallback(m_bad & genv, m_conf & genv, m_pres & genv, m_moved & genv);
+            // an event that ends the episode for every agent: only the agents visited up to it act (mgx_rules.h)
+            does_act = in && !fb;
+            if (A > 1 && m_ends != 0) {                                          // rare, wave-uniform
+                int my_rank = 0;
+                if (in) {
+                    my_rank = draw_rank(rnd + env_of_lane * A, A, agent_of_lane);
+                    ord[env_of_lane * A + my_rank] = (uint8_t)agent_of_lane;
+                }
+                wave_sync();
+                if (in && (m_ends & genv) != 0)
+                    does_act = does_act && my_rank <= event_cutoff(ord + env_of_lane * A, (m_ends & genv) >> (env_of_lane * A), A);
+            }
         }
         if (does_act) {                                                              // commit
             if (ev.go) { rows[lane] = ev.nrow; cur_row = ev.nrow; }
