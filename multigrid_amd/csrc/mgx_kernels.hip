@@ -596,6 +596,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         }
     }
     if (AR && reset_mask != 0 && lane < NVc) cur_row = rows[lane];
+    double my_rew = 0.0;                                                     // this agent's reward (base.py:393), in a register
     if (DO_STEP && !(a.dbg & 2)) {
         const bool in = lane < NVc;
         // (fetched now so that the s_load latency hides behind P1a / P1s)
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             const uint64_t m_succ = __builtin_amdgcn_ballot_w64(does_act && ev.success);
             if (in && !fb) {
                 if (cf.joint_reward ? (m_succ & genv) != 0 : (does_act && ev.success))
-                    rew[lane] = reward_value(scnt[env_of_lane] + 1, cf.max_steps);       // base.py:500-507, 598-602
+                    my_rew = reward_value(scnt[env_of_lane] + 1, cf.max_steps);          // base.py:500-507, 598-602
                 if ((does_act && event_ends_self(cf, ev)) || (m_ends & genv) != 0) {          // base.py:478-498, 509-532
                     cur_row |= 1ull << 32;
                     rows[lane] = cur_row;
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         // ------------------------------------------------------------------ overlay offsets (pre-hook `terminated`, SURVEY
         // App. C Q2), then one lane per env: counters + the env subclass' hook on the clean tile, then the overlay itself
         const int ovl = (in && !(a.dbg & 512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
+        if (HOOKS && in && !fb) rew[lane] = my_rew;                              // (the hooks assign to / add onto the base rewards)
         wave_sync();
         if (lane < Gc) {
             const int e = lane;
@@ -732,7 +734,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             p_truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
         }
         wave_sync();
-        if ((HOOKS || fbw != 0) && in) cur_row = rows[lane];                     // (a hook / the fallback may have terminated it)
+        if ((HOOKS || fbw != 0) && in) {                                         // (a hook / the fallback may have terminated it
+            cur_row = rows[lane];                                                // and rewarded it: their results are in LDS)
+            if (HOOKS || fb) my_rew = rew[lane];
+        }
         if (ROLL && ovl >= 0) ovl_saved = load_cell(mytile + ovl);
         ovl_off = ovl;
         wave_sync();
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (DO_STEP) {
             const u32x2 rowv = {(uint32_t)row, (uint32_t)(row >> 32)};
             if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(p_agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
-            const uint64_t rbits = __builtin_bit_cast(uint64_t, rew[lane]);
+            const uint64_t rbits = __builtin_bit_cast(uint64_t, my_rew);
             const u32x2 rewv = {(uint32_t)rbits, (uint32_t)(rbits >> 32)};
             __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(p_reward + tv0, NVc * 8), lane * 8, 0, 0);
             const bool forced = env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
