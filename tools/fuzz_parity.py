@@ -37,20 +37,38 @@ while time.time() < t_end:
     seed = int(r.integers(0, 1 << 30))
     st = util.random_state(spec, B, seed=seed, density=float(r.choice([0.0, 0.1, 0.3, 0.5])),
                            terminated_p=float(r.choice([0.0, 0.05, 0.3])))
-    env = BatchedMultiGridEnv(spec, B, dev)
+    first_env = int(r.integers(0, 1000))
+    env = BatchedMultiGridEnv(spec, B, dev, first_env=first_env)
     env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
-    roll = BatchedMultiGridEnv(spec, B, dev)
+    roll = BatchedMultiGridEnv(spec, B, dev, first_env=first_env)
     roll.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
     ref = {k: v.copy() for k, v in st.items()}
     sd = spec.as_dict()
     acts = np.stack([util.random_actions(B, A, seed=seed + 1 + t) for t in range(T)])
     if r.random() < 0.5:
         acts[r.random(acts.shape) < 0.1] = -1
-    rr = roll.rollout(torch.from_numpy(acts).to(dev))
-    ctx = f"case {n_case}: {spec} B={B} T={T} seed={seed}"
+    # half of the cases run with the fused auto-reset; the restarts are emulated here in numpy from the definition
+    # (include/mgx.h: layout = (first_env + b + episode * 7919) mod K, step_count 0, episode + 1), then the oracle steps
+    ar = bool(r.random() < 0.5)
+    if ar:
+        K = int(r.integers(1, 6))
+        pool = util.random_state(spec, K, seed=seed + 77, terminated_p=0.0, density=0.3)
+        env.set_layout_pool(pool["grid"], pool["agents"]); roll.set_layout_pool(pool["grid"], pool["agents"])
+        episode = np.zeros(B, dtype=np.int64)
+    rr = roll.rollout(torch.from_numpy(acts).to(dev), auto_reset=ar)
+    ctx = f"case {n_case}: {spec} B={B} T={T} seed={seed} auto_reset={ar}"
     for t in range(T):
+        if ar:
+            done = (ref["agents"][:, :, 4].min(axis=1) > 0) | (ref["step_count"] >= spec.max_steps)
+            lay = (first_env + np.arange(B) + episode * 7919) % K
+            ref["grid"][done] = pool["grid"][lay[done]]
+            ref["agents"][done] = pool["agents"][lay[done]]
+            ref["step_count"][done] = 0
+            episode[done] += 1
         want = ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], acts[t], ref["target"], nthreads=16)
-        got = env.step(torch.from_numpy(acts[t]).to(dev))
+        got = env.step(torch.from_numpy(acts[t]).to(dev), auto_reset=ar)
+        if ar and (env.was_reset.cpu().numpy().astype(bool) != done).any():
+            print("MISMATCH was_reset at step", t, ctx); sys.exit(1)
         for k, (g, w, key) in enumerate(zip(got, want, ("obs", "dir", "reward", "terminated", "truncated"))):
             if g.cpu().numpy().tobytes() != w.tobytes():
                 print("MISMATCH step", t, key, ctx); sys.exit(1)
