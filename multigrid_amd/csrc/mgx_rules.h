@@ -99,19 +99,21 @@ MGX_HD void or_bits(uint64_t (&w)[NW], int pos, uint32_t bits) {
 template <int V, int NW>
 MGX_HD void vis_mask(const uint64_t (&sb)[NW], uint64_t (&vis)[NW]) {
     constexpr uint32_t F = (1u << V) - 1u;
-    constexpr uint32_t FC = F | (F << (32 - V));
     for (int k = 0; k < NW; ++k) vis[k] = 0;
     uint32_t init = 1u << (V / 2);
     init |= brev32(init);
+    // The bits between the two copies (the "gap", [V, 32-V)) may fill with junk -- the carry out of the low copy stops at
+    // bit V because s is zero there, the 3-wide spread leaks one bit into each end of the gap -- and nothing cleans it:
+    // brev32 maps the gap onto itself, `& s` and `& F` drop it wherever a value is used.
 #pragma unroll
     for (int j = V - 1; j >= 0; --j) {
         const uint32_t s0 = get_bits<V, NW>(sb, j * V);
         const uint32_t s = s0 | brev32(s0);                          // mirrored transparency of row j
-        uint32_t u = (((s + (init & s)) ^ s) | init) & FC;           // flood from the seeds, both directions
+        uint32_t u = ((s + (init & s)) ^ s) | init;                  // flood from the seeds, both directions
         u |= brev32(u);                                               // each copy gets the other direction's result
         or_bits<V, NW>(vis, j * V, u & F);
         const uint32_t p = u & s;                                     // visible AND transparent
-        init = (p | (p << 1) | (p >> 1)) & FC;                        // lights (i-1, i, i+1) of row j-1 (both copies)
+        init = p | (p << 1) | (p >> 1);                               // lights (i-1, i, i+1) of row j-1 (both copies)
     }
 }
 
