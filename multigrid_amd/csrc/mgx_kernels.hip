@@ -11,7 +11,7 @@
 //        the reference's sequential handle_actions loop on the LDS tile)                       (base.py:378-476)
 //        then the agent overlay offsets, the env subclass' post-step hook, step_count / truncated
 //   P1d  lane = view: view geometry record, in-bounds lane mask, stores of agent rows / reward / terminated / dir
-//   P2   lane = view CELL, slots unrolled x8: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
+//   P2   lane = view CELL, slots in straight-line blocks of 16: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
 //        see-behind ballot -> 64-bit row mask deposited in lane s; cells stay in registers  (multigrid/utils/obs.py:130-233)
 //   P3   lane = view: bit-parallel line-of-sight flood on the ballot masks (closed form of the sequential sweeps,
 //        obs.py:235-273); own cell := carried object (obs.py:207)
