@@ -111,7 +111,10 @@ typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 #define MGX_SLOTS_SMALL_VIEW 32
 #endif
 constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
-constexpr int kRound = 16;        // view slots whose obs bytes are staged in LDS at a time (P4/P5)
+#ifndef MGX_ROUND
+#define MGX_ROUND 16
+#endif
+constexpr int kRound = MGX_ROUND;        // view slots whose obs bytes are staged in LDS at a time (P4/P5)
 
 // View slots per wavefront = cell registers per lane (x passes per view).
 inline int slots_per_wave(int view_size) { return view_size <= 7 ? kSlotsSmallView : 32; }
