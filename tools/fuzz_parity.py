@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from multigrid_amd import BatchedMultiGridEnv, EnvSpec  # noqa: E402
+from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts  # noqa: E402
 from oracle import binding as ob  # noqa: E402
 from tests import util  # noqa: E402
 
@@ -37,6 +37,17 @@ while time.time() < t_end:
     seed = int(r.integers(0, 1 << 30))
     st = util.random_state(spec, B, seed=seed, density=float(r.choice([0.0, 0.1, 0.3, 0.5])),
                            terminated_p=float(r.choice([0.0, 0.05, 0.3])))
+    hook = r.random() < 0.15
+    if hook:                                    # a hook env kind on generated layouts: BlockedUnlockPickup, 2..4 agents
+        A = int(r.integers(2, 5)); B = min(B, 300)
+        spec = EnvSpec(11, 6, A, V if V <= 9 else 7, max_steps=int(r.integers(5, 80)), joint_reward=True,
+                       env_kind="blockedunlockpickup", see_through_walls=spec.see_through_walls)
+        lr = np.random.default_rng(seed)
+        lay = [layouts.blockedunlockpickup_layout(6, A, lr, lr) for _ in range(B)]
+        st = dict(grid=np.stack([x[0] for x in lay]), agents=np.stack([x[1] for x in lay]),
+                  target=np.stack([layouts.make_aux("blockedunlockpickup", x[0], x[2]) for x in lay]),
+                  rng=np.random.default_rng(seed + 5).integers(0, 2 ** 63, size=(B, 4), dtype=np.int64).astype(np.uint64) | np.uint64(1),
+                  step_count=np.zeros(B, np.int32))
     first_env = int(r.integers(0, 1000))
     env = BatchedMultiGridEnv(spec, B, dev, first_env=first_env)
     env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
@@ -49,7 +60,7 @@ while time.time() < t_end:
         acts[r.random(acts.shape) < 0.1] = -1
     # half of the cases run with the fused auto-reset; the restarts are emulated here in numpy from the definition
     # (include/mgx.h: layout = (first_env + b + episode * 7919) mod K, step_count 0, episode + 1), then the oracle steps
-    ar = bool(r.random() < 0.5)
+    ar = bool(r.random() < 0.5) and not hook
     if ar:
         K = int(r.integers(1, 6))
         pool = util.random_state(spec, K, seed=seed + 77, terminated_p=0.0, density=0.3)
