@@ -381,6 +381,21 @@ def test_fused_auto_reset_equals_reset_then_step(name, spec, B, T):
     fused.check_errors(); split.check_errors(); roll.check_errors()
 
 
+def test_auto_reset_without_was_reset_output():
+    """MgxAutoReset.was_reset is optional (NULL): the state must come out the same."""
+    spec = EnvSpec(8, 8, 2, 7, max_steps=5)
+    a, b = _ar_env(spec, 300, 3), _ar_env(spec, 300, 3)
+    g = torch.Generator(device=dev()); g.manual_seed(2)
+    for t in range(14):
+        act = torch.randint(0, 7, (300, 2), dtype=torch.int8, device=dev(), generator=g)
+        want = [x.clone() for x in a.step(act, auto_reset=True)]
+        b.backend.step(b.batch, b.grid, b.agents, b.rng, b.step_count, act, None, b.err, b.obs, b.dir, b.reward,
+                       b.terminated, b.truncated, auto_reset=(b.first_env, b._pool, b.episode, None))
+        for x, y in zip(want, (b.obs, b.dir, b.reward, b.terminated, b.truncated)):
+            assert torch.equal(x, y)
+    assert torch.equal(a.grid, b.grid) and torch.equal(a.episode, b.episode) and int(a.episode.sum()) > 300
+
+
 ROLL_CASES = [
     ("C2_empty16_a4", EnvSpec(16, 16, 4, 7, max_steps=1024), 2048, 40, 0.0),
     ("objects16_a4", EnvSpec(16, 16, 4, 7, max_steps=30), 1500, 40, 0.3),
