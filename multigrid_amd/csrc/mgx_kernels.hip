@@ -111,6 +111,10 @@ typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 #define MGX_SLOTS_SMALL_VIEW 32
 #endif
 constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
+// cache policy bits of the obs stores (raw buffer store `aux`: 1 = sc0, 2 = nt, 16 = sc1 on gfx94x/gfx950)
+#ifndef MGX_OBS_AUX
+#define MGX_OBS_AUX 0
+#endif
 #ifndef MGX_ROUND
 #define MGX_ROUND 16
 #endif
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                     const int rel = lane16 + 1024 * k;
                     if ((rel + 16 <= rlen) & (rel >= out_skew)) {
 #if MGX_BUF_STORE
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), orsrc, rel, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), orsrc, rel, 0, MGX_OBS_AUX);
 #else
                         *reinterpret_cast<u32x4 *>(gdst + rel) = *reinterpret_cast<const u32x4 *>(out_raw + rel);
 #endif
