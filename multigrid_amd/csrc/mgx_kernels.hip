@@ -198,6 +198,7 @@ __device__ const JumpTable kJump{};
 #define MGX_MARK(name) asm volatile("; MGX_MARK " name ::: "memory")
 #elif MGX_TIMESTAMPS
 __device__ unsigned long long g_stamps[64];
+__device__ unsigned long long g_span[2 * 16384];      // [wave][begin, end] in s_memrealtime ticks (100 MHz), first 16384 waves
 __device__ long long g_stamp_wave = 0;
 #define MGX_MARK(name)                                                                                   \
     do {                                                                                                 \
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #if MGX_TIMESTAMPS
     int stamp_i = 0;
     MGX_MARK("start");
+    if (lane == 0 && wid < 16384) g_span[2 * wid] = __builtin_amdgcn_s_memrealtime();
 #endif
     const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, HOOKS);
     uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
@@ -909,6 +911,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #if MGX_TIMESTAMPS
     __builtin_amdgcn_s_waitcnt(0);
     MGX_MARK("end");
+    if (lane == 0 && wid < 16384) g_span[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (ROLL) {
         // ------------------------------------------------------------------ state write-back, once per launch
@@ -1034,6 +1037,9 @@ void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
 #if MGX_TIMESTAMPS
+int mgx_debug_read_span(unsigned long long *out, int nwaves) {            // [nwaves][2] of the last launch
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * nwaves) == hipSuccess ? 0 : -1;
+}
 int mgx_debug_read_stamps(unsigned long long *out64, long long wave) {   // reads the last launch's stamps, selects the next wave
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
     unsigned long long zero[64] = {0};

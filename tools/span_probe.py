@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""When do the wavefronts of one fused-step launch begin and end (s_memrealtime, 10 ns ticks)?  Needs a library built with
+-DMGX_TIMESTAMPS=1 in place (tools/with_altlib.sh).  Shows the launch ramp, the per-wave duration and the tail."""
+import ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from multigrid_amd import _lib
+lib = _lib.lib()
+dev = torch.device("cuda", 0)
+spec = bench.workload_spec()
+if os.environ.get("MGX_WPB"):
+    lib.mgx_debug_set_waves_per_workgroup(int(os.environ["MGX_WPB"]))
+if os.environ.get("MGX_G"):
+    lib.mgx_debug_set_envs_per_wavefront(int(os.environ["MGX_G"]))
+if os.environ.get("MGX_SKIP"):
+    lib.mgx_debug_skip_phases(int(os.environ["MGX_SKIP"]))
+for B in [int(x) for x in sys.argv[1:]] or [4096]:
+    env = bench.make_env(spec, B, dev, 0)
+    acts = bench.random_actions(64, B, spec.num_agents, dev, 7)
+    li = env.backend.launch_info(B)
+    nw = min(16384, (B + li["envs_per_wavefront"] - 1) // li["envs_per_wavefront"])
+    for t in range(30):
+        env.step(acts[t], auto_reset=bench.AUTO_RESET)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * (2 * nw))()
+    rows = []
+    graph = None
+    if os.environ.get("MGX_GRAPH"):                        # the last launch of a replayed graph of 20 steps
+        graph = torch.cuda.CUDAGraph()
+        s_ = torch.cuda.Stream(dev); s_.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s_):
+            with torch.cuda.graph(graph, stream=s_):
+                for t in range(20):
+                    env.step(acts[t], auto_reset=bench.AUTO_RESET)
+        torch.cuda.current_stream(dev).wait_stream(s_)
+    for r in range(10):
+        if graph is not None:
+            graph.replay()
+        else:
+            env.step(acts[30 + r], auto_reset=bench.AUTO_RESET)
+        torch.cuda.synchronize()
+        lib.mgx_debug_read_span(buf, nw)
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 2).astype(np.int64)
+        t0 = a[:, 0].min()
+        b, e = (a[:, 0] - t0) * 10, (a[:, 1] - t0) * 10          # ns
+        rows.append((b.max(), np.median(e - b), (e - b).max(), e.max(), np.percentile(e, 50), np.percentile(e, 99)))
+        wpb_ = li["threads_per_workgroup"] // 64
+        wg = np.arange(nw) // wpb_
+        print(f"   launch {r}: begin by XCD:", " ".join(f"{int(np.median(b[wg % 8 == k])):5d}" for k in range(8)),
+              "| end:", " ".join(f"{int(np.median(e[wg % 8 == k])):5d}" for k in range(8)))
+    wpb_ = li["threads_per_workgroup"] // 64
+    wg = np.arange(nw) // wpb_
+    print("   begin (ns, last launch) by workgroup id mod 8 (= XCD):", " ".join(f"{int(np.median(b[wg % 8 == k]))}" for k in range(8)),
+          "| end:", " ".join(f"{int(np.median(e[wg % 8 == k]))}" for k in range(8)))
+    print("   begin by position of the workgroup within its XCD's share (quartiles):",
+          " ".join(f"{int(np.median(b[(wg // 8) * 4 // max(1, (wg.max() // 8 + 1)) == q]))}" for q in range(4)))
+    m = np.median(np.array(rows), axis=0)
+    print(f"B={B} waves={nw}: last wave begins at +{m[0]:.0f} ns; wave duration median {m[1]:.0f} / max {m[2]:.0f} ns; "
+          f"waves end: median +{m[4]:.0f}, p99 +{m[5]:.0f}, last +{m[3]:.0f} ns (from the first wave's first instruction)")
