@@ -8,7 +8,14 @@ import os
 from .spec import MgxSpecC
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmgx.so")
+PRODUCT_LIB_PATH = os.path.join(HERE, "lib", "libmgx.so")
+#: MGX_LIBMGX=<path> loads another build of the library (the profiling tools' -DMGX_DEBUG_KNOBS / experiment builds);
+#: bench.py marks every line measured that way `"valid": false`.
+LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
+
+
+def is_product_lib() -> bool:
+    return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
 ABI_VERSION = 3
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4

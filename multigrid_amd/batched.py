@@ -99,10 +99,13 @@ class BatchedMultiGridEnv:
         self._loaded = True
 
     def seed(self, seed: int):
-        """Per-env `np_random = Generator(PCG64(SeedSequence(seed + global_env_index)))` (what
-        `gym.Env.reset(seed=...)` does for one env, multigrid/base.py:269)."""
-        seeds = seed + self.first_env + np.arange(self.batch)
-        self.rng.copy_(torch.from_numpy(rnglib.words_from_seeds(seeds).view(np.int64)))
+        """Per-env `np_random = Generator(PCG64(SeedSequence([seed, global_env_index])))`; global env 0 gets
+        `SeedSequence(seed)`, exactly what `gym.Env.reset(seed=seed)` gives the reference's single env
+        (multigrid/base.py:269).  Keyed on the pair so that consecutive experiment seeds share no stream (seed + index
+        would give env b under seed s+1 the stream of env b+1 under seed s), and a pure function of the GLOBAL env index
+        so that sharding does not change any env's stream."""
+        idx = self.first_env + np.arange(self.batch)
+        self.rng.copy_(torch.from_numpy(rnglib.words_from_seed_and_index(seed, idx).view(np.int64)))
 
     def seed_synthetic(self, seed: int):
         """Benchmark-grade seeding: valid PCG64 states from a hash of the global env index (fast for large B)."""
@@ -251,12 +254,29 @@ class BatchedMultiGridEnv:
 
     # ------------------------------------------------------------------------------------------ checkpoint
     def state_dict(self) -> dict:
-        return {"spec": self.spec.as_dict(), "first_env": self.first_env,
-                "grid": self.grid.cpu().clone(), "agents": self.agents.cpu().clone(),
-                "rng": self.rng.cpu().clone(), "step_count": self.step_count.cpu().clone(),
-                "aux": self.aux.cpu().clone()}
+        """Everything a resumed run needs to continue bit-identically: the env state, and -- when auto-reset is in use --
+        the layout pool, the per-env episode counters and the last `was_reset`."""
+        sd = {"spec": self.spec.as_dict(), "first_env": self.first_env,
+              "grid": self.grid.cpu().clone(), "agents": self.agents.cpu().clone(),
+              "rng": self.rng.cpu().clone(), "step_count": self.step_count.cpu().clone(),
+              "aux": self.aux.cpu().clone()}
+        if getattr(self, "_pool", None) is not None:
+            pg, pa, pt = self._pool
+            sd["pool"] = {"grid": pg.cpu().clone(), "agents": pa.cpu().clone(),
+                          "aux": pt.cpu().clone() if pt is not None else None}
+            sd["episode"] = self.episode.cpu().clone()
+            sd["was_reset"] = self.was_reset.cpu().clone()
+        return sd
 
     def load_state_dict(self, sd: dict):
         if EnvSpec.from_dict(sd["spec"]) != self.spec:
             raise ValueError("state_dict was saved for a different EnvSpec")
-        self.load_state(sd["grid"], sd["agents"], sd["rng"], sd["aux"], sd["step_count"], validate=False)
+        if int(sd.get("first_env", self.first_env)) != self.first_env:
+            raise ValueError(f"state_dict was saved for the shard starting at env {sd['first_env']}, this one starts "
+                             f"at {self.first_env} (layout choice and seeds are functions of the global env index)")
+        self.load_state(sd["grid"], sd["agents"], sd["rng"], sd["aux"], sd["step_count"], validate=True)
+        if sd.get("pool") is not None:
+            p = sd["pool"]
+            self.set_layout_pool(p["grid"].numpy(), p["agents"].numpy(), p["aux"].numpy() if p["aux"] is not None else None)
+            self.episode.copy_(sd["episode"])
+            self.was_reset.copy_(sd["was_reset"])

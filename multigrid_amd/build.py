@@ -1,11 +1,20 @@
 """Build libmgx.so (the HIP kernels + C ABI) in-tree for gfx950.
 
-`python -m multigrid_amd.build` or `multigrid_amd.build.build_lib()`.  hipcc cross-compiles without a GPU.
-The .so stays in the source tree (multigrid_amd/lib/) so that it travels with the repo snapshot to the GPU box
-and shows up as in-tree native code when loaded.
+`python -m multigrid_amd.build [--force] [--debug-knobs]` or `multigrid_amd.build.build_lib()`.  hipcc cross-compiles
+without a GPU.  The .so stays in the source tree (multigrid_amd/lib/) so that it travels with the repo snapshot to the
+GPU box and shows up as in-tree native code when loaded.
+
+Staleness is decided by CONTENT: the SHA-256 of every source the library is compiled from plus the compile command is
+stored beside the library (`<lib>.srchash`); a tree copied with fresh or stale mtimes neither rebuilds needlessly nor
+silently reuses a library built from other sources.
+
+`--debug-knobs` builds lib/libmgx_dbg.so with -DMGX_DEBUG_KNOBS=1: the profiling tools' variant that also exports
+mgx_debug_skip_phases / mgx_debug_set_envs_per_wavefront / mgx_debug_set_waves_per_workgroup.  The product library
+never has them; `MGX_LIBMGX=<path>` makes multigrid_amd load another build and bench.py then marks its line invalid.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -16,6 +25,7 @@ ROOT = os.path.dirname(HERE)
 SRCS = [os.path.join(HERE, "csrc", "mgx_kernels.hip"), os.path.join(HERE, "csrc", "mgx_aux.hip")]
 DEPS = SRCS + [os.path.join(HERE, "csrc", "mgx_rules.h"), os.path.join(ROOT, "include", "mgx.h")]
 LIB = os.path.join(HERE, "lib", "libmgx.so")
+LIB_DBG = os.path.join(HERE, "lib", "libmgx_dbg.so")
 ARCH = "gfx950"
 
 
@@ -26,25 +36,53 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB):
+def flags(defines=()) -> list[str]:
+    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+            *[f"-D{d}" for d in defines]]
+
+
+def source_hash(defines=()) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(flags(defines)).encode())
+    for d in DEPS:
+        h.update(os.path.relpath(d, ROOT).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def stale(lib: str = LIB, defines=()) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    try:
+        with open(lib + ".srchash") as fh:
+            return fh.read().strip() != source_hash(defines)
+    except OSError:
+        return True
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not stale():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wall", f"-I{os.path.join(ROOT, 'include')}", *SRCS, "-o", LIB + ".tmp"]
+def build_lib(force: bool = False, verbose: bool = False, lib: str = LIB, defines=()) -> str:
+    if not force and not stale(lib, defines):
+        return lib
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    cmd = [hipcc(), *flags(defines), f"-I{os.path.join(ROOT, 'include')}", *SRCS, "-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    with open(lib + ".srchash", "w") as fh:
+        fh.write(source_hash(defines) + "\n")
+    return lib
+
+
+def build_debug_lib(force: bool = False, verbose: bool = False, extra_defines=()) -> str:
+    return build_lib(force, verbose, LIB_DBG, ("MGX_DEBUG_KNOBS=1", *extra_defines))
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    force, verbose = "--force" in sys.argv, True
+    extra = tuple(a[2:] for a in sys.argv[1:] if a.startswith("-D"))
+    if "--debug-knobs" in sys.argv:
+        print(build_debug_lib(force, verbose, extra))
+    else:
+        print(build_lib(force, verbose))

@@ -83,6 +83,16 @@ struct KernelArgs {
 #ifndef MGX_BUF_STORE
 #define MGX_BUF_STORE 1
 #endif
+// -DMGX_DEBUG_KNOBS=1 (the tools' build, `python -m multigrid_amd.build --debug-knobs` -> lib/libmgx_dbg.so): phase
+// skipping and launch-geometry overrides for profiling.  The product library has neither the exports nor the branches.
+#ifndef MGX_DEBUG_KNOBS
+#define MGX_DEBUG_KNOBS 0
+#endif
+#if MGX_DEBUG_KNOBS
+#define MGX_DBG(bits) (a.dbg & (bits))
+#else
+#define MGX_DBG(bits) 0
+#endif
 
 // A kernel argument fetched where it is used (s_load from the kernarg segment) instead of living in SGPRs from the
 // kernel's first instruction on: the fused kernel is short of SGPRs, and every spilled one costs VALU
@@ -181,10 +191,10 @@ constexpr int kLdsWaveBudget = MGX_LDS_WAVE_BUDGET;     // keeps >= 12 wavefront
 
 // Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
 // to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
-int choose_Gw(const MgxSpec &sp, int64_t batch) {
+int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false) {
     int Gw = slots_per_wave(sp.view_size) / sp.num_agents;
     if (Gw < 1) Gw = 1;
-    while (Gw > 1 && wave_lds_bytes(sp, Gw) > kLdsWaveBudget) --Gw;
+    while (Gw > 1 && wave_lds_bytes(sp, Gw, roll) > kLdsWaveBudget) --Gw;
     while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
     while (Gw > 1 && (batch + Gw - 1) / Gw < 512) Gw = (Gw + 1) / 2;       // tiny batches: spread over the chip
     return Gw;
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const uint8_t *gsrc = a.grid + ga;
     const int len = (int)(g1 - ga);
     const int avail = (int)min(gtotal - ga, (int64_t)INT_MAX);               // bytes readable from gsrc
-    const int grec = (a.dbg & 1) ? 0 : min((len + 15) & ~15, avail);
+    const int grec = MGX_DBG(1) ? 0 : min((len + 15) & ~15, avail);
     const __amdgpu_buffer_rsrc_t grsrc = make_rsrc(gsrc, grec);
     const int lane16 = 16 * lane;
     const int env_of_lane = (lane * a.inv_A) >> 16, agent_of_lane = lane - env_of_lane * A;   // slot `lane` = (env, agent)
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     my_rng[0] = ((uint64_t)in_rngA.y << 32) | in_rngA.x; my_rng[1] = ((uint64_t)in_rngA.w << 32) | in_rngA.z;
     my_rng[2] = ((uint64_t)in_rngB.y << 32) | in_rngB.x; my_rng[3] = ((uint64_t)in_rngB.w << 32) | in_rngB.z;
     uint64_t my_draw = 0;
-    if (DO_STEP && !ROLL && A > 1 && !(a.dbg & (2 | 128)) && lane < NVc) {
+    if (DO_STEP && !ROLL && A > 1 && !MGX_DBG((2 | 128)) && lane < NVc) {
         uint64_t jk[4];
         jk[0] = ((uint64_t)in_jmpA.y << 32) | in_jmpA.x; jk[1] = ((uint64_t)in_jmpA.w << 32) | in_jmpA.z;
         jk[2] = ((uint64_t)in_jmpB.y << 32) | in_jmpB.x; jk[3] = ((uint64_t)in_jmpB.w << 32) | in_jmpB.z;
@@ -606,13 +616,13 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     if (AR && reset_mask != 0 && lane < NVc) cur_row = rows[lane];
     double my_rew = 0.0;                                                     // this agent's reward (base.py:393), in a register
-    if (DO_STEP && !(a.dbg & 2)) {
+    if (DO_STEP && !MGX_DBG(2)) {
         const bool in = lane < NVc;
         // (fetched now so that the s_load latency hides behind P1a / P1s)
         int32_t *const p_step_count = ROLL ? nullptr : MGX_LATE(step_count);
         uint8_t *const p_truncated = MGX_LATE(truncated);
         MGX_MARK("P1a");
-        if (ROLL && A > 1 && !(a.dbg & 128)) {
+        if (ROLL && A > 1 && !MGX_DBG(128)) {
             // -------------------------------------------------------------- P1a (rollout; the one-step kernels did it in P0):
             // one lane per (env, agent): its draw
             if (in) {
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
         AgentEval ev{};
         uint8_t *mytile = tile + env_of_lane * HW3;
-        if (in && !(a.dbg & 64)) {
+        if (in && !MGX_DBG(64)) {
             const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
                                ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
             ev = eval_agent(cf, mytile, rows + env_of_lane * A, ROLL ? (int)acts[lane] : (int)(int8_t)in_act, cur_row, true, so);
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         MGX_MARK("P1hook");
         // ------------------------------------------------------------------ overlay offsets (pre-hook `terminated`, SURVEY
         // App. C Q2), then one lane per env: counters + the env subclass' hook on the clean tile, then the overlay itself
-        const int ovl = (in && !(a.dbg & 512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
+        const int ovl = (in && !MGX_DBG(512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
         if (HOOKS && in && !fb) rew[lane] = my_rew;                              // (the hooks assign to / add onto the base rewards)
         wave_sync();
         if (lane < Gc) {
@@ -809,7 +819,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
     for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
-    if (!(a.dbg & 4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+    if (!MGX_DBG(4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
         if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
@@ -821,7 +831,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint32_t visLo[NW], visHi[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) { visLo[k] = 0xffffffffu; visHi[k] = 0xffffffffu; }
-    if (masked && !(a.dbg & 8)) {
+    if (masked && !MGX_DBG(8)) {
         uint64_t sb[NW], vis[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) sb[k] = ((uint64_t)sbHi[k] << 32) | sbLo[k];
@@ -844,7 +854,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #pragma unroll
     for (int r0 = 0; r0 < VPW; r0 += kRound) {
         if (r0 < NVc) {
-            if (!(a.dbg & 16)) {
+            if (!MGX_DBG(16)) {
 #pragma unroll
                 for (int it = 0; it < NW; ++it) {
                     if (lc.act[it]) {
@@ -880,7 +890,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             }
             wave_sync();
             MGX_MARK("P5");
-            if (!(a.dbg & 32)) {
+            if (!MGX_DBG(32)) {
                 const int64_t ro0 = o0 + (int64_t)r0 * (V2 * 3);                // this round's obs bytes [ro0, ro1)
                 const int rlen = out_skew + (int)min((int64_t)kRoundBytes, o1 - ro0);   // staged bytes, from the aligned start
                 uint8_t *gdst = MGX_LATE(obs) + (ro0 - out_skew);
@@ -937,9 +947,13 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 }
 
 int g_last_hip_error = 0;
+#if MGX_DEBUG_KNOBS
 int g_debug_skip = 0;
 int g_debug_G = 0;
 int g_debug_wpb = 0;
+#else
+constexpr int g_debug_skip = 0, g_debug_G = 0, g_debug_wpb = 0;
+#endif
 
 template <int MODE>
 int launch(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
@@ -972,14 +986,15 @@ int launch(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStr
     return MGX_OK;
 }
 
-int check_spec(const MgxSpec *sp, int64_t batch) {
+int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false) {
     if (!sp || batch < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size < 3 || !(sp->view_size & 1)) return MGX_ERR_INVALID_ARGUMENT;   // agent.py:78-79
     if (sp->width < 3 || sp->height < 3 || sp->num_agents < 1 || sp->max_steps < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
     if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_LOCKEDHALLWAY) return MGX_ERR_UNSUPPORTED;
-    if (wave_lds_bytes(*sp, 1) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;              // one env must fit one CU's LDS
+    if (wave_lds_bytes(*sp, 1, roll) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;        // one env must fit one CU's LDS (the
+                                                                                     // rollout carve is the larger one)
     return MGX_OK;
 }
 
@@ -987,11 +1002,11 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
               bool roll = false) {
     ka.sp = *sp;
     ka.batch = batch;
-    ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch);
+    ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll);
     const int max_gw = slots_per_wave(sp->view_size) / sp->num_agents;
     if (ka.Gw > max_gw) ka.Gw = max_gw;
     if (ka.Gw < 1) ka.Gw = 1;
-    while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw) > kLdsPerCU) --ka.Gw;
+    while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
     ka.vpw = slots_in_use(*sp, ka.Gw);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
@@ -1031,11 +1046,13 @@ const char *mgx_error_string(int code) {
 
 int mgx_last_hip_error(void) { return g_last_hip_error; }
 
-// Profiling aid (not part of the product ABI): bit p set = the fused kernel skips phase Pp.  Results are
-// then meaningless; tools/phase_probe.py uses it to attribute kernel time to phases.
+#if MGX_DEBUG_KNOBS
+// Profiling aid, only in the tools' build (lib/libmgx_dbg.so; never in libmgx.so): bit p set = the fused kernel skips
+// phase Pp.  Results are then meaningless; tools/phase_probe.py uses it to attribute kernel time to phases.
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
+#endif
 #if MGX_TIMESTAMPS
 int mgx_debug_read_span(unsigned long long *out, int nwaves) {            // [nwaves][2] of the last launch
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * nwaves) == hipSuccess ? 0 : -1;
@@ -1087,7 +1104,7 @@ static int step_common(bool roll, const MgxSpec *spec, int64_t batch, int32_t st
                        uint8_t *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
                        uint8_t *aux, uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated,
                        uint8_t *truncated, int32_t *err, void *stream) {
-    int rc = check_spec(spec, batch);
+    int rc = check_spec(spec, batch, roll);
     if (rc) return rc;
     if (steps < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (batch == 0 || steps == 0) return MGX_OK;

@@ -49,6 +49,16 @@ def words_from_seeds(seeds) -> np.ndarray:
     return out
 
 
+def words_from_seed_and_index(seed: int, global_index) -> np.ndarray:
+    """Env with global index g gets Generator(PCG64(SeedSequence([seed, g]))); g == 0 gets SeedSequence(seed), the
+    reference's single env (multigrid/base.py:269)."""
+    idx = np.asarray(global_index)
+    out = np.empty((len(idx), 4), dtype=np.uint64)
+    for b, g in enumerate(idx):
+        out[b] = words_from_seed(int(seed) if int(g) == 0 else [int(seed), int(g)])
+    return out
+
+
 def synthetic_words(batch: int, seed: int, first_env: int = 0) -> np.ndarray:
     """Cheap valid PCG64 states for benchmarks (any 128-bit state, odd increment), a pure function of the
     GLOBAL env index so that sharding the batch over ranks does not change any env's stream."""

@@ -74,9 +74,21 @@ class OneHotObsWrapper(_ObservationWrapper):
             agent.observation_space["image"] = Box(low=0, high=1, shape=(h, w, dim), dtype=np.uint8)
 
     def observation(self, obs):
-        oh = self.env.unwrapped._benv.one_hot_obs()[0].cpu().numpy()
-        for agent_id in obs:
-            obs[agent_id]["image"] = oh[agent_id]
+        base = self.env.unwrapped
+        if self.env is base:
+            # directly over the env: its partial views are still in HBM, one-hot them there
+            oh = base._benv.one_hot_obs()[0].cpu().numpy()
+            for agent_id in obs:
+                obs[agent_id]["image"] = oh[agent_id]
+            return obs
+        # over another wrapper (e.g. FullyObsWrapper): one-hot the images handed in, as wrappers.py:149-156 does
+        import torch
+        benv = base._benv
+        for agent_id in list(obs):
+            img = torch.from_numpy(np.ascontiguousarray(obs[agent_id]["image"]).astype(np.uint8)).to(benv.device)
+            out = torch.empty(tuple(img.shape[:-1]) + (int(self.dim_sizes.sum()),), dtype=torch.uint8, device=benv.device)
+            benv.backend.one_hot(img, out)
+            obs[agent_id]["image"] = out.cpu().numpy()
         return obs
 
 

@@ -392,7 +392,8 @@ def record_layouts():
             grids.append(env.grid.state.copy()); agents.append(np.asarray(env.agent_states).copy())
             rngs.append(rng_words(env.np_random))
             obs0s.append(np.stack([obs[i]["image"] for i in range(A)]))
-            missions.append(str(obs[0]["mission"]))
+            # mission_space.seed(None) draws OS entropy (base.py:272): only seeded resets have a reproducible mission
+            missions.append(str(obs[0]["mission"]) if sd >= 0 else "<unseeded>")
             targets.append([int(v) for v in np.asarray(env.obj)] if kind == "blockedunlockpickup" else [0, 0, 0])
             acts = ar.integers(0, 7, size=(5, A)).astype(np.int8)
             acts_all.append(acts)

@@ -8,6 +8,7 @@ import pytest
 
 import multigrid_amd as mg
 from multigrid_amd import layouts
+from oracle import binding as ob
 from tests import util
 
 
@@ -150,7 +151,8 @@ def test_wrappers_match_reference(path):
                agents=spec.num_agents, agent_view_size=spec.view_size)
     env.reset(seed=0)
     oh, fo = mg.OneHotObsWrapper(env), mg.FullyObsWrapper(env)
-    assert env.agents[0].observation_space["image"].shape[:2] == (spec.width, spec.height) or True
+    # each wrapper rewrites the agents' image space in its constructor (wrappers.py:43-46, 143-147); the last one wins
+    assert env.agents[0].observation_space["image"].shape == (spec.height, spec.width, 3)
     for t in range(z["obs"].shape[0]):
         env._benv.load_state(layouts.grid_to_product(z["grid"][t]), layouts.pack_agents(z["agents"][t]), validate=False)
         raw = env.gen_obs()
@@ -191,3 +193,69 @@ def test_auto_reset_from_layout_pool():
     assert torch.equal(env.rng, rng_before)                 # the stream keeps running, like an unseeded reset()
     env.step(torch.from_numpy(util.random_actions(B, 2, 9, p_missing=0)))
     assert int(env.reset_done().sum()) == 0
+
+
+def test_one_hot_wrapper_encodes_the_observation_it_is_given():
+    """OneHotObsWrapper(FullyObsWrapper(env)) one-hots the full-grid image (multigrid/wrappers.py:149-156), not the
+    base env's partial view, and the declared image space matches what comes back."""
+    env = make("MultiGrid-Empty-8x8-v0", agents=2)
+    wrapped = mg.OneHotObsWrapper(mg.FullyObsWrapper(env))
+    obs, _ = wrapped.reset(seed=3)
+    full = mg.FullyObsWrapper(env).observation(env.gen_obs())
+    for i in range(2):
+        want = ob.one_hot(full[i]["image"].astype(np.uint8))
+        np.testing.assert_array_equal(obs[i]["image"], want)
+        assert obs[i]["image"].shape == (8, 8, 21)
+    obs, *_ = wrapped.step({0: 2, 1: 1})
+    assert obs[0]["image"].shape == (8, 8, 21) and obs[0]["image"].sum() == 3 * 64
+
+
+def test_state_dict_round_trip_continues_bit_identically_across_auto_resets():
+    import torch
+    spec = mg.EnvSpec(6, 6, 2, max_steps=4)
+    B, K = 10, 5
+    r = np.random.default_rng(0)
+    pool = [layouts.empty_layout(6, 2, agent_start_pos=None, agent_start_dir=None, layout_rng=r) for _ in range(K)]
+    pg, pa = np.stack([p[0] for p in pool]), np.stack([p[1] for p in pool])
+
+    def fresh():
+        e = mg.BatchedMultiGridEnv(spec, B, "cpu", first_env=40, backend=util.OracleBackend(spec))
+        e.load_state(pg[0], pa[0]); e.seed(11)
+        return e
+
+    def run(e, t0, t1):
+        outs = []
+        for t in range(t0, t1):
+            e.reset_done()
+            o = e.step(torch.from_numpy(util.random_actions(B, 2, 50 + t, p_missing=0)))
+            outs.append([x.clone() for x in o] + [e.was_reset.clone()])
+        return outs
+
+    a = fresh(); a.set_layout_pool(pg, pa)
+    run(a, 0, 6)                                       # past the first truncation: episode counters are non-zero
+    sd = a.state_dict()
+    assert int(sd["episode"].sum()) > 0
+    want = run(a, 6, 14)
+    b = fresh()
+    b.load_state_dict(sd)
+    got = run(b, 6, 14)
+    for w, g in zip(want, got):
+        for x, y in zip(w, g):
+            assert torch.equal(x, y)
+    assert torch.equal(a.grid, b.grid) and torch.equal(a.episode, b.episode) and torch.equal(a.rng, b.rng)
+    c = mg.BatchedMultiGridEnv(spec, B, "cpu", first_env=0, backend=util.OracleBackend(spec))
+    with pytest.raises(ValueError, match="shard"):
+        c.load_state_dict(sd)
+
+
+def test_seed_streams_do_not_alias_across_seeds_or_shards():
+    spec = mg.EnvSpec(6, 6, 2, max_steps=4)
+    def words(seed, first, n):
+        e = mg.BatchedMultiGridEnv(spec, n, "cpu", first_env=first, backend=util.OracleBackend(spec))
+        e.seed(seed)
+        return e.rng.numpy().copy()
+    w0, w1 = words(0, 0, 6), words(1, 0, 6)
+    assert len({r.tobytes() for r in np.concatenate([w0, w1])}) == 12          # no stream shared between seeds 0 and 1
+    np.testing.assert_array_equal(words(0, 3, 3), w0[3:])                       # a function of the global env index
+    from multigrid_amd import rng as rnglib
+    np.testing.assert_array_equal(w0[0].view(np.uint64), rnglib.words_from_seed(0))   # env 0 == gym reset(seed=0)
