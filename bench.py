@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the fused HIP step (action apply + gen_obs) on synthetic random-action rollouts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu] [--mode graph|eager]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|c5] [--mode graph|eager]
 
-One "step" = one `MultiGridEnv.step` over the whole per-GPU batch = one launch of the fused kernel.
-Workload at N=1 = BASELINE.json configs[1]: MultiGrid-Empty-16x16-v0, agents=4, view_size=7, batch=4096 envs.
-For N>1 (launched by `python -m torch.distributed.run --nproc-per-node N ...`, one rank per GPU) every rank owns
-an independent shard of `--batch` envs (weak scaling); the data path has NO collective -- envs never interact
- -- and torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
+One "step" = one `MultiGridEnv.step` over the whole per-GPU batch = one launch of the fused kernel (auto-reset fused in).
+Headline workload = BASELINE.json's north-star configuration C4: MultiGrid-Empty-16x16-v0, agents=4, view_size=7,
+batch=65536 envs -- all of it on one GPU at N=1 (it is ~100 MB).  For N>1 (launched by `python -m torch.distributed.run
+--nproc-per-node N ...`, one rank per GPU) the SAME global batch is sharded over the ranks (strong scaling: 8192 envs per
+GPU at N=8); the data path has NO collective -- envs never interact -- and torch.distributed
+(RCCL) is used only for the barrier and the max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  Extra objects:
-  roofline            the fused kernel on the timed workload: algorithmic bytes per launch (SURVEY.md 8d:
-                      339 B per agent-step for this shape) / average launch duration from HIP events over the
-                      timed region on the launch stream
-  roofline_large      same kernel at a working set >> the 256 MiB Infinity Cache (HBM-resident regime)
-  gen_obs_large       the observation-only kernel (311 B per agent-view) at the same large working set
-  cpu_baseline        the CPU oracle (a port of the reference algorithm; the Python reference cannot travel to
-                      the GPU box) timed on this host's cores on a bounded sample of the same workload
+Timing.  W untimed warm-up steps, one untimed calibration replay, then the timed region: a hipGraph holding a whole
+number of K-step blocks is replayed until the region is >= 50 ms (a K-step region alone would be ~0.5 ms at the
+driver's K = 20); `ms_per_step` = region / steps in it, `timed_steps` says how many that was.  The region is bracketed by
+barrier + torch.cuda.synchronize() on both sides, max over ranks.
+
+Prints ONE JSON line on rank 0.  Extra objects (N=1 only, except `roofline`):
+  roofline            the fused kernel on the timed workload: algorithmic bytes per launch / average launch
+                      duration from HIP events over the timed region on the launch stream; `traffic` = HBM bytes per
+                      launch from the committed rocprofv3 PMC passes (profiles/traffic.json)
+  configs             the other BASELINE.json GPU configurations (C2, C3 with its layout pool + hook, C5 with occluders),
+                      each timed the same way, each with its own roofline
+  eager               the same step called from Python once per step (policy-in-the-loop cost: ctypes + launch)
+  fused_rollout       K steps as ONE mgx_rollout launch (open-loop actions only)
+  roofline_large / gen_obs_large / one_hot_large / aux_kernels
+                      the kernels at a working set >> the 256 MiB Infinity Cache (HBM-resident regime)
+  cpu_baseline        the CPU oracle (a C port of the reference algorithm; the Python reference cannot travel to the GPU
+                      box) on all host cores, bounded sample of the same workload;  cpu_baseline_1core: one thread
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -33,35 +44,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts  # noqa: E402
+from multigrid_amd import _lib, workloads  # noqa: E402
 from multigrid_amd.sharding import shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 AUTO_RESET = True              # finished envs (all terminated / truncated) restart; fused into the step launch
+MIN_REGION_MS = 50.0
 
 
-def workload_spec() -> EnvSpec:
-    # MultiGrid-Empty-16x16-v0: multigrid/envs/__init__.py:46, empty.py:145 (max_steps = 4*size^2)
-    if os.environ.get("MGX_WORKLOAD", "c2") == "c5":      # profiling tools only: BASELINE.json configs[4] (64x64, 16 agents, v=9)
-        return EnvSpec(width=64, height=64, num_agents=16, view_size=9, max_steps=4 * 64 * 64, env_kind="empty")
-    return EnvSpec(width=16, height=16, num_agents=4, view_size=7, max_steps=4 * 16 * 16, env_kind="empty")
+def tool_workload() -> str:
+    """Profiling tools pick their configuration with MGX_WORKLOAD=c2|c3|c4|c5 (default c2)."""
+    return os.environ.get("MGX_WORKLOAD", "c2")
 
 
-def make_env(spec, batch, device, first_env, seed=1234):
-    env = BatchedMultiGridEnv(spec, batch, device, first_env=first_env)
-    grid, agents = layouts.empty_layout(spec.width, spec.num_agents)      # agents at (1,1) facing right
-    if spec.width == 64:                                                  # C5: random interior starts (host default_rng(5))
-        r = np.random.default_rng(5)
-        agents = np.broadcast_to(agents, (batch,) + agents.shape).copy()
-        agents[..., 2] = r.integers(1, 63, size=agents.shape[:2]); agents[..., 3] = r.integers(1, 63, size=agents.shape[:2])
-        agents[..., 1] = r.integers(0, 4, size=agents.shape[:2])
-        grid = np.broadcast_to(grid, (batch,) + grid.shape)
-    env.load_state(grid, agents)
-    env.seed_synthetic(seed)
-    if AUTO_RESET:                                                        # the reference's reset() of this env class is one
-        g1, a1 = layouts.empty_layout(spec.width, spec.num_agents)         # fixed layout (empty.py:151-170): a pool of K = 1
-        env.set_layout_pool(g1[None], a1[None])
-    return env
+def workload_spec():
+    return workloads.spec_of(tool_workload())
+
+
+def make_env(spec, batch, device, first_env=0):
+    """(tools/) `batch` envs of the MGX_WORKLOAD configuration starting at global env `first_env`."""
+    name = tool_workload()
+    wl = workloads.make(name, batch=batch, first_env=first_env,
+                        global_batch=max(workloads.GLOBAL_BATCH[name], first_env + batch))
+    assert wl.spec == spec
+    return wl.make_env(device, auto_reset=AUTO_RESET)
 
 
 def random_actions(steps, batch, agents, device, seed):
@@ -70,30 +76,30 @@ def random_actions(steps, batch, agents, device, seed):
     return torch.randint(0, 7, (steps, batch, agents), dtype=torch.int8, device=device, generator=g)
 
 
-def timed_rollout(env, actions, mode, dist_barrier):
-    """Time exactly len(actions) steps.  Returns (wall seconds incl. sync, HIP-event ms over the region)."""
-    K = actions.shape[0]
+def capture_steps(env, actions):
+    """One hipGraph holding `len(actions)` consecutive env.step launches."""
     stream = torch.cuda.current_stream(env.device)
-    graph = None
-    if mode == "graph":
-        graph = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream(env.device)
-        s.wait_stream(stream)
-        with torch.cuda.stream(s):
-            with torch.cuda.graph(graph, stream=s):
-                for t in range(K):
-                    env.step(actions[t], auto_reset=AUTO_RESET)
-        stream.wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(env.device)
+    s.wait_stream(stream)
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            for t in range(actions.shape[0]):
+                env.step(actions[t], auto_reset=AUTO_RESET)
+    stream.wait_stream(s)
+    return graph
+
+
+def timed_region(env, run_once, repeats, dist_barrier):
+    """Time `repeats` calls of run_once (each enqueues a fixed number of steps).  Returns (wall s incl. sync, event ms)."""
+    stream = torch.cuda.current_stream(env.device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     dist_barrier()
     torch.cuda.synchronize(env.device)
     t0 = time.perf_counter()
     ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for t in range(K):
-            env.step(actions[t], auto_reset=AUTO_RESET)
+    for _ in range(repeats):
+        run_once()
     ev1.record(stream)
     torch.cuda.synchronize(env.device)
     t1 = time.perf_counter()
@@ -101,10 +107,35 @@ def timed_rollout(env, actions, mode, dist_barrier):
     return t1 - t0, ev0.elapsed_time(ev1)
 
 
-def kernel_time_ms(fn, iters, device):
-    """Average duration of `fn`'s single kernel launch: `iters` back-to-back launches between two HIP events."""
+def measure_steps(env, K, warmup, mode, dist_barrier, seed, min_region_ms=MIN_REGION_MS, agree=None):
+    """W warm-up steps, a calibration pass, then a timed region of whole K-step blocks lasting >= min_region_ms.
+    Returns dict(wall_s, event_ms, timed_steps, blocks).  `agree(n)` lets all ranks settle on one repeat count."""
+    B, A, dev = env.batch, env.spec.num_agents, env.device
+    block = K * max(1, math.ceil(256 / K))                     # steps enqueued per run_once: >= 256, a multiple of K
+    warm = random_actions(max(warmup, 1), B, A, dev, seed + 1000)
+    for t in range(warmup):
+        env.step(warm[t], auto_reset=AUTO_RESET)
+    acts = random_actions(block, B, A, dev, seed)
+    if mode == "graph":
+        graph = capture_steps(env, acts)
+        run_once = graph.replay
+    else:
+        def run_once():
+            for t in range(block):
+                env.step(acts[t], auto_reset=AUTO_RESET)
+    _, cal_ms = timed_region(env, run_once, 2, dist_barrier)    # untimed for the result: clocks settle, gives the estimate
+    repeats = max(1, math.ceil(min_region_ms / max(cal_ms / 2, 1e-3)))
+    if agree is not None:
+        repeats = agree(repeats)
+    wall_s, ev_ms = timed_region(env, run_once, repeats, dist_barrier)
+    return {"wall_s": wall_s, "event_ms": ev_ms, "timed_steps": block * repeats, "block": block, "repeats": repeats}
+
+
+def kernel_time_ms(fn, iters, device, warm=30):
+    """Average duration of `fn`'s single kernel launch: `iters` back-to-back launches between two HIP events, after
+    `warm` untimed ones."""
     stream = torch.cuda.current_stream(device)
-    for _ in range(max(3, iters // 2)):          # also lets the clocks settle
+    for _ in range(warm):
         fn()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
@@ -116,13 +147,13 @@ def kernel_time_ms(fn, iters, device):
     return ev0.elapsed_time(ev1) / iters
 
 
-def pmc_traffic(kernel: str, batch: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None if this
-    (kernel, batch) was not profiled.  bench.py cannot collect PMC counters on itself."""
+def pmc_traffic(key: str, batch: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json: {key: {batch: {bytes}}}), or
+    None if this (kernel, batch) was not profiled.  bench.py cannot collect PMC counters on itself."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            return json.load(fh)[kernel][str(batch)]["bytes"]
-    except (OSError, KeyError, ValueError):
+            return json.load(fh)[key][str(batch)]["bytes"]
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -132,8 +163,64 @@ def roofline(alg_bytes_per_launch, ms, traffic=None):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
 
 
-def large_batch_points(spec, device, large_batch):
-    env = make_env(spec, large_batch, device, 0)
+def step_roofline(wl_name, spec, B, ms_launch):
+    rf = roofline(B * spec.num_agents * spec.bytes_step(), ms_launch, pmc_traffic(f"{wl_name}_step", B))
+    rf.update(kernel=f"mgx_fused_kernel<{spec.view_size},step,autoreset>", ms_per_launch=round(ms_launch, 5),
+              bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=B * spec.num_agents * spec.bytes_step(),
+              traffic_unit="bytes per launch (rocprofv3 PMC, profiles/traffic.json)")
+    return rf
+
+
+def config_point(name, device, K, warmup):
+    """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline."""
+    wl = workloads.make(name)
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
+    m = measure_steps(env, K, warmup, "graph", lambda: None, seed=4321, min_region_ms=30.0)
+    env.check_errors()
+    B, A = wl.batch, wl.spec.num_agents
+    ms = m["event_ms"] / m["timed_steps"]
+    out = {"workload": wl.title, "batch": B, "agents": A, "grid": f"{wl.spec.width}x{wl.spec.height}",
+           "view_size": wl.spec.view_size, "ms_per_step": round(m["wall_s"] * 1e3 / m["timed_steps"], 6),
+           "value": round(B * A * m["timed_steps"] / m["wall_s"]), "unit": "agent-steps/s",
+           "timed_steps": m["timed_steps"], "layout_pool": int(wl.pool[0].shape[0]),
+           "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,
+           "launch": env.backend.launch_info(B), "roofline": step_roofline(name, wl.spec, B, ms)}
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
+def eager_point(wl, device, steps=2000):
+    """env.step called from Python once per step (what an RL loop that cannot capture its policy pays)."""
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
+    B, A = wl.batch, wl.spec.num_agents
+    acts = random_actions(64, B, A, device, 77)
+    for t in range(200):
+        env.step(acts[t & 63], auto_reset=AUTO_RESET)
+    stream = torch.cuda.current_stream(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for t in range(steps):
+        env.step(acts[t & 63], auto_reset=AUTO_RESET)
+    t_host = time.perf_counter() - t0
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    env.check_errors()
+    out = {"workload": wl.name, "batch": B, "steps": steps, "ms_per_step": round(wall * 1e3 / steps, 6),
+           "host_ms_per_call": round(t_host * 1e3 / steps, 6), "event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 6),
+           "value": round(B * A * steps / wall), "unit": "agent-steps/s",
+           "note": "BatchedMultiGridEnv.step from Python per step (ctypes -> mgx_step_autoreset); no graph"}
+    del env
+    return out
+
+
+def large_batch_points(device, large_batch):
+    wl = workloads.make("c4", batch=large_batch, global_batch=large_batch)
+    spec = wl.spec
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
     acts = random_actions(4, large_batch, spec.num_agents, device, 99)
     i = [0]
 
@@ -142,64 +229,52 @@ def large_batch_points(spec, device, large_batch):
     ms_step = kernel_time_ms(step, 60, device)
     ms_obs = kernel_time_ms(env.gen_obs, 60, device)
     n = large_batch * spec.num_agents
-    r_step = roofline(n * spec.bytes_step(), ms_step, pmc_traffic("step", large_batch))
-    r_step.update(batch=large_batch, kernel="mgx_fused_kernel<7,step>", ms_per_launch=round(ms_step, 4),
+    r_step = roofline(n * spec.bytes_step(), ms_step, pmc_traffic("large_step", large_batch))
+    r_step.update(batch=large_batch, kernel="mgx_fused_kernel<7,step,autoreset>", ms_per_launch=round(ms_step, 4),
                   agent_steps_per_s=round(n / (ms_step * 1e-3)))
-    r_obs = roofline(n * spec.bytes_gen_obs(), ms_obs, pmc_traffic("gen_obs", large_batch))
+    r_obs = roofline(n * spec.bytes_gen_obs(), ms_obs, pmc_traffic("large_gen_obs", large_batch))
     r_obs.update(batch=large_batch, kernel="mgx_fused_kernel<7,gen_obs>", ms_per_launch=round(ms_obs, 4),
                  agent_views_per_s=round(n / (ms_obs * 1e-3)))
+    out = {"roofline_large": r_step, "gen_obs_large": r_obs}
+    out["aux_kernels"] = aux_kernel_points(env, device)
     del env
     torch.cuda.empty_cache()
-    return r_step, r_obs
+    return out
 
 
-def aux_kernel_points(device, batch=1 << 20):
+def aux_kernel_points(env, device):
     """Bandwidth of the kernels either side of the fused step at an HBM-resident size."""
-    spec = workload_spec()
+    spec, batch = env.spec, env.batch
     A, V, H, W = spec.num_agents, spec.view_size, spec.height, spec.width
-    env = make_env(spec, batch, device, 0)
-    acts = random_actions(4, batch, A, device, 7)
-    for t in range(4):
-        env.step(acts[t])
     out = {}
+
+    def entry(t, by):
+        return {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
+                "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
     # one-hot of the step's observations: 3 B in, 21 B out per view cell (wrappers.py:158-190)
     cells = batch * A * V * V
-    t = kernel_time_ms(env.one_hot_obs, 30, device)
-    by = cells * (3 + 21)
-    out["one_hot"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
-                      "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    out["one_hot"] = entry(kernel_time_ms(env.one_hot_obs, 30, device, warm=10), cells * (3 + 21))
     # fully observable encode: grid in, transposed grid out, agent rows in
-    t = kernel_time_ms(env.full_obs, 30, device)
-    by = batch * (2 * H * W * 3 + A * 8)
-    out["full_obs"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
-                       "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    out["full_obs"] = entry(kernel_time_ms(env.full_obs, 30, device, warm=10), batch * (2 * H * W * 3 + A * 8))
     # auto-reset with every env done: agent rows + step counts in, layout out
-    grid, agents = layouts.empty_layout(W, A)
-    K = 64
-    env.set_layout_pool(np.broadcast_to(grid, (K,) + grid.shape).copy(), np.broadcast_to(agents, (K,) + agents.shape).copy())
-
     def reset_all():
         env.step_count.fill_(spec.max_steps)          # every env truncated -> every env is reset
         env.reset_done()
     def fill_only():
         env.step_count.fill_(spec.max_steps)
-    t = kernel_time_ms(reset_all, 30, device) - kernel_time_ms(fill_only, 30, device)
-    by = batch * (H * W * 3 + 2 * A * 8 + 4 + 4 + 4 + 1)
-    out["reset_done_all"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
-                             "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    t = kernel_time_ms(reset_all, 30, device, warm=10) - kernel_time_ms(fill_only, 30, device, warm=10)
+    out["reset_done_all"] = entry(t, batch * (H * W * 3 + 2 * A * 8 + 4 + 4 + 4 + 1))
     env.step_count.zero_()
-    t = kernel_time_ms(env.reset_done, 30, device)     # nobody done: the scan only
-    by = batch * (A * 8 + 4 + 1)
-    out["reset_done_none"] = {"batch": batch, "ms_per_launch": round(t, 5), "algorithmic_bytes": by,
-                              "achieved_GBs": round(by / t / 1e6, 1), "frac": round(by / t / 1e6 / HBM_PEAK_GBS, 4)}
+    out["reset_done_none"] = entry(kernel_time_ms(env.reset_done, 30, device, warm=10), batch * (A * 8 + 4 + 1))
     return out
 
 
-
-def rollout_point(spec, batch, device, steps, first_env, seed):
-    """The same K steps as ONE mgx_rollout launch (env state stays in LDS between steps).  Open-loop actions only."""
-    env = make_env(spec, batch, device, first_env)
-    acts = random_actions(steps, batch, spec.num_agents, device, seed)
+def rollout_point(wl, device, steps):
+    """`steps` steps as ONE mgx_rollout launch (env state stays in LDS between steps).  Open-loop actions only."""
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
+    spec, batch = wl.spec, wl.batch
+    steps = max(2, min(steps, (1 << 30) // max(1, batch * spec.num_agents * spec.view_size ** 2 * 3)))   # obs[T] <= 1 GiB
+    acts = random_actions(steps, batch, spec.num_agents, device, 1234)
     out = env.rollout(acts[:2].contiguous(), auto_reset=AUTO_RESET)   # warm-up + allocation pattern
     A, v = spec.num_agents, spec.view_size
     out = {"obs": torch.empty((steps, batch, A, v, v, 3), dtype=torch.uint8, device=device),
@@ -208,8 +283,8 @@ def rollout_point(spec, batch, device, steps, first_env, seed):
            "terminated": torch.empty((steps, batch, A), dtype=torch.uint8, device=device),
            "truncated": torch.empty((steps, batch), dtype=torch.uint8, device=device),
            "was_reset": torch.empty((steps, batch), dtype=torch.uint8, device=device)}
-    for v in out.values():
-        v.zero_()                                              # first touch of the fresh allocations, outside the timing
+    for x in out.values():
+        x.zero_()                                              # first touch of the fresh allocations, outside the timing
     stream = torch.cuda.current_stream(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
@@ -221,39 +296,37 @@ def rollout_point(spec, batch, device, steps, first_env, seed):
     wall = time.perf_counter() - t0
     env.check_errors()
     n = batch * A * steps
-    res = {"value": round(n / wall), "unit": "agent-steps/s", "steps": steps, "launches": 1,
-           "ms_per_step": round(wall * 1e3 / steps, 6), "event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 6),
-           "note": "mgx_rollout: K steps in one launch, bit-identical to K mgx_step calls (tests/test_hip_parity.py); "
-                   "valid for open-loop action sequences such as this benchmark's random actions"}
+    res = {"workload": wl.name, "batch": batch, "value": round(n / wall), "unit": "agent-steps/s", "steps": steps,
+           "launches": 1, "ms_per_step": round(wall * 1e3 / steps, 6),
+           "event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 6),
+           "note": "mgx_rollout: the steps in one launch, bit-identical to that many mgx_step calls "
+                   "(tests/test_hip_parity.py); valid for open-loop action sequences such as this benchmark's random actions"}
     del env, out
     torch.cuda.empty_cache()
     return res
 
 
-def cpu_baseline(spec, batch, budget_s=12.0):
-    """Oracle (C port of the reference algorithm, OpenMP over envs) on this host, bounded sample."""
+def cpu_baseline(wl, threads, budget_s, sample_envs):
+    """Oracle (C port of the reference algorithm, OpenMP over envs) on this host, bounded sample of the workload."""
     from oracle import binding as ob
-    cores = ob.max_threads()
-    grid, agents = layouts.empty_layout(spec.width, spec.num_agents)
-    from multigrid_amd import rng as rnglib
-    st = dict(grid=np.repeat(grid[None], batch, 0).copy(), agents=np.repeat(agents[None], batch, 0).copy(),
-              rng=rnglib.synthetic_words(batch, 1234), step_count=np.zeros(batch, np.int32))
-    r = np.random.default_rng(1234)
-    acts = r.integers(0, 7, size=(8, batch, spec.num_agents)).astype(np.int8)
-    d = spec.as_dict()
-    ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[0], None, cores)   # warm
+    n_env = min(sample_envs, wl.batch)
+    st = dict(grid=wl.grid[:n_env].copy(), agents=wl.agents[:n_env].copy(), rng=wl.rng[:n_env].copy(),
+              step_count=np.zeros(n_env, np.int32), aux=None if wl.aux is None else wl.aux[:n_env].copy())
+    A = wl.spec.num_agents
+    acts = np.random.default_rng(1234).integers(0, 7, size=(8, n_env, A)).astype(np.int8)
+    d = wl.spec.as_dict()
+    ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[0], st["aux"], threads)   # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[n & 7], None, cores)
+        ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[n & 7], st["aux"], threads)
         n += 1
         el = time.perf_counter() - t0
-        if (el >= budget_s and n >= 8) or n >= 100000:
+        if (el >= budget_s and n >= 4) or n >= 100000:
             break
-    return {"value": round(n * batch * spec.num_agents / el), "unit": "agent-steps/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{n} steps of the same workload (batch {batch}, Empty-16x16, 4 agents) = "
-                      f"{n * batch * spec.num_agents} agent-steps in {el:.1f} s; oracle/mgx_oracle.c, OpenMP "
-                      f"over envs, {cores} threads"}
+    return {"value": round(n * n_env * A / el), "unit": "agent-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the first {n_env} envs of the timed workload ({wl.name}: {wl.title}) = "
+                      f"{n * n_env * A} agent-steps in {el:.1f} s; oracle/mgx_oracle.c, OpenMP over envs, {threads} thread(s), "
+                      f"no auto-reset (as the reference)"}
 
 
 def main():
@@ -261,18 +334,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=4096, help="envs per GPU (BASELINE.json configs[1]: 4096)")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c4",
+                    help="BASELINE.json configuration timed as `value` (default c4, the north-star configuration)")
+    ap.add_argument("--global-batch", type=int, default=0, help="override the configuration's batch (all GPUs together)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
-                    help="graph: the K timed steps are one hipGraph replay; eager: K Python-level env.step calls")
-    ap.add_argument("--settle-steps", type=int, default=3000,
-                    help="untimed launches on a scratch env before the timed region (clock ramp); 0 disables")
+                    help="graph: the timed steps are hipGraph replays; eager: Python-level env.step calls")
     ap.add_argument("--no-auto-reset", action="store_true", help="step finished envs on as the reference does (base.py:408-409)")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline_large / cpu_baseline legs")
-    ap.add_argument("--skip-phases", type=int, default=0,
-                    help="profiling probe: bit p set = the kernel skips phase Pp (results are then garbage)")
-    ap.add_argument("--envs-per-wavefront", type=int, default=0,
-                    help="tuning probe: override the launcher's choice of envs per wavefront (0 = automatic)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement + its roofline")
     args = ap.parse_args()
     global AUTO_RESET
     AUTO_RESET = not args.no_auto_reset
@@ -308,67 +377,59 @@ def main():
             else:
                 dist.barrier(device_ids=[local_rank])
 
-    if args.skip_phases:
-        from multigrid_amd import _lib
-        _lib.lib().mgx_debug_skip_phases(args.skip_phases)
-    if args.envs_per_wavefront:
-        from multigrid_amd import _lib
-        _lib.lib().mgx_debug_set_envs_per_wavefront(args.envs_per_wavefront)
-    spec = workload_spec()
-    B, A = args.batch, spec.num_agents
-    first_env, count = shard_range(world * B, rank, world)      # weak scaling: every rank owns `--batch` envs
-    assert count == B
-    env = make_env(spec, B, device, first_env=first_env)
-    warm = random_actions(max(args.warmup, 1), B, A, device, 1000 + rank)
-    acts = random_actions(args.steps, B, A, device, 1234 + rank)
-    for t in range(args.warmup):
-        env.step(warm[t], auto_reset=AUTO_RESET)
-    if args.settle_steps > 0:
-        # The timed region is ~10 ms; the GPU needs longer than the W warm-up steps to reach its steady clocks.  More
-        # untimed launches of the same kernel, on a scratch copy so that the measured envs' state is exactly "W steps in".
-        scratch = make_env(spec, B, device, first_env=first_env)
-        for t in range(args.settle_steps):
-            scratch.step(warm[t % warm.shape[0]], auto_reset=AUTO_RESET)
-        del scratch
-    torch.cuda.synchronize(device)
-    wall_s, ev_ms = timed_rollout(env, acts, args.mode, barrier)
-    if not args.skip_phases:
-        env.check_errors()
+    def all_max(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if one_gpu_check else device)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    t = torch.tensor([wall_s], dtype=torch.float64, device="cpu" if one_gpu_check else device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
-    total_agent_steps = world * B * A * args.steps
+    name = args.workload
+    G = args.global_batch or workloads.GLOBAL_BATCH[name]
+    first_env, B = shard_range(G, rank, world)                   # strong scaling: the named global batch over the ranks
+    wl = workloads.make(name, batch=B, first_env=first_env, global_batch=G)
+    spec, A = wl.spec, wl.spec.num_agents
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
+    m = measure_steps(env, args.steps, args.warmup, args.mode, barrier, seed=1234 + rank,
+                      agree=lambda n: int(all_max(float(n))))
+    env.check_errors()
+    wall_max = all_max(m["wall_s"])
+    S = m["timed_steps"]
+    valid = _lib.is_product_lib()
     out = {
-        "metric": "agent-steps/sec", "value": round(total_agent_steps / wall_max), "unit": "agent-steps/s",
+        "metric": "agent-steps/sec", "value": round(G * A * S / wall_max), "unit": "agent-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall_max * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(wall_max * 1e3 / S, 6), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"MultiGrid-Empty-16x16-v0 agents=4 view_size=7 batch={B} envs per GPU "
-                               f"(BASELINE.json configs[1]), uniform random actions 0..6",
-                   "batch_per_gpu": B, "global_batch": world * B, "agents": A, "grid": "16x16", "view_size": 7,
-                   "mode": args.mode, "parallelism": f"env-sharded x{world}, no collective",
+        "timed_steps": S, "timed_region_ms": round(wall_max * 1e3, 3),
+        "config": {"workload": wl.title + ", uniform random actions 0..6", "name": name,
+                   "global_batch": G, "batch_per_gpu": B, "agents": A, "grid": f"{spec.width}x{spec.height}",
+                   "view_size": spec.view_size, "mode": args.mode,
+                   "parallelism": f"env-sharded x{world} (strong scaling of the global batch), no collective",
                    "launch": env.backend.launch_info(B),
                    "auto_reset": ("fused into the step launch (mgx_step_autoreset): envs that are done restart from the "
-                                  "env class' fixed reset layout before the next step") if AUTO_RESET else False,
-                   "clock_settle": f"{args.settle_steps} untimed steps on a scratch env before the timed region"},
+                                  "layout pool before the next step") if AUTO_RESET else False,
+                   "layout_pool": int(wl.pool[0].shape[0]),
+                   "timing": f"{m['repeats']} x {m['block']}-step {'hipGraph replays' if args.mode == 'graph' else 'eager blocks'} "
+                             f"(whole multiples of --steps) after {args.warmup} warm-up steps and one calibration pass"},
     }
+    if not valid:
+        out["valid"] = False
+        out["invalid_reason"] = f"MGX_LIBMGX={_lib.LIB_PATH}: not the product library (profiling / experiment build)"
     if rank == 0:
-        ms_launch = ev_ms / args.steps
-        rf = roofline(B * A * spec.bytes_step(), ms_launch, pmc_traffic("step", B))
-        rf.update(kernel="mgx_fused_kernel<7,step>", ms_per_launch=round(ms_launch, 5),
-                  bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=B * A * spec.bytes_step(),
-                  traffic_unit="bytes per launch (rocprofv3 PMC, profiles/traffic.json)",
-                  note="working set fits the 256 MiB Infinity Cache at this batch: latency-bound, see roofline_large")
-        out["roofline"] = rf
-        if not args.no_extras and world == 1:                  # the large-batch / rollout / CPU legs: N=1 only
-            r_step, r_obs = large_batch_points(spec, device, args.large_batch)
-            out["roofline_large"] = r_step
-            out["gen_obs_large"] = r_obs
-            out["fused_rollout"] = rollout_point(spec, B, device, args.steps, first_env, 1234 + rank)
-            out["aux_kernels"] = aux_kernel_points(device)
-            out["cpu_baseline"] = cpu_baseline(spec, B)
+        out["roofline"] = step_roofline(name, spec, B, m["event_ms"] / S)
+        if B * A * spec.bytes_step() < 200e6:
+            out["roofline"]["note"] = ("working set fits the 256 MiB Infinity Cache at this batch: see roofline_large for "
+                                       "the HBM-resident regime")
+        if not args.no_extras and world == 1:                  # everything else: N=1 only
+            del env
+            torch.cuda.empty_cache()
+            out["configs"] = {c: config_point(c, device, 256, 50) for c in ("c2", "c3", "c5") if c != name}
+            out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}
+            out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)
+            out.update(large_batch_points(device, args.large_batch))
+            from oracle import binding as ob
+            out["cpu_baseline"] = cpu_baseline(wl, ob.max_threads(), 8.0, wl.batch)
+            out["cpu_baseline_1core"] = cpu_baseline(wl, 1, 6.0, 2048)
         print(json.dumps(out), flush=True)
     barrier()
     if dist is not None:

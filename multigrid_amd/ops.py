@@ -1,8 +1,14 @@
 """PyTorch-ROCm custom ops over the C ABI of libmgx.so.
 
     torch.ops.mgx.gen_obs(grid, agents, spec) -> (obs, dir)
-    torch.ops.mgx.step(grid!, agents!, rng!, step_count!, actions, target, err!, spec)
+    torch.ops.mgx.step(grid!, agents!, rng!, step_count!, actions, aux!?, err!, spec)
                                                -> (obs, dir, reward, terminated, truncated)
+    torch.ops.mgx.step_autoreset(grid!, agents!, rng!, step_count!, actions, aux!?, err!, pool_grid, pool_agents,
+                                 pool_aux?, episode!, first_env, spec)
+                                               -> (obs, dir, reward, terminated, truncated, was_reset)
+    torch.ops.mgx.rollout(grid!, agents!, rng!, step_count!, actions[T,B,A], aux!?, err!, spec)
+                                               -> (obs[T,...], dir, reward, terminated, truncated)
+    torch.ops.mgx.one_hot(cells, dim_sizes) -> one_hot        torch.ops.mgx.full_obs(grid, agents, spec) -> full
 
 `spec` is the 11-int list of `struct MgxSpec` (include/mgx.h).  Only the CUDA (= HIP on ROCm) dispatch key is
 registered: calling the ops with CPU tensors raises NotImplementedError from the dispatcher -- there is no
@@ -84,23 +90,80 @@ def _gen_obs_impl(grid, agents, spec):
     return obs, dirs
 
 
-def _step_impl(grid, agents, rng, step_count, actions, target, err, spec):
+def _step_impl(grid, agents, rng, step_count, actions, aux, err, spec):
     sc = _spec_from_ints(spec)
+    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err)
+    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, grid.device)
+    _step_into(sc, B, grid, agents, rng, step_count, actions, aux, err, obs, dirs, reward, terminated, truncated)
+    return obs, dirs, reward, terminated, truncated
+
+
+def _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err, T=None):
     B = _check_state(sc, grid, agents)
-    A, v = sc.num_agents, sc.view_size
+    A = sc.num_agents
     _want(rng, "rng", torch.int64, (B, 4))
     _want(step_count, "step_count", torch.int32, (B,))
-    _want(actions, "actions", torch.int8, (B, A))
+    _want(actions, "actions", torch.int8, (B, A) if T is None else (T, B, A))
     _want(err, "err", torch.int32, (2,))
-    if target is not None:
-        _want(target, "aux", torch.uint8, (B, 16))
+    if aux is not None:
+        _want(aux, "aux", torch.uint8, (B, 16))
+    elif sc.env_kind != 0:
+        raise ValueError("mgx: this env kind needs `aux` (the env subclass' hook state, include/mgx.h)")
+    return B
+
+
+def _alloc_outputs(sc, B, dev, T=None):
+    A, v = sc.num_agents, sc.view_size
+    lead = (B,) if T is None else (T, B)
+    return (torch.empty(lead + (A, v, v, 3), dtype=torch.uint8, device=dev),
+            torch.empty(lead + (A,), dtype=torch.uint8, device=dev),
+            torch.empty(lead + (A,), dtype=torch.float64, device=dev),
+            torch.empty(lead + (A,), dtype=torch.uint8, device=dev),
+            torch.empty(lead, dtype=torch.uint8, device=dev))
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _step_autoreset_impl(grid, agents, rng, step_count, actions, aux, err, pool_grid, pool_agents, pool_aux, episode,
+                         first_env, spec):
+    sc = _spec_from_ints(spec)
+    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err)
+    K = pool_grid.shape[0]
+    _want(pool_grid, "pool_grid", torch.uint8, (K, sc.height, sc.width, 3))
+    _want(pool_agents, "pool_agents", torch.uint8, (K, sc.num_agents, 8))
+    if pool_aux is not None:
+        _want(pool_aux, "pool_aux", torch.uint8, (K, 16))
+    _want(episode, "episode", torch.int32, (B,))
     dev = grid.device
-    obs = torch.empty((B, A, v, v, 3), dtype=torch.uint8, device=dev)
-    dirs = torch.empty((B, A), dtype=torch.uint8, device=dev)
-    reward = torch.empty((B, A), dtype=torch.float64, device=dev)
-    terminated = torch.empty((B, A), dtype=torch.uint8, device=dev)
-    truncated = torch.empty((B,), dtype=torch.uint8, device=dev)
-    _step_into(sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated)
+    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, dev)
+    was_reset = torch.empty((B,), dtype=torch.uint8, device=dev)
+    ar = _lib.MgxAutoReset(int(first_env), K, pool_grid.data_ptr(), pool_agents.data_ptr(), _ptr(pool_aux),
+                           episode.data_ptr(), was_reset.data_ptr())
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mgx_step_autoreset(
+            C.byref(sc), B, C.byref(ar), grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
+            actions.data_ptr(), _ptr(aux), obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(),
+            truncated.data_ptr(), err.data_ptr(), _stream(dev))
+    _lib.check(rc, "mgx_step_autoreset")
+    return obs, dirs, reward, terminated, truncated, was_reset
+
+
+def _rollout_impl(grid, agents, rng, step_count, actions, aux, err, spec):
+    sc = _spec_from_ints(spec)
+    if actions.dim() != 3:
+        raise ValueError("mgx: rollout expects actions[T, B, A]")
+    T = actions.shape[0]
+    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err, T=T)
+    dev = grid.device
+    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, dev, T=T)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mgx_rollout(
+            C.byref(sc), B, T, grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
+            actions.data_ptr(), _ptr(aux), obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(),
+            truncated.data_ptr(), err.data_ptr(), _stream(dev))
+    _lib.check(rc, "mgx_rollout")
     return obs, dirs, reward, terminated, truncated
 
 
@@ -143,12 +206,21 @@ _torch_lib.define("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, T
 _torch_lib.define(
     "step(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
     "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_torch_lib.define(
+    "step_autoreset(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+    "Tensor(f!)? aux, Tensor(e!) err, Tensor pool_grid, Tensor pool_agents, Tensor? pool_aux, Tensor(g!) episode, "
+    "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
+_torch_lib.define(
+    "rollout(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+    "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 _torch_lib.define("one_hot(Tensor cells, int[] dim_sizes) -> Tensor")
 _torch_lib.define("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor")
 _torch_lib.impl("one_hot", _one_hot_impl, "CUDA")
 _torch_lib.impl("full_obs", _full_obs_impl, "CUDA")
 _torch_lib.impl("gen_obs", _gen_obs_impl, "CUDA")
 _torch_lib.impl("step", _step_impl, "CUDA")
+_torch_lib.impl("step_autoreset", _step_autoreset_impl, "CUDA")
+_torch_lib.impl("rollout", _rollout_impl, "CUDA")
 
 
 class HipBackend:

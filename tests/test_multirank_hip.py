@@ -1,0 +1,55 @@
+"""The multi-rank path on the REAL kernels: two `torch.distributed.run` ranks each step their shard of C4 (65536 envs,
+strong-scaled: 32768 per rank) on the HIP backend; concat(shards) must equal one process stepping the whole batch.  The
+single-GPU test box has one device, so both ranks use device 0 (MGX_BENCH_ONE_GPU=1, gloo for the rendezvous) -- the code
+path is the one bench.py --gpus N runs, minus RCCL's barrier.  Also: bench.py itself under 2 ranks prints its line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _torchrun(args, extra_env=None, timeout=900):
+    env = dict(os.environ, MGX_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("name,G,T", [("c4", 65536, 12), ("c3", 16384, 12), ("c5", 2048, 6)])
+def test_two_hip_ranks_equal_single_process(tmp_path, name, G, T):
+    out = _torchrun([os.path.join(ROOT, "tests", "shard_worker.py"), name, str(G), str(T), str(tmp_path)])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests.shard_worker import run_shard
+    whole = run_shard(name, G, T, 0, G, torch.device("cuda", 0))
+    shards = [np.load(os.path.join(tmp_path, f"shard{r}.npz")) for r in range(2)]
+    assert int(shards[0]["first"]) == 0 and int(shards[1]["first"]) == int(shards[0]["count"])
+    assert int(shards[0]["count"]) + int(shards[1]["count"]) == G
+    for k, v in whole.items():
+        cat = np.concatenate([s[k] for s in shards])
+        assert cat.tobytes() == v.tobytes(), k
+
+
+def test_bench_under_two_ranks_prints_strong_scaling_line():
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 32768
+    assert "roofline" in d and "configs" not in d and "cpu_baseline" not in d      # extras are N=1 only

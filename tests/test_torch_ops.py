@@ -1,0 +1,114 @@
+"""The torch.ops.mgx.* surface (SURVEY.md section 8b "must export"): every op called through the dispatcher on HIP
+tensors and compared with the oracle, including the in-place schema arguments; CPU tensors are refused."""
+import numpy as np
+import pytest
+import torch
+
+import multigrid_amd.ops as ops
+from multigrid_amd import EnvSpec, workloads
+from oracle import binding as ob
+from tests import util
+from tests.test_full_size import oracle_reset_done
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dev_state(st, spec):
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in st.items() if v is not None}
+    t["rng"] = torch.from_numpy(st["rng"].view(np.int64)).to(DEV)
+    t["err"] = torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32, device=DEV)
+    return t
+
+
+@pytest.mark.parametrize("kind", ["empty", "blockedunlockpickup"])
+def test_step_op_vs_oracle_in_place_args(kind):
+    spec = (EnvSpec(16, 16, 4, 7, max_steps=1024) if kind == "empty"
+            else EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind=kind))
+    B, ints = 777, None
+    st = util.random_state(spec, B, seed=31)
+    st = dict(grid=st["grid"], agents=st["agents"], rng=st["rng"], step_count=st["step_count"],
+              aux=st["target"] if kind != "empty" else None)
+    ref = {k: (v.copy() if v is not None else None) for k, v in st.items()}
+    d = _dev_state(st, spec)
+    ints = ops.spec_to_ints(spec)
+    for t in range(12):
+        act = util.random_actions(B, spec.num_agents, seed=70 + t)
+        want = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["aux"], nthreads=8)
+        got = torch.ops.mgx.step(d["grid"], d["agents"], d["rng"], d["step_count"], torch.from_numpy(act).to(DEV),
+                                 d.get("aux"), d["err"], ints)
+        assert len(got) == 5
+        for g, w in zip(got, want):
+            assert g.cpu().numpy().tobytes() == w.tobytes(), f"step {t}"
+        # the (a!)..(d!) arguments were updated in place
+        assert d["grid"].cpu().numpy().tobytes() == ref["grid"].tobytes()
+        assert d["agents"].cpu().numpy().tobytes() == ref["agents"].tobytes()
+        np.testing.assert_array_equal(d["rng"].cpu().numpy().view(np.uint64), ref["rng"])
+        np.testing.assert_array_equal(d["step_count"].cpu().numpy(), ref["step_count"])
+    assert d["err"].cpu().tolist() == [0, 2 ** 31 - 1]
+    bad = torch.full((B, spec.num_agents), 9, dtype=torch.int8, device=DEV)
+    torch.ops.mgx.step(d["grid"], d["agents"], d["rng"], d["step_count"], bad, d.get("aux"), d["err"], ints)
+    assert int(d["err"][0]) > 0                                     # (e!): unknown actions are counted (base.py:473-474)
+
+
+def test_step_op_refuses_cpu_tensors_and_bad_shapes():
+    spec = EnvSpec(8, 8, 2, 7, max_steps=64)
+    st = util.random_state(spec, 8, seed=1)
+    c = dict(grid=torch.from_numpy(st["grid"]), agents=torch.from_numpy(st["agents"]),
+             rng=torch.from_numpy(st["rng"].view(np.int64)), sc=torch.from_numpy(st["step_count"]),
+             act=torch.zeros((8, 2), dtype=torch.int8), err=torch.zeros(2, dtype=torch.int32))
+    ints = ops.spec_to_ints(spec)
+    with pytest.raises(NotImplementedError):                         # no CPU dispatch key: there is no CPU product path
+        torch.ops.mgx.step(c["grid"], c["agents"], c["rng"], c["sc"], c["act"], None, c["err"], ints)
+    g = {k: v.to(DEV) for k, v in c.items()}
+    with pytest.raises((ValueError, RuntimeError)):
+        torch.ops.mgx.step(g["grid"], g["agents"], g["rng"], g["sc"], g["act"][:, :1].contiguous(), None, g["err"], ints)
+    with pytest.raises((TypeError, RuntimeError)):
+        torch.ops.mgx.step(g["grid"], g["agents"], g["rng"], g["sc"], g["act"].to(torch.int32), None, g["err"], ints)
+
+
+def test_step_autoreset_op_vs_oracle():
+    wl = workloads.make("c3", batch=2000)
+    wl.agents[::2, 0, 1:4] = wl.agents[::2, 0, 1:4]                  # (layout pool starts as they are)
+    spec, B, A = wl.spec, wl.batch, wl.spec.num_agents
+    ref = dict(grid=wl.grid.copy(), agents=wl.agents.copy(), rng=wl.rng.copy(), step_count=np.zeros(B, np.int32), aux=wl.aux.copy())
+    # make restarts happen: half the envs are one step from truncation
+    ref["step_count"][::2] = spec.max_steps - 2
+    d = _dev_state(ref, spec)
+    pool = [torch.from_numpy(p).to(DEV) for p in wl.pool]
+    episode_ref = np.zeros(B, np.int32)
+    episode = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ints = ops.spec_to_ints(spec)
+    resets = 0
+    for t in range(8):
+        act = util.random_actions(B, A, seed=t, p_missing=0.0)
+        was_ref = oracle_reset_done(wl, ref, episode_ref)
+        want = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["aux"], nthreads=8)
+        got = torch.ops.mgx.step_autoreset(d["grid"], d["agents"], d["rng"], d["step_count"], torch.from_numpy(act).to(DEV),
+                                           d["aux"], d["err"], pool[0], pool[1], pool[2], episode, wl.first_env, ints)
+        assert len(got) == 6
+        for g, w in zip(got[:5], want):
+            assert g.cpu().numpy().tobytes() == w.tobytes(), f"step {t}"
+        np.testing.assert_array_equal(got[5].cpu().numpy(), was_ref)
+        np.testing.assert_array_equal(episode.cpu().numpy(), episode_ref)
+        assert d["grid"].cpu().numpy().tobytes() == ref["grid"].tobytes()
+        np.testing.assert_array_equal(d["aux"].cpu().numpy(), ref["aux"])
+        resets += int(was_ref.sum())
+    assert resets >= B // 2
+
+
+def test_rollout_op_equals_step_op():
+    spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
+    B, T = 1000, 10
+    st = util.random_state(spec, B, seed=8)
+    st = dict(grid=st["grid"], agents=st["agents"], rng=st["rng"], step_count=st["step_count"], aux=None)
+    a, b = _dev_state(st, spec), _dev_state(st, spec)
+    acts = torch.from_numpy(np.stack([util.random_actions(B, 4, seed=t) for t in range(T)])).to(DEV)
+    ints = ops.spec_to_ints(spec)
+    out = torch.ops.mgx.rollout(a["grid"], a["agents"], a["rng"], a["step_count"], acts, None, a["err"], ints)
+    for t in range(T):
+        got = torch.ops.mgx.step(b["grid"], b["agents"], b["rng"], b["step_count"], acts[t], None, b["err"], ints)
+        for x, y in zip(out, got):
+            assert torch.equal(x[t], y), f"step {t}"
+    for k in ("grid", "agents", "rng", "step_count"):
+        assert torch.equal(a[k], b[k]), k
