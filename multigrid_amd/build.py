@@ -22,8 +22,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRCS = [os.path.join(HERE, "csrc", "mgx_kernels.hip"), os.path.join(HERE, "csrc", "mgx_aux.hip")]
-DEPS = SRCS + [os.path.join(HERE, "csrc", "mgx_rules.h"), os.path.join(ROOT, "include", "mgx.h")]
+CSRC = os.path.join(HERE, "csrc")
+VIEWS = (3, 5, 7, 9, 11, 13, 15)
+#: translation units: (object name, source, extra defines).  The fused kernel is instantiated in one unit per view size so
+#: that the units compile in parallel (a single unit took a minute).
+UNITS = ([("mgx_kernels", os.path.join(CSRC, "mgx_kernels.hip"), ()), ("mgx_aux", os.path.join(CSRC, "mgx_aux.hip"), ())]
+         + [(f"mgx_fused_v{v}", os.path.join(CSRC, "mgx_fused_inst.hip"), (f"MGX_INST_V={v}",)) for v in VIEWS])
+SRCS = sorted({u[1] for u in UNITS})
+DEPS = SRCS + [os.path.join(CSRC, "mgx_fused.h"), os.path.join(CSRC, "mgx_rules.h"), os.path.join(ROOT, "include", "mgx.h")]
 LIB = os.path.join(HERE, "lib", "libmgx.so")
 LIB_DBG = os.path.join(HERE, "lib", "libmgx_dbg.so")
 ARCH = "gfx950"
@@ -37,7 +43,7 @@ def hipcc() -> str:
 
 
 def flags(defines=()) -> list[str]:
-    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
             *[f"-D{d}" for d in defines]]
 
 
@@ -65,7 +71,23 @@ def build_lib(force: bool = False, verbose: bool = False, lib: str = LIB, define
     if not force and not stale(lib, defines):
         return lib
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    cmd = [hipcc(), *flags(defines), f"-I{os.path.join(ROOT, 'include')}", *SRCS, "-o", lib + ".tmp"]
+    objdir = os.path.join(ROOT, "build", os.path.basename(lib) + ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    cc, inc = hipcc(), f"-I{os.path.join(ROOT, 'include')}"
+
+    def compile_unit(unit):
+        name, src, extra = unit
+        obj = os.path.join(objdir, name + ".o")
+        cmd = [cc, *flags(tuple(defines) + tuple(extra)), inc, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_unit, UNITS))
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -1,0 +1,991 @@
+// mgx_fused.h -- the fused gfx950 (MI355X, CDNA4, wave64) kernel behind the C ABI of libmgx.so (include/mgx.h).
+// Included by mgx_fused_inst.hip (one translation unit per view size: the instantiations compile in parallel) and by
+// mgx_kernels.hip (the C ABI: argument checks, launch geometry, dispatch to the view size's translation unit).
+//
+// One fused kernel does a whole MultiGridEnv.step for the batch.  Every WAVEFRONT is autonomous: it owns Gw consecutive
+// envs (<= 32 agent views, "slots") and a private LDS slice and runs all phases for them without a workgroup barrier:
+//
+//   P0   buffer_load_dwordx4 of the wave's (Gw,H,W,3) uint8 grid bytes, packed agent rows, actions, PCG64 words and
+//        step counts; one s_waitcnt; LDS stores
+//   P1a  lane = (env, agent): that agent's PCG64 draw by jump-ahead                            (multigrid/base.py:396-399)
+//   P1s  lane = (env, agent): order-free evaluation of every action against the pre-step state, committed when the
+//        env's agents cannot have influenced each other; otherwise P1b (rank argsort of the draws) + P1c (lane = env:
+//        the reference's sequential handle_actions loop on the LDS tile)                       (base.py:378-476)
+//        then the agent overlay offsets, the env subclass' post-step hook, step_count / truncated
+//   P1d  lane = view: view geometry record, in-bounds lane mask, stores of agent rows / reward / terminated / dir
+//   P2   lane = view CELL, slots in straight-line blocks of 16: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
+//        see-behind ballot -> 64-bit row mask deposited in lane s; cells stay in registers  (multigrid/utils/obs.py:130-233)
+//   P3   lane = view: bit-parallel line-of-sight flood on the ballot masks (closed form of the sequential sweeps,
+//        obs.py:235-273); own cell := carried object (obs.py:207)
+//   P4   lane = cell: cells whose visibility bit is clear become UNSEEN (obs.py:95-100); 3 bytes each into the obs
+//        byte layout in LDS (the rotate/transpose)
+//   P5   ds_read_b128 -> buffer_store_dwordx4 of the (Gw,A,v,v,3) observation bytes
+//
+// Pure integer / byte work: no MFMA.  The roof is HBM bytes; what the kernel is actually bound by is the number of
+// VALU instructions per view, so the rules of the house are: every HBM byte touched once, 16-byte
+// loads and stores through buffer resources (no per-lane predicates, no 64-bit VALU addressing), per-view data to the
+// cell lanes as LDS broadcasts or SGPR masks, and as few VALU instructions per slot as possible.  Workgroups touch
+// disjoint memory, so the blockIdx -> XCD mapping needs no swizzle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "mgx_rules.h"
+
+namespace mgx_fused {
+
+using namespace mgx;
+
+constexpr int kMaxThreads = 256;
+
+struct KernelArgs {
+    MgxSpec sp;
+    int64_t batch;
+    uint8_t *grid;
+    uint8_t *agents;
+    uint64_t *rng;
+    int32_t *step_count;
+    const int8_t *actions;
+    uint8_t *aux;
+    uint8_t *obs;
+    uint8_t *dir;
+    double *reward;
+    uint8_t *terminated;
+    uint8_t *truncated;
+    int32_t *err;
+    int32_t Gw;         // envs per wavefront
+    int32_t dbg;        // debug: bit p set = skip phase p (profiling only, mgx_debug_skip_phases)
+    int32_t T;          // steps per launch (mgx_rollout), 1 otherwise
+    // per-wavefront LDS slice: its stride and the slot count its carve is derived from (LdsCarve below)
+    int32_t wave_lds;
+    int32_t vpw;
+    int32_t inv_A;      // ceil(2^16 / A): (lane * inv_A) >> 16 == lane / A for lane < 64
+    // fused auto-reset (mgx_step_autoreset / mgx_rollout_autoreset; include/mgx.h: MgxAutoReset)
+    int32_t pool_size;
+    int64_t first_env;
+    const uint8_t *pool_grid;
+    const uint8_t *pool_agents;
+    const uint8_t *pool_aux;
+    int32_t *episode;
+    uint8_t *was_reset;
+};
+
+// gfx950's LDS does take a dword / short access at any byte address (hipcc emits one ds_read_b32 for an align-1 load),
+// but measured it is far slower than the aligned pair + v_alignbyte: 1M envs, fused step 371 us aligned, 581 us with
+// unaligned reads in P2, 602 us with unaligned 16-bit writes in P4, 882 us with both.  Kept for the record only.
+#ifndef MGX_UA_READ
+#define MGX_UA_READ 0
+#endif
+#ifndef MGX_UA_WRITE
+#define MGX_UA_WRITE 0
+#endif
+#ifndef MGX_LATE_ARGS
+#define MGX_LATE_ARGS 1
+#endif
+#ifndef MGX_BUF_STORE
+#define MGX_BUF_STORE 1
+#endif
+// -DMGX_DEBUG_KNOBS=1 (the tools' build, `python -m multigrid_amd.build --debug-knobs` -> lib/libmgx_dbg.so): phase
+// skipping and launch-geometry overrides for profiling.  The product library has neither the exports nor the branches.
+#ifndef MGX_DEBUG_KNOBS
+#define MGX_DEBUG_KNOBS 0
+#endif
+#if MGX_DEBUG_KNOBS
+#define MGX_DBG(bits) (a.dbg & (bits))
+#else
+#define MGX_DBG(bits) 0
+#endif
+
+// A kernel argument fetched where it is used (s_load from the kernarg segment) instead of living in SGPRs from the
+// kernel's first instruction on: the fused kernel is short of SGPRs, and every spilled one costs VALU
+// v_writelane / v_readlane instructions on a VALU-bound kernel.  Only for the fields used late and rarely.
+template <typename T>
+__device__ __forceinline__ T kernarg_at(size_t offset) {
+    typedef const char __attribute__((address_space(4))) *cptr;
+    typedef const T __attribute__((address_space(4))) *tptr;
+    return *(tptr)((cptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+#if MGX_LATE_ARGS
+#define MGX_LATE(field) kernarg_at<decltype(KernelArgs::field)>(offsetof(KernelArgs, field))
+#else
+#define MGX_LATE(field) (a.field)
+#endif
+
+// per-view record written by P1d and read (broadcast) by the wavefront in P2
+struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
+
+typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef const u32_unaligned __attribute__((address_space(3))) *lds_u32_ua_ptr;
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+
+#ifndef MGX_SLOTS_SMALL_VIEW
+#define MGX_SLOTS_SMALL_VIEW 32
+#endif
+constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
+// cache policy bits of the obs stores (raw buffer store `aux`: 1 = sc0, 2 = nt, 16 = sc1 on gfx94x/gfx950)
+#ifndef MGX_OBS_AUX
+#define MGX_OBS_AUX 0
+#endif
+#ifndef MGX_ROUND
+#define MGX_ROUND 16
+#endif
+constexpr int kRound = MGX_ROUND;        // view slots whose obs bytes are staged in LDS at a time (P4/P5)
+
+// View slots per wavefront = cell registers per lane (x passes per view).
+inline int slots_per_wave(int view_size) { return view_size <= 7 ? kSlotsSmallView : 32; }
+
+// Carve of ONE wavefront's LDS slice (byte offsets, all multiples of 16).  Everything is a closed form of
+// (vpw, nw, Gw, A, tile bytes, round bytes) so the kernel recomputes an offset where it needs it instead of carrying
+// fifteen of them in SGPRs from the kernel arguments.  Per-slot arrays first (vpw = slots in use, a multiple of 16).
+struct LdsCarve {
+    int vpw, nw, Gw, A, tile_bytes, round_bytes;
+    bool roll;      // mgx_rollout: tile and PCG64 state live across steps (no aliasing of the tile, rng kept in LDS)
+    bool has_aux;   // env kinds with hook state
+    __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
+    // -- per-step temporaries, all dead once P2 has gathered the cells --
+    __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]  (P1d -> P2)
+    __host__ __device__ int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
+    __host__ __device__ int rew() const { return 24 * vpw; }                         // f64  [vpw]
+    __host__ __device__ int woff() const { return 32 * vpw; }                        // i32  [vpw]     (P1s)
+    __host__ __device__ int temps_end() const { return woff() + 4 * vpw; }
+    // -- state that lives across phases / steps --
+    __host__ __device__ int act() const { return temps_end(); }                      // i8   [vpw]
+    __host__ __device__ int ord() const { return act() + vpw; }                      // u8   [vpw]
+    __host__ __device__ int rng() const { return ord() + vpw; }                      // u64  [Gw][4]   (rollout only)
+    __host__ __device__ int scnt() const { return rng() + (roll ? 32 * Gw : 0); }    // i32  [Gw]
+    __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
+    __host__ __device__ int own_jump() const { return aux() + (has_aux ? 16 * Gw : 0); }
+    __host__ __device__ int jump() const { return own_jump(); }                      // u64  [A][4]: k = 1..A   (rollout only: the
+    __host__ __device__ int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one-step kernels keep them in registers)
+                                                                                     // wall: one WALL cell + the dword after it
+    // P4/P5 staging of one round's obs bytes (skew + pad).  One-step kernels put it over the tile, which is dead once
+    // P2 has gathered the cells; the rollout keeps the tile and uses the (equally dead) temporaries' space + its own.
+    __host__ __device__ int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
+    __host__ __device__ int own_out() const { return wall() + 16; }
+    __host__ __device__ int tile() const { return roll ? own_out() + out_bytes() : own_out(); }   // grid bytes, skew + over-read
+    __host__ __device__ int out() const { return roll ? own_out() : tile(); }
+    __host__ __device__ int total() const {
+        const int t = tile_bytes + 32 > out_bytes() || roll ? tile_bytes + 32 : out_bytes();
+        return (tile() + t + 15) & ~15;
+    }
+};
+
+__host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux) {
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * 3, kRound * V * V * 3, roll, has_aux};
+}
+
+inline int slots_in_use(const MgxSpec &sp, int Gw) {
+    int vpw = (Gw * sp.num_agents + 15) & ~15;     // (the kernel is compiled for slots_per_wave(V) slots)
+    return vpw > slots_per_wave(sp.view_size) ? slots_per_wave(sp.view_size) : vpw;
+}
+
+inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false) {
+    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw), roll,
+                      sp.env_kind != MGX_KIND_EMPTY).total();
+}
+
+constexpr int kLdsPerCU = 160 * 1024;
+#ifndef MGX_LDS_WAVE_BUDGET
+#define MGX_LDS_WAVE_BUDGET (12 * 1024)
+#endif
+constexpr int kLdsWaveBudget = MGX_LDS_WAVE_BUDGET;     // keeps >= 12 wavefronts per CU resident
+
+// Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
+// to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
+inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false) {
+    int Gw = slots_per_wave(sp.view_size) / sp.num_agents;
+    if (Gw < 1) Gw = 1;
+    while (Gw > 1 && wave_lds_bytes(sp, Gw, roll) > kLdsWaveBudget) --Gw;
+    while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
+    while (Gw > 1 && (batch + Gw - 1) / Gw < 512) Gw = (Gw + 1) / 2;       // tiny batches: spread over the chip
+    return Gw;
+}
+
+static __device__ const JumpTable kJump{};
+
+// -DMGX_MARKERS=1 (tools/isa_phase_count.py): comment lines in the assembly that delimit the phases
+// -DMGX_TIMESTAMPS=1 (tools/stamp_probe.py): wavefront `g_stamp_wave` records the shader clock at every marker
+#if MGX_MARKERS
+#define MGX_MARK(name) asm volatile("; MGX_MARK " name ::: "memory")
+#elif MGX_TIMESTAMPS
+static __device__ unsigned long long g_stamps[64];
+static __device__ unsigned long long g_span[2 * 16384];      // [wave][begin, end] in s_memrealtime ticks (100 MHz), first 16384 waves
+static __device__ long long g_stamp_wave = 0;
+#define MGX_MARK(name)                                                                                   \
+    do {                                                                                                 \
+        if (wid == g_stamp_wave && lane == 0 && stamp_i < 64) g_stamps[stamp_i] = __builtin_readcyclecounter(); \
+        ++stamp_i;                                                                                       \
+    } while (0)
+#else
+#define MGX_MARK(name) ((void)0)
+#endif
+
+// LDS traffic between lanes of ONE wavefront needs no s_barrier (the LDS executes a wave's operations in order);
+// this only stops the compiler from moving LDS accesses across the phase boundary.
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// a*b + c on the full-rate 24-bit multiplier (hipcc turns the C expression into quarter-rate v_mul_lo_u32 /
+// v_mad_u64_u32 here)
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// lane `s` of `old` := the wave-uniform value `sval` (v_writelane_b32; clang has no builtin for it)
+#ifndef MGX_ASM_WRITELANE
+#define MGX_ASM_WRITELANE 1
+#endif
+__device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t sval, const int s) {
+#if MGX_ASM_WRITELANE
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(s));
+    return old;
+#else
+    return __builtin_amdgcn_inverse_ballot_w64(1ull << s) ? sval : old;
+#endif
+}
+
+// Raw buffer resource over `bytes` bytes at `base` (wave-uniform).  Lanes whose offset falls outside read zeros and
+// their stores are dropped, so the bulk copies need neither per-lane predicates nor 64-bit VALU address arithmetic.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+
+// lanes whose cell has state byte (bits 16..23) == 0, in one VALU instruction (hipcc does the type compares with an
+// SDWA byte select but spends an extra v_and_b32 on this one)
+__device__ __forceinline__ uint64_t state_is_open(uint32_t c) {
+    uint64_t m;
+    asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD" : "=s"(m) : "v"(c), "v"(0u));
+    return m;
+}
+
+template <int V, int NIT>
+struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V + i
+    int la[NIT], fw[NIT], q3[NIT];
+    bool act[NIT], own[NIT];
+};
+
+// ---- P2 for slots [S0, S0+N): one lane per cell: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall
+// (obs.py:182-202); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.  The agent's own cell still
+// shows the grid here; lane s patches the carried object in afterwards (P3: its see-behind bit, P4: its bytes).
+// Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
+template <int V, int NW, int S0, int N, int VPW>
+__device__ __forceinline__ void gather_group(const uint32_t wall_addr, const ViewRec *rec,
+                                             const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
+                                             const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
+                                             uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+    constexpr int V2 = V * V;
+    ViewRec r[N];
+    uint64_t inbm[N][NW];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        r[n] = rec[S0 + n];                                                  // broadcast reads
+#pragma unroll
+        for (int it = 0; it < NW; ++it)                                      // lane S0+n made this slot's mask in P1d
+            inbm[n][it] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbHi[it], S0 + n) << 32)
+                        | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbLo[it], S0 + n);
+    }
+    uint32_t raw[N][NW];
+#if !MGX_UA_READ
+    uint32_t lo[N][NW], hi[N][NW], sh[N][NW];
+#endif
+    bool inb[N][NW];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            inb[n][it] = __builtin_amdgcn_inverse_ballot_w64(inbm[n][it]);
+            // world cell seen at image[i][j]: pos + fw*forward + la*right; lanes looking outside the grid read the
+            // wavefront's WALL cell instead (obs.py:199-202)
+            const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
+            const uint32_t addr = inb[n][it] ? (uint32_t)off : wall_addr;
+#if MGX_UA_READ
+            raw[n][it] = *(lds_u32_ua_ptr)(uintptr_t)addr;                  // one unaligned ds_read_b32: cell + a junk byte
+#else
+            const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(addr & ~3u);     // LDS byte address -> its dword pair
+            lo[n][it] = p[0]; hi[n][it] = p[1]; sh[n][it] = addr;           // v_alignbyte_b32 only looks at bits [1:0]
+                                                                            // (probed on gfx950: tools/hwprobe/alignbyte.hip)
+#endif
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            constexpr uint64_t kAll = ~0ull;
+            const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
+#if !MGX_UA_READ
+            raw[n][it] = __builtin_amdgcn_alignbyte(hi[n][it], lo[n][it], sh[n][it]);
+#endif
+            const uint32_t c = raw[n][it];                                  // (byte 3 is junk from here on)
+            cell[S0 + n][it] = c;
+            const uint32_t t = c & 0xffu;                                   // obs.py:46-63 see_behind, as lane masks
+            const uint64_t m = __builtin_amdgcn_ballot_w64(t != (uint32_t)T_WALL)
+                             & (__builtin_amdgcn_ballot_w64(t != (uint32_t)T_DOOR) | state_is_open(c)) & act_mask;
+            sbLo[it] = set_lane(sbLo[it], (uint32_t)m, S0 + n);
+            sbHi[it] = set_lane(sbHi[it], (uint32_t)(m >> 32), S0 + n);
+        }
+    }
+}
+
+#ifndef MGX_GROUP
+#define MGX_GROUP 16
+#endif
+constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as one straight-line block
+
+template <int V, int NW, int VPW, int S0 = 0>
+__device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, const ViewRec *rec,
+                                           const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
+                                           const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
+                                           uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+    if constexpr (S0 < VPW) {
+        // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
+        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW>(wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, S0 + kGroup>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+    }
+}
+
+// Every wavefront is autonomous: it owns Gw consecutive envs (<= VPW agent views) and a private LDS slice, and
+// runs all phases for them without any workgroup barrier.  A workgroup is just a bundle of such wavefronts.
+// MODE 0: gen_obs only.  MODE 1: one step.  MODE 2: a.T consecutive steps with the envs' state kept in LDS between
+// steps (mgx_rollout); per-step outputs go to the [t] slices of the output tensors, the state is written back once.
+// HOOKS: the env kind has a post-step hook and 16 bytes of hook state (every kind but EMPTY).  The EMPTY instantiation
+// drops that code and its SGPRs.
+// AR: fused auto-reset -- an env whose episode ended with the previous step restarts from the layout pool before this
+// step's actions are applied (== mgx_reset_done followed by the step, in one launch).
+template <int V, int MODE, bool HOOKS, bool AR>
+__global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
+    constexpr bool DO_STEP = MODE != 0;
+    const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
+    constexpr bool ROLL = MODE == 2;
+    constexpr int V2 = V * V;
+    constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
+    constexpr int VPW = V <= 7 ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave)
+    extern __shared__ __align__(16) uint8_t lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents;
+    const int HW3 = H * W * 3;
+    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const int64_t e0 = wid * a.Gw;
+    if (e0 >= a.batch) return;
+    const int Gc = (int)min((int64_t)a.Gw, a.batch - e0);    // envs of this wavefront
+    const int NVc = Gc * A;                                   // its views (<= VPW)
+    const int64_t v0 = e0 * A;                                // first (env, agent) row
+
+    uint8_t *L = lds + wave * a.wave_lds;
+#if MGX_TIMESTAMPS
+    int stamp_i = 0;
+    MGX_MARK("start");
+    if (lane == 0 && wid < 16384) g_span[2 * wid] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, HOOKS);
+    uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
+    ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
+    int8_t *acts = reinterpret_cast<int8_t *>(L + cv.act());                  // [slot]
+    uint64_t *rngs = reinterpret_cast<uint64_t *>(L + cv.rng());              // [env][4]
+    uint64_t *rnd = reinterpret_cast<uint64_t *>(L + cv.rnd());               // [slot] 53-bit draws
+    uint8_t *ord = L + cv.ord();                                               // [slot] visiting order per env
+    double *rew = reinterpret_cast<double *>(L + cv.rew());                   // [slot]
+    int32_t *scnt = reinterpret_cast<int32_t *>(L + cv.scnt());               // [env]
+    uint4 *auxl = reinterpret_cast<uint4 *>(L + cv.aux());                    // [env] 16-byte hook state (include/mgx.h)
+    uint64_t *jump = reinterpret_cast<uint64_t *>(L + cv.jump());             // [A+1][4]
+
+    MGX_MARK("P0");
+    // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
+    const int64_t g0 = e0 * HW3, g1 = g0 + (int64_t)Gc * HW3;       // byte range of these envs in `grid`
+    const int64_t gtotal = a.batch * (int64_t)HW3;
+    const int64_t ga = g0 & ~(int64_t)15;
+    uint8_t *tile_raw = L + cv.tile();                              // holds global bytes [ga, ...)
+    const int tile_skew = (int)(g0 - ga);
+    uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HW3
+    // Every HBM load of the wavefront is issued here, back to back, into registers; then ONE unconditional
+    // s_waitcnt vmcnt(0); then the LDS stores.  (Waiting under the same lane predicates as the loads makes hipcc's
+    // waitcnt pass believe loads may still be pending and sprinkle vmcnt(0) -- which on CDNA also waits for every
+    // older global STORE -- over the rest of the kernel.)
+    constexpr int U = 8;                                                    // 8 KiB of tile per pass
+    const uint8_t *gsrc = a.grid + ga;
+    const int len = (int)(g1 - ga);
+    const int avail = (int)min(gtotal - ga, (int64_t)INT_MAX);               // bytes readable from gsrc
+    const int grec = MGX_DBG(1) ? 0 : min((len + 15) & ~15, avail);
+    const __amdgpu_buffer_rsrc_t grsrc = make_rsrc(gsrc, grec);
+    const int lane16 = 16 * lane;
+    const int env_of_lane = (lane * a.inv_A) >> 16, agent_of_lane = lane - env_of_lane * A;   // slot `lane` = (env, agent)
+    // (1) what the draws (P1a) need goes out first: this lane's env's PCG64 words and its agent's jump-ahead constants
+    u32x4 in_rngA = {0, 0, 0, 0}, in_rngB = {0, 0, 0, 0};                    // (ROLL: two envs' halves, copied to LDS)
+    u32x4 in_jmpA = {0, 0, 0, 0}, in_jmpB = {0, 0, 0, 0};
+    if (DO_STEP && A > 1) {
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.rng + e0 * 4, Gc * 32);
+        if (ROLL) {                                                              // env-major copy: lane l holds words 2l, 2l+1
+            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, lane16, 0, 0);
+            for (int t = lane; t < A * 4; t += 64) jump[t] = kJump.w[1][t];          // constants for k = 1..A, re-read every step
+        } else {                                                                 // same address for the A lanes of an env
+            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32, 0, 0);
+            in_rngB = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32 + 16, 0, 0);
+            const u32x4 *jk = reinterpret_cast<const u32x4 *>(&kJump.w[1 + agent_of_lane][0]);   // agent k draws k+1 ahead
+            in_jmpA = jk[0]; in_jmpB = jk[1];
+        }
+    }
+    u32x2 in_row = {0, 0};
+    uint32_t in_scnt = 0;
+    u32x4 in_aux = {0, 0, 0, 0};
+    uint8_t in_act = 0;
+    in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
+    uint32_t in_ep = 0;                                                      // AR: env `lane`'s episode count
+    if (DO_STEP) {
+        if (AR && !ROLL) in_ep = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.episode + e0, Gc * 4), lane * 4, 0, 0);
+        in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0, 0);
+        in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0, 0);
+        if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
+    }
+    // (2) the tile
+    u32x4 tv[U], tv2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
+    const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env per wavefront
+    // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
+    // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
+    uint64_t my_rng[4];
+    my_rng[0] = ((uint64_t)in_rngA.y << 32) | in_rngA.x; my_rng[1] = ((uint64_t)in_rngA.w << 32) | in_rngA.z;
+    my_rng[2] = ((uint64_t)in_rngB.y << 32) | in_rngB.x; my_rng[3] = ((uint64_t)in_rngB.w << 32) | in_rngB.z;
+    uint64_t my_draw = 0;
+    if (DO_STEP && !ROLL && A > 1 && !MGX_DBG((2 | 128)) && lane < NVc) {
+        uint64_t jk[4];
+        jk[0] = ((uint64_t)in_jmpA.y << 32) | in_jmpA.x; jk[1] = ((uint64_t)in_jmpA.w << 32) | in_jmpA.z;
+        jk[2] = ((uint64_t)in_jmpB.y << 32) | in_jmpB.x; jk[3] = ((uint64_t)in_jmpB.w << 32) | in_jmpB.z;
+        uint64_t s_lo, s_hi;
+        my_draw = pcg64_draw_at(my_rng, jk, s_lo, s_hi);
+        if (agent_of_lane == A - 1) { uint64_t *dst = a.rng + (e0 + env_of_lane) * 4; dst[0] = s_lo; dst[1] = s_hi; }
+    }
+    // (3b) big tiles: a second burst under the same wait (requested here, once the draws' inputs are dead, so that the
+    // register peak of P0 stays below that of the gather)
+    if (big_tile) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            tv2[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 1024 * U + 4096 * (u >> 2), 0);
+    }
+    // (4) auto-reset test of the one-step kernels, also under the wait (build-defined, include/mgx.h): one lane per env
+    // tests base.py:534-539 on the state the previous step left
+    uint64_t reset_mask0 = 0;
+    if (AR && DO_STEP && !ROLL) {
+        const uint64_t row0 = ((uint64_t)in_row.y << 32) | in_row.x;
+        const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(row0));     // bit = (env, agent) slot
+        bool done = false;
+        if (lane < Gc) {
+            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+            done = (((alive >> mad24(lane, A, 0)) & amask) == 0) | ((int32_t)in_scnt >= a.sp.max_steps);
+            if (a.was_reset) a.was_reset[e0 + lane] = (uint8_t)done;
+        }
+        reset_mask0 = __builtin_amdgcn_ballot_w64(done);
+    }
+    // (5) the small inputs are here long before the tile: their LDS stores go first
+    const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + cv.wall());
+    if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL_WALL;
+    if (lane < NVc) {
+        if (DO_STEP && !ROLL && A > 1) rnd[lane] = my_draw;                      // (only the sequential fallback reads the draws)
+        reinterpret_cast<u32x2 *>(rows)[lane] = in_row;
+        rew[lane] = 0.0;                                                         // base.py:393
+        if (DO_STEP) acts[lane] = (int8_t)in_act;
+    }
+    if (DO_STEP) {
+        if (A > 1 && ROLL && lane < Gc * 2) reinterpret_cast<u32x4 *>(rngs)[lane] = in_rngA;
+        if (lane < Gc) { scnt[lane] = (int32_t)in_scnt; if (cv.has_aux) reinterpret_cast<u32x4 *>(auxl)[lane] = in_aux; }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
+    if (big_tile) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lane16 + 1024 * (U + u) < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * (U + u)) = tv2[u];
+        for (int rel = lane16 + 2048 * U; rel < len; rel += 1024)               // tiles larger than two bursts (16 KiB)
+            *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, 0);
+    }
+    if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
+        const int64_t t0 = gtotal & ~(int64_t)15;
+        for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
+    wave_sync();
+
+    MGX_MARK("P0end");
+    // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
+    // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
+    auto lane_consts = [&]() {
+        LaneConst<V, NW> c;
+#pragma unroll
+        for (int it = 0; it < NW; ++it) {
+            const int k = lane + 64 * it;
+            const int j = k / V, i = k - j * V;
+            c.act[it] = k < V2;
+            c.la[it] = i - V / 2;
+            c.fw[it] = V - 1 - j;
+            c.q3[it] = (i * V + j) * 3;
+            c.own[it] = (i == V / 2) && (j == V - 1);
+        }
+        return c;
+    };
+    LaneConst<V, NW> lc_roll;
+    if (ROLL) lc_roll = lane_consts();            // hoisted out of the step loop; the one-step kernels make them late
+
+    const StepCfg cf = make_cfg(a.sp);
+    const int T = ROLL ? a.T : 1;
+    const int64_t BA = a.batch * A;
+    int8_t next_act = 0;                                                     // ROLL: next step's action, in flight
+    if (ROLL && lane < NVc) next_act = a.actions[v0 + lane];
+    for (int t = 0; t < T; ++t) {
+    const int64_t tv0 = (int64_t)t * BA + v0;                                // this step's (env, agent) output rows
+    if (ROLL) {
+        if (lane < NVc) { acts[lane] = next_act; rew[lane] = 0.0; }
+        if (t + 1 < T && lane < NVc) next_act = a.actions[(int64_t)(t + 1) * BA + v0 + lane];
+        wave_sync();
+    }
+    uint32_t ovl_saved = 0;                                                  // ROLL: clean cell under this agent's overlay
+    int ovl_off = -1;
+    // this lane's agent row, carried in registers through the step (one-step kernels have it from P0); re-read from LDS
+    // only after something else may have changed it (a reset, the sequential fallback, an env hook)
+    uint64_t cur_row = ROLL ? (lane < NVc ? rows[lane] : 0ull) : (((uint64_t)in_row.y << 32) | in_row.x);
+    MGX_MARK("AR");
+    uint64_t reset_mask = 0;                                                 // AR: envs (bit = env of the wave) restarted now
+    if (AR && DO_STEP) {
+        // -------------------------------------------------------------- auto-reset: a finished env takes the pool layout
+        // (first_env + b + episode * 7919) mod K, step_count 0, episode + 1 -- the definition mgx_reset_done implements
+        if (ROLL) {
+            const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(cur_row));   // bit = (env, agent) slot
+            bool done = false;
+            if (lane < Gc) {
+                const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+                done = (((alive >> mad24(lane, A, 0)) & amask) == 0) | (scnt[lane] >= cf.max_steps);
+                if (a.was_reset) a.was_reset[(int64_t)t * a.batch + e0 + lane] = (uint8_t)done;
+            }
+            reset_mask = __builtin_amdgcn_ballot_w64(done);
+        } else {
+            reset_mask = reset_mask0;                                            // (tested in P0, under the load wait)
+        }
+        if (reset_mask != 0) {                                                   // rare: a few envs per thousand steps
+            for (uint64_t m = reset_mask; m != 0; m &= m - 1) {
+                const int e = __builtin_ctzll(m);                                // wave-uniform
+                const int64_t b = e0 + e;
+                int32_t *p_ep = MGX_LATE(episode);
+                const int32_t K = MGX_LATE(pool_size);
+                // (one-step kernels fetched the episode counts in P0: no dependent load in front of the copy)
+                const int32_t ep = ROLL ? p_ep[b] : (int32_t)__builtin_amdgcn_readlane(in_ep, e);
+                const int lay = (K == 1) ? 0 : (int)((uint64_t)(MGX_LATE(first_env) + b + (int64_t)ep * 7919) % (uint64_t)K);
+                wave_sync();
+                if (lane == 0) p_ep[b] = ep + 1;
+                const uint8_t *sg = MGX_LATE(pool_grid) + (int64_t)lay * HW3;
+                uint8_t *etile = tile + e * HW3;
+                uint8_t *gg = MGX_LATE(grid) + b * HW3;
+                const uint32_t etile_addr = (uint32_t)(uintptr_t)(lds_u32_ptr)etile;
+                if (((HW3 | etile_addr | (uint32_t)reinterpret_cast<uintptr_t>(sg) | (uint32_t)reinterpret_cast<uintptr_t>(gg)) & 3u) == 0) {
+#pragma unroll 4
+                    for (int i = lane; i < HW3 / 4; i += 64) {                   // dwords: several loads in flight per lane
+                        const uint32_t v = reinterpret_cast<const uint32_t *>(sg)[i];
+                        reinterpret_cast<uint32_t *>(etile)[i] = v;
+                        if (!ROLL) reinterpret_cast<uint32_t *>(gg)[i] = v;      // (the rollout writes its tile back at the end)
+                    }
+                } else {
+                    for (int i = lane; i < HW3; i += 64) {                       // bytes: layouts of any size / alignment
+                        const uint8_t v = sg[i];
+                        etile[i] = v;
+                        if (!ROLL) gg[i] = v;
+                    }
+                }
+                const uint64_t *sa = reinterpret_cast<const uint64_t *>(MGX_LATE(pool_agents)) + (int64_t)lay * A;
+                for (int j = lane; j < A; j += 64) rows[e * A + j] = sa[j];
+                if (lane == 0) {
+                    scnt[e] = 0;
+                    if (HOOKS) {
+                        const uint4 x = reinterpret_cast<const uint4 *>(MGX_LATE(pool_aux))[lay];
+                        auxl[e] = x;
+                        if (!ROLL) reinterpret_cast<uint4 *>(MGX_LATE(aux))[b] = x;
+                    }
+                }
+            }
+            wave_sync();
+            if (!ROLL && lane < Gc && ((reset_mask >> lane) & 1ull)) in_scnt = 0;
+        }
+    }
+    if (AR && reset_mask != 0 && lane < NVc) cur_row = rows[lane];
+    double my_rew = 0.0;                                                     // this agent's reward (base.py:393), in a register
+    if (DO_STEP && !MGX_DBG(2)) {
+        const bool in = lane < NVc;
+        // (fetched now so that the s_load latency hides behind P1a / P1s)
+        int32_t *const p_step_count = ROLL ? nullptr : MGX_LATE(step_count);
+        uint8_t *const p_truncated = MGX_LATE(truncated);
+        MGX_MARK("P1a");
+        if (ROLL && A > 1 && !MGX_DBG(128)) {
+            // -------------------------------------------------------------- P1a (rollout; the one-step kernels did it in P0):
+            // one lane per (env, agent): its draw
+            if (in) {
+                const int e = env_of_lane, ai = agent_of_lane;
+                uint64_t s_lo, s_hi;
+                rnd[lane] = pcg64_draw_at(rngs + e * 4, jump + ai * 4, s_lo, s_hi);         // base.py:399
+                if (ai == A - 1) { rngs[e * 4 + 0] = s_lo; rngs[e * 4 + 1] = s_hi; }        // (every lane has read it: in-order LDS)
+            }
+        }
+        MGX_MARK("P1s");
+        // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
+        // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
+        int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
+        AgentEval ev{};
+        uint8_t *mytile = tile + env_of_lane * HW3;
+        if (in && !MGX_DBG(64)) {
+            const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
+                               ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
+            ev = eval_agent(cf, mytile, rows + env_of_lane * A, ROLL ? (int)acts[lane] : (int)(int8_t)in_act, cur_row, true, so);
+        }
+        // condition (2) needs the cells the other agents write: exchanged through LDS only when somebody writes at all
+        bool conf = false;
+        if (__builtin_amdgcn_ballot_w64(in && ev.writes) != 0) {
+            if (in) woff[lane] = ev.writes ? ev.off : -1;
+            wave_sync();
+            conf = in && spec_cell_conflict(woff + env_of_lane * A, A, agent_of_lane, ev);
+        }
+        // the common step has none of this in the whole wavefront: one ballot decides whether the masks are needed at all
+        bool fb = false, does_act = in;
+        uint64_t m_ends = 0, m_evt = 0, genv = 0;
+        if (__builtin_amdgcn_ballot_w64(in && (ev.bad | conf | ev.used_presence | ev.success | ev.failure)) != 0) {
+            const uint64_t m_bad = __builtin_amdgcn_ballot_w64(in && ev.bad);
+            const uint64_t m_conf = __builtin_amdgcn_ballot_w64(conf);
+            const uint64_t m_pres = __builtin_amdgcn_ballot_w64(in && ev.used_presence);
+            const uint64_t m_moved = __builtin_amdgcn_ballot_w64(in && ev.moved);
+            m_ends = __builtin_amdgcn_ballot_w64(in && event_ends_all(cf, ev));
+            m_evt = __builtin_amdgcn_ballot_w64(in && (ev.success | ev.failure));
+            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+            genv = in ? (amask << (env_of_lane * A)) : 0ull;                     // the lanes of this lane's env
+            fb = in && spec_needs_fallback(m_bad & genv, m_conf & genv, m_pres & genv, m_moved & genv);
+            // an event that ends the episode for every agent: only the agents visited up to it act (mgx_rules.h)
+            does_act = in && !fb;
+            if (A > 1 && m_ends != 0) {                                          // rare, wave-uniform
+                int my_rank = 0;
+                if (in) {
+                    my_rank = draw_rank(rnd + env_of_lane * A, A, agent_of_lane);
+                    ord[env_of_lane * A + my_rank] = (uint8_t)agent_of_lane;
+                }
+                wave_sync();
+                if (in && (m_ends & genv) != 0)
+                    does_act = does_act && my_rank <= event_cutoff(ord + env_of_lane * A, (m_ends & genv) >> (env_of_lane * A), A);
+            }
+        }
+        if (does_act) {                                                              // commit
+            if (ev.go) { rows[lane] = ev.nrow; cur_row = ev.nrow; }
+            if (ev.unstale) reinterpret_cast<uint8_t *>(auxl + env_of_lane)[4] = 0;
+            if (ev.writes) {
+                store_cell(mytile + ev.off, ev.ncell);
+                if (!ROLL) {                                                     // ROLL writes the whole tile back at the end
+                    uint8_t *gg = MGX_LATE(grid) + (e0 + env_of_lane) * HW3 + ev.off;
+                    gg[0] = (uint8_t)ev.ncell; gg[1] = (uint8_t)(ev.ncell >> 8); gg[2] = (uint8_t)(ev.ncell >> 16);
+                }
+            }
+        }
+        if (m_evt != 0) {                                                        // on_success / on_failure of the agents that acted
+            const uint64_t m_succ = __builtin_amdgcn_ballot_w64(does_act && ev.success);
+            if (in && !fb) {
+                if (cf.joint_reward ? (m_succ & genv) != 0 : (does_act && ev.success))
+                    my_rew = reward_value(scnt[env_of_lane] + 1, cf.max_steps);          // base.py:500-507, 598-602
+                if ((does_act && event_ends_self(cf, ev)) || (m_ends & genv) != 0) {          // base.py:478-498, 509-532
+                    cur_row |= 1ull << 32;
+                    rows[lane] = cur_row;
+                }
+            }
+        }
+        MGX_MARK("P1s_end");
+        const uint64_t fbw = __builtin_amdgcn_ballot_w64(fb);                   // envs that need the sequential loop
+        wave_sync();
+        if (fbw != 0) {
+            if (A > 1) {
+                // ---------------------------------------------------------- P1b: argsort by ranking
+                if (in) {
+                    const int e = env_of_lane, ai = agent_of_lane;
+                    ord[e * A + draw_rank(rnd + e * A, A, ai)] = (uint8_t)ai;
+                }
+                wave_sync();
+            }
+            // -------------------------------------------------------------- P1c: one lane per env: the reference's loop
+            const bool mine = lane < Gc && (lane * A < 64) && ((fbw >> (lane * A)) & 1ull);
+            if (mine) {
+                const int e = lane;
+                const int64_t b = e0 + e;
+                uint8_t *etile = tile + e * HW3;
+                uint8_t *ggrid = MGX_LATE(grid) + b * HW3;
+                auto dirty = [=](int off) {
+                    if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
+                };
+                const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
+                                              scnt[e] + 1, dirty, reinterpret_cast<uint8_t *>(auxl + e), env_kind);
+                int32_t *errp = MGX_LATE(err);
+                if (rc != 0 && errp) { atomicAdd(errp, 1); atomicMin(errp + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
+            }
+            wave_sync();
+        }
+        MGX_MARK("P1hook");
+        // ------------------------------------------------------------------ overlay offsets (pre-hook `terminated`, SURVEY
+        // App. C Q2), then one lane per env: counters + the env subclass' hook on the clean tile, then the overlay itself
+        const int ovl = (in && !MGX_DBG(512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
+        if (HOOKS && in && !fb) rew[lane] = my_rew;                              // (the hooks assign to / add onto the base rewards)
+        wave_sync();
+        if (lane < Gc) {
+            const int e = lane;
+            const int64_t b = e0 + e;
+            const int32_t sc = (ROLL ? scnt[e] : (int32_t)in_scnt) + 1;          // base.py:333
+            if (ROLL) scnt[e] = sc; else p_step_count[b] = sc;
+            uint8_t *etile = tile + e * HW3;
+            uint8_t *ggrid = MGX_LATE(grid) + b * HW3;
+            auto dirty = [=](int off) {
+                if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
+            };
+            uint8_t *eaux = reinterpret_cast<uint8_t *>(auxl + e);
+            post_step_hook(cf, env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
+            if (!ROLL && cv.has_aux) {                                           // the hook state the step may change
+                uint8_t *gaux = MGX_LATE(aux) + b * MGX_AUX_BYTES;
+                if (env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[15] = eaux[15]; }
+                if (env_kind == MGX_KIND_REDBLUEDOORS) gaux[4] = eaux[4];
+            }
+            p_truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
+        }
+        wave_sync();
+        if ((HOOKS || fbw != 0) && in) {                                         // (a hook / the fallback may have terminated it
+            cur_row = rows[lane];                                                // and rewarded it: their results are in LDS)
+            if (HOOKS || fb) my_rew = rew[lane];
+        }
+        if (ROLL && ovl >= 0) ovl_saved = load_cell(mytile + ovl);
+        ovl_off = ovl;
+        wave_sync();
+        if (ovl >= 0) store_cell(mytile + ovl, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
+    } else {
+        const int off = (lane < NVc) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
+        wave_sync();
+        if (off >= 0) store_cell(tile + env_of_lane * HW3 + off, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
+    }
+    wave_sync();
+
+    MGX_MARK("P1d");
+    // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
+    const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + cv.tile() + tile_skew);   // LDS address of env 0 cell 0
+    uint32_t my_carry = 0;                                                   // slot `lane`: what its agent carries
+    uint32_t inbLo[NW], inbHi[NW];                                           // slot `lane`: its in-bounds lanes (P2 reads them
+#pragma unroll                                                               // with v_readlane; padding slots: none in bounds)
+    for (int k = 0; k < NW; ++k) { inbLo[k] = 0; inbHi[k] = 0; }
+    // (the output pointers are fetched first so that the s_load latency hides behind the geometry arithmetic)
+    uint8_t *const p_dir = MGX_LATE(dir);
+    uint8_t *const p_agents = DO_STEP ? MGX_LATE(agents) : nullptr;
+    double *const p_reward = DO_STEP ? MGX_LATE(reward) : nullptr;
+    uint8_t *const p_term = DO_STEP ? MGX_LATE(terminated) : nullptr;
+    if (lane < NVc) {
+        const int e = env_of_lane;
+        const uint64_t row = cur_row;
+        const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
+        ViewRec r;
+        r.origin = (int32_t)tile_addr + e * HW3 + g.origin;
+        r.stepF = g.stepF; r.stepL = g.stepL; r.carry = 0;
+        my_carry = row_carry(row);
+        rec[lane] = r;
+        uint64_t m[NW];
+        inbounds_mask<V, NW>(g, m);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { inbLo[k] = (uint32_t)m[k]; inbHi[k] = (uint32_t)(m[k] >> 32); }
+        if (DO_STEP) {
+            const u32x2 rowv = {(uint32_t)row, (uint32_t)(row >> 32)};
+            if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(p_agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
+            const uint64_t rbits = __builtin_bit_cast(uint64_t, my_rew);
+            const u32x2 rewv = {(uint32_t)rbits, (uint32_t)(rbits >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(p_reward + tv0, NVc * 8), lane * 8, 0, 0);
+            const bool forced = env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row_term(row) | forced),                    // base.py:338 (+ env hook)
+                                                 make_rsrc(p_term + tv0, NVc), lane, 0, 0);
+        }
+        if (p_dir) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)row_dir(row), make_rsrc(p_dir + tv0, NVc), lane, 0, 0);   // base.py:359, 372
+    } else if (lane < ((NVc + kGroup - 1) & ~(kGroup - 1))) {                // padding slots of the last gather group
+        ViewRec r;
+        r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = 0;
+        rec[lane] = r;
+    }
+    wave_sync();
+
+    MGX_MARK("P2");
+    // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
+    const LaneConst<V, NW> lc = ROLL ? lc_roll : lane_consts();
+    uint32_t cell[VPW][NW];                      // registers: every slot's cells, one per lane (and pass); P4 reads
+                                                 // only the gathered ones (s < NVc)
+    uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
+    if (!MGX_DBG(4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+    if (ROLL) {                                                              // take the overlay off again: the tile persists
+        wave_sync();
+        if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
+    }
+
+    MGX_MARK("P3");
+    // ------------------------------------------------------------------ P3: lane s floods the visibility of slot s
+    const bool masked = !a.sp.see_through_walls;                                // obs.py:95-100
+    uint32_t visLo[NW], visHi[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { visLo[k] = 0xffffffffu; visHi[k] = 0xffffffffu; }
+    if (masked && !MGX_DBG(8)) {
+        uint64_t sb[NW], vis[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) sb[k] = ((uint64_t)sbHi[k] << 32) | sbLo[k];
+        constexpr int kOwn = (V - 1) * V + V / 2;                               // the agent's own cell: image[V/2][V-1]
+        sb[kOwn >> 6] = (sb[kOwn >> 6] & ~(1ull << (kOwn & 63)))              // ... shows what it carries (obs.py:207)
+                      | ((uint64_t)see_behind(my_carry) << (kOwn & 63));
+        vis_mask<V, NW>(sb, vis);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { visLo[k] = (uint32_t)vis[k]; visHi[k] = (uint32_t)(vis[k] >> 32); }
+    }
+
+    MGX_MARK("P4");
+    // ------------------------------------------------------------------ P4/P5 in rounds of kRound slots:
+    // P4 masks each cell and transposes it into the obs byte layout in LDS, P5 streams the round to HBM in 16-byte vectors
+    const int64_t o0 = tv0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;  // this wave's obs bytes (of step t)
+    const int out_skew = (int)(o0 & 15);                                        // the same for every round
+    uint8_t *out_raw = L + cv.out();                                          // obs bytes [oa_r, ...) of round r
+    uint8_t *outb = out_raw + out_skew;
+    constexpr int kRoundBytes = kRound * V2 * 3;                                // multiple of 16
+#pragma unroll
+    for (int r0 = 0; r0 < VPW; r0 += kRound) {
+        if (r0 < NVc) {
+            if (!MGX_DBG(16)) {
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    if (lc.act[it]) {
+                        uint8_t *d0 = outb + lc.q3[it];
+                        // whole groups of kGroup slots, like P2 (padding slots write junk into staging space that P5
+                        // never copies): straight-line code whose readlane -> select -> write chains overlap
+#pragma unroll
+                        for (int g0 = 0; g0 < kRound; g0 += kGroup) {
+                            if (r0 + g0 < NVc) {
+#pragma unroll
+                                for (int sl = g0; sl < g0 + kGroup; ++sl) {
+                                    const int s = r0 + sl;
+                                    // (see_through_walls: the masks are all ones -- no branch, it would fence the schedule)
+                                    const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
+                                                     | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
+                                    const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
+                                    uint8_t *d = d0 + sl * (V2 * 3);
+#if MGX_UA_WRITE
+                                    *reinterpret_cast<u16_unaligned *>(d) = (uint16_t)c;    // ds_write_b16 at any byte address
+                                    d[2] = (uint8_t)(c >> 16);                              // ds_write_b8_d16_hi
+#else
+                                    d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+#endif
+                                }
+                            }
+                        }
+                    }
+                }
+                wave_sync();
+                // lane r0+sl: its agent's own cell shows the carried object (obs.py:207; always visible, obs.py:252)
+                if (lane >= r0 && lane < r0 + kRound && lane < NVc)
+                    store_cell(outb + (lane - r0) * (V2 * 3) + ((V / 2) * V + (V - 1)) * 3, my_carry);
+            }
+            wave_sync();
+            MGX_MARK("P5");
+            if (!MGX_DBG(32)) {
+                const int64_t ro0 = o0 + (int64_t)r0 * (V2 * 3);                // this round's obs bytes [ro0, ro1)
+                const int rlen = out_skew + (int)min((int64_t)kRoundBytes, o1 - ro0);   // staged bytes, from the aligned start
+                uint8_t *gdst = MGX_LATE(obs) + (ro0 - out_skew);
+                const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(gdst, rlen);
+                constexpr int kPasses = (kRoundBytes + 15 + 1023) / 1024;
+#pragma unroll
+                for (int k = 0; k < kPasses; ++k) {
+                    const int rel = lane16 + 1024 * k;
+                    if ((rel + 16 <= rlen) & (rel >= out_skew)) {
+#if MGX_BUF_STORE
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), orsrc, rel, 0, MGX_OBS_AUX);
+#else
+                        *reinterpret_cast<u32x4 *>(gdst + rel) = *reinterpret_cast<const u32x4 *>(out_raw + rel);
+#endif
+                    } else if (rel < rlen) {                                    // ragged head / tail of the wave's bytes
+                        const int lo_b = max(rel, out_skew), hi_b = min(rel + 16, rlen);
+#pragma clang loop vectorize(disable) unroll(disable)
+                        for (int B = lo_b; B < hi_b; ++B) gdst[B] = out_raw[B];
+                    }
+                }
+            }
+            wave_sync();
+            MGX_MARK("P5end");
+        }
+    }
+    }   // for t
+
+#if MGX_TIMESTAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    MGX_MARK("end");
+    if (lane == 0 && wid < 16384) g_span[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (ROLL) {
+        // ------------------------------------------------------------------ state write-back, once per launch
+        for (int rel = 16 * lane; rel < len; rel += 16 * 64) {                  // the tile, as it was loaded
+            const int64_t D = ga + rel;
+            if (D >= g0 && D + 16 <= g1) {
+                *reinterpret_cast<uint4 *>(a.grid + D) = *reinterpret_cast<const uint4 *>(tile_raw + rel);
+            } else {
+                const int64_t lo_b = max(D, g0), hi_b = min(D + 16, g1);
+                for (int64_t B = lo_b; B < hi_b; ++B) a.grid[B] = tile_raw[(int)(B - ga)];
+            }
+        }
+        if (lane < NVc) reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = rows[lane];
+        if (A > 1) {
+            if (lane < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane] = rngs[lane];
+            if (lane + 64 < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane + 64] = rngs[lane + 64];
+        }
+        if (lane < Gc) {
+            a.step_count[e0 + lane] = scnt[lane];
+            if (HOOKS && (AR || env_kind >= MGX_KIND_REDBLUEDOORS)) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
+        }
+    }
+}
+
+// The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
+// failed launch (mgx_last_hip_error).
+template <int V, int MODE>
+inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err) {
+    void (*kern)(const KernelArgs) = nullptr;
+    const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
+    const bool ar = MODE != 0 && ka.pool_grid != nullptr;
+    constexpr bool S = MODE != 0;
+    kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S> : mgx_fused_kernel<V, MODE, S, false>)
+                 : (ar ? mgx_fused_kernel<V, MODE, false, S> : mgx_fused_kernel<V, MODE, false, false>);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, stream, ka);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+    return MGX_OK;
+}
+
+template <int V>
+inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream,
+                       int *hip_err) {
+    switch (mode) {
+    case 0: return launch_mode<V, 0>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    case 1: return launch_mode<V, 1>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    case 2: return launch_mode<V, 2>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    default: return MGX_ERR_INVALID_ARGUMENT;
+    }
+}
+
+// One translation unit per view size (mgx_fused_inst.hip, -DMGX_INST_V=<V>) defines its launcher:
+#define MGX_FOR_EACH_VIEW(X) X(3) X(5) X(7) X(9) X(11) X(13) X(15)
+#define MGX_DECLARE_LAUNCHER(V) \
+    int launch_v##V(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err);
+MGX_FOR_EACH_VIEW(MGX_DECLARE_LAUNCHER)
+#undef MGX_DECLARE_LAUNCHER
+
+}  // namespace mgx_fused

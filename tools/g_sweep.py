@@ -13,8 +13,8 @@ acts = bench.random_actions(4, B, spec.num_agents, dev, 7)
 i = [0]
 def step():
     env.step(acts[i[0] & 3]); i[0] += 1
-for G in (5, 6, 7, 8):
-    for wpb in (1, 2, 3, 4):
+for G in [int(x) for x in os.environ.get("MGX_GS", "4,5,6,7,8").split(",")]:
+    for wpb in [int(x) for x in os.environ.get("MGX_WPBS", "1,2,4").split(",")]:
         _lib.lib().mgx_debug_set_envs_per_wavefront(G)
         _lib.lib().mgx_debug_set_waves_per_workgroup(wpb)
         t = bench.kernel_time_ms(step, 20, dev) * 1e3

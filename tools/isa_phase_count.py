@@ -16,9 +16,9 @@ HOOKS = sys.argv[3] if len(sys.argv) > 3 else "0"
 extra = sys.argv[4:]
 out = os.path.join(tempfile.gettempdir(), "mgx_markers.s")
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DMGX_MARKERS=1",
-                       f"-I{ROOT}/include", "-S", "--cuda-device-only", *extra,
-                       f"{ROOT}/multigrid_amd/csrc/mgx_kernels.hip", "-o", out])
-want = f"mgx_fused_kernelILi{V}ELi{MODE}ELb{HOOKS}E"
+                       f"-I{ROOT}/include", "-S", "--cuda-device-only", f"-DMGX_INST_V={V}", *extra,
+                       f"{ROOT}/multigrid_amd/csrc/mgx_fused_inst.hip", "-o", out])
+want = f"mgx_fused_kernelILi{V}ELi{MODE}ELb{HOOKS}E" + (os.environ.get("MGX_KERNEL_SUFFIX", ""))
 cur = None
 phase = "pre"
 counts = collections.OrderedDict()
