@@ -236,7 +236,18 @@ def large_batch_points(device, large_batch):
     r_obs.update(batch=large_batch, kernel="mgx_fused_kernel<7,gen_obs>", ms_per_launch=round(ms_obs, 4),
                  agent_views_per_s=round(n / (ms_obs * 1e-3)))
     out = {"roofline_large": r_step, "gen_obs_large": r_obs}
+    # the step with the observation written one-hot encoded by the same launch (mgx_step_one_hot; what RLlib's default
+    # OneHotObsWrapper registration consumes): algorithmic bytes = bytes_step with the 3 v^2 obs bytes replaced by 21 v^2
+    def step_oh():
+        env.step(acts[i[0] & 3], auto_reset=AUTO_RESET, one_hot=True); i[0] += 1
+    ms_oh = kernel_time_ms(step_oh, 30, device, warm=10)
+    by_oh = spec.bytes_step() + 18 * spec.view_size ** 2
+    r_oh = roofline(n * by_oh, ms_oh, pmc_traffic("large_step_one_hot", large_batch))
+    r_oh.update(batch=large_batch, kernel="mgx_fused_kernel<7,step,autoreset,one_hot>", ms_per_launch=round(ms_oh, 4),
+                bytes_per_agent_step=by_oh, agent_steps_per_s=round(n / (ms_oh * 1e-3)))
+    out["one_hot_large"] = r_oh
     out["aux_kernels"] = aux_kernel_points(env, device)
+    out["one_hot_large"]["unfused_ms"] = round(ms_step + out["aux_kernels"]["one_hot"]["ms_per_launch"], 4)
     del env
     torch.cuda.empty_cache()
     return out

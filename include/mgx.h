@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 3
+#define MGX_ABI_VERSION 4
 
 enum {
     MGX_OK = 0,
@@ -126,7 +126,7 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream);
 
-/* Geometry the two calls above would use. */
+/* Geometry mgx_gen_obs / mgx_step / mgx_rollout would use. */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
 
 /* Replaces OneHotObsWrapper.one_hot (multigrid/wrappers.py:158-190; the wrapper RLlib registration applies to every
@@ -176,6 +176,20 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
                           uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                           uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                           int32_t *err, void *stream);
+
+/* The step / gen_obs with the observation written ONE-HOT encoded: what OneHotObsWrapper.one_hot
+ * (multigrid/wrappers.py:158-190, dim sizes (11, 6, 4)) makes of obs['image'], fused into the same launch -- the
+ * wrapper RLlib registration applies to every env (multigrid/rllib/__init__.py:110-111).  Bit-identical to
+ * mgx_gen_obs / mgx_step[_autoreset] followed by mgx_one_hot, without the 3-byte observation's round trip through HBM:
+ *   obs_one_hot u8[B, A, v, v, 21]   obs_one_hot[b,a,i,j, c0] = obs_one_hot[.., 11 + c1] = obs_one_hot[.., 17 + c2] = 1
+ *                                    for obs[b,a,i,j] = (c0, c1, c2); everything else 0.  16-byte aligned.
+ * `ar` may be NULL (no auto-reset).  Everything else as in mgx_step / mgx_step_autoreset. */
+int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+                        uint8_t *obs_one_hot, uint8_t *dir, void *stream);
+int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+                     uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                     uint8_t *obs_one_hot, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                     int32_t *err, void *stream);
 
 #ifdef __cplusplus
 }

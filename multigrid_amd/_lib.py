@@ -17,13 +17,13 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
 EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
            "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout", "mgx_step_autoreset",
-           "mgx_rollout_autoreset")
+           "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot")
 
 
 class MgxLaunchInfo(C.Structure):
@@ -70,6 +70,10 @@ def lib() -> C.CDLL:
     L.mgx_step_autoreset.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxAutoReset)] + [vp] * 13
     L.mgx_rollout_autoreset.restype = C.c_int
     L.mgx_rollout_autoreset.argtypes = [C.POINTER(MgxSpecC), i64, C.c_int32, C.POINTER(MgxAutoReset)] + [vp] * 13
+    L.mgx_gen_obs_one_hot.restype = C.c_int
+    L.mgx_gen_obs_one_hot.argtypes = [C.POINTER(MgxSpecC), i64, vp, vp, vp, vp, vp]
+    L.mgx_step_one_hot.restype = C.c_int
+    L.mgx_step_one_hot.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxAutoReset)] + [vp] * 13
     L.mgx_one_hot.restype = C.c_int
     L.mgx_one_hot.argtypes = [vp, i64, C.POINTER(C.c_int32), vp, vp]
     L.mgx_full_obs.restype = C.c_int

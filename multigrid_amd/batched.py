@@ -116,11 +116,21 @@ class BatchedMultiGridEnv:
         self.err.copy_(torch.tensor([0, INT32_MAX], dtype=torch.int32))
 
     # ------------------------------------------------------------------------------------------ hot path
-    def gen_obs(self):
-        """multigrid/base.py:348-376 for every env: returns (obs u8[B,A,v,v,3], dir u8[B,A])."""
+    def gen_obs(self, one_hot: bool = False):
+        """multigrid/base.py:348-376 for every env: returns (obs u8[B,A,v,v,3], dir u8[B,A]).
+        one_hot=True: the observation comes out one-hot encoded, u8[B,A,v,v,21] (`OneHotObsWrapper`,
+        multigrid/wrappers.py:158-190), written by the same kernel launch; `obs` is not touched."""
         self._need_state()
+        if one_hot:
+            self.backend.gen_obs(self.batch, self.grid, self.agents, self._one_hot_buffer(), self.dir, one_hot=True)
+            return self._one_hot, self.dir
         self.backend.gen_obs(self.batch, self.grid, self.agents, self.obs, self.dir)
         return self.obs, self.dir
+
+    def _one_hot_buffer(self):
+        if getattr(self, "_one_hot", None) is None:
+            self._one_hot = torch.zeros(tuple(self.obs.shape[:-1]) + (21,), dtype=torch.uint8, device=self.device)
+        return self._one_hot
 
     def _auto_reset_args(self, auto_reset, was_reset):
         if not auto_reset:
@@ -129,8 +139,12 @@ class BatchedMultiGridEnv:
             raise RuntimeError("auto_reset needs set_layout_pool() first")
         return (self.first_env, self._pool, self.episode, was_reset)
 
-    def step(self, actions: torch.Tensor, auto_reset: bool = False):
+    def step(self, actions: torch.Tensor, auto_reset: bool = False, one_hot: bool = False):
         """multigrid/base.py:303-346 for every env.
+
+        one_hot=True: the first element returned is the one-hot observation u8[B,A,v,v,21] (what RLlib's default
+        `OneHotObsWrapper` registration feeds the policy, multigrid/rllib/__init__.py:110-111), produced by the same launch
+        (mgx_step_one_hot); the 3-channel `obs` buffer is not written.
 
         auto_reset=True fuses `reset_done()` into the launch (build-defined, include/mgx.h mgx_step_autoreset): an env
         whose episode ended with the previous step first restarts from the layout pool, then takes this step's
@@ -149,11 +163,16 @@ class BatchedMultiGridEnv:
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {(self.batch, sp.num_agents)} "
                              f"on {self.grid.device}")
         ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
+        kw = {}
+        if ar is not None:
+            kw["auto_reset"] = ar
+        if one_hot:
+            kw["one_hot"] = True
+        obs = self._one_hot_buffer() if one_hot else self.obs
         self.backend.step(self.batch, self.grid, self.agents, self.rng, self.step_count, actions,
                           self.aux if sp.env_kind != "empty" else None, self.err,
-                          self.obs, self.dir, self.reward, self.terminated, self.truncated,
-                          **({"auto_reset": ar} if ar is not None else {}))
-        return self.obs, self.dir, self.reward, self.terminated, self.truncated
+                          obs, self.dir, self.reward, self.terminated, self.truncated, **kw)
+        return obs, self.dir, self.reward, self.terminated, self.truncated
 
     def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False) -> dict:
         """`T` consecutive `step`s in one kernel launch (env state stays in LDS between steps); bit-identical to
@@ -187,9 +206,7 @@ class BatchedMultiGridEnv:
     # ------------------------------------------------------------------------------------------ either side of the path
     def one_hot_obs(self) -> torch.Tensor:
         """`OneHotObsWrapper` (multigrid/wrappers.py:101-190) applied to the current `obs`: u8[B,A,v,v,21]."""
-        if getattr(self, "_one_hot", None) is None:
-            self._one_hot = torch.zeros(tuple(self.obs.shape[:-1]) + (21,), dtype=torch.uint8, device=self.device)
-        self.backend.one_hot(self.obs, self._one_hot)
+        self.backend.one_hot(self.obs, self._one_hot_buffer())
         return self._one_hot
 
     def full_obs(self) -> torch.Tensor:

@@ -140,7 +140,7 @@ inline int slots_per_wave(int view_size) { return view_size <= 7 ? kSlotsSmallVi
 // (vpw, nw, Gw, A, tile bytes, round bytes) so the kernel recomputes an offset where it needs it instead of carrying
 // fifteen of them in SGPRs from the kernel arguments.  Per-slot arrays first (vpw = slots in use, a multiple of 16).
 struct LdsCarve {
-    int vpw, nw, Gw, A, tile_bytes, round_bytes;
+    int vpw, nw, Gw, A, tile_bytes, round_bytes;   // round_bytes: P4/P5 staging of one round (obs bytes, or one-hot cell masks)
     bool roll;      // mgx_rollout: tile and PCG64 state live across steps (no aliasing of the tile, rng kept in LDS)
     bool has_aux;   // env kinds with hook state
     __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
@@ -172,8 +172,11 @@ struct LdsCarve {
     }
 };
 
-__host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux) {
-    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * 3, kRound * V * V * 3, roll, has_aux};
+// one_hot: the round's staging holds one 32-bit one-hot mask per cell (+ a pad dword either side) instead of 3 obs bytes
+__host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
+                                               bool one_hot = false) {
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * 3, one_hot ? kRound * V * V * 4 + 16 : kRound * V * V * 3,
+                    roll, has_aux};
 }
 
 inline int slots_in_use(const MgxSpec &sp, int Gw) {
@@ -181,9 +184,9 @@ inline int slots_in_use(const MgxSpec &sp, int Gw) {
     return vpw > slots_per_wave(sp.view_size) ? slots_per_wave(sp.view_size) : vpw;
 }
 
-inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false) {
+inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false, bool one_hot = false) {
     return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw), roll,
-                      sp.env_kind != MGX_KIND_EMPTY).total();
+                      sp.env_kind != MGX_KIND_EMPTY, one_hot).total();
 }
 
 constexpr int kLdsPerCU = 160 * 1024;
@@ -194,10 +197,10 @@ constexpr int kLdsWaveBudget = MGX_LDS_WAVE_BUDGET;     // keeps >= 12 wavefront
 
 // Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
 // to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
-inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false) {
+inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false, bool one_hot = false) {
     int Gw = slots_per_wave(sp.view_size) / sp.num_agents;
     if (Gw < 1) Gw = 1;
-    while (Gw > 1 && wave_lds_bytes(sp, Gw, roll) > kLdsWaveBudget) --Gw;
+    while (Gw > 1 && wave_lds_bytes(sp, Gw, roll, one_hot) > kLdsWaveBudget) --Gw;
     while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
     while (Gw > 1 && (batch + Gw - 1) / Gw < 512) Gw = (Gw + 1) / 2;       // tiny batches: spread over the chip
     return Gw;
@@ -361,7 +364,9 @@ __device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, co
 // drops that code and its SGPRs.
 // AR: fused auto-reset -- an env whose episode ended with the previous step restarts from the layout pool before this
 // step's actions are applied (== mgx_reset_done followed by the step, in one launch).
-template <int V, int MODE, bool HOOKS, bool AR>
+// OH: the observation is written one-hot encoded, u8[B,A,V,V,21] (OneHotObsWrapper, multigrid/wrappers.py:158-190, dims
+// (11, 6, 4)): P4 leaves a 21-bit mask per cell in LDS, P5 expands mask bits to 0/1 bytes, 16 at a time.
+template <int V, int MODE, bool HOOKS, bool AR, bool OH = false>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
     constexpr bool DO_STEP = MODE != 0;
     const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     MGX_MARK("start");
     if (lane == 0 && wid < 16384) g_span[2 * wid] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, HOOKS);
+    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, HOOKS, OH);
     uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
     ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
     int8_t *acts = reinterpret_cast<int8_t *>(L + cv.act());                  // [slot]
@@ -847,6 +852,78 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
 
     MGX_MARK("P4");
+    if constexpr (OH) {
+        // -------------------------------------------------------------- P4'/P5' (one-hot output) in rounds of kRound slots:
+        // P4' masks each cell and leaves its one-hot bit mask (bit t | bit 11+c | bit 17+s) at its image position in LDS;
+        // P5' turns the masks of the 1-2 cells that each run of 16 output bytes spans into 0/1 bytes and streams them out.
+        constexpr int D = 21;
+        constexpr uint32_t kInvD = 0xFFFFFFFFu / D + 1u;                        // ceil(2^32 / 21): x / 21 exact for x < 2^20
+        const int64_t h0 = tv0 * (int64_t)(V2 * D), h1 = h0 + (int64_t)NVc * V2 * D;
+        const int oh_skew = (int)(h0 & 15);
+        uint32_t *masks = reinterpret_cast<uint32_t *>(L + cv.out()) + 1;      // masks[-1] and masks[cells] are readable pads
+        auto one_hot_mask = [](uint32_t c) -> uint32_t {                        // out-of-range values set no bit (as mgx_one_hot)
+            const uint32_t p0 = min(c & 0xffu, 31u), p1 = min((c >> 8) & 0xffu, 31u), p2 = min((c >> 16) & 0xffu, 31u);
+            return ((1u << p0) & 0x7ffu) | (((1u << p1) & 0x3fu) << 11) | (((1u << p2) & 0xfu) << 17);
+        };
+        if (lane == 0) masks[-1] = 0;
+#pragma unroll
+        for (int r0 = 0; r0 < VPW; r0 += kRound) {
+            if (r0 < NVc) {
+#pragma unroll
+                for (int it = 0; it < NW; ++it) {
+                    if (lc.act[it]) {
+                        uint32_t *d0 = masks + (lc.q3[it] / 3);                  // q3 = 3 * (i*V + j)
+#pragma unroll
+                        for (int g0 = 0; g0 < kRound; g0 += kGroup) {
+                            if (r0 + g0 < NVc) {
+#pragma unroll
+                                for (int sl = g0; sl < g0 + kGroup; ++sl) {
+                                    const int s = r0 + sl;
+                                    const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
+                                                     | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
+                                    const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
+                                    d0[sl * V2] = one_hot_mask(c);
+                                }
+                            }
+                        }
+                    }
+                }
+                wave_sync();
+                if (lane >= r0 && lane < r0 + kRound && lane < NVc)             // own cell := carried object (obs.py:207)
+                    masks[(lane - r0) * V2 + (V / 2) * V + (V - 1)] = one_hot_mask(my_carry);
+                wave_sync();
+                MGX_MARK("P5");
+                const int64_t ro0 = h0 + (int64_t)r0 * (V2 * D);                // this round's output bytes [ro0, ro1)
+                const int rbytes = (int)min((int64_t)kRound * V2 * D, h1 - ro0);
+                const int rlen = oh_skew + rbytes;                              // from the aligned start
+                uint8_t *gdst = MGX_LATE(obs) + (ro0 - oh_skew);
+                const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(gdst, rlen);
+                for (int rel = lane16; rel < rlen; rel += 1024) {
+                    // output bytes [rel, rel + 16) of the aligned run = round bytes x .. x + 15, x = rel - skew (may be < 0:
+                    // shifted by one cell so that the division stays in the positives; masks[-1] is a pad)
+                    const uint32_t xs = (uint32_t)(rel - oh_skew + D);
+                    const uint32_t cq = __umulhi(xs, kInvD);                    // cell + 1
+                    const uint32_t k0 = xs - cq * D;                            // first bit inside that cell: 0..20
+                    const uint32_t bits = (masks[(int)cq - 1] >> k0) | (masks[(int)cq] << (D - k0));   // >= 22 valid bits
+                    u32x4 v;
+                    v.x = (((bits >> 0) & 0xfu) * 0x00204081u) & 0x01010101u;   // 4 bits -> 4 bytes of 0/1
+                    v.y = (((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
+                    v.z = (((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
+                    v.w = (((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
+                    if ((rel + 16 <= rlen) & (rel >= oh_skew)) {
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, rel, 0, MGX_OBS_AUX);
+                    } else {                                                    // ragged head / tail of the wave's bytes
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        const int lo_b = max(rel, oh_skew), hi_b = min(rel + 16, rlen);
+#pragma clang loop vectorize(disable) unroll(disable)
+                        for (int B = lo_b; B < hi_b; ++B) gdst[B] = (uint8_t)(w[(B - rel) >> 2] >> (8 * ((B - rel) & 3)));
+                    }
+                }
+                wave_sync();
+                MGX_MARK("P5end");
+            }
+        }
+    } else {
     // ------------------------------------------------------------------ P4/P5 in rounds of kRound slots:
     // P4 masks each cell and transposes it into the obs byte layout in LDS, P5 streams the round to HBM in 16-byte vectors
     const int64_t o0 = tv0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;  // this wave's obs bytes (of step t)
@@ -919,6 +996,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             MGX_MARK("P5end");
         }
     }
+    }   // if !OH
     }   // for t
 
 #if MGX_TIMESTAMPS
@@ -951,14 +1029,14 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 
 // The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
 // failed launch (mgx_last_hip_error).
-template <int V, int MODE>
+template <int V, int MODE, bool OH>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err) {
     void (*kern)(const KernelArgs) = nullptr;
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
     const bool ar = MODE != 0 && ka.pool_grid != nullptr;
     constexpr bool S = MODE != 0;
-    kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S> : mgx_fused_kernel<V, MODE, S, false>)
-                 : (ar ? mgx_fused_kernel<V, MODE, false, S> : mgx_fused_kernel<V, MODE, false, false>);
+    kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH> : mgx_fused_kernel<V, MODE, S, false, OH>)
+                 : (ar ? mgx_fused_kernel<V, MODE, false, S, OH> : mgx_fused_kernel<V, MODE, false, false, OH>);
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -973,10 +1051,12 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
 template <int V>
 inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream,
                        int *hip_err) {
-    switch (mode) {
-    case 0: return launch_mode<V, 0>(ka, threads, lds_bytes, nwg, stream, hip_err);
-    case 1: return launch_mode<V, 1>(ka, threads, lds_bytes, nwg, stream, hip_err);
-    case 2: return launch_mode<V, 2>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    switch (mode) {                                      // mode | 4: one-hot observations (gen_obs and one step only)
+    case 0: return launch_mode<V, 0, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
     default: return MGX_ERR_INVALID_ARGUMENT;
     }
 }

@@ -52,31 +52,31 @@ int launch(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t n
     }
 }
 
-int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false) {
+int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot = false) {
     if (!sp || batch < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size < 3 || !(sp->view_size & 1)) return MGX_ERR_INVALID_ARGUMENT;   // agent.py:78-79
     if (sp->width < 3 || sp->height < 3 || sp->num_agents < 1 || sp->max_steps < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
     if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_LOCKEDHALLWAY) return MGX_ERR_UNSUPPORTED;
-    if (wave_lds_bytes(*sp, 1, roll) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;        // one env must fit one CU's LDS (the
+    if (wave_lds_bytes(*sp, 1, roll, one_hot) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;   // one env must fit one CU's LDS (the
                                                                                      // rollout carve is the larger one)
     return MGX_OK;
 }
 
 int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg,
-              bool roll = false) {
+              bool roll = false, bool one_hot = false) {
     ka.sp = *sp;
     ka.batch = batch;
-    ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll);
+    ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll, one_hot);
     const int max_gw = slots_per_wave(sp->view_size) / sp->num_agents;
     if (ka.Gw > max_gw) ka.Gw = max_gw;
     if (ka.Gw < 1) ka.Gw = 1;
-    while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll) > kLdsPerCU) --ka.Gw;
+    while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll, one_hot) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
     ka.vpw = slots_in_use(*sp, ka.Gw);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
-    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll);
+    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot);
     struct { int total; } p{ka.wave_lds};
     // wavefronts bundled per workgroup: 2 packs a CU's 160 KiB of LDS tighter than 4 once the chip is full (measured
     // 403 vs 425 us at 1M envs); below that, fewer and larger workgroups launch faster (9.9 vs 10.5 us at 4096 envs)
@@ -147,32 +147,42 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     return MGX_OK;
 }
 
-int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
-                uint8_t *obs, uint8_t *dir, void *stream) {
-    int rc = check_spec(spec, batch);
+static int gen_obs_common(bool one_hot, const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+                          uint8_t *obs, uint8_t *dir, void *stream) {
+    int rc = check_spec(spec, batch, false, one_hot);
     if (rc) return rc;
     if (batch == 0) return MGX_OK;
     if (!grid || !agents || !obs) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16)) return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, one_hot);
     if (rc) return rc;
     ka.grid = const_cast<uint8_t *>(grid);
     ka.agents = const_cast<uint8_t *>(agents);
     ka.obs = obs;
     ka.dir = dir;
     ka.T = 1;
-    return launch(0, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+    return launch(one_hot ? 4 : 0, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
-static int step_common(bool roll, const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar,
+int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+                uint8_t *obs, uint8_t *dir, void *stream) {
+    return gen_obs_common(false, spec, batch, grid, agents, obs, dir, stream);
+}
+
+int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+                        uint8_t *obs_one_hot, uint8_t *dir, void *stream) {
+    return gen_obs_common(true, spec, batch, grid, agents, obs_one_hot, dir, stream);
+}
+
+static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar,
                        uint8_t *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
                        uint8_t *aux, uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated,
                        uint8_t *truncated, int32_t *err, void *stream) {
-    int rc = check_spec(spec, batch, roll);
+    int rc = check_spec(spec, batch, roll, one_hot);
     if (rc) return rc;
-    if (steps < 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (steps < 0 || (roll && one_hot)) return MGX_ERR_INVALID_ARGUMENT;
     if (batch == 0 || steps == 0) return MGX_OK;
     if (!grid || !agents || !step_count || !actions || !obs || !reward || !terminated || !truncated)
         return MGX_ERR_INVALID_ARGUMENT;
@@ -193,20 +203,20 @@ static int step_common(bool roll, const MgxSpec *spec, int64_t batch, int32_t st
         ka.was_reset = ar->was_reset;
     }
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg, roll);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, roll, one_hot);
     if (rc) return rc;
     ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
     ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
     ka.T = roll ? steps : 1;
-    return launch(roll ? 2 : 1, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+    return launch(roll ? 2 : (one_hot ? 5 : 1), ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
 int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
              int32_t *step_count, const int8_t *actions, uint8_t *aux,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream) {
-    return step_common(false, spec, batch, 1, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(false, false, spec, batch, 1, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
                        terminated, truncated, err, stream);
 }
 
@@ -214,7 +224,7 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid
                 int32_t *step_count, const int8_t *actions, uint8_t *aux,
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream) {
-    return step_common(true, spec, batch, steps, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(true, false, spec, batch, steps, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
                        terminated, truncated, err, stream);
 }
 
@@ -223,7 +233,7 @@ int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *a
                        uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                        int32_t *err, void *stream) {
     if (!ar) return MGX_ERR_INVALID_ARGUMENT;
-    return step_common(false, spec, batch, 1, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(false, false, spec, batch, 1, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
                        terminated, truncated, err, stream);
 }
 
@@ -232,7 +242,15 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
                           uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                           int32_t *err, void *stream) {
     if (!ar) return MGX_ERR_INVALID_ARGUMENT;
-    return step_common(true, spec, batch, steps, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(true, false, spec, batch, steps, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+                       terminated, truncated, err, stream);
+}
+
+int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+                     uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                     uint8_t *obs_one_hot, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                     int32_t *err, void *stream) {
+    return step_common(false, true, spec, batch, 1, ar, grid, agents, rng, step_count, actions, aux, obs_one_hot, dir, reward,
                        terminated, truncated, err, stream);
 }
 

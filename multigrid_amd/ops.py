@@ -55,11 +55,12 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _gen_obs_into(sc: MgxSpecC, B, grid, agents, obs, dirs):
+def _gen_obs_into(sc: MgxSpecC, B, grid, agents, obs, dirs, one_hot: bool = False):
+    fn = _lib.lib().mgx_gen_obs_one_hot if one_hot else _lib.lib().mgx_gen_obs
     with torch.cuda.device(grid.device):
-        rc = _lib.lib().mgx_gen_obs(C.byref(sc), B, grid.data_ptr(), agents.data_ptr(), obs.data_ptr(),
-                                    dirs.data_ptr() if dirs is not None else None, _stream(grid.device))
-    _lib.check(rc, "mgx_gen_obs")
+        rc = fn(C.byref(sc), B, grid.data_ptr(), agents.data_ptr(), obs.data_ptr(),
+                dirs.data_ptr() if dirs is not None else None, _stream(grid.device))
+    _lib.check(rc, "mgx_gen_obs_one_hot" if one_hot else "mgx_gen_obs")
 
 
 def _step_into(sc: MgxSpecC, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
@@ -112,10 +113,10 @@ def _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err, T=Non
     return B
 
 
-def _alloc_outputs(sc, B, dev, T=None):
+def _alloc_outputs(sc, B, dev, T=None, channels=3):
     A, v = sc.num_agents, sc.view_size
     lead = (B,) if T is None else (T, B)
-    return (torch.empty(lead + (A, v, v, 3), dtype=torch.uint8, device=dev),
+    return (torch.empty(lead + (A, v, v, channels), dtype=torch.uint8, device=dev),
             torch.empty(lead + (A,), dtype=torch.uint8, device=dev),
             torch.empty(lead + (A,), dtype=torch.float64, device=dev),
             torch.empty(lead + (A,), dtype=torch.uint8, device=dev),
@@ -167,6 +168,43 @@ def _rollout_impl(grid, agents, rng, step_count, actions, aux, err, spec):
     return obs, dirs, reward, terminated, truncated
 
 
+def _gen_obs_one_hot_impl(grid, agents, spec):
+    sc = _spec_from_ints(spec)
+    B = _check_state(sc, grid, agents)
+    A, v = sc.num_agents, sc.view_size
+    obs = torch.empty((B, A, v, v, 21), dtype=torch.uint8, device=grid.device)
+    dirs = torch.empty((B, A), dtype=torch.uint8, device=grid.device)
+    _gen_obs_into(sc, B, grid, agents, obs, dirs, one_hot=True)
+    return obs, dirs
+
+
+def _step_one_hot_impl(grid, agents, rng, step_count, actions, aux, err, pool_grid, pool_agents, pool_aux, episode,
+                       first_env, spec):
+    """pool_grid None = no auto-reset (then pool_agents / pool_aux / episode are ignored)."""
+    sc = _spec_from_ints(spec)
+    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err)
+    dev = grid.device
+    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, dev, channels=21)
+    was_reset = torch.zeros((B,), dtype=torch.uint8, device=dev)
+    ar = None
+    if pool_grid is not None:
+        K = pool_grid.shape[0]
+        _want(pool_grid, "pool_grid", torch.uint8, (K, sc.height, sc.width, 3))
+        _want(pool_agents, "pool_agents", torch.uint8, (K, sc.num_agents, 8))
+        if pool_aux is not None:
+            _want(pool_aux, "pool_aux", torch.uint8, (K, 16))
+        _want(episode, "episode", torch.int32, (B,))
+        ar = C.byref(_lib.MgxAutoReset(int(first_env), K, pool_grid.data_ptr(), pool_agents.data_ptr(), _ptr(pool_aux),
+                                       episode.data_ptr(), was_reset.data_ptr()))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mgx_step_one_hot(
+            C.byref(sc), B, ar, grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
+            actions.data_ptr(), _ptr(aux), obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(),
+            truncated.data_ptr(), err.data_ptr(), _stream(dev))
+    _lib.check(rc, "mgx_step_one_hot")
+    return obs, dirs, reward, terminated, truncated, was_reset
+
+
 ONE_HOT_DIMS = (11, 6, 4)      # len(Type), len(Color), max(len(State), len(Direction))  (multigrid/wrappers.py:139-140)
 
 
@@ -213,6 +251,11 @@ _torch_lib.define(
 _torch_lib.define(
     "rollout(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
     "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_torch_lib.define("gen_obs_one_hot(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
+_torch_lib.define(
+    "step_one_hot(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+    "Tensor(f!)? aux, Tensor(e!) err, Tensor? pool_grid, Tensor? pool_agents, Tensor? pool_aux, Tensor(g!)? episode, "
+    "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
 _torch_lib.define("one_hot(Tensor cells, int[] dim_sizes) -> Tensor")
 _torch_lib.define("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor")
 _torch_lib.impl("one_hot", _one_hot_impl, "CUDA")
@@ -221,6 +264,8 @@ _torch_lib.impl("gen_obs", _gen_obs_impl, "CUDA")
 _torch_lib.impl("step", _step_impl, "CUDA")
 _torch_lib.impl("step_autoreset", _step_autoreset_impl, "CUDA")
 _torch_lib.impl("rollout", _rollout_impl, "CUDA")
+_torch_lib.impl("gen_obs_one_hot", _gen_obs_one_hot_impl, "CUDA")
+_torch_lib.impl("step_one_hot", _step_one_hot_impl, "CUDA")
 
 
 class HipBackend:
@@ -241,8 +286,8 @@ class HipBackend:
         self.sc = spec.to_c()
         self.device = device
 
-    def gen_obs(self, B, grid, agents, obs, dirs):
-        _gen_obs_into(self.sc, B, grid, agents, obs, dirs)
+    def gen_obs(self, B, grid, agents, obs, dirs, one_hot: bool = False):
+        _gen_obs_into(self.sc, B, grid, agents, obs, dirs, one_hot)
 
     @staticmethod
     def _auto_reset_struct(auto_reset):
@@ -253,20 +298,22 @@ class HipBackend:
                                  was_reset.data_ptr() if was_reset is not None else None)
 
     def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated,
-             auto_reset=None):
-        if auto_reset is None:
+             auto_reset=None, one_hot: bool = False):
+        """`one_hot`: `obs` is the u8[B,A,v,v,21] one-hot buffer (mgx_step_one_hot)."""
+        if auto_reset is None and not one_hot:
             _step_into(self.sc, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward,
                        terminated, truncated)
             return
-        ar = self._auto_reset_struct(auto_reset)
+        ar = self._auto_reset_struct(auto_reset) if auto_reset is not None else None
+        fn = _lib.lib().mgx_step_one_hot if one_hot else _lib.lib().mgx_step_autoreset
         with torch.cuda.device(grid.device):
-            rc = _lib.lib().mgx_step_autoreset(
-                C.byref(self.sc), B, C.byref(ar), grid.data_ptr(), agents.data_ptr(),
+            rc = fn(
+                C.byref(self.sc), B, C.byref(ar) if ar is not None else None, grid.data_ptr(), agents.data_ptr(),
                 rng.data_ptr() if rng is not None else None, step_count.data_ptr(), actions.data_ptr(),
                 target.data_ptr() if target is not None else None, obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(),
                 terminated.data_ptr(), truncated.data_ptr(), err.data_ptr() if err is not None else None,
                 _stream(grid.device))
-        _lib.check(rc, "mgx_step_autoreset")
+        _lib.check(rc, "mgx_step_one_hot" if one_hot else "mgx_step_autoreset")
 
     def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
                 truncated, auto_reset=None):
