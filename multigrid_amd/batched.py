@@ -53,6 +53,8 @@ class BatchedMultiGridEnv:
         self.terminated = torch.zeros((B, A), dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
         self._loaded = False
+        self._act_shape = torch.Size((B, A))
+        self._bound = {}                 # (auto_reset, one_hot) -> pre-bound step launcher (ops.HipBackend.bind_step)
 
     # ------------------------------------------------------------------------------------------ state in
     def load_state(self, grid, agents, rng=None, aux=None, step_count=None, validate: bool = True, target=None):
@@ -156,12 +158,21 @@ class BatchedMultiGridEnv:
         An unknown action value does not raise here (no device sync on the hot path); it is recorded in
         `err` and surfaced as ValueError by `check_errors()` (multigrid/base.py:473-474).
         """
-        self._need_state()
-        sp = self.spec
-        if actions.dtype != torch.int8 or tuple(actions.shape) != (self.batch, sp.num_agents) \
-                or actions.device != self.grid.device or not actions.is_contiguous():
-            raise ValueError(f"actions must be a contiguous int8 tensor of shape {(self.batch, sp.num_agents)} "
+        if not self._loaded:
+            self._need_state()
+        if actions.dtype is not torch.int8 or actions.shape != self._act_shape or actions.device != self.grid.device \
+                or not actions.is_contiguous():
+            raise ValueError(f"actions must be a contiguous int8 tensor of shape {tuple(self._act_shape)} "
                              f"on {self.grid.device}")
+        key = (bool(auto_reset), bool(one_hot))
+        fast = self._bound.get(key)
+        if fast is None:
+            fast = self._bind_step(*key)
+        if fast is not False:
+            fast(actions)
+            return (self._one_hot if one_hot else self.obs), self.dir, self.reward, self.terminated, self.truncated
+        # launchers without bind_step (the test-suite's oracle backend)
+        sp = self.spec
         ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
         kw = {}
         if ar is not None:
@@ -173,6 +184,20 @@ class BatchedMultiGridEnv:
                           self.aux if sp.env_kind != "empty" else None, self.err,
                           obs, self.dir, self.reward, self.terminated, self.truncated, **kw)
         return obs, self.dir, self.reward, self.terminated, self.truncated
+
+    def _bind_step(self, auto_reset: bool, one_hot: bool):
+        """Resolve every pointer of the step call once (ops.HipBackend.bind_step); False when the launcher cannot."""
+        bind = getattr(self.backend, "bind_step", None)
+        if bind is None:
+            self._bound[(auto_reset, one_hot)] = False
+            return False
+        ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
+        f = bind(self.batch, self.grid, self.agents, self.rng, self.step_count,
+                 self.aux if self.spec.env_kind != "empty" else None, self.err,
+                 self._one_hot_buffer() if one_hot else self.obs, self.dir, self.reward, self.terminated, self.truncated,
+                 auto_reset=ar, one_hot=one_hot)
+        self._bound[(auto_reset, one_hot)] = f
+        return f
 
     def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False) -> dict:
         """`T` consecutive `step`s in one kernel launch (env state stays in LDS between steps); bit-identical to
@@ -239,6 +264,7 @@ class BatchedMultiGridEnv:
         self._pool = (g.to(self.device).contiguous(), a.to(self.device).contiguous(), t)
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
         self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
+        self._bound.clear()              # (the pre-bound launchers hold the old pool's pointers)
 
     def reset_done(self) -> torch.Tensor:
         """Vector-env auto-reset (build-defined; the reference leaves `if env.is_done(): env.reset()` to its caller):

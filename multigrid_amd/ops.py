@@ -315,6 +315,36 @@ class HipBackend:
                 _stream(grid.device))
         _lib.check(rc, "mgx_step_one_hot" if one_hot else "mgx_step_autoreset")
 
+    def bind_step(self, B, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
+                  auto_reset=None, one_hot: bool = False):
+        """Pre-bound launcher for a policy-in-the-loop caller: every pointer except `actions` is resolved once, so a call
+        costs one ctypes transition + the kernel launch.  The tensors must stay alive and in place (they are the env's
+        own buffers).  Returns f(actions) enqueuing one step on torch's current stream."""
+        L = _lib.lib()
+        ar = self._auto_reset_struct(auto_reset) if auto_reset is not None else None
+        if ar is None and not one_hot:
+            fn, head, what = L.mgx_step, (C.byref(self.sc), B), "mgx_step"
+        else:
+            fn = L.mgx_step_one_hot if one_hot else L.mgx_step_autoreset
+            head, what = (C.byref(self.sc), B, C.byref(ar) if ar is not None else None), fn.__name__
+        pre = (grid.data_ptr(), agents.data_ptr(), rng.data_ptr() if rng is not None else None, step_count.data_ptr())
+        post = (target.data_ptr() if target is not None else None, obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(),
+                terminated.data_ptr(), truncated.data_ptr(), err.data_ptr() if err is not None else None)
+        dev, index = grid.device, grid.device.index
+        keep = (ar, self.sc)                                 # the structs the byref()s point into
+        current_device, current_stream, device_ctx = torch.cuda.current_device, torch.cuda.current_stream, torch.cuda.device
+
+        def step(actions):
+            if current_device() == index:
+                rc = fn(*head, *pre, actions.data_ptr(), *post, current_stream(dev).cuda_stream)
+            else:
+                with device_ctx(dev):
+                    rc = fn(*head, *pre, actions.data_ptr(), *post, current_stream(dev).cuda_stream)
+            if rc:
+                _lib.check(rc, what)
+        step._keep = keep
+        return step
+
     def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
                 truncated, auto_reset=None):
         args = (grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),

@@ -25,7 +25,9 @@ for t in range(W + N):
     env.step(acts[t & 3], auto_reset=bench.AUTO_RESET)
 for t in range(W + N):
     env.gen_obs()
-if os.environ.get("MGX_ONE_HOT"):
+if os.environ.get("MGX_ONE_HOT_STEP"):          # the step with fused one-hot output, and the standalone one-hot kernel
+    for t in range(W + N):
+        env.step(acts[t & 3], auto_reset=bench.AUTO_RESET, one_hot=True)
     for t in range(W + N):
         env.one_hot_obs()
 torch.cuda.synchronize()
