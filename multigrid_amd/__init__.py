@@ -9,12 +9,12 @@ from .spec import EnvSpec  # noqa: F401
 from .batched import BatchedMultiGridEnv  # noqa: F401
 
 __all__ = ["Action", "Color", "Direction", "State", "Type", "EnvSpec", "BatchedMultiGridEnv"]
-from .env import MultiGridEnv  # noqa: F401,E402
+from .env import Agent, MultiGridEnv  # noqa: F401,E402
 from .envs import (CONFIGURATIONS, BlockedUnlockPickupEnv, EmptyEnv, LockedHallwayEnv, PlaygroundEnv,  # noqa: F401,E402
                    RedBlueDoorsEnv, make, spec_for)
 from .rllib import RLlibWrapper, to_rllib_env  # noqa: F401,E402
 
-__all__ += ["MultiGridEnv", "CONFIGURATIONS", "BlockedUnlockPickupEnv", "EmptyEnv", "LockedHallwayEnv", "PlaygroundEnv",
+__all__ += ["Agent", "MultiGridEnv", "CONFIGURATIONS", "BlockedUnlockPickupEnv", "EmptyEnv", "LockedHallwayEnv", "PlaygroundEnv",
             "RedBlueDoorsEnv", "make", "spec_for",
             "RLlibWrapper", "to_rllib_env"]
 from .wrappers import FullyObsWrapper, ImgObsWrapper, OneHotObsWrapper, SingleAgentWrapper  # noqa: F401,E402

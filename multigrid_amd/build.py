@@ -32,6 +32,7 @@ SRCS = sorted({u[1] for u in UNITS})
 DEPS = SRCS + [os.path.join(CSRC, "mgx_fused.h"), os.path.join(CSRC, "mgx_rules.h"), os.path.join(ROOT, "include", "mgx.h")]
 LIB = os.path.join(HERE, "lib", "libmgx.so")
 LIB_DBG = os.path.join(HERE, "lib", "libmgx_dbg.so")
+LIB_CHK = os.path.join(HERE, "lib", "libmgx_chk.so")
 ARCH = "gfx950"
 
 
@@ -101,10 +102,18 @@ def build_debug_lib(force: bool = False, verbose: bool = False, extra_defines=()
     return build_lib(force, verbose, LIB_DBG, ("MGX_DEBUG_KNOBS=1", *extra_defines))
 
 
+def build_checked_lib(force: bool = False, verbose: bool = False) -> str:
+    """lib/libmgx_chk.so: every computed LDS address of the fused kernel asserted inside its wavefront's slice
+    (-DMGX_BOUNDS_CHECK=1); tests/test_checked_build.py runs the soak on it."""
+    return build_lib(force, verbose, LIB_CHK, ("MGX_BOUNDS_CHECK=1",))
+
+
 if __name__ == "__main__":
     force, verbose = "--force" in sys.argv, True
     extra = tuple(a[2:] for a in sys.argv[1:] if a.startswith("-D"))
-    if "--debug-knobs" in sys.argv:
+    if "--checked" in sys.argv:
+        print(build_checked_lib(force, verbose))
+    elif "--debug-knobs" in sys.argv:
         print(build_debug_lib(force, verbose, extra))
     else:
         print(build_lib(force, verbose))

@@ -69,6 +69,7 @@ struct KernelArgs {
     const uint8_t *pool_aux;
     int32_t *episode;
     uint8_t *was_reset;
+    int32_t *bounds;    // -DMGX_BOUNDS_CHECK=1 builds: [0] += LDS accesses outside the wavefront's slice, [1] = last site id
 };
 
 // gfx950's LDS does take a dword / short access at any byte address (hipcc emits one ds_read_b32 for an align-1 load),
@@ -95,6 +96,27 @@ struct KernelArgs {
 #define MGX_DBG(bits) (a.dbg & (bits))
 #else
 #define MGX_DBG(bits) 0
+#endif
+
+// -DMGX_BOUNDS_CHECK=1 (the checked build, `python -m multigrid_amd.build --checked` -> lib/libmgx_chk.so; SURVEY.md
+// section 5 "LDS bounds asserts"): every computed LDS address of the fused kernel is tested against the wavefront's own
+// slice [slice, slice + wave_lds) before it is used; violations are counted in KernelArgs::bounds and read back with
+// mgx_debug_bounds_violations().  The product library has none of it.
+#ifndef MGX_BOUNDS_CHECK
+#define MGX_BOUNDS_CHECK 0
+#endif
+#if MGX_BOUNDS_CHECK
+#define MGX_CHECK_LDS_ADDR(site, addr, bytes)                                                              \
+    do {                                                                                                   \
+        const uint32_t a_ = (uint32_t)(addr), lo_ = (uint32_t)(wave * a.wave_lds);                         \
+        if (a_ < lo_ || a_ + (uint32_t)(bytes) > lo_ + (uint32_t)a.wave_lds) {                             \
+            atomicAdd(a.bounds, 1); a.bounds[1] = (site);                                                  \
+        }                                                                                                  \
+    } while (0)
+#define MGX_CHECK_LDS_PTR(site, ptr, bytes) MGX_CHECK_LDS_ADDR(site, (uint32_t)(uintptr_t)(lds_u32_ptr)(const void *)(ptr) - (uint32_t)(uintptr_t)(lds_u32_ptr)(const void *)lds, bytes)
+#else
+#define MGX_CHECK_LDS_ADDR(site, addr, bytes) ((void)0)
+#define MGX_CHECK_LDS_PTR(site, ptr, bytes) ((void)0)
 #endif
 
 // A kernel argument fetched where it is used (s_load from the kernarg segment) instead of living in SGPRs from the
@@ -281,7 +303,7 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 // shows the grid here; lane s patches the carried object in afterwards (P3: its see-behind bit, P4: its bytes).
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
 template <int V, int NW, int S0, int N, int VPW>
-__device__ __forceinline__ void gather_group(const uint32_t wall_addr, const ViewRec *rec,
+__device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave, const uint32_t wall_addr, const ViewRec *rec,
                                              const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
                                              const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                              uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
@@ -310,6 +332,7 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
             // wavefront's WALL cell instead (obs.py:199-202)
             const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
             const uint32_t addr = inb[n][it] ? (uint32_t)off : wall_addr;
+            if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr & ~3u, 8);
 #if MGX_UA_READ
             raw[n][it] = *(lds_u32_ua_ptr)(uintptr_t)addr;                  // one unaligned ds_read_b32: cell + a junk byte
 #else
@@ -345,14 +368,14 @@ __device__ __forceinline__ void gather_group(const uint32_t wall_addr, const Vie
 constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as one straight-line block
 
 template <int V, int NW, int VPW, int S0 = 0>
-__device__ __forceinline__ void gather_all(int NVc, const uint32_t wall_addr, const ViewRec *rec,
+__device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, int NVc, const uint32_t wall_addr, const ViewRec *rec,
                                            const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
-        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW>(wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
-        gather_all<V, NW, VPW, S0 + kGroup>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW>(a, wave, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, S0 + kGroup>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     }
 }
 
@@ -509,7 +532,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (lane16 + 1024 * u < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
+        if (lane16 + 1024 * u < len) {
+            MGX_CHECK_LDS_PTR(1, tile_raw + lane16 + 1024 * u, 16);
+            *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
+        }
     if (big_tile) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -646,6 +672,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
         AgentEval ev{};
         uint8_t *mytile = tile + env_of_lane * HW3;
+        if (in) MGX_CHECK_LDS_PTR(2, mytile, HW3);
         if (in && !MGX_DBG(64)) {
             const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
                                ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
@@ -768,7 +795,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (ROLL && ovl >= 0) ovl_saved = load_cell(mytile + ovl);
         ovl_off = ovl;
         wave_sync();
-        if (ovl >= 0) store_cell(mytile + ovl, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
+        if (ovl >= 0) {
+            MGX_CHECK_LDS_PTR(3, mytile + ovl, 3);
+            store_cell(mytile + ovl, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
+        }
     } else {
         const int off = (lane < NVc) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
         wave_sync();
@@ -827,7 +857,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
     for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
-    if (!MGX_DBG(4)) gather_all<V, NW, VPW>(NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+    if (!MGX_DBG(4)) gather_all<V, NW, VPW>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
         if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
@@ -882,6 +912,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
                                     const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
+                                    MGX_CHECK_LDS_PTR(7, d0 + sl * V2, 4);
                                     d0[sl * V2] = one_hot_mask(c);
                                 }
                             }
@@ -904,6 +935,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                     const uint32_t xs = (uint32_t)(rel - oh_skew + D);
                     const uint32_t cq = __umulhi(xs, kInvD);                    // cell + 1
                     const uint32_t k0 = xs - cq * D;                            // first bit inside that cell: 0..20
+                    MGX_CHECK_LDS_PTR(8, masks + (int)cq - 1, 8);
                     const uint32_t bits = (masks[(int)cq - 1] >> k0) | (masks[(int)cq] << (D - k0));   // >= 22 valid bits
                     u32x4 v;
                     v.x = (((bits >> 0) & 0xfu) * 0x00204081u) & 0x01010101u;   // 4 bits -> 4 bytes of 0/1
@@ -952,6 +984,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
                                     const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
                                     uint8_t *d = d0 + sl * (V2 * 3);
+                                    MGX_CHECK_LDS_PTR(5, d, 3);
 #if MGX_UA_WRITE
                                     *reinterpret_cast<u16_unaligned *>(d) = (uint16_t)c;    // ds_write_b16 at any byte address
                                     d[2] = (uint8_t)(c >> 16);                              // ds_write_b8_d16_hi
@@ -979,6 +1012,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #pragma unroll
                 for (int k = 0; k < kPasses; ++k) {
                     const int rel = lane16 + 1024 * k;
+                    if (rel < rlen) MGX_CHECK_LDS_PTR(6, out_raw + rel, 16);
                     if ((rel + 16 <= rlen) & (rel >= out_skew)) {
 #if MGX_BUF_STORE
                         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), orsrc, rel, 0, MGX_OBS_AUX);

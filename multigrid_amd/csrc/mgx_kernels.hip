@@ -43,7 +43,19 @@ int g_debug_wpb = 0;
 constexpr int g_debug_skip = 0, g_debug_G = 0, g_debug_wpb = 0;
 #endif
 
-int launch(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
+#if MGX_BOUNDS_CHECK
+int32_t *g_bounds = nullptr;        // device: [0] violations, [1] last site (checked build only; allocated on first launch)
+#endif
+
+int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
+    KernelArgs ka = ka_in;
+#if MGX_BOUNDS_CHECK
+    if (!g_bounds) {
+        if (hipMalloc(reinterpret_cast<void **>(&g_bounds), 8) != hipSuccess) return MGX_ERR_LAUNCH;
+        if (hipMemset(g_bounds, 0, 8) != hipSuccess) return MGX_ERR_LAUNCH;
+    }
+    ka.bounds = g_bounds;
+#endif
     switch (ka.sp.view_size) {
 #define MGX_CASE(V) case V: return launch_v##V(mode, ka, threads, lds_bytes, nwg, stream, &g_last_hip_error);
     MGX_FOR_EACH_VIEW(MGX_CASE)
@@ -118,6 +130,17 @@ int mgx_last_hip_error(void) { return g_last_hip_error; }
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
+#endif
+#if MGX_BOUNDS_CHECK
+// Checked build only: LDS accesses of the fused kernel that fell outside their wavefront's slice since the last call
+// (out[0]) and the site id of the last one (out[1]); synchronises the device.  Returns 0, or -1 on a HIP error.
+int mgx_debug_bounds_violations(int32_t *out2) {
+    out2[0] = out2[1] = 0;
+    if (!g_bounds) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(out2, g_bounds, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return hipMemset(g_bounds, 0, 8) == hipSuccess ? 0 : -1;
+}
 #endif
 #if MGX_TIMESTAMPS
 int mgx_debug_read_span(unsigned long long *out, int nwaves) {            // [nwaves][2] of the last launch

@@ -26,15 +26,19 @@ from .spaces import Box, Dict, Discrete
 from .spec import EnvSpec
 
 
-class AgentView:
-    """Read-only view of one agent, with the attribute names of `multigrid.core.agent.Agent` (agent.py:22-167)."""
+class Agent:
+    """One agent, with the constructor and attribute names of `multigrid.core.agent.Agent` (agent.py:22-167).  Built by the
+    env for `agents=<int>`, or by the caller and handed over as `agents=[Agent(0), Agent(1), ...]` (base.py:170-177).
+    Inside an env its `state` is a read-only view of the env's device-resident agent row."""
 
-    def __init__(self, env: "MultiGridEnv", index: int, mission_space: MissionSpace, view_size: int,
-                 see_through_walls: bool):
+    def __init__(self, index: int, mission_space: MissionSpace | str = "maximize reward", view_size: int = 7,
+                 see_through_walls: bool = False, *, _env: "MultiGridEnv | None" = None):
         # multigrid/core/agent.py:78-79
         assert view_size % 2 == 1
         assert view_size >= 3
-        self._env = env
+        if isinstance(mission_space, str):
+            mission_space = MissionSpace.from_string(mission_space)
+        self._env = _env
         self.index = index
         self.view_size = view_size
         self.see_through_walls = see_through_walls
@@ -49,6 +53,8 @@ class AgentView:
     @property
     def state(self) -> np.ndarray:
         """(9,) int row: [type, color, dir, x, y, terminated, carry_type, carry_color, carry_state]."""
+        if self._env is None:                                    # not in an env yet: a fresh AgentState row (agent.py:234-254)
+            return layouts._fresh_agents(self.index + 1)[self.index]
         return self._env.agent_states[self.index]
 
     @property
@@ -83,6 +89,9 @@ class AgentView:
     def encode(self) -> tuple[int, int, int]:
         s = self.state
         return (int(Type.agent), int(s[1]), int(s[2]))
+
+
+AgentView = Agent          # (round-1 name)
 
 
 class GridView:
@@ -142,8 +151,16 @@ class MultiGridEnv:
         entropy)."""
         if render_mode is not None:
             raise NotImplementedError("rendering is out of scope for multigrid_amd (SURVEY.md section 2)")
-        if not isinstance(agents, int):
-            raise ValueError(f"Invalid argument for agents: {agents}")        # base.py:176-177 (int form only)
+        given_agents = None
+        if not isinstance(agents, int):                                       # base.py:170-177: an iterable of Agent objects
+            try:
+                given_agents = sorted(agents, key=lambda agent: agent.index)
+            except (TypeError, AttributeError):
+                raise ValueError(f"Invalid argument for agents: {agents}")
+            assert {agent.index for agent in given_agents} == set(range(len(given_agents)))
+            agents = len(given_agents)
+            # gen_obs renders every agent with agents[0]'s view (base.py:364-365)
+            agent_view_size, see_through_walls = given_agents[0].view_size, given_agents[0].see_through_walls
         self.mission_space = (MissionSpace.from_string(mission_space) if isinstance(mission_space, str)
                               else mission_space)
         width, height = (grid_size, grid_size) if grid_size else (width, height)
@@ -164,8 +181,13 @@ class MultiGridEnv:
         self.render_mode = None
         self.actions = Action
         self.reward_range = (0, 1)
-        self.agents = [AgentView(self, i, self.mission_space, agent_view_size, see_through_walls)
-                       for i in range(agents)]
+        if given_agents is None:
+            self.agents = [Agent(i, self.mission_space, agent_view_size, see_through_walls, _env=self)
+                           for i in range(agents)]
+        else:
+            self.agents = given_agents
+            for agent in self.agents:
+                agent._env = self                                             # agent.state now views the joint state
         self.grid = GridView(self)
         self.mission: Mission | str | None = None
         if callable(_backend):

@@ -38,7 +38,14 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        if os.environ.get("MGX_SANITIZE") == "1":           # tests/test_checked_build.py: the oracle under ASan + UBSan
+            out = os.path.join(os.environ.get("MGX_SANITIZE_DIR", "/tmp"), "libmgx_oracle_san.so")
+            subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-std=c11",
+                                   "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", out,
+                                   os.path.join(HERE, "mgx_oracle.c")])
+            _lib = C.CDLL(out)
+        else:
+            _lib = C.CDLL(build())
         _lib.mgo_max_threads.restype = C.c_int
         for name in ("mgo_gen_obs_ref", "mgo_step_ref", "mgo_step_batch", "mgo_gen_obs_batch"):
             getattr(_lib, name).restype = C.c_int

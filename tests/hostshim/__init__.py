@@ -16,6 +16,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        if os.environ.get("MGX_SANITIZE") == "1":           # tests/test_checked_build.py: ASan + UBSan build, kept elsewhere
+            out = os.path.join(os.environ.get("MGX_SANITIZE_DIR", "/tmp"), "libmgx_hostshim_san.so")
+            subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+                                   "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", out, SRC])
+            _lib = C.CDLL(out)
+            return _lib
         if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(RULES)):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
                                    "-o", LIB, SRC])

@@ -259,3 +259,27 @@ def test_seed_streams_do_not_alias_across_seeds_or_shards():
     np.testing.assert_array_equal(words(0, 3, 3), w0[3:])                       # a function of the global env index
     from multigrid_amd import rng as rnglib
     np.testing.assert_array_equal(w0[0].view(np.uint64), rnglib.words_from_seed(0))   # env 0 == gym reset(seed=0)
+
+
+def test_agents_given_as_agent_objects():
+    """MultiGridEnv(agents=[Agent(...), ...]) (multigrid/base.py:170-177): sorted by index, agents[0]'s view applies to all
+    (base.py:364-365), and the trajectory equals the agents=<int> env's."""
+    from multigrid_amd.envs import EmptyEnv
+    a = [mg.Agent(1, view_size=5), mg.Agent(0, view_size=5), mg.Agent(2, view_size=7)]
+    assert a[0].state.shape == (9,) and a[0].pos == (-1, -1)            # detached: a fresh AgentState row
+    e1 = EmptyEnv(size=8, agents=a, _backend=lambda spec: util.OracleBackend(spec), device="cpu")
+    e2 = EmptyEnv(size=8, agents=3, agent_view_size=5, _backend=lambda spec: util.OracleBackend(spec), device="cpu")
+    assert [ag.index for ag in e1.agents] == [0, 1, 2] and e1.num_agents == 3 and e1.agents[1] is a[0]
+    o1, _ = e1.reset(seed=4); o2, _ = e2.reset(seed=4)
+    for t in range(10):
+        acts = {i: (t + i) % 7 for i in range(3)}
+        r1, r2 = e1.step(acts), e2.step(acts)
+        for i in range(3):
+            np.testing.assert_array_equal(r1[0][i]["image"], r2[0][i]["image"])
+            assert r1[0][i]["image"].shape == (5, 5, 3)
+        assert r1[1] == r2[1] and r1[2] == r2[2]
+    assert e1.agents[2].pos == e2.agents[2].pos and a[2].state.tolist() == e2.agents[2].state.tolist()
+    with pytest.raises(AssertionError):
+        EmptyEnv(size=8, agents=[mg.Agent(0), mg.Agent(2)], device="cpu", _backend=lambda spec: util.OracleBackend(spec))
+    with pytest.raises(ValueError):
+        EmptyEnv(size=8, agents="two", device="cpu", _backend=lambda spec: util.OracleBackend(spec))

@@ -92,7 +92,19 @@ while time.time() < t_end:
                 or e.step_count.cpu().numpy().tobytes() != ref["step_count"].tobytes() \
                 or (A > 1 and e.rng.cpu().numpy().view(np.uint64).tobytes() != ref["rng"].tobytes()):
             print("MISMATCH final state", ctx); sys.exit(1)
+    # the fused one-hot output of the final state == one-hot of the plain observation
+    o_plain = env.gen_obs()[0].clone()
+    if env.gen_obs(one_hot=True)[0].cpu().numpy().tobytes() != ob.one_hot(o_plain.cpu().numpy()).tobytes():
+        print("MISMATCH one-hot gen_obs", ctx); sys.exit(1)
     env.check_errors(); roll.check_errors()
     n_case += 1; n_steps += T * B
     del env, roll
+from multigrid_amd import _lib  # noqa: E402
+if hasattr(_lib.lib(), "mgx_debug_bounds_violations"):            # the checked build (MGX_LIBMGX=.../libmgx_chk.so)
+    import ctypes
+    v = (ctypes.c_int32 * 2)()
+    assert _lib.lib().mgx_debug_bounds_violations(v) == 0
+    print(f"bounds check: {v[0]} LDS accesses outside their wavefront's slice (last site {v[1]})")
+    if v[0]:
+        sys.exit(1)
 print(f"fuzz ok: {n_case} random cases, {n_steps} env-steps, {budget:.0f} s, seed {seed0}")
