@@ -171,10 +171,14 @@ def step_roofline(wl_name, spec, B, ms_launch):
     return rf
 
 
-def config_point(name, device, K, warmup):
-    """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline."""
+def config_point(name, device, K, warmup, device_generated=False):
+    """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline.
+    device_generated: episode starts come from mgx_reset_generate (the reference's _gen_grid run on the device, one
+    launch in front of every step) instead of the host-made layout pool fused into the step launch."""
     wl = workloads.make(name)
     env = wl.make_env(device, auto_reset=AUTO_RESET)
+    if device_generated:
+        env.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6)
     m = measure_steps(env, K, warmup, "graph", lambda: None, seed=4321, min_region_ms=30.0)
     env.check_errors()
     B, A = wl.batch, wl.spec.num_agents
@@ -182,7 +186,9 @@ def config_point(name, device, K, warmup):
     out = {"workload": wl.title, "batch": B, "agents": A, "grid": f"{wl.spec.width}x{wl.spec.height}",
            "view_size": wl.spec.view_size, "ms_per_step": round(m["wall_s"] * 1e3 / m["timed_steps"], 6),
            "value": round(B * A * m["timed_steps"] / m["wall_s"]), "unit": "agent-steps/s",
-           "timed_steps": m["timed_steps"], "layout_pool": int(wl.pool[0].shape[0]),
+           "timed_steps": m["timed_steps"],
+           "layout_pool": "generated on the device (mgx_reset_generate + mgx_step: two launches per step)" if device_generated
+                          else int(wl.pool[0].shape[0]),
            "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,
            "launch": env.backend.launch_info(B), "roofline": step_roofline(name, wl.spec, B, ms)}
     del env
@@ -435,6 +441,7 @@ def main():
             del env
             torch.cuda.empty_cache()
             out["configs"] = {c: config_point(c, device, 256, 50) for c in ("c2", "c3", "c5") if c != name}
+            out["configs"]["c3_device_generated"] = config_point("c3", device, 256, 50, device_generated=True)
             out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}
             out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)
             out.update(large_batch_points(device, args.large_batch))

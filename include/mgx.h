@@ -177,6 +177,36 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
                           uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                           int32_t *err, void *stream);
 
+/* On-device episode starts.  Every env whose episode is over (the mgx_reset_done test) is
+ * re-initialised by running the reference's own generation ON THE DEVICE, one lane per env, draw for draw:
+ * Agent.reset + _gen_grid of multigrid/base.py:250-301 with place_obj / place_agent (base.py:604-697), RoomGrid's
+ * place_in_room / reject_next_to / place_agent (multigrid/core/roomgrid.py:45-50, 238-259, 376-404) and numpy's
+ * Generator(PCG64).integers (Lemire's method over PCG64's buffered 32-bit outputs).  Two generators per env, as in the
+ * reference (its placement draws come from a construction-time generator, only Room.set_door_pos uses env.np_random,
+ * roomgrid.py:104-106):
+ *   gen_state u64[B,6]  [0..3] = the placement generator's PCG64 state (state_lo, state_hi, inc_lo, inc_hi),
+ *                       [4] = its 32-bit buffer (has_uint32 << 32 | uinteger), [5] = the 32-bit buffer of env.np_random,
+ *                       whose PCG64 words are the `rng` tensor of mgx_step.  In/out.
+ *   blank     u8[H,W,3] the grid before any object or agent is placed: the rooms' walls (RoomGrid, roomgrid.py:203-218),
+ *                       or border walls + goal (EmptyEnv, multigrid/envs/empty.py:156-162)
+ * Kinds:  MGX_GEN_EMPTY_FIXED          EmptyEnv with agent_start_pos / agent_start_dir (empty.py:164-167): no draws
+ *         MGX_GEN_EMPTY_RANDOM         EmptyEnv with agent_start_pos=None: place_agent over the whole grid (empty.py:168-169)
+ *         MGX_GEN_BLOCKEDUNLOCKPICKUP  multigrid/envs/blockedunlockpickup.py:142-164 (room_size; also writes aux[0..2])
+ * Given generators in the same state the result is byte-identical to the reference's reset() (pinned through
+ * multigrid_amd/layouts.py and the reference's reset fixtures).  step_count := 0, episode += 1, was_reset (may be NULL). */
+enum { MGX_GEN_EMPTY_FIXED = 0, MGX_GEN_EMPTY_RANDOM = 1, MGX_GEN_BLOCKEDUNLOCKPICKUP = 2 };
+
+typedef struct MgxLayoutGen {
+    int32_t kind;
+    int32_t room_size;                    /* MGX_GEN_BLOCKEDUNLOCKPICKUP */
+    int32_t start_x, start_y, start_dir;  /* MGX_GEN_EMPTY_FIXED */
+    const uint8_t *blank;
+    uint64_t *gen_state;
+} MgxLayoutGen;
+
+int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
+                       uint64_t *rng, int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream);
+
 /* The step / gen_obs with the observation written ONE-HOT encoded: what OneHotObsWrapper.one_hot
  * (multigrid/wrappers.py:158-190, dim sizes (11, 6, 4)) makes of obs['image'], fused into the same launch -- the
  * wrapper RLlib registration applies to every env (multigrid/rllib/__init__.py:110-111).  Bit-identical to

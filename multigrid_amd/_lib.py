@@ -23,7 +23,8 @@ OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -
 #: every symbol include/mgx.h declares
 EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
            "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout", "mgx_step_autoreset",
-           "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot")
+           "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
+           "mgx_reset_generate")
 
 
 class MgxLaunchInfo(C.Structure):
@@ -35,6 +36,15 @@ class MgxAutoReset(C.Structure):
     """include/mgx.h: struct MgxAutoReset."""
     _fields_ = [("first_env", C.c_int64), ("pool_size", C.c_int32), ("pool_grid", C.c_void_p),
                 ("pool_agents", C.c_void_p), ("pool_aux", C.c_void_p), ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
+
+
+class MgxLayoutGen(C.Structure):
+    """include/mgx.h: struct MgxLayoutGen."""
+    _fields_ = [("kind", C.c_int32), ("room_size", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
+                ("start_dir", C.c_int32), ("blank", C.c_void_p), ("gen_state", C.c_void_p)]
+
+
+GEN_KINDS = {"empty_fixed": 0, "empty_random": 1, "blockedunlockpickup": 2}
 
 
 class MgxError(RuntimeError):
@@ -80,6 +90,8 @@ def lib() -> C.CDLL:
     L.mgx_full_obs.argtypes = [C.POINTER(MgxSpecC), i64, vp, vp, vp, vp]
     L.mgx_reset_done.restype = C.c_int
     L.mgx_reset_done.argtypes = [C.POINTER(MgxSpecC), i64, i64, C.c_int32] + [vp] * 10
+    L.mgx_reset_generate.restype = C.c_int
+    L.mgx_reset_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen)] + [vp] * 8
     L.mgx_launch_info.restype = C.c_int
     L.mgx_launch_info.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLaunchInfo)]
     if L.mgx_abi_version() != ABI_VERSION:

@@ -164,6 +164,9 @@ class BatchedMultiGridEnv:
                 or not actions.is_contiguous():
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {tuple(self._act_shape)} "
                              f"on {self.grid.device}")
+        if auto_reset and getattr(self, "_gen", None) is not None:      # on-device generation: its own launch, then the step
+            self.reset_done()
+            auto_reset = False
         key = (bool(auto_reset), bool(one_hot))
         fast = self._bound.get(key)
         if fast is None:
@@ -261,10 +264,41 @@ class BatchedMultiGridEnv:
             t = t.to(self.device).contiguous()
         elif sp.env_kind != "empty":
             raise ValueError(f"env_kind {sp.env_kind!r} needs per-layout aux")
+        self._gen = None
         self._pool = (g.to(self.device).contiguous(), a.to(self.device).contiguous(), t)
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
         self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
         self._bound.clear()              # (the pre-bound launchers hold the old pool's pointers)
+
+    def set_layout_generator(self, kind: str, layout_seed: int = 0, *, room_size: int = 0, start=(1, 1, 0)):
+        """Episode starts generated ON THE DEVICE (mgx_reset_generate) instead of picked from a host-made pool: every
+        finished env runs the reference's own `_gen_grid` (rejection-sampling placement with numpy-compatible draws) in a
+        kernel, one lane per env.
+
+        kind         'empty_fixed' (EmptyEnv, agents at `start` = (x, y, dir)), 'empty_random' (EmptyEnv with
+                     agent_start_pos=None) or 'blockedunlockpickup' (`room_size`)
+        layout_seed  seeds every env's placement generator: Generator(PCG64(SeedSequence([layout_seed, global index])))
+        `reset_done()` and `step(auto_reset=True)` then use the generator (the latter as two launches: generate + step).
+        """
+        sp = self.spec
+        if kind == "blockedunlockpickup":
+            if sp.env_kind != "blockedunlockpickup" or (sp.width, sp.height) != (2 * room_size - 1, room_size):
+                raise ValueError("blockedunlockpickup generator: the spec must be a BlockedUnlockPickup grid of (2*room_size-1) x room_size")
+            blank = layouts.roomgrid_blank(room_size, 1, 2)
+        elif kind in ("empty_fixed", "empty_random"):
+            if sp.env_kind != "empty" or sp.width != sp.height:
+                raise ValueError("empty generator: the spec must be a square Empty grid")
+            blank = layouts.empty_blank(sp.width)
+        else:
+            raise ValueError(f"unknown layout generator {kind!r}")
+        idx = self.first_env + np.arange(self.batch)
+        self._gen = {"kind": kind, "room_size": int(room_size), "start": tuple(int(v) for v in start),
+                     "blank": torch.from_numpy(blank).to(self.device).contiguous(),
+                     "gen_state": torch.from_numpy(rnglib.layout_gen_state(layout_seed, idx).view(np.int64)).to(self.device)}
+        self._pool = None
+        self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
+        self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
+        self._bound.clear()
 
     def reset_done(self) -> torch.Tensor:
         """Vector-env auto-reset (build-defined; the reference leaves `if env.is_done(): env.reset()` to its caller):
@@ -272,8 +306,12 @@ class BatchedMultiGridEnv:
         running as an unseeded `reset()` does.  Returns was_reset u8[B].  Observations of the restarted envs are
         produced by the next `gen_obs()` / `step()`."""
         self._need_state()
+        if getattr(self, "_gen", None) is not None:
+            self.backend.reset_generate(self.batch, self._gen, self.grid, self.agents, self.rng, self.step_count,
+                                        self.aux if self.spec.env_kind != "empty" else None, self.episode, self.was_reset)
+            return self.was_reset
         if getattr(self, "_pool", None) is None:
-            raise RuntimeError("call set_layout_pool() first")
+            raise RuntimeError("call set_layout_pool() or set_layout_generator() first")
         self.backend.reset_done(self.batch, self.first_env, self._pool, self.grid, self.agents, self.step_count,
                                 self.aux, self.episode, self.was_reset)
         return self.was_reset
@@ -303,6 +341,11 @@ class BatchedMultiGridEnv:
               "grid": self.grid.cpu().clone(), "agents": self.agents.cpu().clone(),
               "rng": self.rng.cpu().clone(), "step_count": self.step_count.cpu().clone(),
               "aux": self.aux.cpu().clone()}
+        if getattr(self, "_gen", None) is not None:
+            sd["generator"] = {"kind": self._gen["kind"], "room_size": self._gen["room_size"], "start": self._gen["start"],
+                               "gen_state": self._gen["gen_state"].cpu().clone()}
+            sd["episode"] = self.episode.cpu().clone()
+            sd["was_reset"] = self.was_reset.cpu().clone()
         if getattr(self, "_pool", None) is not None:
             pg, pa, pt = self._pool
             sd["pool"] = {"grid": pg.cpu().clone(), "agents": pa.cpu().clone(),
@@ -318,6 +361,12 @@ class BatchedMultiGridEnv:
             raise ValueError(f"state_dict was saved for the shard starting at env {sd['first_env']}, this one starts "
                              f"at {self.first_env} (layout choice and seeds are functions of the global env index)")
         self.load_state(sd["grid"], sd["agents"], sd["rng"], sd["aux"], sd["step_count"], validate=True)
+        if sd.get("generator") is not None:
+            g = sd["generator"]
+            self.set_layout_generator(g["kind"], 0, room_size=g["room_size"], start=g["start"])
+            self._gen["gen_state"].copy_(g["gen_state"])
+            self.episode.copy_(sd["episode"])
+            self.was_reset.copy_(sd["was_reset"])
         if sd.get("pool") is not None:
             p = sd["pool"]
             self.set_layout_pool(p["grid"].numpy(), p["agents"].numpy(), p["aux"].numpy() if p["aux"] is not None else None)

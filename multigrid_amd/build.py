@@ -26,7 +26,8 @@ CSRC = os.path.join(HERE, "csrc")
 VIEWS = (3, 5, 7, 9, 11, 13, 15)
 #: translation units: (object name, source, extra defines).  The fused kernel is instantiated in one unit per view size so
 #: that the units compile in parallel (a single unit took a minute).
-UNITS = ([("mgx_kernels", os.path.join(CSRC, "mgx_kernels.hip"), ()), ("mgx_aux", os.path.join(CSRC, "mgx_aux.hip"), ())]
+UNITS = ([("mgx_kernels", os.path.join(CSRC, "mgx_kernels.hip"), ()), ("mgx_aux", os.path.join(CSRC, "mgx_aux.hip"), ()),
+          ("mgx_layout_gen", os.path.join(CSRC, "mgx_layout_gen.hip"), ())]
          + [(f"mgx_fused_v{v}", os.path.join(CSRC, "mgx_fused_inst.hip"), (f"MGX_INST_V={v}",)) for v in VIEWS])
 SRCS = sorted({u[1] for u in UNITS})
 DEPS = SRCS + [os.path.join(CSRC, "mgx_fused.h"), os.path.join(CSRC, "mgx_rules.h"), os.path.join(ROOT, "include", "mgx.h")]

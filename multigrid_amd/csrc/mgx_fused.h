@@ -84,6 +84,9 @@ struct KernelArgs {
 #ifndef MGX_LATE_ARGS
 #define MGX_LATE_ARGS 1
 #endif
+#ifndef MGX_P4_B16
+#define MGX_P4_B16 1
+#endif
 #ifndef MGX_BUF_STORE
 #define MGX_BUF_STORE 1
 #endif
@@ -971,6 +974,15 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 for (int it = 0; it < NW; ++it) {
                     if (lc.act[it]) {
                         uint8_t *d0 = outb + lc.q3[it];
+#if MGX_P4_B16
+                        // A cell's 3 bytes go out as one ALIGNED 2-byte store + one byte store (an LDS store costs the same
+                        // VGPR -> LDS transfer whatever its width, so 2 stores instead of 3).  A view is an odd number of
+                        // bytes, so the parity of a cell's first byte alternates from slot to slot: even slots use [0], odd [1].
+                        const uint32_t par0 = (uint32_t)(out_skew + lc.q3[it]) & 1u;
+                        uint8_t *const d16[2] = {d0 + par0, d0 + (par0 ^ 1u)};                  // the 2-byte part: bytes 0-1 or 1-2
+                        uint8_t *const d8[2] = {d0 + 2u * (par0 ^ 1u), d0 + 2u * par0};         // the other byte: 2 or 0
+                        const uint32_t sh16[2] = {8u * par0, 8u * (par0 ^ 1u)}, sh8[2] = {16u * (par0 ^ 1u), 16u * par0};
+#endif
                         // whole groups of kGroup slots, like P2 (padding slots write junk into staging space that P5
                         // never copies): straight-line code whose readlane -> select -> write chains overlap
 #pragma unroll
@@ -983,9 +995,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
                                     const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
-                                    uint8_t *d = d0 + sl * (V2 * 3);
+                                    [[maybe_unused]] uint8_t *d = d0 + sl * (V2 * 3);
                                     MGX_CHECK_LDS_PTR(5, d, 3);
-#if MGX_UA_WRITE
+#if MGX_P4_B16
+                                    *reinterpret_cast<uint16_t *>(d16[sl & 1] + sl * (V2 * 3)) = (uint16_t)(c >> sh16[sl & 1]);
+                                    d8[sl & 1][sl * (V2 * 3)] = (uint8_t)(c >> sh8[sl & 1]);
+#elif MGX_UA_WRITE
                                     *reinterpret_cast<u16_unaligned *>(d) = (uint16_t)c;    // ds_write_b16 at any byte address
                                     d[2] = (uint8_t)(c >> 16);                              // ds_write_b8_d16_hi
 #else

@@ -150,6 +150,25 @@ def empty_layout(size: int, num_agents: int, agent_start_pos=(1, 1), agent_start
     return grid.to_product(), pack_agents(ag)
 
 
+def roomgrid_blank(room_size: int, num_rows: int, num_cols: int) -> np.ndarray:
+    """The walls of a RoomGrid before any object is placed (multigrid/core/roomgrid.py:203-218): u8[H,W,3].  The
+    template the on-device generator starts an episode from (mgx_reset_generate)."""
+    rs = room_size
+    grid = _Grid((rs - 1) * num_cols + 1, (rs - 1) * num_rows + 1)
+    for row in range(num_rows):
+        for col in range(num_cols):
+            grid.wall_rect(col * (rs - 1), row * (rs - 1), rs, rs)
+    return grid.to_product()
+
+
+def empty_blank(size: int) -> np.ndarray:
+    """EmptyEnv's grid before the agents are placed (multigrid/envs/empty.py:156-162): border walls + the goal."""
+    grid = _Grid(size, size)
+    grid.wall_rect(0, 0, size, size)
+    grid.set(size - 2, size - 2, GOAL_CELL)
+    return grid.to_product()
+
+
 # ---- multigrid/envs/blockedunlockpickup.py:142-164 ------------------------------------------------------
 def blockedunlockpickup_layout(room_size: int, num_agents: int, layout_rng, np_random):
     """Returns (grid u8[H,W,3], agents u8[A,8], target u8[4] = target box (type, color, state, 0))."""

@@ -375,5 +375,17 @@ class HipBackend:
                 _stream(grid.device))
         _lib.check(rc, "mgx_reset_done")
 
+    def reset_generate(self, B, gen, grid, agents, rng, step_count, aux, episode, was_reset):
+        """gen = dict(kind, room_size, start=(x, y, dir), blank u8[H,W,3], gen_state i64[B,6]) -- include/mgx.h MgxLayoutGen"""
+        sx, sy, sd = gen.get("start", (0, 0, 0))
+        g = _lib.MgxLayoutGen(_lib.GEN_KINDS[gen["kind"]], int(gen.get("room_size", 0)), int(sx), int(sy), int(sd),
+                              gen["blank"].data_ptr(), gen["gen_state"].data_ptr())
+        with torch.cuda.device(grid.device):
+            rc = _lib.lib().mgx_reset_generate(
+                C.byref(self.sc), B, C.byref(g), grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
+                aux.data_ptr() if aux is not None else None, episode.data_ptr(),
+                was_reset.data_ptr() if was_reset is not None else None, _stream(grid.device))
+        _lib.check(rc, "mgx_reset_generate")
+
     def launch_info(self, B) -> dict:
         return _lib.launch_info(self.spec, B)

@@ -73,3 +73,30 @@ def synthetic_words(batch: int, seed: int, first_env: int = 0) -> np.ndarray:
         out[:, k] = z ^ (z >> np.uint64(31))
     out[:, 2] |= np.uint64(1)
     return out
+
+
+def gen_words_from_generator(gen: np.random.Generator) -> np.ndarray:
+    """numpy Generator(PCG64) -> u64[5] = [state_lo, state_hi, inc_lo, inc_hi, has_uint32 << 32 | uinteger]: the PCG64 words
+    plus numpy's 32-bit output buffer, which `Generator.integers` draws through (include/mgx.h: gen_state)."""
+    st = gen.bit_generator.state
+    w = words_from_bitgen_state(st)
+    return np.concatenate([w, np.array([(int(st["has_uint32"]) << 32) | int(st["uinteger"])], dtype=np.uint64)])
+
+
+def generator_from_gen_words(words5) -> np.random.Generator:
+    w = [int(x) for x in np.asarray(words5, dtype=np.uint64)]
+    bg = np.random.PCG64()
+    st = bitgen_state_from_words(w[:4])
+    st["has_uint32"], st["uinteger"] = w[4] >> 32, w[4] & 0xFFFFFFFF
+    bg.state = st
+    return np.random.Generator(bg)
+
+
+def layout_gen_state(layout_seed: int, global_index) -> np.ndarray:
+    """gen_state u64[B,6] for mgx_reset_generate: env g's placement generator is Generator(PCG64(SeedSequence([layout_seed,
+    g]))) (the reference seeds it from OS entropy at construction), empty 32-bit buffers."""
+    idx = np.asarray(global_index)
+    out = np.zeros((len(idx), 6), dtype=np.uint64)
+    for b, g in enumerate(idx):
+        out[b, :4] = words_from_seed([int(layout_seed), int(g)])
+    return out

@@ -26,8 +26,8 @@ class MgoSpec(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(HERE, "mgx_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, "mgx_oracle.c"), os.path.join(HERE, "mgx_layout_oracle.c")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", HERE, "-B", "libmgx_oracle.so"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
@@ -42,7 +42,7 @@ def lib() -> C.CDLL:
             out = os.path.join(os.environ.get("MGX_SANITIZE_DIR", "/tmp"), "libmgx_oracle_san.so")
             subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-std=c11",
                                    "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", out,
-                                   os.path.join(HERE, "mgx_oracle.c")])
+                                   os.path.join(HERE, "mgx_oracle.c"), os.path.join(HERE, "mgx_layout_oracle.c")])
             _lib = C.CDLL(out)
         else:
             _lib = C.CDLL(build())
@@ -187,3 +187,35 @@ def full_obs(grid_state, agent_state) -> np.ndarray:
     out = np.empty_like(g)
     lib().mgo_full_obs(_p(g, C.c_int64), _p(a, C.c_int64), g.shape[0], g.shape[1], a.shape[0], _p(out, C.c_int64))
     return out
+
+
+# ---- episode-start generation (oracle/mgx_layout_oracle.c) -----------------------------------------------------------
+def gen_words(gen: np.random.Generator) -> np.ndarray:
+    """numpy Generator(PCG64) -> u64[5] = [state_lo, state_hi, inc_lo, inc_hi, has_uint32 << 32 | uinteger]."""
+    st = gen.bit_generator.state
+    s, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+    m = (1 << 64) - 1
+    return np.array([s & m, s >> 64, inc & m, inc >> 64, (int(st["has_uint32"]) << 32) | int(st["uinteger"])], dtype=np.uint64)
+
+
+def np_integers(words5: np.ndarray, lo: int, hi: int, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.int64)
+    lib().mgo_np_integers(_p(words5, C.c_uint64), C.c_int64(lo), C.c_int64(hi), C.c_int64(n), _p(out, C.c_int64))
+    return out
+
+
+def bup_layout(room_size: int, A: int, lay_words: np.ndarray, np_words: np.ndarray, blank: np.ndarray):
+    """blank: u8[H,W,3] walls only.  Generator words are advanced in place.  Returns (grid, agents u8[A,8], aux u8[16])."""
+    grid = np.ascontiguousarray(blank, dtype=np.uint8).copy()
+    agents = np.zeros((A, 8), np.uint8); aux = np.zeros(16, np.uint8)
+    lib().mgo_bup_layout(room_size, A, _p(lay_words, C.c_uint64), _p(np_words, C.c_uint64), _p(grid, C.c_uint8),
+                         _p(agents, C.c_uint8), _p(aux, C.c_uint8))
+    return grid, agents, aux
+
+
+def empty_random_layout(A: int, lay_words: np.ndarray, blank: np.ndarray):
+    grid = np.ascontiguousarray(blank, dtype=np.uint8).copy()
+    H, W, _ = grid.shape
+    agents = np.zeros((A, 8), np.uint8)
+    lib().mgo_empty_random_layout(W, H, A, _p(lay_words, C.c_uint64), _p(grid, C.c_uint8), _p(agents, C.c_uint8))
+    return grid, agents

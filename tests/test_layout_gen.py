@@ -1,0 +1,158 @@
+"""On-device episode starts (mgx_reset_generate).
+
+CPU (`not gpu`): the chain that pins the generator to the reference --
+  numpy itself  ==  the oracle's restatement of Generator(PCG64).integers (mixed with random() calls, buffered halves)
+  layouts.py (pinned by the reference's reset fixtures, tests/test_env_compat.py)  ==  oracle/mgx_layout_oracle.c
+GPU: the HIP kernel == the oracle, env by env, over many episodes, interleaved with steps; and the generated episodes
+have the reference's structure (box right, locked door + matching key, ball in front of the door, agents left)."""
+import numpy as np
+import pytest
+import torch
+
+from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts, rng as rnglib
+from oracle import binding as ob
+from tests import util
+
+
+def test_oracle_integers_equal_numpy():
+    r = np.random.default_rng(123)
+    for trial in range(200):
+        g = np.random.Generator(np.random.PCG64(int(r.integers(0, 2 ** 40))))
+        for k in range(int(r.integers(0, 4))):
+            g.random()
+        if r.random() < 0.5:
+            g.integers(0, 5)                                   # leaves a buffered 32-bit half behind
+        w = ob.gen_words(g)
+        np.testing.assert_array_equal(w, rnglib.gen_words_from_generator(g))
+        for k in range(20):
+            lo = int(r.integers(-5, 5))
+            hi = lo + (int(r.integers(1, 300)) if r.random() < 0.9 else int(r.integers(1, 2 ** 31)))
+            assert int(g.integers(lo, hi)) == int(ob.np_integers(w, lo, hi, 1)[0])
+            if r.random() < 0.3:                               # random() draws 64 bits and leaves the buffer alone
+                g.random(); tmp = w[:4].copy(); ob.pcg64_random(tmp, 1); w[:4] = tmp
+        np.testing.assert_array_equal(ob.gen_words(g), w)
+        g2 = rnglib.generator_from_gen_words(w)
+        assert int(g2.integers(0, 1000)) == int(g.integers(0, 1000))
+
+
+def test_layout_oracle_equals_layouts_py():
+    r = np.random.default_rng(7)
+    blank = layouts.roomgrid_blank(6, 1, 2)
+    for seed in range(300):
+        A = int(r.integers(1, 5))
+        lg, ng = np.random.default_rng(1000 + seed), np.random.default_rng(2000 + seed)
+        if seed % 3 == 0:
+            ng.integers(0, 7)
+        lw, nw = ob.gen_words(lg), ob.gen_words(ng)
+        g_ref, a_ref, t_ref = layouts.blockedunlockpickup_layout(6, A, lg, ng)
+        g, a, aux = ob.bup_layout(6, A, lw, nw, blank)
+        np.testing.assert_array_equal(g, g_ref); np.testing.assert_array_equal(a, a_ref)
+        np.testing.assert_array_equal(aux[:3], t_ref[:3])
+        np.testing.assert_array_equal(lw, ob.gen_words(lg)); np.testing.assert_array_equal(nw, ob.gen_words(ng))
+    for seed in range(100):
+        A, size = int(r.integers(1, 6)), int(r.integers(5, 12))
+        lg = np.random.default_rng(5000 + seed); lw = ob.gen_words(lg)
+        g_ref, a_ref = layouts.empty_layout(size, A, agent_start_pos=None, agent_start_dir=None, layout_rng=lg)
+        np.testing.assert_array_equal(g_ref, layouts.empty_blank(size))
+        g, a = ob.empty_random_layout(A, lw, layouts.empty_blank(size))
+        np.testing.assert_array_equal(a, a_ref); np.testing.assert_array_equal(lw, ob.gen_words(lg))
+
+
+CASES = [
+    ("bup_a2", EnvSpec(11, 6, 2, 7, max_steps=7, joint_reward=True, env_kind="blockedunlockpickup"),
+     dict(kind="blockedunlockpickup", room_size=6), 3000),
+    ("bup_a4_rs8", EnvSpec(15, 8, 4, 7, max_steps=5, joint_reward=True, env_kind="blockedunlockpickup"),
+     dict(kind="blockedunlockpickup", room_size=8), 1001),
+    ("empty_random_9_a3", EnvSpec(9, 9, 3, 7, max_steps=6), dict(kind="empty_random"), 2000),
+    ("empty_random_5_a6", EnvSpec(5, 5, 6, 5, max_steps=4), dict(kind="empty_random"), 515),
+    ("empty_fixed_16_a4", EnvSpec(16, 16, 4, 7, max_steps=5), dict(kind="empty_fixed", start=(1, 1, 0)), 4099),
+]
+
+
+def _run(env, spec, T, dev):
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    outs = []
+    for t in range(T):
+        act = torch.randint(0, 7, (env.batch, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+        o = env.step(act, auto_reset=True)
+        outs.append([x.cpu().clone() for x in o] + [env.was_reset.cpu().clone()])
+    return outs
+
+
+def _make(spec, gen, B, dev, backend=None):
+    env = BatchedMultiGridEnv(spec, B, dev, first_env=17, backend=backend)
+    if spec.env_kind == "blockedunlockpickup":
+        g0, a0, t0 = layouts.blockedunlockpickup_layout(gen["room_size"], spec.num_agents, np.random.default_rng(1), np.random.default_rng(2))
+        env.load_state(g0, a0, aux=layouts.make_aux("blockedunlockpickup", g0, target=t0))
+    else:
+        g0, a0 = layouts.empty_layout(spec.width, spec.num_agents)
+        env.load_state(g0, a0)
+    env.seed_synthetic(3)
+    env.set_layout_generator(layout_seed=11, **gen)
+    return env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,spec,gen,B", CASES, ids=[c[0] for c in CASES])
+def test_device_generation_equals_oracle_over_many_episodes(name, spec, gen, B):
+    dev = "cuda:0"
+    T = 4 * spec.max_steps + 3
+    hip = _make(spec, gen, B, dev)
+    ref = _make(spec, gen, B, "cpu", backend=util.OracleBackend(spec, nthreads=8))
+    got, want = _run(hip, spec, T, dev), None
+    # the oracle side consumes the same actions (generated on the device, copied over)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    for t in range(T):
+        act = torch.randint(0, 7, (B, spec.num_agents), dtype=torch.int8, device=dev, generator=g).cpu()
+        ref.reset_done()
+        o = ref.step(act)
+        for k, (x, y) in enumerate(zip(got[t][:5], o)):
+            assert torch.equal(x, y), f"{name} step {t} output {k}"
+        assert torch.equal(got[t][5], ref.was_reset), f"{name} step {t} was_reset"
+    for f in ("grid", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(hip, f).cpu(), getattr(ref, f)), f
+    assert torch.equal(hip._gen["gen_state"].cpu(), ref._gen["gen_state"])
+    assert int(hip.episode.sum()) >= 3 * B
+    hip.check_errors()
+
+
+@pytest.mark.gpu
+def test_generated_bup_episodes_have_the_reference_structure():
+    dev = "cuda:0"
+    spec = EnvSpec(11, 6, 2, 7, max_steps=1, joint_reward=True, env_kind="blockedunlockpickup")
+    B = 20000
+    env = _make(spec, dict(kind="blockedunlockpickup", room_size=6), B, dev)
+    env.step(torch.zeros((B, 2), dtype=torch.int8, device=dev))          # truncates every env
+    assert int(env.reset_done().sum()) == B
+    g, a, aux = env.grid.cpu().numpy(), env.agents.cpu().numpy(), env.aux.cpu().numpy()
+    t = g[..., 0]
+    assert ((t == 7).sum(axis=(1, 2)) == 1).all() and (t[:, :, 6:] == 7).sum() == B          # one box, right room
+    door = (t == 4)
+    assert (door.sum(axis=(1, 2)) == 1).all() and door[:, 1:5, 5].sum() == B and (g[..., 2][door] == 2).all()   # locked, in the wall
+    ys = door[:, :, 5].argmax(axis=1)
+    assert (t[np.arange(B), ys, 4] == 6).all()                                               # ball in front of it
+    key = (t == 5)
+    assert (key.sum(axis=(1, 2)) == 1).all() and key[:, :, :5].sum() == B
+    assert (g[..., 1][key] == g[..., 1][door]).all()                                          # the key fits the door
+    assert (a[:, :, 2] >= 1).all() and (a[:, :, 2] <= 4).all() and (a[:, :, 4] == 0).all()    # agents in the left room, alive
+    np.testing.assert_array_equal(aux[:, 0], 7); np.testing.assert_array_equal(aux[:, 1], g[..., 1][t == 7])
+    # all four door rows and all six colours occur: the draws are not degenerate
+    assert len(np.unique(ys)) == 4 and len(np.unique(aux[:, 1])) == 6
+    assert len({r.tobytes() for r in g[:2000]}) > 1500
+
+
+def test_generator_state_round_trip_on_cpu():
+    spec = EnvSpec(11, 6, 2, 7, max_steps=3, joint_reward=True, env_kind="blockedunlockpickup")
+    gen = dict(kind="blockedunlockpickup", room_size=6)
+    a = _make(spec, gen, 40, "cpu", backend=util.OracleBackend(spec))
+    acts = [torch.from_numpy(util.random_actions(40, 2, t, p_missing=0)) for t in range(14)]
+    for t in range(6):
+        a.step(acts[t], auto_reset=True)
+    sd = a.state_dict()
+    want = [[x.clone() for x in a.step(acts[t], auto_reset=True)] for t in range(6, 14)]
+    b = BatchedMultiGridEnv(spec, 40, "cpu", first_env=17, backend=util.OracleBackend(spec))
+    b.load_state_dict(sd)
+    for t in range(6, 14):
+        for x, y in zip(want[t - 6], b.step(acts[t], auto_reset=True)):
+            assert torch.equal(x, y)
+    assert torch.equal(a.grid, b.grid) and torch.equal(a._gen["gen_state"], b._gen["gen_state"])

@@ -164,5 +164,31 @@ class OracleBackend:
                 step_count[b] = 0
                 episode[b] += 1
 
+    def reset_generate(self, B, gen, grid, agents, rng, step_count, aux, episode, was_reset):
+        """mgx_reset_generate on the layout oracle (oracle/mgx_layout_oracle.c), env by env."""
+        blank = gen["blank"].numpy()
+        gs = gen["gen_state"].numpy().view(np.uint64)
+        r = rng.numpy().view(np.uint64)
+        A = self.spec.num_agents
+        for b in range(B):
+            done = bool((agents[b, :, 4] != 0).all()) or int(step_count[b]) >= self.spec.max_steps
+            was_reset[b] = int(done)
+            if not done:
+                continue
+            lay = gs[b, :5].copy()
+            npw = np.concatenate([r[b], gs[b, 5:6]])
+            if gen["kind"] == "blockedunlockpickup":
+                g, a, x = ob.bup_layout(gen["room_size"], A, lay, npw, blank)
+                aux[b] = torch.from_numpy(x)
+            elif gen["kind"] == "empty_random":
+                g, a = ob.empty_random_layout(A, lay, blank)
+            else:
+                g = blank.copy(); a = np.zeros((A, 8), np.uint8)
+                a[:, 0] = np.arange(A) % 6; a[:, 1] = gen["start"][2]; a[:, 2] = gen["start"][0]; a[:, 3] = gen["start"][1]; a[:, 5] = 1
+            grid[b] = torch.from_numpy(g); agents[b] = torch.from_numpy(a)
+            gs[b, :5] = lay; gs[b, 5] = npw[4]; r[b] = npw[:4]
+            step_count[b] = 0
+            episode[b] += 1
+
     def launch_info(self, B):
         return {}
