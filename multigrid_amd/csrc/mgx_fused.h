@@ -87,6 +87,9 @@ struct KernelArgs {
 #ifndef MGX_P4_B16
 #define MGX_P4_B16 1
 #endif
+#ifndef MGX_DRAWS_FIRST
+#define MGX_DRAWS_FIRST 0
+#endif
 #ifndef MGX_BUF_STORE
 #define MGX_BUF_STORE 1
 #endif
@@ -480,10 +483,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     // (2) the tile
     u32x4 tv[U], tv2[U];
+    const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env per wavefront
+#if !MGX_DRAWS_FIRST
 #pragma unroll
     for (int u = 0; u < U; ++u)
         tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
-    const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env per wavefront
+#endif
     // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
     // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
     uint64_t my_rng[4];
@@ -498,6 +503,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         my_draw = pcg64_draw_at(my_rng, jk, s_lo, s_hi);
         if (agent_of_lane == A - 1) { uint64_t *dst = a.rng + (e0 + env_of_lane) * 4; dst[0] = s_lo; dst[1] = s_hi; }
     }
+#if MGX_DRAWS_FIRST
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
+#endif
     // (3b) big tiles: a second burst under the same wait (requested here, once the draws' inputs are dead, so that the
     // register peak of P0 stays below that of the gather)
     if (big_tile) {
