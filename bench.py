@@ -332,10 +332,11 @@ def cpu_baseline(wl, threads, budget_s, sample_envs):
     A = wl.spec.num_agents
     acts = np.random.default_rng(1234).integers(0, 7, size=(8, n_env, A)).astype(np.int8)
     d = wl.spec.as_dict()
-    ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[0], st["aux"], threads)   # warm
+    out = ob.step_outputs(d, n_env)                             # reused: the timing is the oracle, not page faults
+    ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[0], st["aux"], threads, out)   # warm
     n, t0 = 0, time.perf_counter()
     while True:
-        ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[n & 7], st["aux"], threads)
+        ob.step_batch(d, st["grid"], st["agents"], st["rng"], st["step_count"], acts[n & 7], st["aux"], threads, out)
         n += 1
         el = time.perf_counter() - t0
         if (el >= budget_s and n >= 4) or n >= 100000:

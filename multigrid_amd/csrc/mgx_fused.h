@@ -87,6 +87,9 @@ struct KernelArgs {
 #ifndef MGX_P4_B16
 #define MGX_P4_B16 1
 #endif
+#ifndef MGX_WRITELANE_NOP
+#define MGX_WRITELANE_NOP 0
+#endif
 #ifndef MGX_DRAWS_FIRST
 #define MGX_DRAWS_FIRST 0
 #endif
@@ -275,7 +278,13 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
 #endif
 __device__ __forceinline__ uint32_t set_lane(uint32_t old, uint32_t sval, const int s) {
 #if MGX_ASM_WRITELANE
+    // (the data operand of v_writelane has no software hazard: only an SGPR used as LANE SELECT after a VALU write needs
+    // wait states; the lane is an immediate here.  -DMGX_WRITELANE_NOP=1 restores the conservative s_nop of round 1.)
+#if MGX_WRITELANE_NOP
     asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(s));
+#else
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(s));
+#endif
     return old;
 #else
     return __builtin_amdgcn_inverse_ballot_w64(1ull << s) ? sval : old;

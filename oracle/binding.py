@@ -126,19 +126,30 @@ class RefEnv:
         return obs, direction, reward, terminated.astype(bool), bool(truncated[0]), order
 
 
-def step_batch(spec: dict, grid, agents, rng, step_count, actions, target=None, nthreads: int = 1):
+def step_outputs(spec: dict, B: int):
+    """Output buffers of step_batch, to reuse across calls (fresh 38 MB arrays page-fault on every call at 65 536 envs)."""
+    sp = make_spec(spec)
+    A, v = sp.num_agents, sp.view_size
+    return (np.zeros((B, A, v, v, 3), dtype=np.uint8), np.zeros((B, A), dtype=np.uint8), np.zeros((B, A), dtype=np.float64),
+            np.zeros((B, A), dtype=np.uint8), np.zeros((B,), dtype=np.uint8))
+
+
+def step_batch(spec: dict, grid, agents, rng, step_count, actions, target=None, nthreads: int = 1, out=None):
     """Product-layout batched step on numpy arrays (modified in place; `target` = aux u8[B,16], include/mgx.h).
-    Returns (obs, dir, reward, terminated, truncated)."""
+    Returns (obs, dir, reward, terminated, truncated) -- the arrays of `out` (step_outputs) when given."""
     sp = make_spec(spec)
     B = grid.shape[0]
     A, v = sp.num_agents, sp.view_size
     for arr in (grid, agents, rng, step_count, actions):
         assert arr.flags.c_contiguous
-    obs = np.empty((B, A, v, v, 3), dtype=np.uint8)
-    d = np.empty((B, A), dtype=np.uint8)
-    reward = np.empty((B, A), dtype=np.float64)
-    terminated = np.empty((B, A), dtype=np.uint8)
-    truncated = np.empty((B,), dtype=np.uint8)
+    if out is not None:
+        obs, d, reward, terminated, truncated = out
+    else:
+        obs = np.empty((B, A, v, v, 3), dtype=np.uint8)
+        d = np.empty((B, A), dtype=np.uint8)
+        reward = np.empty((B, A), dtype=np.float64)
+        terminated = np.empty((B, A), dtype=np.uint8)
+        truncated = np.empty((B,), dtype=np.uint8)
     err_env = C.c_int64(-1)
     tgt = _p(target, C.c_uint8) if target is not None else None
     rc = lib().mgo_step_batch(
