@@ -173,8 +173,8 @@ def step_roofline(wl_name, spec, B, ms_launch):
 
 def config_point(name, device, K, warmup, device_generated=False):
     """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline.
-    device_generated: episode starts come from mgx_reset_generate (the reference's _gen_grid run on the device, one
-    launch in front of every step) instead of the host-made layout pool fused into the step launch."""
+    device_generated: episode starts are generated ON THE DEVICE (the reference's _gen_grid with numpy-exact draws, in the
+    tail of the step's own launch: mgx_step_generate) instead of picked from the host-made layout pool."""
     wl = workloads.make(name)
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     if device_generated:
@@ -187,7 +187,7 @@ def config_point(name, device, K, warmup, device_generated=False):
            "view_size": wl.spec.view_size, "ms_per_step": round(m["wall_s"] * 1e3 / m["timed_steps"], 6),
            "value": round(B * A * m["timed_steps"] / m["wall_s"]), "unit": "agent-steps/s",
            "timed_steps": m["timed_steps"],
-           "layout_pool": "generated on the device (mgx_reset_generate + mgx_step: two launches per step)" if device_generated
+           "layout_pool": "generated on the device in the step's own launch (mgx_step_generate)" if device_generated
                           else int(wl.pool[0].shape[0]),
            "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,
            "launch": env.backend.launch_info(B), "roofline": step_roofline(name, wl.spec, B, ms)}
@@ -284,6 +284,29 @@ def aux_kernel_points(env, device):
     env.step_count.zero_()
     out["reset_done_none"] = entry(kernel_time_ms(env.reset_done, 30, device, warm=10), batch * (A * 8 + 4 + 1))
     return out
+
+
+def generation_point(device, batch=1 << 18):
+    """mgx_reset_generate on BlockedUnlockPickup envs: the scan alone (nobody done) and with EVERY env restarting (each runs
+    the reference's _gen_grid: ~25 numpy-compatible draws + rejection sampling per episode)."""
+    wl = workloads.make("c3", batch=batch, global_batch=batch)
+    env = wl.make_env(device, auto_reset=False)
+    env.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6)
+    spec = wl.spec
+    t_none = kernel_time_ms(env.reset_done, 30, device, warm=10)
+
+    def reset_all():
+        env.step_count.fill_(spec.max_steps)
+        env.reset_done()
+    def fill_only():
+        env.step_count.fill_(spec.max_steps)
+    t_all = kernel_time_ms(reset_all, 20, device, warm=5) - kernel_time_ms(fill_only, 20, device, warm=5)
+    assert int(env.episode.min().item()) >= 25
+    del env
+    torch.cuda.empty_cache()
+    return {"batch": batch, "scan_ms": round(t_none, 5), "all_envs_regenerated_ms": round(t_all, 5),
+            "episodes_per_s": round(batch / (t_all * 1e-3)),
+            "note": "BlockedUnlockPickup 11x6, 2 agents: one lane per env runs the reference's _gen_grid on the device"}
 
 
 def rollout_point(wl, device, steps):
@@ -446,6 +469,7 @@ def main():
             out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}
             out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)
             out.update(large_batch_points(device, args.large_batch))
+            out["device_generation"] = generation_point(device)
             from oracle import binding as ob
             out["cpu_baseline"] = cpu_baseline(wl, ob.max_threads(), 8.0, wl.batch)
             out["cpu_baseline_1core"] = cpu_baseline(wl, 1, 6.0, 2048)

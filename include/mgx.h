@@ -207,6 +207,15 @@ typedef struct MgxLayoutGen {
 int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
                        uint64_t *rng, int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream);
 
+/* mgx_step followed by mgx_reset_generate, in ONE launch: the envs whose episode ends with this step (all agents terminated
+ * or step_count >= max_steps after it) are regenerated in the tail of the step's own kernel; the outputs are the step's
+ * (the terminal observation); the state tensors come out holding the next episode's start.  Bit-identical to the two calls.
+ * `was_reset` (may be NULL) = the envs that were regenerated. */
+int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
+                      uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                      uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                      int32_t *err, int32_t *episode, uint8_t *was_reset, void *stream);
+
 /* The step / gen_obs with the observation written ONE-HOT encoded: what OneHotObsWrapper.one_hot
  * (multigrid/wrappers.py:158-190, dim sizes (11, 6, 4)) makes of obs['image'], fused into the same launch -- the
  * wrapper RLlib registration applies to every env (multigrid/rllib/__init__.py:110-111).  Bit-identical to

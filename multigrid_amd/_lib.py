@@ -24,7 +24,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -
 EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
            "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout", "mgx_step_autoreset",
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
-           "mgx_reset_generate")
+           "mgx_reset_generate", "mgx_step_generate")
 
 
 class MgxLaunchInfo(C.Structure):
@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
     L.mgx_reset_done.argtypes = [C.POINTER(MgxSpecC), i64, i64, C.c_int32] + [vp] * 10
     L.mgx_reset_generate.restype = C.c_int
     L.mgx_reset_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen)] + [vp] * 8
+    L.mgx_step_generate.restype = C.c_int
+    L.mgx_step_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen)] + [vp] * 15
     L.mgx_launch_info.restype = C.c_int
     L.mgx_launch_info.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLaunchInfo)]
     if L.mgx_abi_version() != ABI_VERSION:

@@ -164,15 +164,19 @@ class BatchedMultiGridEnv:
                 or not actions.is_contiguous():
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {tuple(self._act_shape)} "
                              f"on {self.grid.device}")
-        if auto_reset and getattr(self, "_gen", None) is not None:      # on-device generation: its own launch, then the step
-            self.reset_done()
+        generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
+        if generate:
+            # on-device generation: the envs whose episode ends with THIS step are regenerated right after it (in the tail
+            # of the same launch when the launcher can: mgx_step_generate); `was_reset` = the envs regenerated by this call
             auto_reset = False
-        key = (bool(auto_reset), bool(one_hot))
+        key = (bool(auto_reset), bool(one_hot), generate and not one_hot)
         fast = self._bound.get(key)
         if fast is None:
             fast = self._bind_step(*key)
         if fast is not False:
             fast(actions)
+            if generate and one_hot:
+                self.reset_done()
             return (self._one_hot if one_hot else self.obs), self.dir, self.reward, self.terminated, self.truncated
         # launchers without bind_step (the test-suite's oracle backend)
         sp = self.spec
@@ -186,20 +190,24 @@ class BatchedMultiGridEnv:
         self.backend.step(self.batch, self.grid, self.agents, self.rng, self.step_count, actions,
                           self.aux if sp.env_kind != "empty" else None, self.err,
                           obs, self.dir, self.reward, self.terminated, self.truncated, **kw)
+        if generate:
+            self.reset_done()
         return obs, self.dir, self.reward, self.terminated, self.truncated
 
-    def _bind_step(self, auto_reset: bool, one_hot: bool):
+    def _bind_step(self, auto_reset: bool, one_hot: bool, generate: bool = False):
         """Resolve every pointer of the step call once (ops.HipBackend.bind_step); False when the launcher cannot."""
+        key = (auto_reset, one_hot, generate)
         bind = getattr(self.backend, "bind_step", None)
         if bind is None:
-            self._bound[(auto_reset, one_hot)] = False
+            self._bound[key] = False
             return False
         ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
         f = bind(self.batch, self.grid, self.agents, self.rng, self.step_count,
                  self.aux if self.spec.env_kind != "empty" else None, self.err,
                  self._one_hot_buffer() if one_hot else self.obs, self.dir, self.reward, self.terminated, self.truncated,
-                 auto_reset=ar, one_hot=one_hot)
-        self._bound[(auto_reset, one_hot)] = f
+                 auto_reset=ar, one_hot=one_hot,
+                 **({"generate": (self._gen, self.episode, self.was_reset)} if generate else {}))
+        self._bound[key] = f
         return f
 
     def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False) -> dict:
@@ -278,7 +286,9 @@ class BatchedMultiGridEnv:
         kind         'empty_fixed' (EmptyEnv, agents at `start` = (x, y, dir)), 'empty_random' (EmptyEnv with
                      agent_start_pos=None) or 'blockedunlockpickup' (`room_size`)
         layout_seed  seeds every env's placement generator: Generator(PCG64(SeedSequence([layout_seed, global index])))
-        `reset_done()` and `step(auto_reset=True)` then use the generator (the latter as two launches: generate + step).
+        `reset_done()` then regenerates every finished env; `step(auto_reset=True)` regenerates the envs whose episode ends
+        with that step right after it -- in the tail of the step's own launch (mgx_step_generate), so the returned
+        observation is the terminal one and the state tensors already hold the next episode's start.
         """
         sp = self.spec
         if kind == "blockedunlockpickup":

@@ -32,6 +32,7 @@
 #include <stdint.h>
 
 #include "mgx_rules.h"
+#include "mgx_layout_gen.h"
 
 namespace mgx_fused {
 
@@ -69,6 +70,7 @@ struct KernelArgs {
     const uint8_t *pool_aux;
     int32_t *episode;
     uint8_t *was_reset;
+    MgxLayoutGen gen;   // mgx_step_generate: finished envs are regenerated in the tail of the launch (template flag GEN)
     int32_t *bounds;    // -DMGX_BOUNDS_CHECK=1 builds: [0] += LDS accesses outside the wavefront's slice, [1] = last site id
 };
 
@@ -404,7 +406,9 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // step's actions are applied (== mgx_reset_done followed by the step, in one launch).
 // OH: the observation is written one-hot encoded, u8[B,A,V,V,21] (OneHotObsWrapper, multigrid/wrappers.py:158-190, dims
 // (11, 6, 4)): P4 leaves a 21-bit mask per cell in LDS, P5 expands mask bits to 0/1 bytes, 16 at a time.
-template <int V, int MODE, bool HOOKS, bool AR, bool OH = false>
+// GEN: the envs whose episode ends with this step are regenerated in the tail of the launch (== mgx_reset_generate run right
+// after the step: the reference's _gen_grid on the device, mgx_layout_gen.h).
+template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
     constexpr bool DO_STEP = MODE != 0;
     const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
@@ -1068,6 +1072,49 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }   // if !OH
     }   // for t
 
+    if constexpr (GEN && MODE == 1) {
+        // -------------------------------------------------------------- the envs whose episode ended with THIS step
+        // (base.py:534-539 on the post-step state, which is still in LDS) start their next one here: Agent.reset + _gen_grid
+        // by the env's lane, straight into the HBM state (every store of the step itself precedes it in program order)
+        bool done_now = false;
+        if (lane < Gc) {
+            bool all_term = true;
+            for (int k = 0; k < A; ++k) all_term &= row_term(rows[lane * A + k]);
+            done_now = all_term | (scnt[lane] + 1 >= cf.max_steps);
+            uint8_t *wr = MGX_LATE(was_reset);
+            if (wr) wr[e0 + lane] = (uint8_t)done_now;
+        }
+        const uint64_t gmask = __builtin_amdgcn_ballot_w64(done_now);
+        if (gmask != 0) {                                                        // rare
+#define MGX_LATE_GEN(f) kernarg_at<decltype(MgxLayoutGen::f)>(offsetof(KernelArgs, gen) + offsetof(MgxLayoutGen, f))
+            MgxLayoutGen gen;
+            gen.kind = MGX_LATE_GEN(kind); gen.room_size = MGX_LATE_GEN(room_size);
+            gen.start_x = MGX_LATE_GEN(start_x); gen.start_y = MGX_LATE_GEN(start_y); gen.start_dir = MGX_LATE_GEN(start_dir);
+            gen.blank = MGX_LATE_GEN(blank); gen.gen_state = MGX_LATE_GEN(gen_state);
+#undef MGX_LATE_GEN
+            mgx_gen::copy_blank(gen, MGX_LATE(grid), e0, HW3, gmask, lane);
+            if (done_now) {
+                const int64_t b = e0 + lane;
+                mgx_gen::NpGen lay, npr;
+                uint64_t *gs = gen.gen_state + b * 6, *rg = MGX_LATE(rng) + b * 4;
+                for (int k = 0; k < 4; ++k) {
+                    lay.s[k] = gs[k];
+                    // (this launch advanced the env's PCG64 words in P0: read them past the L1)
+                    npr.s[k] = __hip_atomic_load(rg + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                lay.buf = gs[4]; npr.buf = gs[5];
+                const uint4 naux = mgx_gen::generate_episode(gen, W, H, A, lay, npr, L + cv.rec() + lane * (2 * A),
+                                                             MGX_LATE(grid) + b * HW3,
+                                                             reinterpret_cast<uint64_t *>(MGX_LATE(agents)) + b * A);
+                if (HOOKS) reinterpret_cast<uint4 *>(MGX_LATE(aux))[b] = naux;
+                for (int k = 0; k < 4; ++k) { gs[k] = lay.s[k]; rg[k] = npr.s[k]; }
+                gs[4] = lay.buf; gs[5] = npr.buf;
+                MGX_LATE(step_count)[b] = 0;                                     // base.py:292
+                MGX_LATE(episode)[b] += 1;
+            }
+        }
+    }
+
 #if MGX_TIMESTAMPS
     __builtin_amdgcn_s_waitcnt(0);
     MGX_MARK("end");
@@ -1098,14 +1145,18 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 
 // The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
 // failed launch (mgx_last_hip_error).
-template <int V, int MODE, bool OH>
+template <int V, int MODE, bool OH, bool GEN = false>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err) {
     void (*kern)(const KernelArgs) = nullptr;
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
     const bool ar = MODE != 0 && ka.pool_grid != nullptr;
     constexpr bool S = MODE != 0;
-    kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH> : mgx_fused_kernel<V, MODE, S, false, OH>)
-                 : (ar ? mgx_fused_kernel<V, MODE, false, S, OH> : mgx_fused_kernel<V, MODE, false, false, OH>);
+    if constexpr (GEN) {                                                     // (generation replaces the pool pick-up)
+        kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
+    } else {
+        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH> : mgx_fused_kernel<V, MODE, S, false, OH>)
+                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH> : mgx_fused_kernel<V, MODE, false, false, OH>);
+    }
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1120,12 +1171,13 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
 template <int V>
 inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream,
                        int *hip_err) {
-    switch (mode) {                                      // mode | 4: one-hot observations (gen_obs and one step only)
+    switch (mode) {                     // mode | 4: one-hot observations (gen_obs and one step only); | 8: tail generation
     case 0: return launch_mode<V, 0, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
     case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
     case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
     case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
     case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    case 9: return launch_mode<V, 1, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err);   // | 8: generate
     default: return MGX_ERR_INVALID_ARGUMENT;
     }
 }

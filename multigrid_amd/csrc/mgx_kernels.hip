@@ -200,6 +200,7 @@ int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const uint8_t *grid,
 }
 
 static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar,
+                       const MgxLayoutGen *gen, int32_t *gen_episode, uint8_t *gen_was_reset,
                        uint8_t *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
                        uint8_t *aux, uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated,
                        uint8_t *truncated, int32_t *err, void *stream) {
@@ -232,6 +233,29 @@ static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t bat
     ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
     ka.T = roll ? steps : 1;
+    if (gen) {
+        if (roll || one_hot || ar || !gen->blank || !gen->gen_state || !gen_episode || !rng) return MGX_ERR_INVALID_ARGUMENT;
+        if (misaligned(gen->gen_state, 8) || misaligned(gen_episode, 4)) return MGX_ERR_INVALID_ARGUMENT;
+        if (spec->width > 254 || spec->height > 254) return MGX_ERR_UNSUPPORTED;
+        switch (gen->kind) {
+        case MGX_GEN_EMPTY_FIXED:
+            if (spec->env_kind != MGX_KIND_EMPTY || gen->start_x < 0 || gen->start_x >= spec->width || gen->start_y < 0
+                || gen->start_y >= spec->height || gen->start_dir < 0 || gen->start_dir > 3)
+                return MGX_ERR_INVALID_ARGUMENT;
+            break;
+        case MGX_GEN_EMPTY_RANDOM:
+            if (spec->env_kind != MGX_KIND_EMPTY) return MGX_ERR_INVALID_ARGUMENT;
+            break;
+        case MGX_GEN_BLOCKEDUNLOCKPICKUP:
+            if (spec->env_kind != MGX_KIND_BLOCKEDUNLOCKPICKUP || gen->room_size < 4
+                || spec->width != 2 * gen->room_size - 1 || spec->height != gen->room_size)
+                return MGX_ERR_INVALID_ARGUMENT;
+            break;
+        default: return MGX_ERR_UNSUPPORTED;
+        }
+        ka.gen = *gen; ka.episode = gen_episode; ka.was_reset = gen_was_reset;
+        return launch(9, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+    }
     return launch(roll ? 2 : (one_hot ? 5 : 1), ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
@@ -239,7 +263,7 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
              int32_t *step_count, const int8_t *actions, uint8_t *aux,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream) {
-    return step_common(false, false, spec, batch, 1, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(false, false, spec, batch, 1, nullptr, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
                        terminated, truncated, err, stream);
 }
 
@@ -247,7 +271,7 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid
                 int32_t *step_count, const int8_t *actions, uint8_t *aux,
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream) {
-    return step_common(true, false, spec, batch, steps, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(true, false, spec, batch, steps, nullptr, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
                        terminated, truncated, err, stream);
 }
 
@@ -256,7 +280,7 @@ int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *a
                        uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                        int32_t *err, void *stream) {
     if (!ar) return MGX_ERR_INVALID_ARGUMENT;
-    return step_common(false, false, spec, batch, 1, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(false, false, spec, batch, 1, ar, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
                        terminated, truncated, err, stream);
 }
 
@@ -265,7 +289,7 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
                           uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                           int32_t *err, void *stream) {
     if (!ar) return MGX_ERR_INVALID_ARGUMENT;
-    return step_common(true, false, spec, batch, steps, ar, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
+    return step_common(true, false, spec, batch, steps, ar, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
                        terminated, truncated, err, stream);
 }
 
@@ -273,8 +297,17 @@ int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar,
                      uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                      uint8_t *obs_one_hot, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                      int32_t *err, void *stream) {
-    return step_common(false, true, spec, batch, 1, ar, grid, agents, rng, step_count, actions, aux, obs_one_hot, dir, reward,
+    return step_common(false, true, spec, batch, 1, ar, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs_one_hot, dir, reward,
                        terminated, truncated, err, stream);
+}
+
+int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
+                      uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
+                      uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                      int32_t *err, int32_t *episode, uint8_t *was_reset, void *stream) {
+    if (!gen) return MGX_ERR_INVALID_ARGUMENT;
+    return step_common(false, false, spec, batch, 1, nullptr, gen, episode, was_reset, grid, agents, rng, step_count, actions,
+                       aux, obs, dir, reward, terminated, truncated, err, stream);
 }
 
 }  // extern "C"

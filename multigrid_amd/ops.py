@@ -315,21 +315,33 @@ class HipBackend:
                 _stream(grid.device))
         _lib.check(rc, "mgx_step_one_hot" if one_hot else "mgx_step_autoreset")
 
+    @staticmethod
+    def _layout_gen_struct(gen):
+        sx, sy, sd = gen.get("start", (0, 0, 0))
+        return _lib.MgxLayoutGen(_lib.GEN_KINDS[gen["kind"]], int(gen.get("room_size", 0)), int(sx), int(sy), int(sd),
+                                 gen["blank"].data_ptr(), gen["gen_state"].data_ptr())
+
     def bind_step(self, B, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
-                  auto_reset=None, one_hot: bool = False):
+                  auto_reset=None, one_hot: bool = False, generate=None):
         """Pre-bound launcher for a policy-in-the-loop caller: every pointer except `actions` is resolved once, so a call
         costs one ctypes transition + the kernel launch.  The tensors must stay alive and in place (they are the env's
         own buffers).  Returns f(actions) enqueuing one step on torch's current stream."""
         L = _lib.lib()
         ar = self._auto_reset_struct(auto_reset) if auto_reset is not None else None
-        if ar is None and not one_hot:
+        tail = ()
+        if generate is not None:                    # generate = (gen dict, episode, was_reset): mgx_step_generate
+            gen, episode, was_reset = generate
+            ar = self._layout_gen_struct(gen)       # (kept alive below, like the auto-reset struct)
+            fn, head, what = L.mgx_step_generate, (C.byref(self.sc), B, C.byref(ar)), "mgx_step_generate"
+            tail = (episode.data_ptr(), was_reset.data_ptr() if was_reset is not None else None)
+        elif ar is None and not one_hot:
             fn, head, what = L.mgx_step, (C.byref(self.sc), B), "mgx_step"
         else:
             fn = L.mgx_step_one_hot if one_hot else L.mgx_step_autoreset
             head, what = (C.byref(self.sc), B, C.byref(ar) if ar is not None else None), fn.__name__
         pre = (grid.data_ptr(), agents.data_ptr(), rng.data_ptr() if rng is not None else None, step_count.data_ptr())
         post = (target.data_ptr() if target is not None else None, obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(),
-                terminated.data_ptr(), truncated.data_ptr(), err.data_ptr() if err is not None else None)
+                terminated.data_ptr(), truncated.data_ptr(), err.data_ptr() if err is not None else None) + tail
         dev, index = grid.device, grid.device.index
         keep = (ar, self.sc)                                 # the structs the byref()s point into
         current_device, current_stream, device_ctx = torch.cuda.current_device, torch.cuda.current_stream, torch.cuda.device
@@ -377,9 +389,7 @@ class HipBackend:
 
     def reset_generate(self, B, gen, grid, agents, rng, step_count, aux, episode, was_reset):
         """gen = dict(kind, room_size, start=(x, y, dir), blank u8[H,W,3], gen_state i64[B,6]) -- include/mgx.h MgxLayoutGen"""
-        sx, sy, sd = gen.get("start", (0, 0, 0))
-        g = _lib.MgxLayoutGen(_lib.GEN_KINDS[gen["kind"]], int(gen.get("room_size", 0)), int(sx), int(sy), int(sd),
-                              gen["blank"].data_ptr(), gen["gen_state"].data_ptr())
+        g = self._layout_gen_struct(gen)
         with torch.cuda.device(grid.device):
             rc = _lib.lib().mgx_reset_generate(
                 C.byref(self.sc), B, C.byref(g), grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),

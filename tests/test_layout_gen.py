@@ -104,8 +104,8 @@ def test_device_generation_equals_oracle_over_many_episodes(name, spec, gen, B):
     g = torch.Generator(device=dev); g.manual_seed(5)
     for t in range(T):
         act = torch.randint(0, 7, (B, spec.num_agents), dtype=torch.int8, device=dev, generator=g).cpu()
+        o = [x.clone() for x in ref.step(act)]                  # step, then the finished envs are regenerated
         ref.reset_done()
-        o = ref.step(act)
         for k, (x, y) in enumerate(zip(got[t][:5], o)):
             assert torch.equal(x, y), f"{name} step {t} output {k}"
         assert torch.equal(got[t][5], ref.was_reset), f"{name} step {t} was_reset"
@@ -114,6 +114,18 @@ def test_device_generation_equals_oracle_over_many_episodes(name, spec, gen, B):
     assert torch.equal(hip._gen["gen_state"].cpu(), ref._gen["gen_state"])
     assert int(hip.episode.sum()) >= 3 * B
     hip.check_errors()
+    # the fused launch (mgx_step_generate) == the two launches (mgx_step, mgx_reset_generate), also with the one-hot output
+    two = _make(spec, gen, B, dev)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    for t in range(T):
+        act = torch.randint(0, 7, (B, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+        o = two.step(act, one_hot=(t % 2 == 1))
+        two.reset_done()
+        if t % 2 == 0:
+            assert torch.equal(o[0].cpu(), got[t][0]), f"{name} two-launch step {t}"
+        assert torch.equal(two.was_reset.cpu(), got[t][5])
+    for f in ("grid", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(hip, f), getattr(two, f)), f
 
 
 @pytest.mark.gpu
