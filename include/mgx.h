@@ -188,7 +188,9 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
  *                       [4] = its 32-bit buffer (has_uint32 << 32 | uinteger), [5] = the 32-bit buffer of env.np_random,
  *                       whose PCG64 words are the `rng` tensor of mgx_step.  In/out.
  *   blank     u8[H,W,3] the grid before any object or agent is placed: the rooms' walls (RoomGrid, roomgrid.py:203-218),
- *                       or border walls + goal (EmptyEnv, multigrid/envs/empty.py:156-162)
+ *                       or border walls + goal at (W-2, H-2) (EmptyEnv, multigrid/envs/empty.py:156-162).  It is what gets
+ *                       copied into a restarted env's grid; the placement tests use the same layout in closed form, so it
+ *                       must be exactly that (multigrid_amd.layouts.roomgrid_blank / empty_blank produce it)
  * Kinds:  MGX_GEN_EMPTY_FIXED          EmptyEnv with agent_start_pos / agent_start_dir (empty.py:164-167): no draws
  *         MGX_GEN_EMPTY_RANDOM         EmptyEnv with agent_start_pos=None: place_agent over the whole grid (empty.py:168-169)
  *         MGX_GEN_BLOCKEDUNLOCKPICKUP  multigrid/envs/blockedunlockpickup.py:142-164 (room_size; also writes aux[0..2])

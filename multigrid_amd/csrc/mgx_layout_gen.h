@@ -49,7 +49,7 @@ constexpr int kMaxObjects = 4;
 // What the owning lane knows about its env while placing: the blank template (global, read-only), the objects placed so
 // far (registers) and the agents' positions (LDS, 2 bytes per agent).
 struct Placer {
-    const uint8_t *blank;
+    int kind, rs;                         // the blank layout is a closed form of the kind: no memory round trip per test
     int W, H, A;
     int n_obj;
     uint32_t obj_pos[kMaxObjects];        // x | y << 8
@@ -57,7 +57,11 @@ struct Placer {
     uint8_t *apos;                        // LDS: [A][2] (x, y); 0xff = not on the grid (-1)
 
     __device__ int type_at(int x, int y) const {
-        int t = blank[(y * W + x) * 3];
+        // the blank layout (what copy_blank wrote): RoomGrid walls (roomgrid.py:203-218: rooms of rs x rs sharing walls) for
+        // BlockedUnlockPickup; border walls + the goal at (W-2, H-2) for EmptyEnv (empty.py:156-162)
+        const bool border = (x == 0) | (y == 0) | (x == W - 1) | (y == H - 1);
+        int t = border | ((kind == MGX_GEN_BLOCKEDUNLOCKPICKUP) & (x == rs - 1)) ? (int)T_WALL : (int)T_EMPTY;
+        if (kind != MGX_GEN_BLOCKEDUNLOCKPICKUP && x == W - 2 && y == H - 2) t = T_GOAL;
         const uint32_t p = (uint32_t)x | ((uint32_t)y << 8);
 #pragma unroll
         for (int k = 0; k < kMaxObjects; ++k) t = (k < n_obj && obj_pos[k] == p) ? (int)(obj_cell[k] & 0xff) : t;
@@ -96,7 +100,7 @@ struct Placer {
 __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W, int H, int A, NpGen &lay, NpGen &npr,
                                                   uint8_t *apos, uint8_t *grid, uint64_t *rows) {
     Placer P;
-    P.blank = gen.blank; P.W = W; P.H = H; P.A = A; P.n_obj = 0;
+    P.kind = gen.kind; P.rs = gen.room_size; P.W = W; P.H = H; P.A = A; P.n_obj = 0;
     P.apos = apos;
     for (int k = 0; k < kMaxObjects; ++k) { P.obj_pos[k] = 0xffffffffu; P.obj_cell[k] = 0; }
     auto write_row = [&](int i, int x, int y, int d) {                              // colours cycle (constants.py:77-82)

@@ -21,8 +21,15 @@ if os.environ.get("MGX_SKIP"):
 spec = bench.workload_spec()
 env = bench.make_env(spec, B, dev, 0)
 acts = bench.random_actions(4, B, spec.num_agents, dev, 7)
-for t in range(W + N):
-    env.step(acts[t & 3], auto_reset=bench.AUTO_RESET)
+if os.environ.get("MGX_GRAPH"):                 # the steps as hipGraph replays (what bench.py times): W + N launches in all
+    for t in range(8):
+        env.step(acts[t & 3], auto_reset=bench.AUTO_RESET)
+    a2 = bench.random_actions(W + N, B, spec.num_agents, dev, 8)
+    graph = bench.capture_steps(env, a2)
+    graph.replay()
+else:
+    for t in range(W + N):
+        env.step(acts[t & 3], auto_reset=bench.AUTO_RESET)
 for t in range(W + N):
     env.gen_obs()
 if os.environ.get("MGX_ONE_HOT_STEP"):          # the step with fused one-hot output, and the standalone one-hot kernel

@@ -28,17 +28,22 @@ POINTS = [("c2", "c2", 4096, {}), ("c3", "c3", 16384, {}), ("c4", "c4", 65536, {
 
 
 def kind_of(name: str):
-    m = re.search(r"mgx_fused_kernel<(\d+), (\d), (\w+), (\w+)(?:, (\w+))?>", name)
+    m = re.search(r"mgx_fused_kernel<(\d+), (\d), (\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", name)
     if m:
-        mode, oh = m.group(2), m.group(5) == "true"
-        return {"0": "gen_obs", "1": "step", "2": "rollout"}[mode] + ("_one_hot" if oh else "")
+        mode, oh, gen = m.group(2), m.group(5) == "true", m.group(6) == "true"
+        return {"0": "gen_obs", "1": "step", "2": "rollout"}[mode] + ("_one_hot" if oh else "") + ("_generate" if gen else "")
     for k in ("one_hot_kernel", "full_obs_kernel", "reset_done_kernel"):
         if k in name:
             return k
     return None
 
 
+PARSE_ONLY = "--parse-only" in sys.argv      # re-summarise CSVs that are already there
+
+
 def rocprof(args, outdir, cmd, extra_env):
+    if PARSE_ONLY:
+        return
     subprocess.run(["rocprofv3", *args, "--output-format", "csv", "-d", outdir, "-o", "p", "--", *cmd],
                    env=dict(ENV, **extra_env), cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
 
@@ -72,6 +77,8 @@ lines, traffic = [], {"_comment": "HBM-side traffic per launch from rocprofv3 --
 quick = "--quick" in sys.argv
 for key, wl, B, xenv in POINTS:
     e = dict(MGX_WORKLOAD=wl, **xenv)
+    if B < (1 << 20):
+        e["MGX_GRAPH"] = "1"                 # the configurations' steps run as hipGraph replays, as bench.py times them
     cmd = [sys.executable, "tools/large_step.py", str(B), str(N), str(WARM)]
     d = os.path.join(OUT, f"{key}_trace")
     rocprof(["--kernel-trace"], d, cmd, e)
@@ -98,8 +105,8 @@ for key, wl, B, xenv in POINTS:
 # the default bench command under kernel-trace --stats
 d = os.path.join(OUT, "bench_trace")
 log = os.path.join(OUT, "bench_under_rocprof.json")
-with open(log, "w") as fh:
-    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
+with open(log, "a" if PARSE_ONLY else "w") as fh:
+    subprocess.run(["true"] if PARSE_ONLY else ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
                     sys.executable, "bench.py", "--no-extras"], env=ENV, cwd=ROOT, stdout=fh, stderr=subprocess.DEVNULL)
 rows = []
 for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
@@ -112,7 +119,8 @@ with open(os.path.join(OUT, "bench_kernel_stats.txt"), "w") as fh:
                  f"total_ns={r['TotalDurationNs']} pct={r['Percentage']}\n")
 txt = "\n".join(lines)
 open(os.path.join(OUT, "summary.txt"), "w").write(
-    f"# tools/profile_round.py {TAG}: rocprofv3 kernel-trace, first {WARM} launches of each kernel discarded; separate --pmc passes\n" + txt + "\n")
+    f"# tools/profile_round.py {TAG}: rocprofv3 kernel-trace, first {WARM} launches of each kernel discarded; the steps of the\n"
+    f"# configurations (B < 1M) are hipGraph replays, as bench.py times them; separate --pmc passes (FETCH_SIZE, WRITE_SIZE)\n" + txt + "\n")
 json.dump(traffic, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
 print(txt)
 print(open(os.path.join(OUT, "bench_kernel_stats.txt")).read())
