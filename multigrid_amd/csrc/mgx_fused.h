@@ -809,7 +809,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             post_step_hook(cf, env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
             if (!ROLL && cv.has_aux) {                                           // the hook state the step may change
                 uint8_t *gaux = MGX_LATE(aux) + b * MGX_AUX_BYTES;
-                if (env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[15] = eaux[15]; }
+                if (env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[2] = eaux[2]; gaux[15] = eaux[15]; }
                 if (env_kind == MGX_KIND_REDBLUEDOORS) gaux[4] = eaux[4];
             }
             p_truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339

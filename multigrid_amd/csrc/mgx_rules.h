@@ -412,7 +412,14 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             }
         }
     } else if (env_kind == MGX_KIND_LOCKEDHALLWAY) {
-        const int nd = aux[0];
+        // aux[0] < 0x80: the explicit format (n <= 6 doors with their positions); aux[0] & 0x80: the geometric format for
+        // more rooms -- doors sit in the middle of their room's wall (add_door(..., rand_pos=False)), so door k = (row k/2,
+        // side k%2) is at x = side ? 2(rs-1) : rs-1, y = row(rs-1) + rs/2; 16-bit unlocked mask in aux[1], aux[2];
+        // aux[3] = rs; aux[4] = len(self.rooms) (a dict keyed by colour: < n when colours repeat, include/mgx.h)
+        const bool geo = (aux[0] & 0x80) != 0;
+        const int nd = aux[0] & 0x7f, rs = aux[3];
+        const int target = geo ? (int)aux[4] : nd;
+        uint32_t mask = geo ? ((uint32_t)aux[1] | ((uint32_t)aux[2] << 8)) : (uint32_t)aux[1];
         for (int a = 0; a < A; ++a) {
             if (act[a] != ACT_TOGGLE) continue;
             const uint64_t r = rows[a];
@@ -420,20 +427,29 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;
             const uint8_t *c = tile + (fy * cf.W + fx) * 3;
             if (c[0] != T_DOOR || c[2] == S_LOCKED) continue;                   // isinstance(Door) and not is_locked
-            for (int k = 0; k < nd; ++k) {
-                if (aux[2 + 2 * k] != fx || aux[3 + 2 * k] != fy) continue;
-                if (!((aux[1] >> k) & 1)) {                                      // not yet in self.unlocked_doors
-                    aux[1] = (uint8_t)(aux[1] | (1u << k));
-                    const double rv = reward_value(step_count, cf.max_steps);
-                    if (cf.joint_reward) { for (int b = 0; b < A; ++b) rew[b] += rv; }   // `+=`, not `=`
-                    else rew[a] += rv;
-                }
-                break;
+            int k = -1;
+            if (geo) {
+                const int side = (fx == 2 * (rs - 1)) ? 1 : ((fx == rs - 1) ? 0 : -1);
+                const int yy = fy - rs / 2;
+                if (side >= 0 && yy >= 0 && yy % (rs - 1) == 0) k = 2 * (yy / (rs - 1)) + side;
+                if (k >= nd) k = -1;
+            } else {
+                for (int j = 0; j < nd; ++j)
+                    if (aux[2 + 2 * j] == fx && aux[3 + 2 * j] == fy) { k = j; break; }
+            }
+            if (k < 0) continue;
+            if (!((mask >> k) & 1u)) {                                           // not yet in self.unlocked_doors
+                mask |= 1u << k;
+                const double rv = reward_value(step_count, cf.max_steps);
+                if (cf.joint_reward) { for (int b = 0; b < A; ++b) rew[b] += rv; }   // `+=`, not `=`
+                else rew[a] += rv;
             }
         }
+        aux[1] = (uint8_t)mask;
+        if (geo) aux[2] = (uint8_t)(mask >> 8);
         int cnt = 0;
-        for (int k = 0; k < nd; ++k) cnt += (aux[1] >> k) & 1;
-        aux[15] = (uint8_t)(cnt == nd);          // len(unlocked_doors) == len(rooms): `terminations` only, not agent state
+        for (int k = 0; k < nd; ++k) cnt += (mask >> k) & 1u;
+        aux[15] = (uint8_t)(cnt == target);      // len(unlocked_doors) == len(rooms): `terminations` only, not agent state
     }
 }
 

@@ -82,8 +82,8 @@ class LockedHallwayEnv(MultiGridEnv):
                  max_steps: int | None = None, joint_reward: bool = True, **kwargs):
         assert room_size >= 4
         assert num_rooms % 2 == 0
-        if num_rooms > 6:
-            raise ValueError("multigrid_amd: LockedHallway supports at most 6 rooms (the shipped configurations)")
+        if num_rooms > 16:
+            raise ValueError("multigrid_amd: LockedHallway supports at most 16 rooms (16-bit unlocked-door mask)")
         self.num_rooms, self.room_size = num_rooms, room_size
         self.max_hallway_keys, self.max_keys_per_room = max_hallway_keys, max_keys_per_room
         if max_steps is None:

@@ -369,10 +369,20 @@ def make_aux(kind: str, grid_hwc: np.ndarray, target=None) -> np.ndarray:
         aux[:4] = (bx, by, rx, ry)
     elif kind == "lockedhallway":
         doors = sorted((int(x), int(y)) for y, x in np.argwhere(g[..., 0] == Type.door))
-        assert len(doors) <= 6
-        aux[0] = len(doors)
-        for k, (x, y) in enumerate(doors):
-            aux[2 + 2 * k], aux[3 + 2 * k] = x, y
+        if len(doors) <= 6:                                      # explicit positions (include/mgx.h)
+            aux[0] = len(doors)
+            for k, (x, y) in enumerate(doors):
+                aux[2 + 2 * k], aux[3 + 2 * k] = x, y
+        else:                                                    # geometric format: doors sit mid-wall, two per row of rooms
+            rs = min(x for x, _ in doors) + 1
+            want = sorted(((rs - 1) * (1 + side), row * (rs - 1) + rs // 2) for row in range(len(doors) // 2) for side in (0, 1))
+            if doors != want or len(doors) > 16:
+                raise ValueError("LockedHallway with more than 6 doors: they must sit mid-wall, two per row (at most 16)")
+            aux[0] = 0x80 | len(doors)
+            aux[3] = rs
+            # len(self.rooms): the reference keys its rooms by door colour (locked_hallway.py:166-176), so repeated colours
+            # count once -- and that count is what ends the episode (locked_hallway.py:222-225)
+            aux[4] = len({int(g[y, x, 1]) for x, y in doors})
     return aux
 
 

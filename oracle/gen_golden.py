@@ -101,6 +101,7 @@ def spec_of(env, kind, extra=None):
         d["red_door"] = [int(v) for v in env.red_door.cur_pos or door_pos(env, "red")]
     if kind == "lockedhallway":
         d["doors"] = sorted([int(x), int(y)] for x, y in np.argwhere(env.grid.state[..., 0] == 4))
+        d["num_room_keys"] = len(env.rooms)          # rooms keyed by colour: what ends the episode (locked_hallway.py:222-225)
     d.update(extra or {})
     return d
 
@@ -333,6 +334,14 @@ def record_hook_envs():
            np.random.default_rng(377), p_missing=0.05, note="random rollout")
     record("playground_a3", make_env("MultiGrid-Playground-v0", agents=3), "empty", 78, 100,
            np.random.default_rng(378), p_missing=0.05, note="Playground: no hook, 19x19 RoomGrid layout, max_steps 100")
+    # more rooms than colours (not a registered id: the class called directly): doors repeat colours, len(self.rooms) < doors
+    _MAKE_COUNT[0] += 1
+    ref_envs.LockedHallwayEnv._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
+    record("lh_8rooms_a8_joint", ref_envs.LockedHallwayEnv(num_rooms=8, agents=8, joint_reward=True), "lockedhallway", 81,
+           None, None, edit=lh_unlock,
+           script=[[N] * 8, [T] + [N] * 7, [T] * 8, [T] * 8, [F] * 8, [T] * 8, [L] * 8, [T] * 8] +
+                  np.random.default_rng(6).integers(0, 7, size=(30, 8)).tolist(),
+           note="8 rooms, 6 colours: rooms dict keyed by colour; every agent unlocks a door")
 
 
 def record_wrappers():

@@ -387,7 +387,13 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
     if (sp->env_kind == KIND_LOCKEDHALLWAY) {                          /* locked_hallway.py:203-227 */
         int64_t *aux = target;
         const int H = sp->height;
-        const int nd = (int)aux[0];
+        /* aux[0] & 0x80: the geometric door format for more than 6 rooms (the doors sit mid-wall: add_door(rand_pos=False)):
+         * mask in aux[1] | aux[2] << 8, aux[3] = room_size, aux[4] = len(self.rooms) -- a dict keyed by colour, so
+         * fewer than the number of doors when colours repeat (locked_hallway.py:166-176) */
+        const int geo = ((int)aux[0] & 0x80) != 0;
+        const int nd = (int)aux[0] & 0x7f, rs = (int)aux[3];
+        const int n_rooms = geo ? (int)aux[4] : nd;
+        int64_t mask = geo ? (aux[1] | (aux[2] << 8)) : aux[1];
         for (int a = 0; a < A; ++a) {
             if (actions[a] != A_TOGGLE) continue;
             const int64_t *s = agent_state + (size_t)a * AS_DIM;
@@ -396,19 +402,26 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
             if (fx < 0 || fx >= sp->width || fy < 0 || fy >= H) continue;
             const int64_t *c = grid_state + ((size_t)fx * H + fy) * 3;
             if (c[0] != T_DOOR || c[2] == S_LOCKED) continue;          /* isinstance(Door) and not is_locked */
-            for (int d = 0; d < nd; ++d) {
-                if (aux[2 + 2 * d] != fx || aux[3 + 2 * d] != fy) continue;
-                if (aux[1] & (1 << d)) break;                          /* already in self.unlocked_doors */
-                aux[1] |= (1 << d);
-                const double r = reward_value(*step_count, sp->max_steps);
-                if (sp->joint_reward) { for (int b = 0; b < A; ++b) rewards[b] += r; }   /* `+=`, not `=` */
-                else rewards[a] += r;
-                break;
+            int d = -1;
+            if (geo) {
+                for (int k = 0; k < nd; ++k) {
+                    const int64_t dx = (k & 1) ? 2 * (rs - 1) : rs - 1, dy = (int64_t)(k >> 1) * (rs - 1) + rs / 2;
+                    if (dx == fx && dy == fy) { d = k; break; }
+                }
+            } else {
+                for (int k = 0; k < nd; ++k) if (aux[2 + 2 * k] == fx && aux[3 + 2 * k] == fy) { d = k; break; }
             }
+            if (d < 0 || (mask & (1 << d))) continue;                  /* not a room door / already in self.unlocked_doors */
+            mask |= (1 << d);
+            const double r = reward_value(*step_count, sp->max_steps);
+            if (sp->joint_reward) { for (int b = 0; b < A; ++b) rewards[b] += r; }   /* `+=`, not `=` */
+            else rewards[a] += r;
         }
+        aux[1] = mask & 0xff;
+        if (geo) aux[2] = (mask >> 8) & 0xff;
         int cnt = 0;
-        for (int d = 0; d < nd; ++d) cnt += (int)((aux[1] >> d) & 1);
-        aux[15] = (cnt == nd);                                         /* len(unlocked_doors) == len(rooms) */
+        for (int d = 0; d < nd; ++d) cnt += (int)((mask >> d) & 1);
+        aux[15] = (cnt == n_rooms);                                    /* len(unlocked_doors) == len(rooms) */
         if (aux[15]) for (int b = 0; b < A; ++b) terminated[b] = 1;    /* the returned dict only, not agent state */
     }
     return 0;
@@ -515,6 +528,7 @@ int mgo_step_batch(const MgoSpec *sp, int64_t B, uint8_t *grid, uint8_t *agents,
             pack_env(sp, gs, as, grid + b * gsz, agents + (size_t)b * A * 8);
             if (sp->env_kind == KIND_LOCKEDHALLWAY && target) {
                 ((uint8_t *)target)[b * MGO_AUX + 1] = (uint8_t)tgt[1];
+                ((uint8_t *)target)[b * MGO_AUX + 2] = (uint8_t)tgt[2];
                 ((uint8_t *)target)[b * MGO_AUX + 15] = (uint8_t)tgt[15];
             }
             if (sp->env_kind == KIND_REDBLUEDOORS && target) ((uint8_t *)target)[b * MGO_AUX + 4] = (uint8_t)tgt[4];

@@ -49,9 +49,14 @@ def golden_aux(d: dict) -> np.ndarray:
         a[0:2] = d["blue_door"]; a[2:4] = d["red_door"]
     elif kind == "lockedhallway":
         doors = d["doors"]
-        a[0] = len(doors)
-        for i, (x, y) in enumerate(doors):
-            a[2 + 2 * i], a[3 + 2 * i] = x, y
+        if len(doors) <= 6:
+            a[0] = len(doors)
+            for i, (x, y) in enumerate(doors):
+                a[2 + 2 * i], a[3 + 2 * i] = x, y
+        else:                                          # geometric format (include/mgx.h): room_size, len(self.rooms)
+            a[0] = 0x80 | len(doors)
+            a[3] = min(x for x, _ in doors) + 1
+            a[4] = d["num_room_keys"]
     return a
 
 
