@@ -35,6 +35,12 @@
  *                                                        `self.unlocked_doors` (updated by the step), [2+2k, 3+2k] =
  *                                                        door k (x,y), [15] = 1 when the last step reported every agent
  *                                                        terminated (multigrid/envs/locked_hallway.py:203-227)
+ *                                                        With more than 6 rooms: [0] = 0x80 | number of doors (<= 16),
+ *                                                        [1], [2] = unlocked mask (16 bits), [3] = room_size, [4] =
+ *                                                        len(self.rooms) (rooms are keyed by door colour: repeated
+ *                                                        colours count once, and that count ends the episode); door k =
+ *                                                        (row k/2, side k%2) sits mid-wall at x = side ? 2(rs-1) : rs-1,
+ *                                                        y = row (rs-1) + rs/2 (add_door(..., rand_pos=False))
 
  *   obs         u8 [B, A, v, v, 3] image[i][j][c] exactly as multigrid/utils/obs.py:65-102 returns it
  *   dir         u8 [B, A]         obs['direction'] (multigrid/base.py:359, 372)
