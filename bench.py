@@ -78,16 +78,7 @@ def random_actions(steps, batch, agents, device, seed):
 
 def capture_steps(env, actions):
     """One hipGraph holding `len(actions)` consecutive env.step launches."""
-    stream = torch.cuda.current_stream(env.device)
-    graph = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream(env.device)
-    s.wait_stream(stream)
-    with torch.cuda.stream(s):
-        with torch.cuda.graph(graph, stream=s):
-            for t in range(actions.shape[0]):
-                env.step(actions[t], auto_reset=AUTO_RESET)
-    stream.wait_stream(s)
-    return graph
+    return env.capture_steps(actions, auto_reset=AUTO_RESET)
 
 
 def timed_region(env, run_once, repeats, dist_barrier):
@@ -470,6 +461,12 @@ def main():
             out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)
             out.update(large_batch_points(device, args.large_batch))
             out["device_generation"] = generation_point(device)
+            try:                                            # policy in the loop (examples/closed_loop.py), one hipGraph per iteration
+                sys.path.insert(0, os.path.join(ROOT, "examples"))
+                import closed_loop
+                out["closed_loop"] = {c: closed_loop.run(c, steps=100, device=str(device)) for c in ("c4", "c2")}
+            except Exception as e:                          # an example must not take the bench line down
+                out["closed_loop"] = {"error": repr(e)[:200]}
             from oracle import binding as ob
             out["cpu_baseline"] = cpu_baseline(wl, ob.max_threads(), 8.0, wl.batch)
             out["cpu_baseline_1core"] = cpu_baseline(wl, 1, 6.0, 2048)

@@ -210,6 +210,22 @@ class BatchedMultiGridEnv:
         self._bound[key] = f
         return f
 
+    def capture_steps(self, actions: torch.Tensor, auto_reset: bool = False, one_hot: bool = False):
+        """A hipGraph of `len(actions)` consecutive `step` launches reading `actions[t]` (i8[T,B,A], kept by reference: refill
+        it between replays).  `graph.replay()` then costs no Python per step; the outputs of the LAST step are in the env's
+        buffers.  (A policy in the loop is captured the same way: see examples/closed_loop.py.)"""
+        self._need_state()
+        stream = torch.cuda.current_stream(self.device)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(stream)
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for t in range(actions.shape[0]):
+                    self.step(actions[t], auto_reset=auto_reset, one_hot=one_hot)
+        stream.wait_stream(side)
+        return graph
+
     def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False) -> dict:
         """`T` consecutive `step`s in one kernel launch (env state stays in LDS between steps); bit-identical to
         calling `step(actions[t])` for t = 0..T-1.  For open-loop action sequences (random / scripted policies).

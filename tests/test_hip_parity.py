@@ -500,3 +500,23 @@ def test_random_specs_soak():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "10", "12345"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_captured_graph_of_steps_equals_eager_steps():
+    """BatchedMultiGridEnv.capture_steps: a hipGraph of T step launches == T eager steps, and it can be replayed."""
+    spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
+    B, T = 2048, 12
+    st = util.random_state(spec, B, seed=4)
+    a = BatchedMultiGridEnv(spec, B, dev()); a.load_state(st["grid"], st["agents"], st["rng"], None, st["step_count"])
+    b = BatchedMultiGridEnv(spec, B, dev()); b.load_state(st["grid"], st["agents"], st["rng"], None, st["step_count"])
+    acts = torch.from_numpy(np.stack([util.random_actions(B, 4, seed=t) for t in range(T)])).to(dev())
+    graph = a.capture_steps(acts)
+    for rep in range(2):
+        graph.replay()
+        for t in range(T):
+            want = b.step(acts[t])
+        torch.cuda.synchronize()
+        for x, y in zip((a.obs, a.dir, a.reward, a.terminated, a.truncated), want):
+            assert torch.equal(x, y)
+        assert torch.equal(a.grid, b.grid) and torch.equal(a.rng, b.rng) and torch.equal(a.step_count, b.step_count)
+    a.check_errors()
