@@ -57,6 +57,7 @@ struct KernelArgs {
     int32_t *err;
     int32_t Gw;         // envs per wavefront
     int32_t dbg;        // debug: bit p set = skip phase p (profiling only, mgx_debug_skip_phases)
+    int32_t flags;      // bit 0: the grid does not fit the Infinity Cache -- launch the STREAM instantiation (nt tile loads)
     int32_t T;          // steps per launch (mgx_rollout), 1 otherwise
     // per-wavefront LDS slice: its stride and the slot count its carve is derived from (LdsCarve below)
     int32_t wave_lds;
@@ -159,7 +160,17 @@ typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 // cache policy bits of the obs stores (raw buffer store `aux`: 1 = sc0, 2 = nt, 16 = sc1 on gfx94x/gfx950)
 #ifndef MGX_OBS_AUX
-#define MGX_OBS_AUX 0
+#define MGX_OBS_AUX 2       // nt: the observation is written once and read by another kernel (C4 -4.6 %, C3 -2 %, C5 -1.7 %)
+#endif
+#ifndef MGX_IN_AUX
+#define MGX_IN_AUX 0        // small state loads (agent rows, PCG64 words, step counts, actions) of the STREAM instantiations
+#endif
+#ifndef MGX_OUT_AUX
+#define MGX_OUT_AUX 0       // small per-agent outputs (rows, reward, terminated, dir)
+#endif
+// cache policy bits of the grid tile loads (same encoding)
+#ifndef MGX_TILE_AUX
+#define MGX_TILE_AUX 0
 #endif
 #ifndef MGX_ROUND
 #define MGX_ROUND 16
@@ -408,7 +419,8 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // (11, 6, 4)): P4 leaves a 21-bit mask per cell in LDS, P5 expands mask bits to 0/1 bytes, 16 at a time.
 // GEN: the envs whose episode ends with this step are regenerated in the tail of the launch (== mgx_reset_generate run right
 // after the step: the reference's _gen_grid on the device, mgx_layout_gen.h).
-template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false>
+// STREAM: the grid tensor is larger than the Infinity Cache can keep between steps: non-temporal tile loads.
+template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
     constexpr bool DO_STEP = MODE != 0;
     const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
@@ -436,6 +448,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     if (lane == 0 && wid < 16384) g_span[2 * wid] = __builtin_amdgcn_s_memrealtime();
 #endif
     const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, HOOKS, OH);
+    constexpr int kInAux = STREAM ? MGX_IN_AUX : 0;                           // the small state loads of P0
     uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
     ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
     int8_t *acts = reinterpret_cast<int8_t *>(L + cv.act());                  // [slot]
@@ -473,11 +486,11 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     if (DO_STEP && A > 1) {
         const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.rng + e0 * 4, Gc * 32);
         if (ROLL) {                                                              // env-major copy: lane l holds words 2l, 2l+1
-            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, lane16, 0, 0);
+            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, lane16, 0,kInAux);
             for (int t = lane; t < A * 4; t += 64) jump[t] = kJump.w[1][t];          // constants for k = 1..A, re-read every step
         } else {                                                                 // same address for the A lanes of an env
-            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32, 0, 0);
-            in_rngB = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32 + 16, 0, 0);
+            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32, 0,kInAux);
+            in_rngB = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32 + 16, 0,kInAux);
             const u32x4 *jk = reinterpret_cast<const u32x4 *>(&kJump.w[1 + agent_of_lane][0]);   // agent k draws k+1 ahead
             in_jmpA = jk[0]; in_jmpB = jk[1];
         }
@@ -486,21 +499,27 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     uint32_t in_scnt = 0;
     u32x4 in_aux = {0, 0, 0, 0};
     uint8_t in_act = 0;
-    in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
+    in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0,kInAux);
     uint32_t in_ep = 0;                                                      // AR: env `lane`'s episode count
     if (DO_STEP) {
         if (AR && !ROLL) in_ep = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.episode + e0, Gc * 4), lane * 4, 0, 0);
-        in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0, 0);
-        in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0, 0);
+        in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0,kInAux);
+        in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0,kInAux);
         if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
     }
     // (2) the tile
     u32x4 tv[U], tv2[U];
     const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env per wavefront
+    // Cache policy of the tile loads (template flag STREAM, chosen at launch): a grid tensor that fits the 256 MiB Infinity
+    // Cache is re-read from there by the next step and is best left to the default policy; one that does not is a pure
+    // stream and is loaded non-temporal (measured: 1 M envs -3.5 % step / -6.5 % gen_obs and C5 -4 % with nt, C4 +3 %).
+    // (A launch-time branch around the two forms cost 3-4 % everywhere: the loads must stay in the straight-line burst.)
+    constexpr int kTileAux = STREAM ? 2 : MGX_TILE_AUX;
+#define MGX_TILE_BURST(dst, base)                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                     \
+        dst[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), (base) + 4096 * (u >> 2), kTileAux);
 #if !MGX_DRAWS_FIRST
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
+    MGX_TILE_BURST(tv, 0)
 #endif
     // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
     // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
@@ -518,17 +537,14 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
 #if MGX_DRAWS_FIRST
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        tv[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 4096 * (u >> 2), 0);
+    MGX_TILE_BURST(tv, 0)
 #endif
     // (3b) big tiles: a second burst under the same wait (requested here, once the draws' inputs are dead, so that the
     // register peak of P0 stays below that of the gather)
     if (big_tile) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            tv2[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), 1024 * U + 4096 * (u >> 2), 0);
+        MGX_TILE_BURST(tv2, 1024 * U)
     }
+#undef MGX_TILE_BURST
     // (4) auto-reset test of the one-step kernels, also under the wait (build-defined, include/mgx.h): one lane per env
     // tests base.py:534-539 on the state the previous step left
     uint64_t reset_mask0 = 0;
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         for (int u = 0; u < U; ++u)
             if (lane16 + 1024 * (U + u) < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * (U + u)) = tv2[u];
         for (int rel = lane16 + 2048 * U; rel < len; rel += 1024)               // tiles larger than two bursts (16 KiB)
-            *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, 0);
+            *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, kTileAux);
     }
     if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
         const int64_t t0 = gtotal & ~(int64_t)15;
@@ -860,15 +876,15 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         for (int k = 0; k < NW; ++k) { inbLo[k] = (uint32_t)m[k]; inbHi[k] = (uint32_t)(m[k] >> 32); }
         if (DO_STEP) {
             const u32x2 rowv = {(uint32_t)row, (uint32_t)(row >> 32)};
-            if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(p_agents + v0 * 8, NVc * 8), lane * 8, 0, 0);
+            if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(p_agents + v0 * 8, NVc * 8), lane * 8, 0,MGX_OUT_AUX);
             const uint64_t rbits = __builtin_bit_cast(uint64_t, my_rew);
             const u32x2 rewv = {(uint32_t)rbits, (uint32_t)(rbits >> 32)};
-            __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(p_reward + tv0, NVc * 8), lane * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(p_reward + tv0, NVc * 8), lane * 8, 0,MGX_OUT_AUX);
             const bool forced = env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row_term(row) | forced),                    // base.py:338 (+ env hook)
-                                                 make_rsrc(p_term + tv0, NVc), lane, 0, 0);
+                                                 make_rsrc(p_term + tv0, NVc), lane, 0, MGX_OUT_AUX);
         }
-        if (p_dir) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)row_dir(row), make_rsrc(p_dir + tv0, NVc), lane, 0, 0);   // base.py:359, 372
+        if (p_dir) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)row_dir(row), make_rsrc(p_dir + tv0, NVc), lane, 0,MGX_OUT_AUX);   // base.py:359, 372
     } else if (lane < ((NVc + kGroup - 1) & ~(kGroup - 1))) {                // padding slots of the last gather group
         ViewRec r;
         r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = 0;
@@ -1145,8 +1161,11 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 
 // The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
 // failed launch (mgx_last_hip_error).
-template <int V, int MODE, bool OH, bool GEN = false>
+template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err) {
+    if constexpr (!STREAM && MODE != 2 && !GEN) {            // (rollouts read the tile once per launch; GEN: small envs)
+        if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    }
     void (*kern)(const KernelArgs) = nullptr;
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
     const bool ar = MODE != 0 && ka.pool_grid != nullptr;
@@ -1154,8 +1173,8 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
     if constexpr (GEN) {                                                     // (generation replaces the pool pick-up)
         kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
     } else {
-        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH> : mgx_fused_kernel<V, MODE, S, false, OH>)
-                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH> : mgx_fused_kernel<V, MODE, false, false, OH>);
+        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM>)
+                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH, false, STREAM> : mgx_fused_kernel<V, MODE, false, false, OH, false, STREAM>);
     }
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
