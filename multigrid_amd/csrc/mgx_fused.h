@@ -162,6 +162,9 @@ constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 #ifndef MGX_OBS_AUX
 #define MGX_OBS_AUX 2       // nt: the observation is written once and read by another kernel (C4 -4.6 %, C3 -2 %, C5 -1.7 %)
 #endif
+#ifndef MGX_OH_AUX
+#define MGX_OH_AUX 0        // one-hot observation stores: default policy (nt measured 6 % slower on this 7x larger write stream)
+#endif
 #ifndef MGX_IN_AUX
 #define MGX_IN_AUX 0        // small state loads (agent rows, PCG64 words, step counts, actions) of the STREAM instantiations
 #endif
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                     v.z = (((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
                     v.w = (((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
                     if ((rel + 16 <= rlen) & (rel >= oh_skew)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, rel, 0, MGX_OBS_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, rel, 0, MGX_OH_AUX);
                     } else {                                                    // ragged head / tail of the wave's bytes
                         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                         const int lo_b = max(rel, oh_skew), hi_b = min(rel + 16, rlen);
