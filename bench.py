@@ -223,7 +223,10 @@ def large_batch_points(device, large_batch):
 
     def step():
         env.step(acts[i[0] & 3], auto_reset=AUTO_RESET); i[0] += 1
-    ms_step = kernel_time_ms(step, 60, device)
+    # 250 untimed steps first: right after the start all agents of an env stand on one cell, which sends most envs
+    # through the sequential fallback (343 us per step over the first 50 steps, 270 us from step 150 on: tools/time_curve.py);
+    # the timed steps are the steady state of the random-action rollout, as the headline's are
+    ms_step = kernel_time_ms(step, 60, device, warm=250)
     ms_obs = kernel_time_ms(env.gen_obs, 60, device)
     n = large_batch * spec.num_agents
     r_step = roofline(n * spec.bytes_step(), ms_step, pmc_traffic("large_step", large_batch))

@@ -93,6 +93,9 @@ struct KernelArgs {
 #ifndef MGX_WRITELANE_NOP
 #define MGX_WRITELANE_NOP 0
 #endif
+#ifndef MGX_LDS_DMA
+#define MGX_LDS_DMA 0
+#endif
 #ifndef MGX_DRAWS_FIRST
 #define MGX_DRAWS_FIRST 0
 #endif
@@ -511,16 +514,28 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
     }
     // (2) the tile
-    u32x4 tv[U], tv2[U];
+    [[maybe_unused]] u32x4 tv[U], tv2[U];
     const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env per wavefront
     // Cache policy of the tile loads (template flag STREAM, chosen at launch): a grid tensor that fits the 256 MiB Infinity
     // Cache is re-read from there by the next step and is best left to the default policy; one that does not is a pure
     // stream and is loaded non-temporal (measured: 1 M envs -3.5 % step / -6.5 % gen_obs and C5 -4 % with nt, C4 +3 %).
     // (A launch-time branch around the two forms cost 3-4 % everywhere: the loads must stay in the straight-line burst.)
     constexpr int kTileAux = STREAM ? 2 : MGX_TILE_AUX;
+#if MGX_LDS_DMA
+    // the tile goes HBM -> LDS directly (buffer_load_dwordx4 ... lds: wave-uniform LDS base in M0 + 16 bytes per lane, which
+    // is exactly the tile's layout): no staging VGPRs, no ds_write pass.  Lanes past the wave's bytes are masked off -- an
+    // out-of-range lane would still write its zeros into LDS.
+    typedef __attribute__((address_space(3))) void *lds_void_ptr;
+#define MGX_TILE_BURST(dst, base)                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                     \
+        if (lane16 + (base) + 1024 * u < len)                                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void_ptr)(tile_raw + (base) + 1024 * u), 16, lane16,   \
+                                                     (base) + 1024 * u, 0, kTileAux);
+#else
 #define MGX_TILE_BURST(dst, base)                                                                                     \
     _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                     \
         dst[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), (base) + 4096 * (u >> 2), kTileAux);
+#endif
 #if !MGX_DRAWS_FIRST
     MGX_TILE_BURST(tv, 0)
 #endif
@@ -576,16 +591,20 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (lane < Gc) { scnt[lane] = (int32_t)in_scnt; if (cv.has_aux) reinterpret_cast<u32x4 *>(auxl)[lane] = in_aux; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
+#if !MGX_LDS_DMA
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (lane16 + 1024 * u < len) {
             MGX_CHECK_LDS_PTR(1, tile_raw + lane16 + 1024 * u, 16);
             *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
         }
+#endif
     if (big_tile) {
+#if !MGX_LDS_DMA
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (lane16 + 1024 * (U + u) < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * (U + u)) = tv2[u];
+#endif
         for (int rel = lane16 + 2048 * U; rel < len; rel += 1024)               // tiles larger than two bursts (16 KiB)
             *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, kTileAux);
     }

@@ -18,7 +18,7 @@ out = os.path.join(tempfile.gettempdir(), "mgx_markers.s")
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DMGX_MARKERS=1",
                        f"-I{ROOT}/include", "-S", "--cuda-device-only", f"-DMGX_INST_V={V}", *extra,
                        f"{ROOT}/multigrid_amd/csrc/mgx_fused_inst.hip", "-o", out])
-want = f"mgx_fused_kernelILi{V}ELi{MODE}ELb{HOOKS}E" + (os.environ.get("MGX_KERNEL_SUFFIX", ""))
+want = f"mgx_fused_kernelILi{V}ELi{MODE}ELb{HOOKS}E" + (os.environ.get("MGX_KERNEL_SUFFIX", ""))   # e.g. "Lb1ELb0ELb0ELb0EEEv": AR, OH, GEN, STREAM
 cur = None
 phase = "pre"
 counts = collections.OrderedDict()

@@ -21,6 +21,7 @@ OUT = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 os.makedirs(OUT, exist_ok=True)
 ENV = dict(os.environ, TMPDIR="/tmp")
 WARM, N = 40, 60
+WARM_LARGE = 250      # the 1M-env point: steady state of the rollout (tools/time_curve.py)
 
 #: (key, MGX_WORKLOAD, batch, extra env)
 POINTS = [("c2", "c2", 4096, {}), ("c3", "c3", 16384, {}), ("c4", "c4", 65536, {}), ("c5", "c5", 32768, {}),
@@ -79,10 +80,11 @@ for key, wl, B, xenv in POINTS:
     e = dict(MGX_WORKLOAD=wl, **xenv)
     if B < (1 << 20):
         e["MGX_GRAPH"] = "1"                 # the configurations' steps run as hipGraph replays, as bench.py times them
-    cmd = [sys.executable, "tools/large_step.py", str(B), str(N), str(WARM)]
+    warm = WARM_LARGE if B >= (1 << 20) else WARM
+    cmd = [sys.executable, "tools/large_step.py", str(B), str(N), str(warm)]
     d = os.path.join(OUT, f"{key}_trace")
     rocprof(["--kernel-trace"], d, cmd, e)
-    for k, v in sorted(durations(d, WARM).items()):
+    for k, v in sorted(durations(d, warm).items()):
         lines.append(f"trace {key} B={B} {k}: warm_calls={len(v)} avg_ns={sum(v) / len(v):.1f} min_ns={min(v)} max_ns={max(v)}")
     if quick:
         continue
