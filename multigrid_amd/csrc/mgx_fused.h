@@ -58,6 +58,7 @@ struct KernelArgs {
     int32_t Gw;         // envs per wavefront
     int32_t dbg;        // debug: bit p set = skip phase p (profiling only, mgx_debug_skip_phases)
     int32_t flags;      // bit 0: the grid does not fit the Infinity Cache -- launch the STREAM instantiation (nt tile loads)
+                        // bit 1: few wavefronts (latency regime) -- launch the DMA instantiation (LDS-DMA tile loads)
     int32_t T;          // steps per launch (mgx_rollout), 1 otherwise
     // per-wavefront LDS slice: its stride and the slot count its carve is derived from (LdsCarve below)
     int32_t wave_lds;
@@ -426,7 +427,8 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // GEN: the envs whose episode ends with this step are regenerated in the tail of the launch (== mgx_reset_generate run right
 // after the step: the reference's _gen_grid on the device, mgx_layout_gen.h).
 // STREAM: the grid tensor is larger than the Infinity Cache can keep between steps: non-temporal tile loads.
-template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false>
+// DMA: the tile is loaded HBM -> LDS by LDS-DMA (small launches: P0).
+template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false, bool DMA = (MGX_LDS_DMA != 0)>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
     constexpr bool DO_STEP = MODE != 0;
     const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
@@ -521,21 +523,22 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     // stream and is loaded non-temporal (measured: 1 M envs -3.5 % step / -6.5 % gen_obs and C5 -4 % with nt, C4 +3 %).
     // (A launch-time branch around the two forms cost 3-4 % everywhere: the loads must stay in the straight-line burst.)
     constexpr int kTileAux = STREAM ? 2 : MGX_TILE_AUX;
-#if MGX_LDS_DMA
-    // the tile goes HBM -> LDS directly (buffer_load_dwordx4 ... lds: wave-uniform LDS base in M0 + 16 bytes per lane, which
-    // is exactly the tile's layout): no staging VGPRs, no ds_write pass.  Lanes past the wave's bytes are masked off -- an
-    // out-of-range lane would still write its zeros into LDS.
+    // DMA instantiations: the tile goes HBM -> LDS directly (buffer_load_dwordx4 ... lds: wave-uniform LDS base in M0 + 16
+    // bytes per lane, which is exactly the tile's layout): no staging VGPRs (78 instead of 95: the register peak of the
+    // step kernel was this burst), no ds_write pass.  Lanes past the wave's bytes are masked off -- an out-of-range lane
+    // would still write its zeros into LDS.  Shorter for a lone wave (-3..5 % up to 2048 wavefronts), but the LDS-DMA path
+    // has less throughput than loads + ds_write_b128 (+4 % at 65536 envs): chosen at launch by the number of wavefronts.
     typedef __attribute__((address_space(3))) void *lds_void_ptr;
 #define MGX_TILE_BURST(dst, base)                                                                                     \
-    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                     \
-        if (lane16 + (base) + 1024 * u < len)                                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void_ptr)(tile_raw + (base) + 1024 * u), 16, lane16,   \
-                                                     (base) + 1024 * u, 0, kTileAux);
-#else
-#define MGX_TILE_BURST(dst, base)                                                                                     \
-    _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                     \
-        dst[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), (base) + 4096 * (u >> 2), kTileAux);
-#endif
+    if constexpr (DMA) {                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                 \
+            if (lane16 + (base) + 1024 * u < len)                                                                     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void_ptr)(tile_raw + (base) + 1024 * u), 16, lane16, \
+                                                         (base) + 1024 * u, 0, kTileAux);                            \
+    } else {                                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                 \
+            dst[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), (base) + 4096 * (u >> 2), kTileAux); \
+    }
 #if !MGX_DRAWS_FIRST
     MGX_TILE_BURST(tv, 0)
 #endif
@@ -591,20 +594,20 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         if (lane < Gc) { scnt[lane] = (int32_t)in_scnt; if (cv.has_aux) reinterpret_cast<u32x4 *>(auxl)[lane] = in_aux; }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
-#if !MGX_LDS_DMA
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (lane16 + 1024 * u < len) {
-            MGX_CHECK_LDS_PTR(1, tile_raw + lane16 + 1024 * u, 16);
-            *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
-        }
-#endif
-    if (big_tile) {
-#if !MGX_LDS_DMA
+    if constexpr (!DMA) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (lane16 + 1024 * (U + u) < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * (U + u)) = tv2[u];
-#endif
+            if (lane16 + 1024 * u < len) {
+                MGX_CHECK_LDS_PTR(1, tile_raw + lane16 + 1024 * u, 16);
+                *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
+            }
+    }
+    if (big_tile) {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (lane16 + 1024 * (U + u) < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * (U + u)) = tv2[u];
+        }
         for (int rel = lane16 + 2048 * U; rel < len; rel += 1024)               // tiles larger than two bursts (16 KiB)
             *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, kTileAux);
     }
@@ -1183,10 +1186,13 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 
 // The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
 // failed launch (mgx_last_hip_error).
-template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false>
+template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err) {
-    if constexpr (!STREAM && MODE != 2 && !GEN) {            // (rollouts read the tile once per launch; GEN: small envs)
-        if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
+    if constexpr (!STREAM && !DMA && MODE != 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
+        if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
+        if constexpr (!OH) {
+            if (ka.flags & 2) return launch_mode<V, MODE, OH, GEN, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
+        }
     }
     void (*kern)(const KernelArgs) = nullptr;
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
@@ -1195,8 +1201,8 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
     if constexpr (GEN) {                                                     // (generation replaces the pool pick-up)
         kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
     } else {
-        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM>)
-                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH, false, STREAM> : mgx_fused_kernel<V, MODE, false, false, OH, false, STREAM>);
+        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM, DMA> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM, DMA>)
+                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH, false, STREAM, DMA> : mgx_fused_kernel<V, MODE, false, false, OH, false, STREAM, DMA>);
     }
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
