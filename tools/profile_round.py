@@ -29,10 +29,11 @@ POINTS = [("c2", "c2", 4096, {}), ("c3", "c3", 16384, {}), ("c4", "c4", 65536, {
 
 
 def kind_of(name: str):
-    m = re.search(r"mgx_fused_kernel<(\d+), (\d), (\w+), (\w+)(?:, (\w+))?(?:, (\w+))?>", name)
-    if m:
-        mode, oh, gen = m.group(2), m.group(5) == "true", m.group(6) == "true"
-        return {"0": "gen_obs", "1": "step", "2": "rollout"}[mode] + ("_one_hot" if oh else "") + ("_generate" if gen else "")
+    m = re.search(r"mgx_fused_kernel<([^>]*)>", name)
+    if m:                                   # <V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA>
+        t = [x.strip() for x in m.group(1).split(",")] + ["false"] * 8
+        return ({"0": "gen_obs", "1": "step", "2": "rollout"}[t[1]] + ("_one_hot" if t[4] == "true" else "")
+                + ("_generate" if t[5] == "true" else ""))
     for k in ("one_hot_kernel", "full_obs_kernel", "reset_done_kernel"):
         if k in name:
             return k
