@@ -88,8 +88,11 @@ def build_lib(force: bool = False, verbose: bool = False, lib: str = LIB, define
         return obj
 
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_unit, UNITS))
+    # -DMGX_SINGLE_TU=1 (tools' builds with kernel-side globals, e.g. -DMGX_TIMESTAMPS=1): mgx_kernels.hip includes the
+    # per-view instantiations itself
+    units = [u for u in UNITS if not (u[0].startswith("mgx_fused_v") and "MGX_SINGLE_TU=1" in defines)]
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_unit, units))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
