@@ -265,8 +265,8 @@ def aux_kernel_points(env, device):
     # one-hot of the step's observations: 3 B in, 21 B out per view cell (wrappers.py:158-190)
     cells = batch * A * V * V
     out["one_hot"] = entry(kernel_time_ms(env.one_hot_obs, 30, device, warm=10), cells * (3 + 21))
-    # fully observable encode: grid in, transposed grid out, agent rows in
-    out["full_obs"] = entry(kernel_time_ms(env.full_obs, 30, device, warm=10), batch * (2 * H * W * 3 + A * 8))
+    # fully observable encode: packed grid in (2 B per cell), transposed (type, color, state) bytes out, agent rows in
+    out["full_obs"] = entry(kernel_time_ms(env.full_obs, 30, device, warm=10), batch * (H * W * (2 + 3) + A * 8))
     # auto-reset with every env done: agent rows + step counts in, layout out
     def reset_all():
         env.step_count.fill_(spec.max_steps)          # every env truncated -> every env is reset
@@ -274,7 +274,7 @@ def aux_kernel_points(env, device):
     def fill_only():
         env.step_count.fill_(spec.max_steps)
     t = kernel_time_ms(reset_all, 30, device, warm=10) - kernel_time_ms(fill_only, 30, device, warm=10)
-    out["reset_done_all"] = entry(t, batch * (H * W * 3 + 2 * A * 8 + 4 + 4 + 4 + 1))
+    out["reset_done_all"] = entry(t, batch * (H * W * 2 + 2 * A * 8 + 4 + 4 + 4 + 1))
     env.step_count.zero_()
     out["reset_done_none"] = entry(kernel_time_ms(env.reset_done, 30, device, warm=10), batch * (A * 8 + 4 + 1))
     return out

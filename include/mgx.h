@@ -11,8 +11,17 @@
  * functions do not synchronise.
  *
  * Tensor layouts (all contiguous, device memory):
- *   grid        u8 [B, H, W, 3]   cell (x, y) = (type, color, state) at ((b*H + y)*W + x)*3.  This is the [y][x]
- *                                 transpose of the reference's Grid.state (W,H,3) (multigrid/core/grid.py:54).
+ *   grid        u16[B, H, W]      PACKED cells (MgxCell): cell (x, y) of env b at (b*H + y)*W + x -- the [y][x] transpose of
+ *                                 the reference's Grid.state (W,H,3) (multigrid/core/grid.py:54), each (type, color, state)
+ *                                 triple in 16 bits:
+ *                                     [3:0] type   [10:8] color   [13:12] state   [15] opaque   (other bits zero)
+ *                                 opaque = 1 for a cell one cannot see through (multigrid/utils/obs.py:46-63: a wall, or a door
+ *                                 that is not open); it is part of the format (the kernels keep it up to date on every cell
+ *                                 they write).  Two bytes per cell instead of the reference's three int64: a third less grid
+ *                                 traffic and aligned 16-bit cell accesses on the device.  mgx_pack_grid / mgx_unpack_grid
+ *                                 convert from / to u8[B,H,W,3] (type, color, state) bytes on the device; values the 16 bits
+ *                                 cannot hold (type > 15, color > 7, state > 3 -- the reference has types 0-10, colors 0-5,
+ *                                 states 0-2 and directions 0-3) are reported by mgx_pack_grid.
  *   agents      u8 [B, A, 8]      packed AgentState row (multigrid/core/agent.py:222-232, 72 B -> 8 B):
  *                                 [0]=color [1]=dir [2]=x [3]=y [4]=terminated [5]=carry.type [6]=carry.color
  *                                 [7]=carry.state ; "carrying nothing" = the empty cell (1,0,0) (agent.py:337-346).
@@ -59,7 +68,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 4
+#define MGX_ABI_VERSION 5
 
 enum {
     MGX_OK = 0,
@@ -72,6 +81,9 @@ enum {
 enum { MGX_KIND_EMPTY = 0, MGX_KIND_BLOCKEDUNLOCKPICKUP = 1, MGX_KIND_REDBLUEDOORS = 2, MGX_KIND_LOCKEDHALLWAY = 3 };
 
 #define MGX_AUX_BYTES 16
+
+typedef uint16_t MgxCell;        /* packed grid cell, see "grid" above */
+#define MGX_CELL_BYTES 2
 
 #define MGX_MAX_AGENTS 32
 #define MGX_MAX_VIEW 15
@@ -107,7 +119,7 @@ int mgx_last_hip_error(void);
 
 /* Replaces gen_obs_grid_encoding (multigrid/utils/obs.py:65-102) as called from MultiGridEnv.gen_obs
  * (multigrid/base.py:361-366), for B envs.  `dir` may be NULL. */
-int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents,
                 uint8_t *obs, uint8_t *dir, void *stream);
 
 /* Replaces MultiGridEnv.step (multigrid/base.py:303-346: step_count += 1, handle_actions 378-476, gen_obs
@@ -115,7 +127,7 @@ int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const u
  * (multigrid/envs/blockedunlockpickup.py:166-175, redbluedoors.py:170-187, locked_hallway.py:203-227), for B envs, in one
  * fused kernel launch.
  * grid / agents / rng / step_count are updated in place. */
-int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+int mgx_step(const MgxSpec *spec, int64_t batch, MgxCell *grid, uint8_t *agents, uint64_t *rng,
              int32_t *step_count, const int8_t *actions, uint8_t *aux,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream);
@@ -127,10 +139,18 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
  * BASELINE.json); a policy in the loop needs mgx_step.
  *   actions i8[steps,B,A]   obs u8[steps,B,A,v,v,3]   dir u8[steps,B,A]   reward f64[steps,B,A]
  *   terminated u8[steps,B,A]   truncated u8[steps,B]        (state tensors as in mgx_step, updated once at the end) */
-int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, MgxCell *grid, uint8_t *agents, uint64_t *rng,
                 int32_t *step_count, const int8_t *actions, uint8_t *aux,
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream);
+
+/* Grid format conversion on the device (the reference's Grid.state holds (type, color, state) triples):
+ *   mgx_pack_grid    cells3 u8[n_cells, 3] -> packed u16[n_cells]; bad[0] (i32, device, may be NULL; the caller zeroes it)
+ *                    += the number of cells with a value the packed format cannot hold (they are stored truncated)
+ *   mgx_unpack_grid  packed u16[n_cells] -> cells3 u8[n_cells, 3]
+ * n_cells = B*H*W for a whole grid tensor (both layouts are [b][y][x]). */
+int mgx_pack_grid(const uint8_t *cells3, int64_t n_cells, MgxCell *packed, int32_t *bad, void *stream);
+int mgx_unpack_grid(const MgxCell *packed, int64_t n_cells, uint8_t *cells3, void *stream);
 
 /* Geometry mgx_gen_obs / mgx_step / mgx_rollout would use. */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
@@ -145,17 +165,17 @@ int mgx_one_hot(const uint8_t *cells, int64_t n_cells, const int32_t *dim_sizes,
 /* Replaces FullyObsWrapper.observation (multigrid/wrappers.py:48-58): out u8[B, W, H, 3] = Grid.state ([x][y], the
  * reference's own orientation) with every agent's (10, color, dir) written at its position in index order,
  * terminated agents included. */
-int mgx_full_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents, uint8_t *out,
+int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents, uint8_t *out,
                  void *stream);
 
 /* Vector-env auto-reset (build-defined: the reference has no batching; its caller tests is_done(), base.py:534-539,
  * and calls reset(), base.py:250-301).  Every env b whose episode is over -- all agents terminated or
  * step_count >= max_steps -- is re-initialised from a pool of K pre-generated layouts
- * (pool_grid u8[K,H,W,3], pool_agents u8[K,A,8], pool_aux u8[K,16] or NULL):
+ * (pool_grid u16[K,H,W] packed cells, pool_agents u8[K,A,8], pool_aux u8[K,16] or NULL):
  *   layout = (first_env + b + episode[b] * 7919) mod K;  step_count[b] = 0;  episode[b] += 1;  was_reset[b] = 1.
  * The env's PCG64 stream is left running, as an unseeded reset() does for Empty envs.  `was_reset` may be NULL. */
-int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const uint8_t *pool_grid,
-                   const uint8_t *pool_agents, const uint8_t *pool_aux, uint8_t *grid, uint8_t *agents,
+int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const MgxCell *pool_grid,
+                   const uint8_t *pool_agents, const uint8_t *pool_aux, MgxCell *grid, uint8_t *agents,
                    int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream);
 
 /* The two calls below fuse mgx_reset_done into the step: an env whose episode ended with the PREVIOUS step (all agents
@@ -166,19 +186,19 @@ int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_
 typedef struct MgxAutoReset {
     int64_t first_env;            /* global index of env 0 of this shard */
     int32_t pool_size;            /* K >= 1 */
-    const uint8_t *pool_grid;     /* u8[K,H,W,3] */
+    const MgxCell *pool_grid;     /* u16[K,H,W] packed cells */
     const uint8_t *pool_agents;   /* u8[K,A,8] */
     const uint8_t *pool_aux;      /* u8[K,16]; NULL for MGX_KIND_EMPTY */
     int32_t *episode;             /* i32[B], in/out */
     uint8_t *was_reset;           /* out, may be NULL */
 } MgxAutoReset;
 
-int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, MgxCell *grid, uint8_t *agents,
                        uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                        uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                        int32_t *err, void *stream);
 
-int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar, uint8_t *grid,
+int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar, MgxCell *grid,
                           uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                           uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                           int32_t *err, void *stream);
@@ -193,7 +213,7 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
  *   gen_state u64[B,6]  [0..3] = the placement generator's PCG64 state (state_lo, state_hi, inc_lo, inc_hi),
  *                       [4] = its 32-bit buffer (has_uint32 << 32 | uinteger), [5] = the 32-bit buffer of env.np_random,
  *                       whose PCG64 words are the `rng` tensor of mgx_step.  In/out.
- *   blank     u8[H,W,3] the grid before any object or agent is placed: the rooms' walls (RoomGrid, roomgrid.py:203-218),
+ *   blank     u16[H,W]  (packed cells) the grid before any object or agent is placed: the rooms' walls (RoomGrid, roomgrid.py:203-218),
  *                       or border walls + goal at (W-2, H-2) (EmptyEnv, multigrid/envs/empty.py:156-162).  It is what gets
  *                       copied into a restarted env's grid; the placement tests use the same layout in closed form, so it
  *                       must be exactly that (multigrid_amd.layouts.roomgrid_blank / empty_blank produce it)
@@ -208,18 +228,18 @@ typedef struct MgxLayoutGen {
     int32_t kind;
     int32_t room_size;                    /* MGX_GEN_BLOCKEDUNLOCKPICKUP */
     int32_t start_x, start_y, start_dir;  /* MGX_GEN_EMPTY_FIXED */
-    const uint8_t *blank;
+    const MgxCell *blank;
     uint64_t *gen_state;
 } MgxLayoutGen;
 
-int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
+int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,
                        uint64_t *rng, int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream);
 
 /* mgx_step followed by mgx_reset_generate, in ONE launch: the envs whose episode ends with this step (all agents terminated
  * or step_count >= max_steps after it) are regenerated in the tail of the step's own kernel; the outputs are the step's
  * (the terminal observation); the state tensors come out holding the next episode's start.  Bit-identical to the two calls.
  * `was_reset` (may be NULL) = the envs that were regenerated. */
-int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
+int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,
                       uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                       uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                       int32_t *err, int32_t *episode, uint8_t *was_reset, void *stream);
@@ -231,9 +251,9 @@ int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *ge
  *   obs_one_hot u8[B, A, v, v, 21]   obs_one_hot[b,a,i,j, c0] = obs_one_hot[.., 11 + c1] = obs_one_hot[.., 17 + c2] = 1
  *                                    for obs[b,a,i,j] = (c0, c1, c2); everything else 0.  16-byte aligned.
  * `ar` may be NULL (no auto-reset).  Everything else as in mgx_step / mgx_step_autoreset. */
-int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents,
                         uint8_t *obs_one_hot, uint8_t *dir, void *stream);
-int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, MgxCell *grid, uint8_t *agents,
                      uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                      uint8_t *obs_one_hot, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                      int32_t *err, void *stream);

@@ -17,14 +17,14 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
 EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
            "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout", "mgx_step_autoreset",
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
-           "mgx_reset_generate", "mgx_step_generate")
+           "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid")
 
 
 class MgxLaunchInfo(C.Structure):
@@ -94,6 +94,10 @@ def lib() -> C.CDLL:
     L.mgx_reset_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen)] + [vp] * 8
     L.mgx_step_generate.restype = C.c_int
     L.mgx_step_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen)] + [vp] * 15
+    L.mgx_pack_grid.restype = C.c_int
+    L.mgx_pack_grid.argtypes = [vp, i64, vp, vp, vp]
+    L.mgx_unpack_grid.restype = C.c_int
+    L.mgx_unpack_grid.argtypes = [vp, i64, vp, vp]
     L.mgx_launch_info.restype = C.c_int
     L.mgx_launch_info.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLaunchInfo)]
     if L.mgx_abi_version() != ABI_VERSION:

@@ -5,7 +5,8 @@ This is the tensor-level form of `multigrid.base.MultiGridEnv` (multigrid/base.p
 (batch, agent) shape.  The per-env dict API lives in multigrid_amd/env.py on top of this class.
 
 State (device tensors, layouts in include/mgx.h):
-    grid u8[B,H,W,3]   agents u8[B,A,8]   rng i64[B,4] (PCG64 words)   step_count i32[B]   aux u8[B,16]
+    cells i16[B,H,W] (packed grid cells, include/mgx.h MgxCell; `grid` = the same as (type, color, state) bytes
+    u8[B,H,W,3])   agents u8[B,A,8]   rng i64[B,4] (PCG64 words)   step_count i32[B]   aux u8[B,16]
 Outputs of `step` (pre-allocated, overwritten by every call -- clone what you keep):
     obs u8[B,A,v,v,3]  dir u8[B,A]  reward f64[B,A]  terminated u8[B,A]  truncated u8[B]
 """
@@ -41,7 +42,7 @@ class BatchedMultiGridEnv:
             backend = HipBackend(spec, self.device)
         self.backend = backend
         B, A, dev = self.batch, spec.num_agents, self.device
-        self.grid = torch.zeros(spec.grid_shape(B), dtype=torch.uint8, device=dev)
+        self.cells = torch.zeros(spec.cells_shape(B), dtype=torch.int16, device=dev)    # packed cells (MgxCell bit patterns)
         self.agents = torch.zeros(spec.agents_shape(B), dtype=torch.uint8, device=dev)
         self.rng = torch.zeros((B, 4), dtype=torch.int64, device=dev)
         self.step_count = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -55,6 +56,13 @@ class BatchedMultiGridEnv:
         self._loaded = False
         self._act_shape = torch.Size((B, A))
         self._bound = {}                 # (auto_reset, one_hot) -> pre-bound step launcher (ops.HipBackend.bind_step)
+
+    @property
+    def grid(self) -> torch.Tensor:
+        """The grid as (type, color, state) bytes u8[B,H,W,3] ([y][x]: layouts.grid_from_product gives the reference's
+        Grid.state) -- unpacked from `cells` on every access; for inspection, tests and checkpoints, not the hot path."""
+        c = self.cells.to(torch.int32)
+        return torch.stack((c & 0xF, (c >> 8) & 0x7, (c >> 12) & 0x3), dim=-1).to(torch.uint8)
 
     # ------------------------------------------------------------------------------------------ state in
     def load_state(self, grid, agents, rng=None, aux=None, step_count=None, validate: bool = True, target=None):
@@ -78,7 +86,7 @@ class BatchedMultiGridEnv:
             an = a.cpu().numpy()
             if (an[..., 2] >= sp.width).any() or (an[..., 3] >= sp.height).any() or (an[..., 1] > 3).any():
                 raise ValueError("agent position / direction out of range")
-        self.grid.copy_(g)
+        self.cells.copy_(torch.from_numpy(layouts.pack_cells(g.cpu().numpy()).view(np.int16)))
         self.agents.copy_(a)
         if rng is not None:
             r = np.asarray(rng.cpu() if torch.is_tensor(rng) else rng)
@@ -124,9 +132,9 @@ class BatchedMultiGridEnv:
         multigrid/wrappers.py:158-190), written by the same kernel launch; `obs` is not touched."""
         self._need_state()
         if one_hot:
-            self.backend.gen_obs(self.batch, self.grid, self.agents, self._one_hot_buffer(), self.dir, one_hot=True)
+            self.backend.gen_obs(self.batch, self.cells, self.agents, self._one_hot_buffer(), self.dir, one_hot=True)
             return self._one_hot, self.dir
-        self.backend.gen_obs(self.batch, self.grid, self.agents, self.obs, self.dir)
+        self.backend.gen_obs(self.batch, self.cells, self.agents, self.obs, self.dir)
         return self.obs, self.dir
 
     def _one_hot_buffer(self):
@@ -160,10 +168,10 @@ class BatchedMultiGridEnv:
         """
         if not self._loaded:
             self._need_state()
-        if actions.dtype is not torch.int8 or actions.shape != self._act_shape or actions.device != self.grid.device \
+        if actions.dtype is not torch.int8 or actions.shape != self._act_shape or actions.device != self.cells.device \
                 or not actions.is_contiguous():
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {tuple(self._act_shape)} "
-                             f"on {self.grid.device}")
+                             f"on {self.cells.device}")
         generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
         if generate:
             # on-device generation: the envs whose episode ends with THIS step are regenerated right after it (in the tail
@@ -187,7 +195,7 @@ class BatchedMultiGridEnv:
         if one_hot:
             kw["one_hot"] = True
         obs = self._one_hot_buffer() if one_hot else self.obs
-        self.backend.step(self.batch, self.grid, self.agents, self.rng, self.step_count, actions,
+        self.backend.step(self.batch, self.cells, self.agents, self.rng, self.step_count, actions,
                           self.aux if sp.env_kind != "empty" else None, self.err,
                           obs, self.dir, self.reward, self.terminated, self.truncated, **kw)
         if generate:
@@ -202,7 +210,7 @@ class BatchedMultiGridEnv:
             self._bound[key] = False
             return False
         ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
-        f = bind(self.batch, self.grid, self.agents, self.rng, self.step_count,
+        f = bind(self.batch, self.cells, self.agents, self.rng, self.step_count,
                  self.aux if self.spec.env_kind != "empty" else None, self.err,
                  self._one_hot_buffer() if one_hot else self.obs, self.dir, self.reward, self.terminated, self.truncated,
                  auto_reset=ar, one_hot=one_hot,
@@ -237,8 +245,8 @@ class BatchedMultiGridEnv:
         self._need_state()
         sp, B = self.spec, self.batch
         if actions.dtype != torch.int8 or actions.dim() != 3 or tuple(actions.shape[1:]) != (B, sp.num_agents) \
-                or actions.device != self.grid.device or not actions.is_contiguous():
-            raise ValueError(f"actions must be a contiguous int8 tensor of shape (T, {B}, {sp.num_agents}) on {self.grid.device}")
+                or actions.device != self.cells.device or not actions.is_contiguous():
+            raise ValueError(f"actions must be a contiguous int8 tensor of shape (T, {B}, {sp.num_agents}) on {self.cells.device}")
         T, A, v, dev = actions.shape[0], sp.num_agents, sp.view_size, self.device
         if out is None:
             out = {"obs": torch.empty((T, B, A, v, v, 3), dtype=torch.uint8, device=dev),
@@ -249,7 +257,7 @@ class BatchedMultiGridEnv:
         if auto_reset and "was_reset" not in out:
             out["was_reset"] = torch.empty((T, B), dtype=torch.uint8, device=dev)
         ar = self._auto_reset_args(auto_reset, out.get("was_reset"))
-        self.backend.rollout(B, T, self.grid, self.agents, self.rng, self.step_count, actions,
+        self.backend.rollout(B, T, self.cells, self.agents, self.rng, self.step_count, actions,
                              self.aux if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],
                              out["reward"], out["terminated"], out["truncated"],
                              **({"auto_reset": ar} if ar is not None else {}))
@@ -268,7 +276,7 @@ class BatchedMultiGridEnv:
         if getattr(self, "_full", None) is None:
             self._full = torch.zeros((self.batch, self.spec.width, self.spec.height, 3), dtype=torch.uint8,
                                      device=self.device)
-        self.backend.full_obs(self.batch, self.grid, self.agents, self._full)
+        self.backend.full_obs(self.batch, self.cells, self.agents, self._full)
         return self._full
 
     def set_layout_pool(self, grids, agents, auxs=None):
@@ -289,7 +297,8 @@ class BatchedMultiGridEnv:
         elif sp.env_kind != "empty":
             raise ValueError(f"env_kind {sp.env_kind!r} needs per-layout aux")
         self._gen = None
-        self._pool = (g.to(self.device).contiguous(), a.to(self.device).contiguous(), t)
+        cells = torch.from_numpy(layouts.pack_cells(g.numpy()).view(np.int16))
+        self._pool = (cells.to(self.device).contiguous(), a.to(self.device).contiguous(), t)
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
         self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
         self._bound.clear()              # (the pre-bound launchers hold the old pool's pointers)
@@ -319,7 +328,7 @@ class BatchedMultiGridEnv:
             raise ValueError(f"unknown layout generator {kind!r}")
         idx = self.first_env + np.arange(self.batch)
         self._gen = {"kind": kind, "room_size": int(room_size), "start": tuple(int(v) for v in start),
-                     "blank": torch.from_numpy(blank).to(self.device).contiguous(),
+                     "blank": torch.from_numpy(layouts.pack_cells(blank).view(np.int16)).to(self.device).contiguous(),
                      "gen_state": torch.from_numpy(rnglib.layout_gen_state(layout_seed, idx).view(np.int64)).to(self.device)}
         self._pool = None
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
@@ -333,12 +342,12 @@ class BatchedMultiGridEnv:
         produced by the next `gen_obs()` / `step()`."""
         self._need_state()
         if getattr(self, "_gen", None) is not None:
-            self.backend.reset_generate(self.batch, self._gen, self.grid, self.agents, self.rng, self.step_count,
+            self.backend.reset_generate(self.batch, self._gen, self.cells, self.agents, self.rng, self.step_count,
                                         self.aux if self.spec.env_kind != "empty" else None, self.episode, self.was_reset)
             return self.was_reset
         if getattr(self, "_pool", None) is None:
             raise RuntimeError("call set_layout_pool() or set_layout_generator() first")
-        self.backend.reset_done(self.batch, self.first_env, self._pool, self.grid, self.agents, self.step_count,
+        self.backend.reset_done(self.batch, self.first_env, self._pool, self.cells, self.agents, self.step_count,
                                 self.aux, self.episode, self.was_reset)
         return self.was_reset
 
@@ -374,7 +383,7 @@ class BatchedMultiGridEnv:
             sd["was_reset"] = self.was_reset.cpu().clone()
         if getattr(self, "_pool", None) is not None:
             pg, pa, pt = self._pool
-            sd["pool"] = {"grid": pg.cpu().clone(), "agents": pa.cpu().clone(),
+            sd["pool"] = {"grid": torch.from_numpy(layouts.unpack_cells(pg.cpu().numpy())), "agents": pa.cpu().clone(),
                           "aux": pt.cpu().clone() if pt is not None else None}
             sd["episode"] = self.episode.cpu().clone()
             sd["was_reset"] = self.was_reset.cpu().clone()

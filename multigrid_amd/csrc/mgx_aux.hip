@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void one_hot_kernel(const uint8_t *__restrict_
             uint32_t c[4];
             for (int k = 0; k < 4; ++k) {
                 const int i = threadIdx.x * 4 + k;
-                c[k] = i < ncell ? load_cell(src + i * 3) : 0u;
+                c[k] = i < ncell ? load_obs_cell(src + i * 3) : 0u;
             }
             c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
         }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void one_hot_kernel(const uint8_t *__restrict_
 // agents there, and streams that buffer out with 16-byte vectors.  Input and output of an env have the same size, so the
 // two buffers share one 16-byte skew.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int G, int wave_lds, uint32_t inv_W,
+__global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int G, int wave_lds, int in_buf, uint32_t inv_W,
                                                        uint32_t inv_HW, int64_t batch, const uint8_t *__restrict__ grid,
                                                        const uint8_t *__restrict__ agents, uint8_t *__restrict__ out) {
     extern __shared__ __align__(16) uint8_t lds[];
@@ -118,37 +118,39 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
     const int64_t e0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * G;
     if (e0 >= batch) return;
     const int Gc = (int)min((int64_t)G, batch - e0);
-    const int HW = H * W, HW3 = HW * 3;
-    const int64_t g0 = e0 * HW3, gtotal = batch * (int64_t)HW3;
+    const int HW = H * W, HWB = HW * kCellBytes, HW3 = HW * 3;
+    // input: packed cells [y][x], 2 bytes each; output: (type, color, state) bytes [x][y] -- each with its own 16-byte skew
+    const int64_t g0 = e0 * HWB, gtotal = batch * (int64_t)HWB;
     const int64_t ga = g0 & ~(int64_t)15;
-    const int skew = (int)(g0 - ga);
-    const int len = skew + Gc * HW3;                               // staged bytes, from the aligned start
-    const int buf = (G * HW3 + 15 + 16 + 15) & ~15;                // one buffer: skew + over-read pad
-    uint8_t *in_raw = lds + wave * wave_lds, *out_raw = in_raw + buf;
+    const int iskew = (int)(g0 - ga);
+    const int ilen = iskew + Gc * HWB;                             // staged input bytes, from the aligned start
+    const int64_t o0 = e0 * HW3;
+    const int64_t oa = o0 & ~(int64_t)15;
+    const int oskew = (int)(o0 - oa);
+    const int olen = oskew + Gc * HW3;
+    uint8_t *in_raw = lds + wave * wave_lds, *out_raw = in_raw + in_buf;
     const int lane16 = lane * 16;
     // (1) tile -> LDS; lanes past the end of the tensor read zeros (never used)
     // (range rounded up to the aligned 16 bytes that hold the tensor's last byte: the range check is per dword)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(grid + ga, (int)min((gtotal - ga + 15) & ~(int64_t)15, (int64_t)INT_MAX & ~15));
-    for (int rel = lane16; rel < len; rel += 1024 * 4) {
+    for (int rel = lane16; rel < ilen; rel += 1024 * 4) {
         u32x4 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, rel + 1024 * u, 0, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (rel + 1024 * u < len) *reinterpret_cast<u32x4 *>(in_raw + rel + 1024 * u) = v[u];
+            if (rel + 1024 * u < ilen) *reinterpret_cast<u32x4 *>(in_raw + rel + 1024 * u) = v[u];
     }
     wave_sync();
-    // (2) one lane per cell: [y][x] -> [x][y]
-    const uint32_t in_addr = (uint32_t)(uintptr_t)(lds_u32_ptr)(in_raw + skew);
-    uint8_t *out_cells = out_raw + skew;
+    // (2) one lane per cell: [y][x] packed -> [x][y] bytes
+    const uint8_t *in_cells = in_raw + iskew;
+    uint8_t *out_cells = out_raw + oskew;
     const int ncell = Gc * HW;
     for (int i = lane; i < ncell; i += 64) {
         const int e = (int)__umulhi((uint32_t)i, inv_HW);                                    // i / HW  (i < 2^16)
         const int r = i - e * HW;
         const int y = (int)__umulhi((uint32_t)r, inv_W), xx = r - y * W;                    // r / W
-        const uint32_t a = in_addr + (uint32_t)i * 3u;
-        const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(a & ~3u);
-        const uint32_t c = __builtin_amdgcn_alignbyte(p[1], p[0], a);                       // 3-byte cell (+1 junk byte)
+        const uint32_t c = load_cell(in_cells + i * kCellBytes);
         uint8_t *d = out_cells + e * HW3 + (xx * H + y) * 3;
         d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
     }
@@ -163,21 +165,54 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
         for (int j = ai + 1; j < A; ++j) shadowed |= ((((uint32_t)rows[e * A + j]) >> 16) & 0xffffu) == pos;
         const int x = row_x(r), y = row_y(r);
         if (!shadowed && x < W && y < H)
-            store_cell(out_cells + e * HW3 + (x * H + y) * 3, (uint32_t)T_AGENT | ((uint32_t)(r & 0xffffu) << 8));
+            store_obs_cell(out_cells + e * HW3 + (x * H + y) * 3, (uint32_t)T_AGENT | ((uint32_t)(r & 0xffffu) << 8));
     }
     wave_sync();
     // (4) stream out
-    uint8_t *gdst = out + ga;
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc(gdst, len);
-    for (int rel = lane16; rel < len; rel += 1024) {
-        if ((rel >= skew) & (rel + 16 <= len)) {
+    uint8_t *gdst = out + oa;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(gdst, olen);
+    for (int rel = lane16; rel < olen; rel += 1024) {
+        if ((rel >= oskew) & (rel + 16 <= olen)) {
             __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), ro, rel, 0, 0);
         } else {
-            const int lo_b = max(rel, skew), hi_b = min(rel + 16, len);
+            const int lo_b = max(rel, oskew), hi_b = min(rel + 16, olen);
 #pragma clang loop vectorize(disable) unroll(disable)
             for (int B = lo_b; B < hi_b; ++B) gdst[B] = out_raw[B];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pack / unpack: (type, color, state) bytes <-> packed 16-bit cells (include/mgx.h).  One thread converts 8 cells: 24 bytes in
+// three dword pairs on one side, one 16-byte vector on the other.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restrict__ c3, int64_t n, uint16_t *__restrict__ out,
+                                                        int32_t *bad) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    int nbad = 0;
+    uint16_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t c = (i0 + k < n) ? load_obs_cell(c3 + (i0 + k) * 3) : 0u;
+        nbad += ((c & 0xf0u) != 0) | (((c >> 8) & 0xf8u) != 0) | (((c >> 16) & 0xfcu) != 0);
+        v[k] = (uint16_t)cell_pack(c);
+    }
+    if (i0 + 8 <= n && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        u32x4 w;
+        w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
+        w.z = v[4] | ((uint32_t)v[5] << 16); w.w = v[6] | ((uint32_t)v[7] << 16);
+        *reinterpret_cast<u32x4 *>(out + i0) = w;
+    } else {
+        for (int k = 0; k < 8 && i0 + k < n; ++k) out[i0 + k] = v[k];
+    }
+    if (nbad && bad) atomicAdd(bad, nbad);
+}
+
+__global__ __launch_bounds__(256) void unpack_grid_kernel(const uint16_t *__restrict__ in, int64_t n, uint8_t *__restrict__ c3) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    for (int k = 0; k < 8 && i0 + k < n; ++k) store_obs_cell(c3 + (i0 + k) * 3, cell_unpack(in[i0 + k]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -208,7 +243,7 @@ __device__ __forceinline__ void copy_layouts(int n, int units, uint32_t inv_unit
 }
 
 template <typename VecT>
-__global__ __launch_bounds__(256) void reset_done_kernel(int HW3, int A, int max_steps, int64_t batch, int64_t first_env,
+__global__ __launch_bounds__(256) void reset_done_kernel(int HWB, int A, int max_steps, int64_t batch, int64_t first_env,
                                                          int K, uint32_t inv_units, uint32_t inv_A,
                                                          const uint8_t *__restrict__ pool_grid,
                                                          const uint8_t *__restrict__ pool_agents,
@@ -246,7 +281,7 @@ __global__ __launch_bounds__(256) void reset_done_kernel(int HW3, int A, int max
     }
     wave_sync();
     const int *l_env = s_env[wave], *l_lay = s_lay[wave];
-    copy_layouts<VecT>(n, HW3 / (int)sizeof(VecT), inv_units, e0, HW3, l_env, l_lay, pool_grid, grid, lane);
+    copy_layouts<VecT>(n, HWB / (int)sizeof(VecT), inv_units, e0, HWB, l_env, l_lay, pool_grid, grid, lane);
     copy_layouts<uint64_t>(n, A, inv_A, e0, (int64_t)A * MGX_AGENT_STRIDE, l_env, l_lay, pool_agents, agents, lane);   // 8-byte rows
     if (aux && pool_aux)
         for (int j = lane; j < n; j += 64)
@@ -281,45 +316,71 @@ int mgx_one_hot(const uint8_t *cells, int64_t n_cells, const int32_t *dim_sizes,
     return finish_launch();
 }
 
-int mgx_full_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents, uint8_t *out,
+int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents, uint8_t *out,
                  void *stream) {
     if (!spec || batch < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->width < 3 || spec->height < 3 || spec->num_agents < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->width > 255 || spec->height > 255) return MGX_ERR_UNSUPPORTED;
-    const int HW3 = spec->width * spec->height * 3;
-    if (2 * (HW3 + 48) > 64 * 1024) return MGX_ERR_UNSUPPORTED;
+    const int HW = spec->width * spec->height;
+    if ((kCellBytes + 3) * HW + 2 * 48 > 64 * 1024) return MGX_ERR_UNSUPPORTED;
     if (batch == 0) return MGX_OK;
     if (!grid || !agents || !out || misaligned(agents, 8) || misaligned(grid, 16) || misaligned(out, 16))
         return MGX_ERR_INVALID_ARGUMENT;
-    int G = (6 * 1024) / HW3;                                     // ~12 KiB of LDS per wavefront
+    int G = (6 * 1024) / (HW * 3);                                // ~10 KiB of LDS per wavefront
     if (G < 1) G = 1;
-    if (G * spec->width * spec->height > 65535) G = 65535 / (spec->width * spec->height);
+    if (G * HW > 65535) G = 65535 / HW;
     while (G > 1 && (batch + G - 1) / G < 4096) G = (G + 1) / 2;  // small batches: spread over the chip
-    const int buf = (G * HW3 + 15 + 16 + 15) & ~15;
-    const int wave_lds = 2 * buf;
+    const int in_buf = (G * HW * kCellBytes + 15 + 16 + 15) & ~15;         // skew + over-read pad
+    const int out_buf = (G * HW * 3 + 15 + 16 + 15) & ~15;
+    const int wave_lds = in_buf + out_buf;
     int wpb = 4;
     while (wpb > 1 && wpb * wave_lds > 64 * 1024) wpb >>= 1;
     const int64_t nwaves = (batch + G - 1) / G;
     const int64_t blocks = (nwaves + wpb - 1) / wpb;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     const uint32_t inv_W = (uint32_t)(((1ull << 32) + spec->width - 1) / spec->width);
-    const uint32_t hw = (uint32_t)(spec->width * spec->height);
+    const uint32_t hw = (uint32_t)HW;
     const uint32_t inv_HW = (uint32_t)(((1ull << 32) + hw - 1) / hw);
     hipLaunchKernelGGL(full_obs_kernel, dim3((unsigned)blocks), dim3(64 * wpb), (size_t)(wpb * wave_lds),
-                       static_cast<hipStream_t>(stream), spec->width, spec->height, spec->num_agents, G, wave_lds, inv_W,
-                       inv_HW, batch, grid, agents, out);
+                       static_cast<hipStream_t>(stream), spec->width, spec->height, spec->num_agents, G, wave_lds, in_buf, inv_W,
+                       inv_HW, batch, reinterpret_cast<const uint8_t *>(grid), agents, out);
     return finish_launch();
 }
 
-int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const uint8_t *pool_grid,
-                   const uint8_t *pool_agents, const uint8_t *pool_aux, uint8_t *grid, uint8_t *agents,
+int mgx_pack_grid(const uint8_t *cells3, int64_t n_cells, MgxCell *packed, int32_t *bad, void *stream) {
+    if (n_cells < 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (n_cells == 0) return MGX_OK;
+    if (!cells3 || !packed || misaligned(packed, 2) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
+    const int64_t blocks = (n_cells + 2047) / 2048;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3, n_cells,
+                       packed, bad);
+    return finish_launch();
+}
+
+int mgx_unpack_grid(const MgxCell *packed, int64_t n_cells, uint8_t *cells3, void *stream) {
+    if (n_cells < 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (n_cells == 0) return MGX_OK;
+    if (!cells3 || !packed || misaligned(packed, 2)) return MGX_ERR_INVALID_ARGUMENT;
+    const int64_t blocks = (n_cells + 2047) / 2048;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(unpack_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), packed, n_cells,
+                       cells3);
+    return finish_launch();
+}
+
+int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_t pool_size, const MgxCell *pool_grid_c,
+                   const uint8_t *pool_agents, const uint8_t *pool_aux, MgxCell *grid_c, uint8_t *agents,
                    int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream) {
     if (!spec || batch < 0 || pool_size < 1 || first_env < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (batch == 0) return MGX_OK;
+    const uint8_t *pool_grid = reinterpret_cast<const uint8_t *>(pool_grid_c);
+    uint8_t *grid = reinterpret_cast<uint8_t *>(grid_c);
     if (!pool_grid || !pool_agents || !grid || !agents || !step_count || !episode) return MGX_ERR_INVALID_ARGUMENT;
-    if (misaligned(agents, 8) || misaligned(pool_agents, 8) || misaligned(aux, 16) || misaligned(pool_aux, 16))
+    if (misaligned(agents, 8) || misaligned(pool_agents, 8) || misaligned(aux, 16) || misaligned(pool_aux, 16)
+        || misaligned(grid, 2) || misaligned(pool_grid, 2))
         return MGX_ERR_INVALID_ARGUMENT;
-    const int HW3 = spec->width * spec->height * 3;
+    const int HW3 = spec->width * spec->height * kCellBytes;      // bytes of one env's grid
     const int64_t blocks = (batch + 255) / 256;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     // widest copy unit that divides the layout size and the base addresses

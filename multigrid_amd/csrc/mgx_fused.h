@@ -5,7 +5,7 @@
 // One fused kernel does a whole MultiGridEnv.step for the batch.  Every WAVEFRONT is autonomous: it owns Gw consecutive
 // envs (<= 32 agent views, "slots") and a private LDS slice and runs all phases for them without a workgroup barrier:
 //
-//   P0   buffer_load_dwordx4 of the wave's (Gw,H,W,3) uint8 grid bytes, packed agent rows, actions, PCG64 words and
+//   P0   buffer_load_dwordx4 of the wave's (Gw,H,W) packed 16-bit grid cells, packed agent rows, actions, PCG64 words and
 //        step counts; one s_waitcnt; LDS stores
 //   P1a  lane = (env, agent): that agent's PCG64 draw by jump-ahead                            (multigrid/base.py:396-399)
 //   P1s  lane = (env, agent): order-free evaluation of every action against the pre-step state, committed when the
@@ -76,12 +76,9 @@ struct KernelArgs {
     int32_t *bounds;    // -DMGX_BOUNDS_CHECK=1 builds: [0] += LDS accesses outside the wavefront's slice, [1] = last site id
 };
 
-// gfx950's LDS does take a dword / short access at any byte address (hipcc emits one ds_read_b32 for an align-1 load),
-// but measured it is far slower than the aligned pair + v_alignbyte: 1M envs, fused step 371 us aligned, 581 us with
-// unaligned reads in P2, 602 us with unaligned 16-bit writes in P4, 882 us with both.  Kept for the record only.
-#ifndef MGX_UA_READ
-#define MGX_UA_READ 0
-#endif
+// gfx950's LDS does take a short access at any byte address (hipcc emits ds_write_b16 for an align-1 store), but measured
+// it is far slower than aligned accesses (round 1, 3-byte cells: fused step 371 us aligned, 602 us with unaligned 16-bit
+// writes in P4).  Kept for the record only.
 #ifndef MGX_UA_WRITE
 #define MGX_UA_WRITE 0
 #endif
@@ -154,6 +151,7 @@ __device__ __forceinline__ T kernarg_at(size_t offset) {
 struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
 
 typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
+typedef const int16_t __attribute__((address_space(3))) *lds_i16_ptr;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef const u32_unaligned __attribute__((address_space(3))) *lds_u32_ua_ptr;
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
@@ -226,7 +224,7 @@ struct LdsCarve {
 // one_hot: the round's staging holds one 32-bit one-hot mask per cell (+ a pad dword either side) instead of 3 obs bytes
 __host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
                                                bool one_hot = false) {
-    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * 3, one_hot ? kRound * V * V * 4 + 16 : kRound * V * V * 3,
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * kCellBytes, one_hot ? kRound * V * V * 4 + 16 : kRound * V * V * 3,
                     roll, has_aux};
 }
 
@@ -353,10 +351,7 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
             inbm[n][it] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbHi[it], S0 + n) << 32)
                         | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbLo[it], S0 + n);
     }
-    uint32_t raw[N][NW];
-#if !MGX_UA_READ
-    uint32_t lo[N][NW], hi[N][NW], sh[N][NW];
-#endif
+    int32_t raw[N][NW];
     bool inb[N][NW];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -367,14 +362,9 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
             // wavefront's WALL cell instead (obs.py:199-202)
             const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
             const uint32_t addr = inb[n][it] ? (uint32_t)off : wall_addr;
-            if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr & ~3u, 8);
-#if MGX_UA_READ
-            raw[n][it] = *(lds_u32_ua_ptr)(uintptr_t)addr;                  // one unaligned ds_read_b32: cell + a junk byte
-#else
-            const lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)(addr & ~3u);     // LDS byte address -> its dword pair
-            lo[n][it] = p[0]; hi[n][it] = p[1]; sh[n][it] = addr;           // v_alignbyte_b32 only looks at bits [1:0]
-                                                                            // (probed on gfx950: tools/hwprobe/alignbyte.hip)
-#endif
+            if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr, 2);
+            // one aligned, sign-extending 16-bit read per cell (ds_read_i16): bit 15 of a packed cell = opaque
+            raw[n][it] = (int32_t)*(lds_i16_ptr)(uintptr_t)addr;
         }
     }
 #pragma unroll
@@ -383,14 +373,9 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
         for (int it = 0; it < NW; ++it) {
             constexpr uint64_t kAll = ~0ull;
             const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
-#if !MGX_UA_READ
-            raw[n][it] = __builtin_amdgcn_alignbyte(hi[n][it], lo[n][it], sh[n][it]);
-#endif
-            const uint32_t c = raw[n][it];                                  // (byte 3 is junk from here on)
-            cell[S0 + n][it] = c;
-            const uint32_t t = c & 0xffu;                                   // obs.py:46-63 see_behind, as lane masks
-            const uint64_t m = __builtin_amdgcn_ballot_w64(t != (uint32_t)T_WALL)
-                             & (__builtin_amdgcn_ballot_w64(t != (uint32_t)T_DOOR) | state_is_open(c)) & act_mask;
+            cell[S0 + n][it] = (uint32_t)raw[n][it];                        // (bits 16..31 repeat the opaque bit from here on)
+            // obs.py:46-63 see_behind as a lane mask: the cell's opaque bit is the sign of the load -- one compare
+            const uint64_t m = __builtin_amdgcn_ballot_w64(raw[n][it] >= 0) & act_mask;
             sbLo[it] = set_lane(sbLo[it], (uint32_t)m, S0 + n);
             sbHi[it] = set_lane(sbHi[it], (uint32_t)(m >> 32), S0 + n);
         }
@@ -441,7 +426,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents;
-    const int HW3 = H * W * 3;
+    const int HWB = H * W * kCellBytes;                     // bytes of one env's grid (packed cells)
     const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     const int64_t e0 = wid * a.Gw;
     if (e0 >= a.batch) return;
@@ -470,12 +455,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 
     MGX_MARK("P0");
     // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
-    const int64_t g0 = e0 * HW3, g1 = g0 + (int64_t)Gc * HW3;       // byte range of these envs in `grid`
-    const int64_t gtotal = a.batch * (int64_t)HW3;
+    const int64_t g0 = e0 * HWB, g1 = g0 + (int64_t)Gc * HWB;       // byte range of these envs in `grid`
+    const int64_t gtotal = a.batch * (int64_t)HWB;
     const int64_t ga = g0 & ~(int64_t)15;
     uint8_t *tile_raw = L + cv.tile();                              // holds global bytes [ga, ...)
     const int tile_skew = (int)(g0 - ga);
-    uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HW3
+    uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HWB
     // Every HBM load of the wavefront is issued here, back to back, into registers; then ONE unconditional
     // s_waitcnt vmcnt(0); then the LDS stores.  (Waiting under the same lane predicates as the loads makes hipcc's
     // waitcnt pass believe loads may still be pending and sprinkle vmcnt(0) -- which on CDNA also waits for every
@@ -582,7 +567,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
     // (5) the small inputs are here long before the tile: their LDS stores go first
     const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + cv.wall());
-    if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL_WALL;
+    if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL16_WALL;
     if (lane < NVc) {
         if (DO_STEP && !ROLL && A > 1) rnd[lane] = my_draw;                      // (only the sequential fallback reads the draws)
         reinterpret_cast<u32x2 *>(rows)[lane] = in_row;
@@ -683,19 +668,19 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 const int lay = (K == 1) ? 0 : (int)((uint64_t)(MGX_LATE(first_env) + b + (int64_t)ep * 7919) % (uint64_t)K);
                 wave_sync();
                 if (lane == 0) p_ep[b] = ep + 1;
-                const uint8_t *sg = MGX_LATE(pool_grid) + (int64_t)lay * HW3;
-                uint8_t *etile = tile + e * HW3;
-                uint8_t *gg = MGX_LATE(grid) + b * HW3;
+                const uint8_t *sg = MGX_LATE(pool_grid) + (int64_t)lay * HWB;
+                uint8_t *etile = tile + e * HWB;
+                uint8_t *gg = MGX_LATE(grid) + b * HWB;
                 const uint32_t etile_addr = (uint32_t)(uintptr_t)(lds_u32_ptr)etile;
-                if (((HW3 | etile_addr | (uint32_t)reinterpret_cast<uintptr_t>(sg) | (uint32_t)reinterpret_cast<uintptr_t>(gg)) & 3u) == 0) {
+                if (((HWB | etile_addr | (uint32_t)reinterpret_cast<uintptr_t>(sg) | (uint32_t)reinterpret_cast<uintptr_t>(gg)) & 3u) == 0) {
 #pragma unroll 4
-                    for (int i = lane; i < HW3 / 4; i += 64) {                   // dwords: several loads in flight per lane
+                    for (int i = lane; i < HWB / 4; i += 64) {                   // dwords: several loads in flight per lane
                         const uint32_t v = reinterpret_cast<const uint32_t *>(sg)[i];
                         reinterpret_cast<uint32_t *>(etile)[i] = v;
                         if (!ROLL) reinterpret_cast<uint32_t *>(gg)[i] = v;      // (the rollout writes its tile back at the end)
                     }
                 } else {
-                    for (int i = lane; i < HW3; i += 64) {                       // bytes: layouts of any size / alignment
+                    for (int i = lane; i < HWB; i += 64) {                       // bytes: layouts of any size / alignment
                         const uint8_t v = sg[i];
                         etile[i] = v;
                         if (!ROLL) gg[i] = v;
@@ -739,8 +724,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
         int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
         AgentEval ev{};
-        uint8_t *mytile = tile + env_of_lane * HW3;
-        if (in) MGX_CHECK_LDS_PTR(2, mytile, HW3);
+        uint8_t *mytile = tile + env_of_lane * HWB;
+        if (in) MGX_CHECK_LDS_PTR(2, mytile, HWB);
         if (in && !MGX_DBG(64)) {
             const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
                                ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
@@ -785,8 +770,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             if (ev.writes) {
                 store_cell(mytile + ev.off, ev.ncell);
                 if (!ROLL) {                                                     // ROLL writes the whole tile back at the end
-                    uint8_t *gg = MGX_LATE(grid) + (e0 + env_of_lane) * HW3 + ev.off;
-                    gg[0] = (uint8_t)ev.ncell; gg[1] = (uint8_t)(ev.ncell >> 8); gg[2] = (uint8_t)(ev.ncell >> 16);
+                    store_cell(MGX_LATE(grid) + (e0 + env_of_lane) * HWB + ev.off, ev.ncell);
                 }
             }
         }
@@ -818,10 +802,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             if (mine) {
                 const int e = lane;
                 const int64_t b = e0 + e;
-                uint8_t *etile = tile + e * HW3;
-                uint8_t *ggrid = MGX_LATE(grid) + b * HW3;
+                uint8_t *etile = tile + e * HWB;
+                uint8_t *ggrid = MGX_LATE(grid) + b * HWB;
                 auto dirty = [=](int off) {
-                    if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
+                    if (!ROLL) store_cell16(ggrid + off, load_cell16(etile + off));
                 };
                 const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
                                               scnt[e] + 1, dirty, reinterpret_cast<uint8_t *>(auxl + e), env_kind);
@@ -841,10 +825,10 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             const int64_t b = e0 + e;
             const int32_t sc = (ROLL ? scnt[e] : (int32_t)in_scnt) + 1;          // base.py:333
             if (ROLL) scnt[e] = sc; else p_step_count[b] = sc;
-            uint8_t *etile = tile + e * HW3;
-            uint8_t *ggrid = MGX_LATE(grid) + b * HW3;
+            uint8_t *etile = tile + e * HWB;
+            uint8_t *ggrid = MGX_LATE(grid) + b * HWB;
             auto dirty = [=](int off) {
-                if (!ROLL) { ggrid[off] = etile[off]; ggrid[off + 1] = etile[off + 1]; ggrid[off + 2] = etile[off + 2]; }
+                if (!ROLL) store_cell16(ggrid + off, load_cell16(etile + off));
             };
             uint8_t *eaux = reinterpret_cast<uint8_t *>(auxl + e);
             post_step_hook(cf, env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
@@ -860,17 +844,17 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             cur_row = rows[lane];                                                // and rewarded it: their results are in LDS)
             if (HOOKS || fb) my_rew = rew[lane];
         }
-        if (ROLL && ovl >= 0) ovl_saved = load_cell(mytile + ovl);
+        if (ROLL && ovl >= 0) ovl_saved = load_cell16(mytile + ovl);
         ovl_off = ovl;
         wave_sync();
         if (ovl >= 0) {
-            MGX_CHECK_LDS_PTR(3, mytile + ovl, 3);
-            store_cell(mytile + ovl, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
+            MGX_CHECK_LDS_PTR(3, mytile + ovl, 2);
+            store_cell16(mytile + ovl, agent_cell16(cur_row));
         }
     } else {
         const int off = (lane < NVc) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
         wave_sync();
-        if (off >= 0) store_cell(tile + env_of_lane * HW3 + off, (uint32_t)T_AGENT | ((uint32_t)(cur_row & 0xffffu) << 8));
+        if (off >= 0) store_cell16(tile + env_of_lane * HWB + off, agent_cell16(cur_row));
     }
     wave_sync();
 
@@ -891,7 +875,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
         const uint64_t row = cur_row;
         const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
         ViewRec r;
-        r.origin = (int32_t)tile_addr + e * HW3 + g.origin;
+        r.origin = (int32_t)tile_addr + e * HWB + g.origin;
         r.stepF = g.stepF; r.stepL = g.stepL; r.carry = 0;
         my_carry = row_carry(row);
         rec[lane] = r;
@@ -928,7 +912,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     if (!MGX_DBG(4)) gather_all<V, NW, VPW>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
-        if (ovl_off >= 0) store_cell(tile + env_of_lane * HW3 + ovl_off, ovl_saved);
+        if (ovl_off >= 0) store_cell16(tile + env_of_lane * HWB + ovl_off, ovl_saved);
     }
 
     MGX_MARK("P3");
@@ -979,7 +963,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     const int s = r0 + sl;
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
-                                    const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
+                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN);
                                     MGX_CHECK_LDS_PTR(7, d0 + sl * V2, 4);
                                     d0[sl * V2] = one_hot_mask(c);
                                 }
@@ -1059,7 +1043,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     // (see_through_walls: the masks are all ones -- no branch, it would fence the schedule)
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
-                                    const uint32_t c = __builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN;
+                                    // packed cell -> the observation's (type, color, state) bytes
+                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN);
                                     [[maybe_unused]] uint8_t *d = d0 + sl * (V2 * 3);
                                     MGX_CHECK_LDS_PTR(5, d, 3);
 #if MGX_P4_B16
@@ -1079,7 +1064,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 wave_sync();
                 // lane r0+sl: its agent's own cell shows the carried object (obs.py:207; always visible, obs.py:252)
                 if (lane >= r0 && lane < r0 + kRound && lane < NVc)
-                    store_cell(outb + (lane - r0) * (V2 * 3) + ((V / 2) * V + (V - 1)) * 3, my_carry);
+                    store_obs_cell(outb + (lane - r0) * (V2 * 3) + ((V / 2) * V + (V - 1)) * 3, my_carry);
             }
             wave_sync();
             MGX_MARK("P5");
@@ -1133,7 +1118,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
             gen.start_x = MGX_LATE_GEN(start_x); gen.start_y = MGX_LATE_GEN(start_y); gen.start_dir = MGX_LATE_GEN(start_dir);
             gen.blank = MGX_LATE_GEN(blank); gen.gen_state = MGX_LATE_GEN(gen_state);
 #undef MGX_LATE_GEN
-            mgx_gen::copy_blank(gen, MGX_LATE(grid), e0, HW3, gmask, lane);
+            mgx_gen::copy_blank(gen, MGX_LATE(grid), e0, HWB, gmask, lane);
             if (done_now) {
                 const int64_t b = e0 + lane;
                 mgx_gen::NpGen lay, npr;
@@ -1145,7 +1130,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                 }
                 lay.buf = gs[4]; npr.buf = gs[5];
                 const uint4 naux = mgx_gen::generate_episode(gen, W, H, A, lay, npr, L + cv.rec() + lane * (2 * A),
-                                                             MGX_LATE(grid) + b * HW3,
+                                                             MGX_LATE(grid) + b * HWB,
                                                              reinterpret_cast<uint64_t *>(MGX_LATE(agents)) + b * A);
                 if (HOOKS) reinterpret_cast<uint4 *>(MGX_LATE(aux))[b] = naux;
                 for (int k = 0; k < 4; ++k) { gs[k] = lay.s[k]; rg[k] = npr.s[k]; }

@@ -87,7 +87,7 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll, one_hot) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
     // a grid tensor beyond half of the 256 MiB Infinity Cache is streamed (nt tile loads): mgx_fused.h, P0
-    ka.flags = (batch * (int64_t)sp->width * sp->height * 3 > (int64_t)128 << 20) ? 1 : 0;
+    ka.flags = (batch * (int64_t)sp->width * sp->height * kCellBytes > (int64_t)128 << 20) ? 1 : 0;
     ka.vpw = slots_in_use(*sp, ka.Gw);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot);
@@ -173,7 +173,7 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     return MGX_OK;
 }
 
-static int gen_obs_common(bool one_hot, const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+static int gen_obs_common(bool one_hot, const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents,
                           uint8_t *obs, uint8_t *dir, void *stream) {
     int rc = check_spec(spec, batch, false, one_hot);
     if (rc) return rc;
@@ -184,7 +184,7 @@ static int gen_obs_common(bool one_hot, const MgxSpec *spec, int64_t batch, cons
     int threads = 0, lds = 0; int64_t nwg = 0;
     rc = fill_args(ka, spec, batch, threads, lds, nwg, false, one_hot);
     if (rc) return rc;
-    ka.grid = const_cast<uint8_t *>(grid);
+    ka.grid = reinterpret_cast<uint8_t *>(const_cast<MgxCell *>(grid));
     ka.agents = const_cast<uint8_t *>(agents);
     ka.obs = obs;
     ka.dir = dir;
@@ -192,19 +192,19 @@ static int gen_obs_common(bool one_hot, const MgxSpec *spec, int64_t batch, cons
     return launch(one_hot ? 4 : 0, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
-int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+int mgx_gen_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents,
                 uint8_t *obs, uint8_t *dir, void *stream) {
     return gen_obs_common(false, spec, batch, grid, agents, obs, dir, stream);
 }
 
-int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const uint8_t *grid, const uint8_t *agents,
+int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents,
                         uint8_t *obs_one_hot, uint8_t *dir, void *stream) {
     return gen_obs_common(true, spec, batch, grid, agents, obs_one_hot, dir, stream);
 }
 
 static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar,
                        const MgxLayoutGen *gen, int32_t *gen_episode, uint8_t *gen_was_reset,
-                       uint8_t *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
+                       MgxCell *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
                        uint8_t *aux, uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated,
                        uint8_t *truncated, int32_t *err, void *stream) {
     int rc = check_spec(spec, batch, roll, one_hot);
@@ -225,14 +225,14 @@ static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t bat
         if (spec->env_kind != MGX_KIND_EMPTY && !ar->pool_aux) return MGX_ERR_INVALID_ARGUMENT;
         if (misaligned(ar->pool_agents, 8) || misaligned(ar->pool_aux, 16) || misaligned(ar->episode, 4))
             return MGX_ERR_INVALID_ARGUMENT;
-        ka.pool_size = ar->pool_size; ka.first_env = ar->first_env; ka.pool_grid = ar->pool_grid;
+        ka.pool_size = ar->pool_size; ka.first_env = ar->first_env; ka.pool_grid = reinterpret_cast<const uint8_t *>(ar->pool_grid);
         ka.pool_agents = ar->pool_agents; ka.pool_aux = ar->pool_aux; ka.episode = ar->episode;
         ka.was_reset = ar->was_reset;
     }
     int threads = 0, lds = 0; int64_t nwg = 0;
     rc = fill_args(ka, spec, batch, threads, lds, nwg, roll, one_hot);
     if (rc) return rc;
-    ka.grid = grid; ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
+    ka.grid = reinterpret_cast<uint8_t *>(grid); ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
     ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
     ka.truncated = truncated; ka.err = err;
     ka.T = roll ? steps : 1;
@@ -262,7 +262,7 @@ static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t bat
     return launch(roll ? 2 : (one_hot ? 5 : 1), ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
-int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+int mgx_step(const MgxSpec *spec, int64_t batch, MgxCell *grid, uint8_t *agents, uint64_t *rng,
              int32_t *step_count, const int8_t *actions, uint8_t *aux,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream) {
@@ -270,7 +270,7 @@ int mgx_step(const MgxSpec *spec, int64_t batch, uint8_t *grid, uint8_t *agents,
                        terminated, truncated, err, stream);
 }
 
-int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid, uint8_t *agents, uint64_t *rng,
+int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, MgxCell *grid, uint8_t *agents, uint64_t *rng,
                 int32_t *step_count, const int8_t *actions, uint8_t *aux,
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream) {
@@ -278,7 +278,7 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, uint8_t *grid
                        terminated, truncated, err, stream);
 }
 
-int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, MgxCell *grid, uint8_t *agents,
                        uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                        uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                        int32_t *err, void *stream) {
@@ -287,7 +287,7 @@ int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *a
                        terminated, truncated, err, stream);
 }
 
-int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar, uint8_t *grid,
+int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar, MgxCell *grid,
                           uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                           uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                           int32_t *err, void *stream) {
@@ -296,7 +296,7 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
                        terminated, truncated, err, stream);
 }
 
-int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, uint8_t *grid, uint8_t *agents,
+int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, MgxCell *grid, uint8_t *agents,
                      uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                      uint8_t *obs_one_hot, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                      int32_t *err, void *stream) {
@@ -304,7 +304,7 @@ int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar,
                        terminated, truncated, err, stream);
 }
 
-int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
+int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,
                       uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                       uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                       int32_t *err, int32_t *episode, uint8_t *was_reset, void *stream) {

@@ -140,8 +140,7 @@ __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W
             }
         }
         for (int k = 0; k < kMaxObjects; ++k) {
-            uint8_t *c = grid + (((P.obj_pos[k] >> 8) & 0xff) * W + (P.obj_pos[k] & 0xff)) * 3;
-            c[0] = (uint8_t)P.obj_cell[k]; c[1] = (uint8_t)(P.obj_cell[k] >> 8); c[2] = (uint8_t)(P.obj_cell[k] >> 16);
+            store_cell(grid + (((P.obj_pos[k] >> 8) & 0xff) * W + (P.obj_pos[k] & 0xff)) * kCellBytes, P.obj_cell[k]);
         }
         aux.x = (uint32_t)T_BOX | (box_color << 8);                                  // the target box `self.obj` (include/mgx.h)
     }
@@ -149,15 +148,16 @@ __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W
 }
 
 // the blank layout into the grid of every env of `mask` (bit = env e0 + bit), all 64 lanes copying
-__device__ __forceinline__ void copy_blank(const MgxLayoutGen &gen, uint8_t *grid_base, int64_t e0, int HW3, uint64_t mask, int lane) {
-    const bool dw = ((HW3 | (int)(uintptr_t)gen.blank | (int)(uintptr_t)grid_base) & 3) == 0;
+__device__ __forceinline__ void copy_blank(const MgxLayoutGen &gen, uint8_t *grid_base, int64_t e0, int HWB, uint64_t mask, int lane) {
+    const uint8_t *blank = reinterpret_cast<const uint8_t *>(gen.blank);
+    const bool dw = ((HWB | (int)(uintptr_t)blank | (int)(uintptr_t)grid_base) & 3) == 0;
     for (uint64_t m = mask; m != 0; m &= m - 1) {
-        uint8_t *dst = grid_base + (e0 + __builtin_ctzll(m)) * HW3;
+        uint8_t *dst = grid_base + (e0 + __builtin_ctzll(m)) * HWB;
         if (dw) {
-            for (int i = lane; i < HW3 / 4; i += 64)
-                reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(gen.blank)[i];
+            for (int i = lane; i < HWB / 4; i += 64)
+                reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(blank)[i];
         } else {
-            for (int i = lane; i < HW3; i += 64) dst[i] = gen.blank[i];
+            for (int i = lane; i < HWB; i += 64) dst[i] = blank[i];
         }
     }
 }

@@ -47,7 +47,7 @@ struct GenArgs {
 __global__ __launch_bounds__(64) void reset_generate_kernel(const GenArgs a) {
     extern __shared__ uint8_t lds[];
     const int lane = threadIdx.x;
-    const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents, HW3 = H * W * 3;
+    const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents, HWB = H * W * kCellBytes;
     const int64_t e0 = (int64_t)blockIdx.x * 64;
     const int64_t b = e0 + lane;
     bool done = false;
@@ -60,13 +60,13 @@ __global__ __launch_bounds__(64) void reset_generate_kernel(const GenArgs a) {
     }
     const uint64_t mask = __builtin_amdgcn_ballot_w64(done);
     if (mask == 0) return;
-    copy_blank(a.gen, a.grid, e0, HW3, mask, lane);                                  // (1) all lanes
+    copy_blank(a.gen, a.grid, e0, HWB, mask, lane);                                  // (1) all lanes
     if (!done) return;
     NpGen lay, npr;                                                                  // (2) the owning lane
     uint64_t *gs = a.gen.gen_state + b * 6;
     for (int k = 0; k < 4; ++k) { lay.s[k] = gs[k]; npr.s[k] = a.rng[b * 4 + k]; }
     lay.buf = gs[4]; npr.buf = gs[5];
-    const uint4 aux = generate_episode(a.gen, W, H, A, lay, npr, lds + lane * (2 * A), a.grid + b * HW3,
+    const uint4 aux = generate_episode(a.gen, W, H, A, lay, npr, lds + lane * (2 * A), a.grid + b * HWB,
                                        reinterpret_cast<uint64_t *>(a.agents) + b * A);
     if (a.aux) reinterpret_cast<uint4 *>(a.aux)[b] = aux;
     for (int k = 0; k < 4; ++k) { gs[k] = lay.s[k]; a.rng[b * 4 + k] = npr.s[k]; }
@@ -83,7 +83,7 @@ inline bool misaligned(const void *p, uintptr_t al) { return (reinterpret_cast<u
 
 extern "C" {
 
-int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, uint8_t *grid, uint8_t *agents,
+int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,
                        uint64_t *rng, int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream) {
     if (!spec || !gen || batch < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->width < 3 || spec->height < 3 || spec->num_agents < 1 || spec->num_agents > MGX_MAX_AGENTS)
@@ -111,7 +111,7 @@ int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *g
     }
     const int64_t blocks = (batch + 63) / 64;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
-    GenArgs ga{*spec, batch, *gen, grid, agents, rng, step_count, aux, episode, was_reset};
+    GenArgs ga{*spec, batch, *gen, reinterpret_cast<uint8_t *>(grid), agents, rng, step_count, aux, episode, was_reset};
     hipLaunchKernelGGL(reset_generate_kernel, dim3((unsigned)blocks), dim3(64), (size_t)(64 * 2 * spec->num_agents),
                        static_cast<hipStream_t>(stream), ga);
     hipError_t e = hipGetLastError();

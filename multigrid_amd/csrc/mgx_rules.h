@@ -26,10 +26,18 @@ enum : int { ACT_LEFT = 0, ACT_RIGHT = 1, ACT_FORWARD = 2, ACT_PICKUP = 3, ACT_D
 // packed agent row (include/mgx.h)
 enum : int { AG_COLOR = 0, AG_DIR = 1, AG_X = 2, AG_Y = 3, AG_TERM = 4, AG_CARRY = 5 };
 
-// A cell packed little-endian into 24 bits: type | color << 8 | state << 16.
+// A cell as the rules see it ("logical" cell, also the obs / carried-object byte order), little-endian in 24 bits:
+// type | color << 8 | state << 16.
 constexpr uint32_t CELL_EMPTY = 1u;                       // (1,0,0)  world_object.py:131-137
 constexpr uint32_t CELL_WALL = 2u | (5u << 8);            // (2,5,0)  obs.py:14
 constexpr uint32_t CELL_UNSEEN = 0u;                      // (0,0,0)  obs.py:15
+
+// A cell as the GRID stores it (HBM and the LDS tile; include/mgx.h "packed cell"), 16 bits:
+//   [3:0] type   [10:8] color   [13:12] state   [15] opaque = !see_behind(cell)   (all other bits zero)
+// Two bytes instead of three cut the grid stream by a third and make every cell an aligned 16-bit LDS access (no dword pair
+// + v_alignbyte); the opaque bit is the sign of the sign-extended load, so the see-behind ballot of the gather is ONE compare.
+constexpr int kCellBytes = MGX_CELL_BYTES;
+constexpr uint32_t CELL16_WALL = 0x8502u;                 // cell_pack(CELL_WALL)
 
 // multigrid/core/constants.py:21-30 DIR_TO_VEC, branch-free: 0:(1,0) 1:(0,1) 2:(-1,0) 3:(0,-1)
 MGX_HD int dir_dx(int d) { return (d == 0) - (d == 2); }
@@ -132,8 +140,25 @@ MGX_HD uint64_t row_set_pos(uint64_t r, int x, int y) {
 }
 MGX_HD uint64_t row_set_carry(uint64_t r, uint32_t c) { return (r & 0xffffffffffull) | ((uint64_t)c << 40); }
 
-MGX_HD uint32_t load_cell(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
-MGX_HD void store_cell(uint8_t *p, uint32_t c) { p[0] = (uint8_t)c; p[1] = (uint8_t)(c >> 8); p[2] = (uint8_t)(c >> 16); }
+// logical <-> packed.  Values outside the packed ranges (type > 15, color > 7, state > 3) do not occur in the reference
+// (types 0-10, colors 0-5, states 0-2 / directions 0-3) and are refused where grids enter (mgx_pack_grid reports them).
+MGX_HD uint32_t cell_pack(uint32_t c) {
+    return (c & 0x070fu) | ((c >> 4) & 0x3000u) | (see_behind(c) ? 0u : 0x8000u);
+}
+MGX_HD uint32_t cell_unpack(uint32_t p) { return (p & 0x070fu) | ((p & 0x3000u) << 4); }
+// the agent overlay cell (10, color, dir) of a packed agent row (obs.py:163-173); never opaque
+MGX_HD uint32_t agent_cell16(uint64_t row) {
+    return (uint32_t)T_AGENT | (((uint32_t)row & 0x7u) << 8) | ((((uint32_t)row >> 8) & 0x3u) << 12);
+}
+
+// grid cells (tile / HBM): 2 bytes, aligned
+MGX_HD uint32_t load_cell16(const uint8_t *p) { return *reinterpret_cast<const uint16_t *>(p); }
+MGX_HD void store_cell16(uint8_t *p, uint32_t c16) { *reinterpret_cast<uint16_t *>(p) = (uint16_t)c16; }
+MGX_HD uint32_t load_cell(const uint8_t *p) { return cell_unpack(load_cell16(p)); }
+MGX_HD void store_cell(uint8_t *p, uint32_t c) { store_cell16(p, cell_pack(c)); }
+// observation cells: the reference's 3 bytes (type, color, state), any alignment
+MGX_HD uint32_t load_obs_cell(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+MGX_HD void store_obs_cell(uint8_t *p, uint32_t c) { p[0] = (uint8_t)c; p[1] = (uint8_t)(c >> 8); p[2] = (uint8_t)(c >> 16); }
 
 // base.py:598-602 `1 - 0.9 * (step_count / max_steps)` in Python float arithmetic: three correctly rounded
 // IEEE-754 binary64 operations, never contracted into an fma (the library is built with -ffp-contract=off).
@@ -191,7 +216,7 @@ MGX_HD int draw_rank(const uint64_t *rnd, int A, int a) {
 
 // ---------------------------------------------------------------------------------------------------
 // handle_actions for ONE env (multigrid/base.py:378-476 with on_success 478-507 / on_failure 509-532).
-//   tile : H*W*3 bytes [y][x][c]        rows : A packed agent rows      act : A int8
+//   tile : H*W packed cells [y][x]       rows : A packed agent rows      act : A int8
 //   ord  : A bytes, visiting order      rew  : A doubles, pre-zeroed (base.py:393)
 //   dirty(off): called with the byte offset of every tile cell this step changed (tile already updated).
 // Returns 0, or MGX_ERR_UNKNOWN_ACTION at the first invalid action in visiting order.
@@ -261,7 +286,7 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     const int d = row_dir(row), x = row_x(row), y = row_y(row);
     const int fx = x + dir_dx(d), fy = y + dir_dy(d);                       // agent.py:111-118
     const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
-    ev.off = inb ? (fy * cf.W + fx) * 3 : 0;
+    ev.off = inb ? (fy * cf.W + fx) * kCellBytes : 0;
     const uint32_t cell = load_cell(tile + ev.off);
     const uint32_t type = cell & 0xff, gstate = (cell >> 16) & 0xff;
     const bool stale = inb & (ev.off == stale_off);
@@ -314,7 +339,7 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
 // The reference's loop (base.py:402-474): agents act one after the other in `ord`, each seeing the previous ones' effects.
 // `stale` points at the env's stale-door flag (aux[4] of a RedBlueDoors env) or is NULL.
 MGX_HD int stale_offset(const StepCfg &cf, const uint8_t *aux, int env_kind) {
-    return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.W + aux[0]) * 3 : -1;
+    return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.W + aux[0]) * kCellBytes : -1;
 }
 
 template <class Dirty>
@@ -397,14 +422,14 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
         for (int a = 0; a < A; ++a)
             if ((row_carry(rows[a]) & 0xffffu) == want) on_success(cf, rows, a, step_count, rew);
     } else if (env_kind == MGX_KIND_REDBLUEDOORS) {
-        const int boff = (aux[1] * cf.W + aux[0]) * 3, roff = (aux[3] * cf.W + aux[2]) * 3;
+        const int boff = (aux[1] * cf.W + aux[0]) * kCellBytes, roff = (aux[3] * cf.W + aux[2]) * kCellBytes;
         for (int a = 0; a < A; ++a) {
             if (act[a] != ACT_TOGGLE) continue;
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if (fx != aux[0] || fy != aux[1]) continue;                         // fwd_obj == self.blue_door
-            if (tile[boff + 2] != S_OPEN || aux[4]) continue;                   // ... and self.blue_door.is_open (the OBJECT)
-            if (tile[roff + 2] == S_OPEN) {
+            if (((load_cell(tile + boff) >> 16) & 0xff) != S_OPEN || aux[4]) continue;                   // ... and self.blue_door.is_open (the OBJECT)
+            if (((load_cell(tile + roff) >> 16) & 0xff) == S_OPEN) {
                 on_success(cf, rows, a, step_count, rew);
             } else {
                 set_terminated(rows, A, a, cf.failure_any);                      // on_failure
@@ -425,8 +450,8 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;
-            const uint8_t *c = tile + (fy * cf.W + fx) * 3;
-            if (c[0] != T_DOOR || c[2] == S_LOCKED) continue;                   // isinstance(Door) and not is_locked
+            const uint32_t c = load_cell(tile + (fy * cf.W + fx) * kCellBytes);
+            if ((c & 0xff) != T_DOOR || ((c >> 16) & 0xff) == S_LOCKED) continue;                   // isinstance(Door) and not is_locked
             int k = -1;
             if (geo) {
                 const int side = (fx == 2 * (rs - 1)) ? 1 : ((fx == rs - 1) ? 0 : -1);
@@ -461,7 +486,7 @@ MGX_HD void overlay_agents(const StepCfg &cf, uint8_t *tile, const uint64_t *row
         if (row_term(r)) continue;
         const int x = row_x(r), y = row_y(r);
         if (x >= cf.W || y >= cf.H) continue;
-        store_cell(tile + (y * cf.W + x) * 3, (uint32_t)T_AGENT | ((uint32_t)(r & 0xffffu) << 8));
+        store_cell16(tile + (y * cf.W + x) * kCellBytes, agent_cell16(r));
     }
 }
 
@@ -479,7 +504,7 @@ MGX_HD int overlay_offset(const StepCfg &cf, const uint64_t *rows, int ai) {
     }
     const int x = row_x(r), y = row_y(r);
     if (row_term(r) | shadowed | (x >= cf.W) | (y >= cf.H)) return -1;
-    return (y * cf.W + x) * 3;
+    return (y * cf.W + x) * kCellBytes;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -494,9 +519,9 @@ template <int V>
 MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d) {
     const int dx = dir_dx(d), dy = dir_dy(d), h = V / 2;
     ViewGeom g;
-    g.origin = (y * W + x) * 3;
-    g.stepF = (dy * W + dx) * 3;
-    g.stepL = (dx * W - dy) * 3;
+    g.origin = (y * W + x) * kCellBytes;
+    g.stepF = (dy * W + dx) * kCellBytes;
+    g.stepL = (dx * W - dy) * kCellBytes;
     // room ahead and to both sides, as selects (one lane per view: the lanes hold all four directions)
     const bool d0 = d == 0, d1 = d == 1, d2 = d == 2;
     g.fmax = d0 ? W - 1 - x : (d1 ? H - 1 - y : (d2 ? x : y));

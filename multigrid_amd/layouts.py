@@ -98,6 +98,27 @@ def grid_from_product(grid_hwc: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(np.swapaxes(np.asarray(grid_hwc), -3, -2)).astype(np.int64)
 
 
+def pack_cells(grid_hwc: np.ndarray) -> np.ndarray:
+    """(type, color, state) bytes u8[...,3] -> the device's packed cells u16[...] (include/mgx.h MgxCell):
+    [3:0] type | [10:8] color | [13:12] state | [15] opaque, opaque = not see_behind (multigrid/utils/obs.py:46-63: a wall,
+    or a door that is not open).  Values the 16 bits cannot hold (the reference has none) are refused."""
+    g = np.asarray(grid_hwc)
+    if g.shape[-1] != 3:
+        raise ValueError("pack_cells expects (type, color, state) triples in the last axis")
+    t, c, s = (g[..., k].astype(np.uint16) for k in range(3))
+    if (t > 15).any() or (c > 7).any() or (s > 3).any():
+        raise ValueError("cell value outside the packed format (type <= 15, color <= 7, state <= 3)")
+    opaque = (t == Type.wall) | ((t == Type.door) & (s != State.open))
+    return (t | (c << 8) | (s << 12) | (opaque.astype(np.uint16) << 15)).astype(np.uint16)
+
+
+def unpack_cells(cells: np.ndarray) -> np.ndarray:
+    """Packed cells u16[...] (or their int16 view) -> (type, color, state) bytes u8[...,3]."""
+    p = np.asarray(cells)
+    p = p.view(np.uint16) if p.dtype == np.int16 else p.astype(np.uint16)
+    return np.stack((p & 0xf, (p >> 8) & 0x7, (p >> 12) & 0x3), axis=-1).astype(np.uint8)
+
+
 # ---- multigrid/base.py:604-697 -------------------------------------------------------------------------
 def _place_obj(grid: _Grid, ag: np.ndarray, rng, cell, top=None, size=None, reject_fn=None, max_tries=np.inf):
     top = (0, 0) if top is None else (max(top[0], 0), max(top[1], 0))

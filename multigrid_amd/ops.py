@@ -9,6 +9,10 @@
     torch.ops.mgx.rollout(grid!, agents!, rng!, step_count!, actions[T,B,A], aux!?, err!, spec)
                                                -> (obs[T,...], dir, reward, terminated, truncated)
     torch.ops.mgx.one_hot(cells, dim_sizes) -> one_hot        torch.ops.mgx.full_obs(grid, agents, spec) -> full
+    torch.ops.mgx.pack_grid(cells3 u8[...,3]) -> (grid i16[...], bad i32[1])     torch.ops.mgx.unpack_grid(grid) -> cells3
+
+`grid` / `pool_grid` are PACKED cells, int16 tensors [B,H,W] holding the MgxCell bit patterns of include/mgx.h (type |
+color << 8 | state << 12 | opaque << 15); pack_grid / unpack_grid convert from / to (type, color, state) bytes on the device.
 
 `spec` is the 11-int list of `struct MgxSpec` (include/mgx.h).  Only the CUDA (= HIP on ROCm) dispatch key is
 registered: calling the ops with CPU tensors raises NotImplementedError from the dispatcher -- there is no
@@ -76,7 +80,7 @@ def _step_into(sc: MgxSpecC, B, grid, agents, rng, step_count, actions, target, 
 
 def _check_state(sc: MgxSpecC, grid, agents):
     B = grid.shape[0]
-    _want(grid, "grid", torch.uint8, (B, sc.height, sc.width, 3))
+    _want(grid, "grid", torch.int16, (B, sc.height, sc.width))
     _want(agents, "agents", torch.uint8, (B, sc.num_agents, 8))
     return B
 
@@ -132,7 +136,7 @@ def _step_autoreset_impl(grid, agents, rng, step_count, actions, aux, err, pool_
     sc = _spec_from_ints(spec)
     B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err)
     K = pool_grid.shape[0]
-    _want(pool_grid, "pool_grid", torch.uint8, (K, sc.height, sc.width, 3))
+    _want(pool_grid, "pool_grid", torch.int16, (K, sc.height, sc.width))
     _want(pool_agents, "pool_agents", torch.uint8, (K, sc.num_agents, 8))
     if pool_aux is not None:
         _want(pool_aux, "pool_aux", torch.uint8, (K, 16))
@@ -189,7 +193,7 @@ def _step_one_hot_impl(grid, agents, rng, step_count, actions, aux, err, pool_gr
     ar = None
     if pool_grid is not None:
         K = pool_grid.shape[0]
-        _want(pool_grid, "pool_grid", torch.uint8, (K, sc.height, sc.width, 3))
+        _want(pool_grid, "pool_grid", torch.int16, (K, sc.height, sc.width))
         _want(pool_agents, "pool_agents", torch.uint8, (K, sc.num_agents, 8))
         if pool_aux is not None:
             _want(pool_aux, "pool_aux", torch.uint8, (K, 16))
@@ -239,6 +243,27 @@ def _full_obs_impl(grid, agents, spec):
     return out
 
 
+def _pack_grid_impl(cells3):
+    _want(cells3, "cells3", torch.uint8)
+    if cells3.shape[-1] != 3:
+        raise ValueError("mgx: pack_grid expects (type, color, state) bytes in the last axis")
+    out = torch.empty(tuple(cells3.shape[:-1]), dtype=torch.int16, device=cells3.device)
+    bad = torch.zeros((1,), dtype=torch.int32, device=cells3.device)
+    with torch.cuda.device(cells3.device):
+        rc = _lib.lib().mgx_pack_grid(cells3.data_ptr(), out.numel(), out.data_ptr(), bad.data_ptr(), _stream(cells3.device))
+    _lib.check(rc, "mgx_pack_grid")
+    return out, bad
+
+
+def _unpack_grid_impl(grid):
+    _want(grid, "grid", torch.int16)
+    out = torch.empty(tuple(grid.shape) + (3,), dtype=torch.uint8, device=grid.device)
+    with torch.cuda.device(grid.device):
+        rc = _lib.lib().mgx_unpack_grid(grid.data_ptr(), grid.numel(), out.data_ptr(), _stream(grid.device))
+    _lib.check(rc, "mgx_unpack_grid")
+    return out
+
+
 _torch_lib = torch.library.Library("mgx", "DEF")
 _torch_lib.define("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
 _torch_lib.define(
@@ -258,6 +283,10 @@ _torch_lib.define(
     "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
 _torch_lib.define("one_hot(Tensor cells, int[] dim_sizes) -> Tensor")
 _torch_lib.define("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor")
+_torch_lib.define("pack_grid(Tensor cells3) -> (Tensor, Tensor)")
+_torch_lib.define("unpack_grid(Tensor grid) -> Tensor")
+_torch_lib.impl("pack_grid", _pack_grid_impl, "CUDA")
+_torch_lib.impl("unpack_grid", _unpack_grid_impl, "CUDA")
 _torch_lib.impl("one_hot", _one_hot_impl, "CUDA")
 _torch_lib.impl("full_obs", _full_obs_impl, "CUDA")
 _torch_lib.impl("gen_obs", _gen_obs_impl, "CUDA")
@@ -388,7 +417,7 @@ class HipBackend:
         _lib.check(rc, "mgx_reset_done")
 
     def reset_generate(self, B, gen, grid, agents, rng, step_count, aux, episode, was_reset):
-        """gen = dict(kind, room_size, start=(x, y, dir), blank u8[H,W,3], gen_state i64[B,6]) -- include/mgx.h MgxLayoutGen"""
+        """gen = dict(kind, room_size, start=(x, y, dir), blank i16[H,W] (packed cells), gen_state i64[B,6]) -- include/mgx.h MgxLayoutGen"""
         g = self._layout_gen_struct(gen)
         with torch.cuda.device(grid.device):
             rc = _lib.lib().mgx_reset_generate(

@@ -60,7 +60,12 @@ class EnvSpec:
 
     # ---- shapes of the device tensors (include/mgx.h) ----
     def grid_shape(self, batch: int):
+        """(type, color, state) bytes per cell: the form grids are given in and read back as"""
         return (batch, self.height, self.width, 3)
+
+    def cells_shape(self, batch: int):
+        """packed 16-bit cells: the form the device holds (include/mgx.h MgxCell)"""
+        return (batch, self.height, self.width)
 
     def agents_shape(self, batch: int):
         return (batch, self.num_agents, 8)

@@ -33,11 +33,18 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+def _layouts():
+    from multigrid_amd import layouts
+    return layouts
+
+
 def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=False):
     """tile u8[H,W,3], rows8 u8[A,8], act i8[A], rng4 u64[4], target = aux u8[16]; all updated in place.
     Returns dict(obs, reward, terminated, truncated, order, rc, n_dirty)."""
     sc = spec.to_c()
     A, v = spec.num_agents, spec.view_size
+    # the rules work on packed 16-bit cells (include/mgx.h MgxCell); the tests speak (type, color, state) bytes
+    tile3, tile = tile, np.ascontiguousarray(_layouts().pack_cells(tile))
     over = np.empty_like(tile)
     rew = np.empty(A, np.float64); term = np.empty(A, np.uint8); trunc = np.zeros(1, np.uint8)
     order = np.empty(A, np.uint8); nd = C.c_int32(0); scnt = C.c_int32(int(step_count))
@@ -48,6 +55,8 @@ def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=Fals
                              C.byref(nd), int(force_serial))
     obs = np.empty((A, v, v, 3), np.uint8)
     assert lib().shim_obs_env(C.byref(sc), _p(over, C.c_uint8), _p(rows, C.c_uint64), _p(obs, C.c_uint8)) == 0
+    assert np.array_equal(_layouts().pack_cells(_layouts().unpack_cells(tile)), tile), "opaque bits out of date"
+    tile3[...] = _layouts().unpack_cells(tile)
     return dict(obs=obs, reward=rew, terminated=term, truncated=int(trunc[0]), order=order, rc=rc,
                 n_dirty=nd.value, step_count=scnt.value, serial=nd.value < 0)
 
@@ -55,7 +64,7 @@ def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=Fals
 def obs_env(spec, tile, rows8):
     sc = spec.to_c()
     A, v = spec.num_agents, spec.view_size
-    over = tile.copy()
+    over = np.ascontiguousarray(_layouts().pack_cells(tile))
     rows = np.ascontiguousarray(rows8).view(np.uint64).reshape(A)
     lib().shim_overlay(C.byref(sc), _p(over, C.c_uint8), _p(rows, C.c_uint64))
     obs = np.empty((A, v, v, 3), np.uint8)

@@ -16,14 +16,14 @@ using namespace mgx;
 
 static const JumpTable kJump{};
 
-extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated, NOT overlaid */,
+extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cells, updated, NOT overlaid */,
                              uint8_t *tile_overlaid /* out: tile with agent overlay (render input) */,
                              uint64_t *rows /* A, updated */, const int8_t *act, uint64_t *rng /* 4, updated */,
                              int32_t *step_count, uint8_t *aux /* 16, updated */, double *rew /* A out */,
                              uint8_t *terminated /* A out */, uint8_t *truncated, uint8_t *order_out,
                              int32_t *n_dirty, int force_serial) {
     const StepCfg cf = make_cfg(*sp);
-    const int A = cf.A, HW3 = cf.H * cf.W * 3;
+    const int A = cf.A, HWB = cf.H * cf.W * kCellBytes;
     std::vector<uint64_t> rnd(A);
     std::vector<uint8_t> ord(A, 0);
     for (int a = 0; a < A; ++a) rew[a] = 0.0;
@@ -89,13 +89,13 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W*3, updated,
     post_step_hook(cf, sp->env_kind, tile, rows, act, aux, sc, rew, dirty);       // on the clean tile, like the kernel
     const bool forced = sp->env_kind == MGX_KIND_LOCKEDHALLWAY && aux[15];
     for (int a = 0; a < A; ++a) terminated[a] = (uint8_t)(row_term(rows[a]) | forced);
-    std::memcpy(tile_overlaid, tile, HW3);
+    std::memcpy(tile_overlaid, tile, HWB);
     for (int ai = 0; ai < A; ++ai)
-        if (ovl[ai] >= 0) store_cell(tile_overlaid + ovl[ai], (uint32_t)T_AGENT | ((uint32_t)(rows[ai] & 0xffffu) << 8));
+        if (ovl[ai] >= 0) store_cell16(tile_overlaid + ovl[ai], agent_cell16(rows[ai]));
     {   // must equal the reference's ascending loop (overlay_agents) run on the pre-hook rows
-        std::vector<uint8_t> ref(tile, tile + HW3);
+        std::vector<uint8_t> ref(tile, tile + HWB);
         overlay_agents(cf, ref.data(), pre_rows.data());
-        if (std::memcmp(ref.data(), tile_overlaid, HW3) != 0) return -99;
+        if (std::memcmp(ref.data(), tile_overlaid, HWB) != 0) return -99;
     }
     *truncated = (uint8_t)(sc >= cf.max_steps);
     return rc;
@@ -128,7 +128,7 @@ static void obs_env(const MgxSpec *sp, const uint8_t *tile, const uint64_t *rows
                 if (!((vis[k >> 6] >> (k & 63)) & 1)) cells[i * V + j] = CELL_UNSEEN;
             }
         }
-        for (int qq = 0; qq < V2; ++qq) store_cell(obs + ((size_t)a * V2 + qq) * 3, cells[qq]);
+        for (int qq = 0; qq < V2; ++qq) store_obs_cell(obs + ((size_t)a * V2 + qq) * 3, cells[qq]);
     }
 }
 

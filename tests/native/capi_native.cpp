@@ -63,15 +63,19 @@ int main(int argc, char **argv) {
         for (int k = 0; k < 4; ++k) rng[b * 4 + k] = ((uint64_t)rnd() << 32) | rnd();
         rng[b * 4 + 2] |= 1;                                         // PCG64 increments are odd
     }
-    Dev<uint8_t> d_grid, d_agents, d_obs, d_dir, d_term, d_trunc; Dev<uint64_t> d_rng; Dev<int32_t> d_sc, d_err; Dev<int8_t> d_act;
-    Dev<double> d_rew;
-    HIP_OK((hipError_t)d_grid.alloc(B * gsz)); HIP_OK((hipError_t)d_agents.alloc((size_t)B * A * 8)); HIP_OK((hipError_t)d_rng.alloc((size_t)B * 4));
+    Dev<uint8_t> d_cells3, d_agents, d_obs, d_dir, d_term, d_trunc; Dev<uint64_t> d_rng; Dev<int32_t> d_sc, d_err; Dev<int8_t> d_act;
+    Dev<double> d_rew; Dev<MgxCell> d_grid;       // the device holds packed cells (include/mgx.h)
+    HIP_OK((hipError_t)d_cells3.alloc(B * gsz)); HIP_OK((hipError_t)d_grid.alloc((size_t)B * W * H)); HIP_OK((hipError_t)d_agents.alloc((size_t)B * A * 8)); HIP_OK((hipError_t)d_rng.alloc((size_t)B * 4));
     HIP_OK((hipError_t)d_sc.alloc(B)); HIP_OK((hipError_t)d_err.alloc(2)); HIP_OK((hipError_t)d_act.alloc((size_t)B * A));
     HIP_OK((hipError_t)d_obs.alloc(B * osz)); HIP_OK((hipError_t)d_dir.alloc((size_t)B * A)); HIP_OK((hipError_t)d_rew.alloc((size_t)B * A));
     HIP_OK((hipError_t)d_term.alloc((size_t)B * A)); HIP_OK((hipError_t)d_trunc.alloc(B));
-    HIP_OK((hipError_t)d_grid.up(grid)); HIP_OK((hipError_t)d_agents.up(agents)); HIP_OK((hipError_t)d_rng.up(rng)); HIP_OK((hipError_t)d_sc.up(sc));
+    HIP_OK((hipError_t)d_cells3.up(grid)); HIP_OK((hipError_t)d_agents.up(agents)); HIP_OK((hipError_t)d_rng.up(rng)); HIP_OK((hipError_t)d_sc.up(sc));
     std::vector<int32_t> err0 = {0, INT32_MAX}; HIP_OK((hipError_t)d_err.up(err0));
     hipStream_t stream; HIP_OK(hipStreamCreate(&stream));
+    // the reference's (type, color, state) triples -> packed cells, on the device; err[0] doubles as the bad-cell counter
+    MGX_OK_(mgx_pack_grid(d_cells3.p, B * (int64_t)W * H, d_grid.p, d_err.p, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    { std::vector<int32_t> e; HIP_OK((hipError_t)d_err.down(e)); if (e[0] != 0) { std::fprintf(stderr, "unpackable cells\n"); return 9; } }
 
     std::vector<uint8_t> h_obs, h_dir, h_term, h_trunc, h_grid, h_agents, o_obs(B * osz), o_dir((size_t)B * A), o_term((size_t)B * A), o_trunc(B);
     std::vector<double> h_rew, o_rew((size_t)B * A); std::vector<uint64_t> h_rng; std::vector<int32_t> h_sc; std::vector<int8_t> act((size_t)B * A);
@@ -91,7 +95,9 @@ int main(int argc, char **argv) {
         if (mgo_step_batch(&sp, B, grid.data(), agents.data(), rng.data(), sc.data(), act.data(), nullptr, o_obs.data(), o_dir.data(),
                            o_rew.data(), o_term.data(), o_trunc.data(), &bad, 8)) return 6;
         HIP_OK((hipError_t)d_obs.down(h_obs)); HIP_OK((hipError_t)d_dir.down(h_dir)); HIP_OK((hipError_t)d_rew.down(h_rew)); HIP_OK((hipError_t)d_term.down(h_term));
-        HIP_OK((hipError_t)d_trunc.down(h_trunc)); HIP_OK((hipError_t)d_grid.down(h_grid)); HIP_OK((hipError_t)d_agents.down(h_agents));
+        MGX_OK_(mgx_unpack_grid(d_grid.p, B * (int64_t)W * H, d_cells3.p, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK((hipError_t)d_trunc.down(h_trunc)); HIP_OK((hipError_t)d_cells3.down(h_grid)); HIP_OK((hipError_t)d_agents.down(h_agents));
         HIP_OK((hipError_t)d_rng.down(h_rng)); HIP_OK((hipError_t)d_sc.down(h_sc));
         const bool same = h_obs == o_obs && h_dir == o_dir && h_term == o_term && h_trunc == o_trunc && h_grid == grid
                        && h_agents == agents && h_rng == rng && h_sc == sc

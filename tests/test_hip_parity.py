@@ -102,7 +102,7 @@ def test_torch_ops_registered_and_match():
     import multigrid_amd.ops as ops
     spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
     st = util.random_state(spec, 64, seed=5)
-    g = torch.from_numpy(st["grid"]).to(dev()); a = torch.from_numpy(st["agents"]).to(dev())
+    g = util.dev_cells(st["grid"], dev()); a = torch.from_numpy(st["agents"]).to(dev())
     obs, dirs = torch.ops.mgx.gen_obs(g, a, ops.spec_to_ints(spec))
     o_ref, d_ref = ob.gen_obs_batch(spec.as_dict(), st["grid"], st["agents"])
     np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
@@ -195,11 +195,11 @@ def test_full_size_properties_c4_shape():
 
 
 def test_tensors_beyond_4gib_address_correctly():
-    """7.5 M envs of the C2 shape: obs is 4.4 GB and grid 5.8 GB, so byte offsets leave 32 bits.  The first and the last
+    """8.5 M envs of the C2 shape: obs is 5.0 GB and the packed grid 4.35 GB, so byte offsets leave 32 bits.  The first and the last
     2048 envs (with an odd, ragged tail) must come out exactly as when those envs are stepped on their own -- env-local
     results cannot depend on where the env sits in the batch."""
     spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
-    B, n = 7_500_003, 2048
+    B, n = 8_500_003, 2048
     free, _ = torch.cuda.mem_get_info()
     if free < 24 * (1 << 30):
         pytest.skip("needs ~14 GB of free HBM")
@@ -207,7 +207,7 @@ def test_tensors_beyond_4gib_address_correctly():
     big = BatchedMultiGridEnv(spec, B, dev()); big.load_state(grid, agents); big.seed_synthetic(11)
     head = BatchedMultiGridEnv(spec, n, dev(), first_env=0); head.load_state(grid, agents); head.seed_synthetic(11)
     tail = BatchedMultiGridEnv(spec, n, dev(), first_env=B - n); tail.load_state(grid, agents); tail.seed_synthetic(11)
-    assert big.obs.numel() > (1 << 32) and big.grid.numel() > (1 << 32)
+    assert big.obs.numel() > (1 << 32) and big.cells.numel() * 2 > (1 << 32)
     g = torch.Generator(device=dev()); g.manual_seed(3)
     for t in range(6):
         act = torch.randint(0, 7, (B, 4), dtype=torch.int8, device=dev(), generator=g)
@@ -215,7 +215,7 @@ def test_tensors_beyond_4gib_address_correctly():
         oh = head.step(act[:n].contiguous()); ot = tail.step(act[B - n:].contiguous())
         for w, a, b in zip(ob_, oh, ot):
             assert torch.equal(w[:n], a) and torch.equal(w[B - n:], b)
-    assert torch.equal(big.grid[B - n:], tail.grid) and torch.equal(big.agents[B - n:], tail.agents)
+    assert torch.equal(big.cells[B - n:], tail.cells) and torch.equal(big.agents[B - n:], tail.agents)
     assert torch.equal(big.rng[B - n:], tail.rng) and torch.equal(big.step_count[B - n:], tail.step_count)
     o1, _ = big.gen_obs()
     assert torch.equal(o1[B - n:], tail.obs) and torch.equal(o1[:n], head.obs)
@@ -259,7 +259,7 @@ def test_one_hot_and_full_obs_vs_oracle_at_scale():
     g, a = st["grid"], st["agents"]
     for b in range(0, B, 97):
         np.testing.assert_array_equal(full[b], ob.full_obs(layouts.grid_from_product(g[b]), layouts.unpack_agents(a[b])))
-    got = torch.ops.mgx.full_obs(env.grid, env.agents, ops.spec_to_ints(spec))
+    got = torch.ops.mgx.full_obs(env.cells, env.agents, ops.spec_to_ints(spec))
     assert torch.equal(got, env.full_obs())
 
 
@@ -389,7 +389,7 @@ def test_auto_reset_without_was_reset_output():
     for t in range(14):
         act = torch.randint(0, 7, (300, 2), dtype=torch.int8, device=dev(), generator=g)
         want = [x.clone() for x in a.step(act, auto_reset=True)]
-        b.backend.step(b.batch, b.grid, b.agents, b.rng, b.step_count, act, None, b.err, b.obs, b.dir, b.reward,
+        b.backend.step(b.batch, b.cells, b.agents, b.rng, b.step_count, act, None, b.err, b.obs, b.dir, b.reward,
                        b.terminated, b.truncated, auto_reset=(b.first_env, b._pool, b.episode, None))
         for x, y in zip(want, (b.obs, b.dir, b.reward, b.terminated, b.truncated)):
             assert torch.equal(x, y)

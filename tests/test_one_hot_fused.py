@@ -98,7 +98,7 @@ def test_one_hot_torch_ops():
     B = 515
     st = util.random_state(spec, B, seed=12)
     ints = ops.spec_to_ints(spec)
-    g = torch.from_numpy(st["grid"]).to(DEV); a = torch.from_numpy(st["agents"]).to(DEV)
+    g = util.dev_cells(st["grid"], DEV); a = torch.from_numpy(st["agents"]).to(DEV)
     oh, dirs = torch.ops.mgx.gen_obs_one_hot(g, a, ints)
     o_ref, d_ref = ob.gen_obs_batch(spec.as_dict(), st["grid"], st["agents"])
     np.testing.assert_array_equal(oh.cpu().numpy(), ob.one_hot(o_ref))
@@ -111,4 +111,4 @@ def test_one_hot_torch_ops():
     assert got[0].cpu().numpy().tobytes() == ob.one_hot(want[0]).tobytes()
     for x, w in zip(got[1:5], want[1:]):
         assert x.cpu().numpy().tobytes() == w.tobytes()
-    assert g.cpu().numpy().tobytes() == ref["grid"].tobytes()
+    assert util.grid3(g).tobytes() == ref["grid"].tobytes()

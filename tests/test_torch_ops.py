@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import multigrid_amd.ops as ops
-from multigrid_amd import EnvSpec, workloads
+from multigrid_amd import EnvSpec, layouts, workloads
 from oracle import binding as ob
 from tests import util
 from tests.test_full_size import oracle_reset_done
@@ -16,6 +16,7 @@ DEV = "cuda:0"
 
 def _dev_state(st, spec):
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in st.items() if v is not None}
+    t["grid"] = util.dev_cells(st["grid"], DEV)                      # the ops take packed cells (include/mgx.h MgxCell)
     t["rng"] = torch.from_numpy(st["rng"].view(np.int64)).to(DEV)
     t["err"] = torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32, device=DEV)
     return t
@@ -41,7 +42,7 @@ def test_step_op_vs_oracle_in_place_args(kind):
         for g, w in zip(got, want):
             assert g.cpu().numpy().tobytes() == w.tobytes(), f"step {t}"
         # the (a!)..(d!) arguments were updated in place
-        assert d["grid"].cpu().numpy().tobytes() == ref["grid"].tobytes()
+        assert util.grid3(d["grid"]).tobytes() == ref["grid"].tobytes()
         assert d["agents"].cpu().numpy().tobytes() == ref["agents"].tobytes()
         np.testing.assert_array_equal(d["rng"].cpu().numpy().view(np.uint64), ref["rng"])
         np.testing.assert_array_equal(d["step_count"].cpu().numpy(), ref["step_count"])
@@ -54,7 +55,7 @@ def test_step_op_vs_oracle_in_place_args(kind):
 def test_step_op_refuses_cpu_tensors_and_bad_shapes():
     spec = EnvSpec(8, 8, 2, 7, max_steps=64)
     st = util.random_state(spec, 8, seed=1)
-    c = dict(grid=torch.from_numpy(st["grid"]), agents=torch.from_numpy(st["agents"]),
+    c = dict(grid=torch.from_numpy(layouts.pack_cells(st["grid"]).view(np.int16)), agents=torch.from_numpy(st["agents"]),
              rng=torch.from_numpy(st["rng"].view(np.int64)), sc=torch.from_numpy(st["step_count"]),
              act=torch.zeros((8, 2), dtype=torch.int8), err=torch.zeros(2, dtype=torch.int32))
     ints = ops.spec_to_ints(spec)
@@ -75,7 +76,7 @@ def test_step_autoreset_op_vs_oracle():
     # make restarts happen: half the envs are one step from truncation
     ref["step_count"][::2] = spec.max_steps - 2
     d = _dev_state(ref, spec)
-    pool = [torch.from_numpy(p).to(DEV) for p in wl.pool]
+    pool = [util.dev_cells(wl.pool[0], DEV)] + [torch.from_numpy(p).to(DEV) for p in wl.pool[1:]]
     episode_ref = np.zeros(B, np.int32)
     episode = torch.zeros(B, dtype=torch.int32, device=DEV)
     ints = ops.spec_to_ints(spec)
@@ -91,7 +92,7 @@ def test_step_autoreset_op_vs_oracle():
             assert g.cpu().numpy().tobytes() == w.tobytes(), f"step {t}"
         np.testing.assert_array_equal(got[5].cpu().numpy(), was_ref)
         np.testing.assert_array_equal(episode.cpu().numpy(), episode_ref)
-        assert d["grid"].cpu().numpy().tobytes() == ref["grid"].tobytes()
+        assert util.grid3(d["grid"]).tobytes() == ref["grid"].tobytes()
         np.testing.assert_array_equal(d["aux"].cpu().numpy(), ref["aux"])
         resets += int(was_ref.sum())
     assert resets >= B // 2

@@ -107,6 +107,24 @@ def random_state(spec: EnvSpec, B: int, seed: int, density: float = 0.25, termin
     return dict(grid=grid, agents=agents, rng=rng, step_count=step_count, target=target)
 
 
+def dev_cells(grid3, device):
+    """(type, color, state) bytes u8[...,3] (numpy) -> the device's packed cells (int16 tensor) through torch.ops.mgx.pack_grid
+    (the kernel is checked against layouts.pack_cells on the way)."""
+    import multigrid_amd.ops  # noqa: F401  (registers the ops)
+    cells, bad = torch.ops.mgx.pack_grid(torch.from_numpy(np.ascontiguousarray(grid3)).to(device))
+    assert int(bad[0]) == 0
+    assert np.array_equal(cells.cpu().numpy().view(np.uint16), layouts.pack_cells(grid3))
+    return cells
+
+
+def grid3(cells) -> np.ndarray:
+    """packed cells (int16 tensor on the device) -> (type, color, state) bytes (numpy) through torch.ops.mgx.unpack_grid"""
+    import multigrid_amd.ops  # noqa: F401
+    out = torch.ops.mgx.unpack_grid(cells).cpu().numpy()
+    assert np.array_equal(layouts.pack_cells(out).view(np.int16), cells.cpu().numpy()), "opaque bits out of date"
+    return out
+
+
 def random_actions(B, A, seed, p_missing=0.05):
     r = np.random.default_rng(seed)
     a = r.integers(0, 7, size=(B, A)).astype(np.int8)
@@ -123,21 +141,34 @@ class OracleBackend:
     def __init__(self, spec: EnvSpec, nthreads: int = 1):
         self.spec, self.d, self.nthreads = spec, spec.as_dict(), nthreads
 
-    def gen_obs(self, B, grid, agents, obs, dirs):
-        o, d = ob.gen_obs_batch(self.d, grid.numpy(), agents.numpy(), self.nthreads)
+    # `grid` arrives as BatchedMultiGridEnv holds it: packed cells (int16 MgxCell bit patterns); the oracle works on the
+    # reference's (type, color, state) triples
+    @staticmethod
+    def _g3(grid):
+        return layouts.unpack_cells(grid.numpy())
+
+    @staticmethod
+    def _store(grid, g3):
+        grid.copy_(torch.from_numpy(layouts.pack_cells(g3).view(np.int16)))
+
+    def gen_obs(self, B, grid, agents, obs, dirs, one_hot: bool = False):
+        assert not one_hot
+        o, d = ob.gen_obs_batch(self.d, self._g3(grid), agents.numpy(), self.nthreads)
         obs.copy_(torch.from_numpy(o))
         if dirs is not None:
             dirs.copy_(torch.from_numpy(d))
 
     def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated):
+        g3 = self._g3(grid)
         try:
             o, d, r, te, tr = ob.step_batch(
-                self.d, grid.numpy(), agents.numpy(), rng.numpy().view(np.uint64), step_count.numpy(),
+                self.d, g3, agents.numpy(), rng.numpy().view(np.uint64), step_count.numpy(),
                 actions.numpy(), target.numpy() if target is not None else None, self.nthreads)
         except ValueError:
             err[0] += 1
             err[1] = 0
             return
+        self._store(grid, g3)
         obs.copy_(torch.from_numpy(o)); dirs.copy_(torch.from_numpy(d)); reward.copy_(torch.from_numpy(r))
         terminated.copy_(torch.from_numpy(te)); truncated.copy_(torch.from_numpy(tr))
 
@@ -151,7 +182,7 @@ class OracleBackend:
         out.copy_(torch.from_numpy(ob.one_hot(cells.numpy())))
 
     def full_obs(self, B, grid, agents, out):
-        g, a = grid.numpy(), agents.numpy()
+        g, a = self._g3(grid), agents.numpy()
         for b in range(B):
             out[b] = torch.from_numpy(ob.full_obs(layouts.grid_from_product(g[b]), layouts.unpack_agents(a[b])).astype(np.uint8))
 
@@ -171,7 +202,7 @@ class OracleBackend:
 
     def reset_generate(self, B, gen, grid, agents, rng, step_count, aux, episode, was_reset):
         """mgx_reset_generate on the layout oracle (oracle/mgx_layout_oracle.c), env by env."""
-        blank = gen["blank"].numpy()
+        blank = layouts.unpack_cells(gen["blank"].numpy())
         gs = gen["gen_state"].numpy().view(np.uint64)
         r = rng.numpy().view(np.uint64)
         A = self.spec.num_agents
@@ -190,7 +221,7 @@ class OracleBackend:
             else:
                 g = blank.copy(); a = np.zeros((A, 8), np.uint8)
                 a[:, 0] = np.arange(A) % 6; a[:, 1] = gen["start"][2]; a[:, 2] = gen["start"][0]; a[:, 3] = gen["start"][1]; a[:, 5] = 1
-            grid[b] = torch.from_numpy(g); agents[b] = torch.from_numpy(a)
+            self._store(grid[b], g); agents[b] = torch.from_numpy(a)
             gs[b, :5] = lay; gs[b, 5] = npw[4]; r[b] = npw[:4]
             step_count[b] = 0
             episode[b] += 1
