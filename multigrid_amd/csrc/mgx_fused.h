@@ -363,22 +363,37 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
             const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
             const uint32_t addr = inb[n][it] ? (uint32_t)off : wall_addr;
             if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr, 2);
-            // one aligned, sign-extending 16-bit read per cell (ds_read_i16): bit 15 of a packed cell = opaque
+            // one aligned, sign-extending 16-bit read per cell (ds_read_i16): bit 15 of a packed cell (opaque) becomes the sign
             raw[n][it] = (int32_t)*(lds_i16_ptr)(uintptr_t)addr;
         }
     }
+    // obs.py:46-63 see_behind as a lane mask: the cell's opaque bit is the sign of the load -- ONE compare per cell, whose
+    // SGPR pair goes straight into lane s of sbLo / sbHi.  HARDWARE HAZARD (found on gfx950, not in the ISA manual's table,
+    // which lists only the lane-select operand): a v_writelane_b32 whose DATA operand is an SGPR (or VCC) written by the
+    // immediately preceding VALU instruction deposits the register's OLD value.  So the sequence is software-pipelined by
+    // hand -- compare of cell k, then the two writelanes of cell k-1 -- in one asm block per cell: three instructions lie
+    // between a compare and the writelanes that read it, and no s_nop is spent (one after the last compare of the group).
+    uint64_t pend = 0;
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-#pragma unroll
-        for (int it = 0; it < NW; ++it) {
-            constexpr uint64_t kAll = ~0ull;
-            const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
-            cell[S0 + n][it] = (uint32_t)raw[n][it];                        // (bits 16..31 repeat the opaque bit from here on)
-            // obs.py:46-63 see_behind as a lane mask: the cell's opaque bit is the sign of the load -- one compare
-            const uint64_t m = __builtin_amdgcn_ballot_w64(raw[n][it] >= 0) & act_mask;
-            sbLo[it] = set_lane(sbLo[it], (uint32_t)m, S0 + n);
-            sbHi[it] = set_lane(sbHi[it], (uint32_t)(m >> 32), S0 + n);
+    for (int k = 0; k < N * NW; ++k) {
+        const int n = k / NW, it = k - n * NW, pn = (k - 1) / NW, pit = (k - 1) - pn * NW;
+        constexpr uint64_t kAll = ~0ull;
+        cell[S0 + n][it] = (uint32_t)raw[n][it];                            // (bits 16..31 repeat the opaque bit from here on)
+        uint64_t cur;
+        if (k == 0) {
+            asm volatile("v_cmp_lt_i32_e64 %0, -1, %1\n\ts_nop 1" : "=s"(cur) : "v"(raw[n][it]));   // (only one compare follows it)
+        } else {
+            asm volatile("v_cmp_lt_i32_e64 %0, -1, %3\n\tv_writelane_b32 %1, %4, %6\n\tv_writelane_b32 %2, %5, %6"
+                         : "=&s"(cur), "+v"(sbLo[pit]), "+v"(sbHi[pit])
+                         : "v"(raw[n][it]), "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + pn));
         }
+        const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
+        pend = cur & act_mask;                                               // (an SALU op, or nothing)
+    }
+    {
+        constexpr int pn = (N * NW - 1) / NW, pit = (N * NW - 1) - pn * NW;
+        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                     : "+v"(sbLo[pit]), "+v"(sbHi[pit]) : "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + pn));
     }
 }
 
