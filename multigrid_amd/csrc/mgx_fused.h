@@ -151,7 +151,7 @@ __device__ __forceinline__ T kernarg_at(size_t offset) {
 struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
 
 typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
-typedef const int16_t __attribute__((address_space(3))) *lds_i16_ptr;
+typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef const u32_unaligned __attribute__((address_space(3))) *lds_u32_ua_ptr;
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
@@ -183,7 +183,8 @@ constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 constexpr int kRound = MGX_ROUND;        // view slots whose obs bytes are staged in LDS at a time (P4/P5)
 
 // View slots per wavefront = cell registers per lane (x passes per view).
-inline int slots_per_wave(int view_size) { return view_size <= 7 ? kSlotsSmallView : 32; }
+// (the rollout kernel, whose step loop already holds ~160 VGPRs, stays at 32)
+inline int slots_per_wave(int view_size, bool roll = false) { return (view_size <= 7 && !roll) ? kSlotsSmallView : 32; }
 
 // Carve of ONE wavefront's LDS slice (byte offsets, all multiples of 16).  Everything is a closed form of
 // (vpw, nw, Gw, A, tile bytes, round bytes) so the kernel recomputes an offset where it needs it instead of carrying
@@ -194,10 +195,11 @@ struct LdsCarve {
     bool has_aux;   // env kinds with hook state
     __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
     // -- per-step temporaries, all dead once P2 has gathered the cells --
+    // (the view records, written in P1d, lie over the draws and the rewards, both dead by then)
     __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]  (P1d -> P2)
     __host__ __device__ int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
-    __host__ __device__ int rew() const { return 24 * vpw; }                         // f64  [vpw]
-    __host__ __device__ int woff() const { return 32 * vpw; }                        // i32  [vpw]     (P1s)
+    __host__ __device__ int rew() const { return 16 * vpw; }                         // f64  [vpw]     (P0 -> hooks), same space
+    __host__ __device__ int woff() const { return 24 * vpw; }                        // i32  [vpw]     (P1s)
     __host__ __device__ int temps_end() const { return woff() + 4 * vpw; }
     // -- state that lives across phases / steps --
     __host__ __device__ int act() const { return temps_end(); }                      // i8   [vpw]
@@ -228,13 +230,13 @@ __host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int G
                     roll, has_aux};
 }
 
-inline int slots_in_use(const MgxSpec &sp, int Gw) {
+inline int slots_in_use(const MgxSpec &sp, int Gw, bool roll = false) {
     int vpw = (Gw * sp.num_agents + 15) & ~15;     // (the kernel is compiled for slots_per_wave(V) slots)
-    return vpw > slots_per_wave(sp.view_size) ? slots_per_wave(sp.view_size) : vpw;
+    return vpw > slots_per_wave(sp.view_size, roll) ? slots_per_wave(sp.view_size, roll) : vpw;
 }
 
 inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false, bool one_hot = false) {
-    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw), roll,
+    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw, roll), roll,
                       sp.env_kind != MGX_KIND_EMPTY, one_hot).total();
 }
 
@@ -247,7 +249,7 @@ constexpr int kLdsWaveBudget = MGX_LDS_WAVE_BUDGET;     // keeps >= 12 wavefront
 // Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
 // to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
 inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false, bool one_hot = false) {
-    int Gw = slots_per_wave(sp.view_size) / sp.num_agents;
+    int Gw = slots_per_wave(sp.view_size, roll) / sp.num_agents;
     if (Gw < 1) Gw = 1;
     while (Gw > 1 && wave_lds_bytes(sp, Gw, roll, one_hot) > kLdsWaveBudget) --Gw;
     while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
@@ -338,7 +340,7 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 template <int V, int NW, int S0, int N, int VPW>
 __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave, const uint32_t wall_addr, const ViewRec *rec,
                                              const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
-                                             const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
+                                             const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW / 2][NW],
                                              uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     constexpr int V2 = V * V;
     ViewRec r[N];
@@ -351,7 +353,7 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
             inbm[n][it] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbHi[it], S0 + n) << 32)
                         | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbLo[it], S0 + n);
     }
-    int32_t raw[N][NW];
+    uint32_t raw[N][NW];
     bool inb[N][NW];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -363,11 +365,11 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
             const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
             const uint32_t addr = inb[n][it] ? (uint32_t)off : wall_addr;
             if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr, 2);
-            // one aligned, sign-extending 16-bit read per cell (ds_read_i16): bit 15 of a packed cell (opaque) becomes the sign
-            raw[n][it] = (int32_t)*(lds_i16_ptr)(uintptr_t)addr;
+            // one aligned 16-bit read per cell (ds_read_u16)
+            raw[n][it] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
         }
     }
-    // obs.py:46-63 see_behind as a lane mask: the cell's opaque bit is the sign of the load -- ONE compare per cell, whose
+    // obs.py:46-63 see_behind as a lane mask: the cell's opaque bit is the sign of its 16 bits -- ONE compare per cell, whose
     // SGPR pair goes straight into lane s of sbLo / sbHi.  HARDWARE HAZARD (found on gfx950, not in the ISA manual's table,
     // which lists only the lane-select operand): a v_writelane_b32 whose DATA operand is an SGPR (or VCC) written by the
     // immediately preceding VALU instruction deposits the register's OLD value.  So the sequence is software-pipelined by
@@ -378,12 +380,12 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
     for (int k = 0; k < N * NW; ++k) {
         const int n = k / NW, it = k - n * NW, pn = (k - 1) / NW, pit = (k - 1) - pn * NW;
         constexpr uint64_t kAll = ~0ull;
-        cell[S0 + n][it] = (uint32_t)raw[n][it];                            // (bits 16..31 repeat the opaque bit from here on)
+        if ((n & 1) == 0) cell[(S0 + n) >> 1][it] = raw[n][it] | (raw[n + 1][it] << 16);    // two slots' cells per register
         uint64_t cur;
         if (k == 0) {
-            asm volatile("v_cmp_lt_i32_e64 %0, -1, %1\n\ts_nop 1" : "=s"(cur) : "v"(raw[n][it]));   // (only one compare follows it)
+            asm volatile("v_cmp_lt_i16_e64 %0, -1, %1\n\ts_nop 1" : "=s"(cur) : "v"(raw[n][it]));   // (only one compare follows it)
         } else {
-            asm volatile("v_cmp_lt_i32_e64 %0, -1, %3\n\tv_writelane_b32 %1, %4, %6\n\tv_writelane_b32 %2, %5, %6"
+            asm volatile("v_cmp_lt_i16_e64 %0, -1, %3\n\tv_writelane_b32 %1, %4, %6\n\tv_writelane_b32 %2, %5, %6"
                          : "=&s"(cur), "+v"(sbLo[pit]), "+v"(sbHi[pit])
                          : "v"(raw[n][it]), "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + pn));
         }
@@ -405,7 +407,7 @@ constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as 
 template <int V, int NW, int VPW, int S0 = 0>
 __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, int NVc, const uint32_t wall_addr, const ViewRec *rec,
                                            const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
-                                           const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW][NW],
+                                           const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW / 2][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     constexpr bool ROLL = MODE == 2;
     constexpr int V2 = V * V;
     constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
-    constexpr int VPW = V <= 7 ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave)
+    constexpr int VPW = (V <= 7 && !ROLL) ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave)
     extern __shared__ __align__(16) uint8_t lds[];
 
     const int lane = threadIdx.x & 63;
@@ -919,8 +921,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     MGX_MARK("P2");
     // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
     const LaneConst<V, NW> lc = ROLL ? lc_roll : lane_consts();
-    uint32_t cell[VPW][NW];                      // registers: every slot's cells, one per lane (and pass); P4 reads
-                                                 // only the gathered ones (s < NVc)
+    uint32_t cell[VPW / 2][NW];                  // registers: every slot's packed cells, one per lane (and pass), slots 2p and
+                                                 // 2p+1 in the halves of one register; P4 reads only the gathered ones (s < NVc)
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
     for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     const int s = r0 + sl;
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
-                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN);
+                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? ((s & 1) ? cell[s >> 1][it] >> 16 : cell[s >> 1][it]) : CELL_UNSEEN);
                                     MGX_CHECK_LDS_PTR(7, d0 + sl * V2, 4);
                                     d0[sl * V2] = one_hot_mask(c);
                                 }
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
                                     // packed cell -> the observation's (type, color, state) bytes
-                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? cell[s][it] : CELL_UNSEEN);
+                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? ((s & 1) ? cell[s >> 1][it] >> 16 : cell[s >> 1][it]) : CELL_UNSEEN);
                                     [[maybe_unused]] uint8_t *d = d0 + sl * (V2 * 3);
                                     MGX_CHECK_LDS_PTR(5, d, 3);
 #if MGX_P4_B16

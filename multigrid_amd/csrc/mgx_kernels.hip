@@ -81,14 +81,14 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     ka.sp = *sp;
     ka.batch = batch;
     ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll, one_hot);
-    const int max_gw = slots_per_wave(sp->view_size) / sp->num_agents;
+    const int max_gw = slots_per_wave(sp->view_size, roll) / sp->num_agents;
     if (ka.Gw > max_gw) ka.Gw = max_gw;
     if (ka.Gw < 1) ka.Gw = 1;
     while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll, one_hot) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
     // a grid tensor beyond half of the 256 MiB Infinity Cache is streamed (nt tile loads): mgx_fused.h, P0
     ka.flags = (batch * (int64_t)sp->width * sp->height * kCellBytes > (int64_t)128 << 20) ? 1 : 0;
-    ka.vpw = slots_in_use(*sp, ka.Gw);
+    ka.vpw = slots_in_use(*sp, ka.Gw, roll);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot);
     struct { int total; } p{ka.wave_lds};
