@@ -157,7 +157,7 @@ typedef const u32_unaligned __attribute__((address_space(3))) *lds_u32_ua_ptr;
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 
 #ifndef MGX_SLOTS_SMALL_VIEW
-#define MGX_SLOTS_SMALL_VIEW 32
+#define MGX_SLOTS_SMALL_VIEW 64
 #endif
 constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 // cache policy bits of the obs stores (raw buffer store `aux`: 1 = sc0, 2 = nt, 16 = sc1 on gfx94x/gfx950)
@@ -182,9 +182,13 @@ constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 #endif
 constexpr int kRound = MGX_ROUND;        // view slots whose obs bytes are staged in LDS at a time (P4/P5)
 
-// View slots per wavefront = cell registers per lane (x passes per view).
+// View slots per wavefront.  Views of up to 7x7 (one lane pass per view): 64 slots in the throughput instantiations, whose
+// cell registers hold two slots each (the per-agent phases then run on all 64 lanes: their cost per view halves); 32 in the
+// latency instantiations (DMA: launches of <= 2048 wavefronts use at most 32 slots anyway, and the packing is two more
+// instructions on a lone wave's chain) and in the rollout kernel.
 // (the rollout kernel, whose step loop already holds ~160 VGPRs, stays at 32)
 inline int slots_per_wave(int view_size, bool roll = false) { return (view_size <= 7 && !roll) ? kSlotsSmallView : 32; }
+constexpr int kSlotsLatency = 32;        // DMA instantiations
 
 // Carve of ONE wavefront's LDS slice (byte offsets, all multiples of 16).  Everything is a closed form of
 // (vpw, nw, Gw, A, tile bytes, round bytes) so the kernel recomputes an offset where it needs it instead of carrying
@@ -337,10 +341,10 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 // (obs.py:182-202); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.  The agent's own cell still
 // shows the grid here; lane s patches the carried object in afterwards (P3: its see-behind bit, P4: its bytes).
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
-template <int V, int NW, int S0, int N, int VPW>
+template <int V, int NW, int S0, int N, int VPW, bool HALF>
 __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave, const uint32_t wall_addr, const ViewRec *rec,
                                              const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
-                                             const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW / 2][NW],
+                                             const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
                                              uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     constexpr int V2 = V * V;
     ViewRec r[N];
@@ -380,7 +384,11 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
     for (int k = 0; k < N * NW; ++k) {
         const int n = k / NW, it = k - n * NW, pn = (k - 1) / NW, pit = (k - 1) - pn * NW;
         constexpr uint64_t kAll = ~0ull;
-        if ((n & 1) == 0) cell[(S0 + n) >> 1][it] = raw[n][it] | (raw[n + 1][it] << 16);    // two slots' cells per register
+        if constexpr (HALF) {
+            if ((n & 1) == 0) cell[(S0 + n) >> 1][it] = raw[n][it] | (raw[n + 1][it] << 16);    // two slots' cells per register
+        } else {
+            cell[S0 + n][it] = raw[n][it];
+        }
         uint64_t cur;
         if (k == 0) {
             asm volatile("v_cmp_lt_i16_e64 %0, -1, %1\n\ts_nop 1" : "=s"(cur) : "v"(raw[n][it]));   // (only one compare follows it)
@@ -404,15 +412,15 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
 #endif
 constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as one straight-line block
 
-template <int V, int NW, int VPW, int S0 = 0>
+template <int V, int NW, int VPW, bool HALF, int S0 = 0>
 __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, int NVc, const uint32_t wall_addr, const ViewRec *rec,
                                            const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
-                                           const LaneConst<V, NW> &lc, uint32_t (&cell)[VPW / 2][NW],
+                                           const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
-        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW>(a, wave, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
-        gather_all<V, NW, VPW, S0 + kGroup>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW, HALF>(a, wave, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, HALF, S0 + kGroup>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     }
 }
 
@@ -437,7 +445,8 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     constexpr bool ROLL = MODE == 2;
     constexpr int V2 = V * V;
     constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
-    constexpr int VPW = (V <= 7 && !ROLL) ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave)
+    constexpr bool HALF = !DMA && !ROLL;         // cell registers hold two slots' packed cells each
+    constexpr int VPW = (V <= 7 && HALF) ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave; DMA: kSlotsLatency)
     extern __shared__ __align__(16) uint8_t lds[];
 
     const int lane = threadIdx.x & 63;
@@ -921,12 +930,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     MGX_MARK("P2");
     // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
     const LaneConst<V, NW> lc = ROLL ? lc_roll : lane_consts();
-    uint32_t cell[VPW / 2][NW];                  // registers: every slot's packed cells, one per lane (and pass), slots 2p and
-                                                 // 2p+1 in the halves of one register; P4 reads only the gathered ones (s < NVc)
+    uint32_t cell[HALF ? VPW / 2 : VPW][NW];     // registers: every slot's packed cells, one per lane (and pass); HALF: slots 2p
+                                                 // and 2p+1 in the halves of one register; P4 reads only the gathered ones (s < NVc)
     uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
 #pragma unroll
     for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
-    if (!MGX_DBG(4)) gather_all<V, NW, VPW>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+    if (!MGX_DBG(4)) gather_all<V, NW, VPW, HALF>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     if (ROLL) {                                                              // take the overlay off again: the tile persists
         wave_sync();
         if (ovl_off >= 0) store_cell16(tile + env_of_lane * HWB + ovl_off, ovl_saved);
@@ -951,6 +960,12 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     }
 
     MGX_MARK("P4");
+    // slot s's packed cell in this lane (HALF: bits 16.. of an even slot's value are the odd slot's cell -- cell_unpack's masks
+    // drop them)
+    auto slot_cell = [&](const int s, const int it) -> uint32_t {
+        if constexpr (HALF) return (s & 1) ? cell[s >> 1][it] >> 16 : cell[s >> 1][it];
+        else return cell[s][it];
+    };
     if constexpr (OH) {
         // -------------------------------------------------------------- P4'/P5' (one-hot output) in rounds of kRound slots:
         // P4' masks each cell and leaves its one-hot bit mask (bit t | bit 11+c | bit 17+s) at its image position in LDS;
@@ -980,7 +995,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     const int s = r0 + sl;
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
-                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? ((s & 1) ? cell[s >> 1][it] >> 16 : cell[s >> 1][it]) : CELL_UNSEEN);
+                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? slot_cell(s, it) : CELL_UNSEEN);
                                     MGX_CHECK_LDS_PTR(7, d0 + sl * V2, 4);
                                     d0[sl * V2] = one_hot_mask(c);
                                 }
@@ -1061,7 +1076,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
                                     const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
                                                      | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
                                     // packed cell -> the observation's (type, color, state) bytes
-                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? ((s & 1) ? cell[s >> 1][it] >> 16 : cell[s >> 1][it]) : CELL_UNSEEN);
+                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? slot_cell(s, it) : CELL_UNSEEN);
                                     [[maybe_unused]] uint8_t *d = d0 + sl * (V2 * 3);
                                     MGX_CHECK_LDS_PTR(5, d, 3);
 #if MGX_P4_B16

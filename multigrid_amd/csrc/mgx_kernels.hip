@@ -100,7 +100,8 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     threads = 64 * wpb;
     lds_bytes = wpb * p.total;
     const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
-    if (nwaves <= 2048 && !(ka.flags & 1)) ka.flags |= 2;    // latency regime: LDS-DMA tile loads (mgx_fused.h, P0)
+    // latency regime: LDS-DMA tile loads, 32 view slots with unpacked cell registers (mgx_fused.h: DMA instantiations)
+    if (nwaves <= 2048 && !(ka.flags & 1) && ka.Gw * sp->num_agents <= kSlotsLatency) ka.flags |= 2;
     nwg = (nwaves + wpb - 1) / wpb;
     if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
     return MGX_OK;
