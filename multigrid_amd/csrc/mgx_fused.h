@@ -187,7 +187,8 @@ constexpr int kRound = MGX_ROUND;        // view slots whose obs bytes are stage
 // latency instantiations (DMA: launches of <= 2048 wavefronts use at most 32 slots anyway, and the packing is two more
 // instructions on a lone wave's chain) and in the rollout kernel.
 // (the rollout kernel, whose step loop already holds ~160 VGPRs, stays at 32)
-inline int slots_per_wave(int view_size, bool roll = false) { return (view_size <= 7 && !roll) ? kSlotsSmallView : 32; }
+// `narrow`: the rollout and the gen_obs-only kernels (little per-agent work to amortise: measured 3-5 % faster at 32)
+inline int slots_per_wave(int view_size, bool narrow = false) { return (view_size <= 7 && !narrow) ? kSlotsSmallView : 32; }
 constexpr int kSlotsLatency = 32;        // DMA instantiations
 
 // Carve of ONE wavefront's LDS slice (byte offsets, all multiples of 16).  Everything is a closed form of
@@ -234,13 +235,13 @@ __host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int G
                     roll, has_aux};
 }
 
-inline int slots_in_use(const MgxSpec &sp, int Gw, bool roll = false) {
+inline int slots_in_use(const MgxSpec &sp, int Gw, bool narrow = false) {
     int vpw = (Gw * sp.num_agents + 15) & ~15;     // (the kernel is compiled for slots_per_wave(V) slots)
-    return vpw > slots_per_wave(sp.view_size, roll) ? slots_per_wave(sp.view_size, roll) : vpw;
+    return vpw > slots_per_wave(sp.view_size, narrow) ? slots_per_wave(sp.view_size, narrow) : vpw;
 }
 
-inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false, bool one_hot = false) {
-    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw, roll), roll,
+inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false, bool one_hot = false, bool obs_only = false) {
+    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw, roll || obs_only), roll,
                       sp.env_kind != MGX_KIND_EMPTY, one_hot).total();
 }
 
@@ -252,10 +253,10 @@ constexpr int kLdsWaveBudget = MGX_LDS_WAVE_BUDGET;     // keeps >= 12 wavefront
 
 // Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
 // to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
-inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false, bool one_hot = false) {
-    int Gw = slots_per_wave(sp.view_size, roll) / sp.num_agents;
+inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false, bool one_hot = false, bool obs_only = false) {
+    int Gw = slots_per_wave(sp.view_size, roll || obs_only) / sp.num_agents;
     if (Gw < 1) Gw = 1;
-    while (Gw > 1 && wave_lds_bytes(sp, Gw, roll, one_hot) > kLdsWaveBudget) --Gw;
+    while (Gw > 1 && wave_lds_bytes(sp, Gw, roll, one_hot, obs_only) > kLdsWaveBudget) --Gw;
     while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
     while (Gw > 1 && (batch + Gw - 1) / Gw < 512) Gw = (Gw + 1) / 2;       // tiny batches: spread over the chip
     return Gw;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
     constexpr bool ROLL = MODE == 2;
     constexpr int V2 = V * V;
     constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
-    constexpr bool HALF = !DMA && !ROLL;         // cell registers hold two slots' packed cells each
+    constexpr bool HALF = !DMA && MODE == 1;     // cell registers hold two slots' packed cells each (throughput step kernels)
     constexpr int VPW = (V <= 7 && HALF) ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave; DMA: kSlotsLatency)
     extern __shared__ __align__(16) uint8_t lds[];
 

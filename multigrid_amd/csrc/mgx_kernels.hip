@@ -64,33 +64,33 @@ int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_
     }
 }
 
-int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot = false) {
+int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot = false, bool obs_only = false) {
     if (!sp || batch < 0) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size < 3 || !(sp->view_size & 1)) return MGX_ERR_INVALID_ARGUMENT;   // agent.py:78-79
     if (sp->width < 3 || sp->height < 3 || sp->num_agents < 1 || sp->max_steps < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
     if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_LOCKEDHALLWAY) return MGX_ERR_UNSUPPORTED;
-    if (wave_lds_bytes(*sp, 1, roll, one_hot) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;   // one env must fit one CU's LDS (the
+    if (wave_lds_bytes(*sp, 1, roll, one_hot, obs_only) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;   // one env must fit one CU's LDS (the
                                                                                      // rollout carve is the larger one)
     return MGX_OK;
 }
 
 int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg,
-              bool roll = false, bool one_hot = false) {
+              bool roll = false, bool one_hot = false, bool obs_only = false) {
     ka.sp = *sp;
     ka.batch = batch;
-    ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll, one_hot);
-    const int max_gw = slots_per_wave(sp->view_size, roll) / sp->num_agents;
+    ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll, one_hot, obs_only);
+    const int max_gw = slots_per_wave(sp->view_size, roll || obs_only) / sp->num_agents;
     if (ka.Gw > max_gw) ka.Gw = max_gw;
     if (ka.Gw < 1) ka.Gw = 1;
-    while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll, one_hot) > kLdsPerCU) --ka.Gw;
+    while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only) > kLdsPerCU) --ka.Gw;
     ka.dbg = g_debug_skip;
     // a grid tensor beyond half of the 256 MiB Infinity Cache is streamed (nt tile loads): mgx_fused.h, P0
     ka.flags = (batch * (int64_t)sp->width * sp->height * kCellBytes > (int64_t)128 << 20) ? 1 : 0;
-    ka.vpw = slots_in_use(*sp, ka.Gw, roll);
+    ka.vpw = slots_in_use(*sp, ka.Gw, roll || obs_only);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
-    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot);
+    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only);
     struct { int total; } p{ka.wave_lds};
     // wavefronts bundled per workgroup: 2 packs a CU's 160 KiB of LDS tighter than 4 once the chip is full (measured
     // 403 vs 425 us at 1M envs); below that, fewer and larger workgroups launch faster (9.9 vs 10.5 us at 4096 envs)
@@ -176,14 +176,14 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
 
 static int gen_obs_common(bool one_hot, const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents,
                           uint8_t *obs, uint8_t *dir, void *stream) {
-    int rc = check_spec(spec, batch, false, one_hot);
+    int rc = check_spec(spec, batch, false, one_hot, true);
     if (rc) return rc;
     if (batch == 0) return MGX_OK;
     if (!grid || !agents || !obs) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16)) return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, one_hot);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, one_hot, true);
     if (rc) return rc;
     ka.grid = reinterpret_cast<uint8_t *>(const_cast<MgxCell *>(grid));
     ka.agents = const_cast<uint8_t *>(agents);
