@@ -98,6 +98,58 @@ def test_random_states_vs_oracle(name, spec, B, T):
     env.check_errors()
 
 
+# The library has two families of instantiations (multigrid_amd/csrc/mgx_fused.h): launches of <= 2048 wavefronts take the
+# latency ones (LDS-DMA tile loads, 32 view slots, one cell per register), larger launches the throughput ones (64 view slots
+# for views up to 7x7, two slots' packed cells per register).  The cases above are small; these are sized to land in the
+# throughput instantiations with ragged batches, odd agent counts (partly filled slot groups), every view width class, a hook
+# env and the fused auto-reset.
+THROUGHPUT_CASES = [
+    ("t_a3_v5_nooverlap", EnvSpec(9, 7, 3, 5, max_steps=50, allow_agent_overlap=False, failure_termination_mode="any"), 50001, 5),
+    ("t_a1_v3_seethrough", EnvSpec(8, 8, 1, 3, max_steps=30, see_through_walls=True), 140001, 4),
+    ("t_bup_a2_v7", EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup"), 70003, 5),
+    ("t_a7_v7", EnvSpec(12, 12, 7, 7, max_steps=40), 20011, 5),
+    ("t_a5_v7_all", EnvSpec(16, 16, 5, 7, max_steps=40, success_termination_mode="all", joint_reward=True), 26003, 5),
+    ("t_a2_v9", EnvSpec(10, 8, 2, 9, max_steps=30), 40001, 4),
+    ("t_a5_v11", EnvSpec(13, 12, 5, 11, max_steps=40), 13001, 4),
+    ("t_a2_v15", EnvSpec(24, 24, 2, 15, max_steps=40), 40003, 3),
+]
+
+
+@pytest.mark.parametrize("name,spec,B,T", THROUGHPUT_CASES, ids=[c[0] for c in THROUGHPUT_CASES])
+def test_throughput_instantiations_vs_oracle(name, spec, B, T):
+    li = BatchedMultiGridEnv(spec, 1, dev()).backend.launch_info(B)
+    assert -(-B // li["envs_per_wavefront"]) > 2048, li                  # (else the latency instantiation would run)
+    test_random_states_vs_oracle(name, spec, B, T)
+    # ... and through the fused auto-reset (restarts emulated in numpy from the definition, include/mgx.h)
+    st = util.random_state(spec, B, seed=77, terminated_p=0.3)
+    st["step_count"][::3] = spec.max_steps - 1
+    K = 5
+    pool = util.random_state(spec, K, seed=78, terminated_p=0.0, density=0.3)
+    env = BatchedMultiGridEnv(spec, B, dev(), first_env=123)
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    env.set_layout_pool(pool["grid"], pool["agents"], pool["target"] if spec.env_kind != "empty" else None)
+    ref = {k: v.copy() for k, v in st.items()}
+    episode = np.zeros(B, np.int64)
+    for t in range(3):
+        done = (ref["agents"][:, :, 4] != 0).all(axis=1) | (ref["step_count"] >= spec.max_steps)
+        lay = (123 + np.arange(B) + episode * 7919) % K
+        ref["grid"][done] = pool["grid"][lay[done]]; ref["agents"][done] = pool["agents"][lay[done]]
+        if spec.env_kind != "empty":
+            ref["target"][done] = pool["target"][lay[done]]
+        ref["step_count"][done] = 0; episode[done] += 1
+        act = util.random_actions(B, spec.num_agents, seed=2000 + t)
+        want = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["target"], nthreads=8)
+        got = env.step(torch.from_numpy(act).to(dev()), auto_reset=True)
+        ctx = f"{name} auto-reset step {t}"
+        np.testing.assert_array_equal(env.was_reset.cpu().numpy(), done.astype(np.uint8), err_msg=ctx)
+        for g, w in zip(got, want):
+            assert g.cpu().numpy().tobytes() == w.tobytes(), ctx
+        np.testing.assert_array_equal(env.grid.cpu().numpy(), ref["grid"], err_msg=ctx)
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"], err_msg=ctx)
+    assert int(episode.sum()) > B // 4
+    env.check_errors()
+
+
 def test_torch_ops_registered_and_match():
     import multigrid_amd.ops as ops
     spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
