@@ -3,7 +3,8 @@
 // mgx_kernels.hip (the C ABI: argument checks, launch geometry, dispatch to the view size's translation unit).
 //
 // One fused kernel does a whole MultiGridEnv.step for the batch.  Every WAVEFRONT is autonomous: it owns Gw consecutive
-// envs (<= 32 agent views, "slots") and a private LDS slice and runs all phases for them without a workgroup barrier:
+// envs (<= 64 agent views, "slots": slots_per_wave) and a private LDS slice and runs all phases for them without a workgroup
+// barrier:
 //
 //   P0   buffer_load_dwordx4 of the wave's (Gw,H,W) packed 16-bit grid cells, packed agent rows, actions, PCG64 words and
 //        step counts; one s_waitcnt; LDS stores
@@ -13,12 +14,13 @@
 //        the reference's sequential handle_actions loop on the LDS tile)                       (base.py:378-476)
 //        then the agent overlay offsets, the env subclass' post-step hook, step_count / truncated
 //   P1d  lane = view: view geometry record, in-bounds lane mask, stores of agent rows / reward / terminated / dir
-//   P2   lane = view CELL, slots in straight-line blocks of 16: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall,
-//        see-behind ballot -> 64-bit row mask deposited in lane s; cells stay in registers  (multigrid/utils/obs.py:130-233)
+//   P2   lane = view CELL, slots in straight-line blocks of 16: rotate-to-facing gather from the LDS tile (one aligned 16-bit
+//        read per cell), out-of-bounds -> wall, see-behind ballot (the cell's opaque bit) -> 64-bit row mask deposited in lane s;
+//        cells stay in registers, two slots per register in the throughput instantiations (multigrid/utils/obs.py:130-233)
 //   P3   lane = view: bit-parallel line-of-sight flood on the ballot masks (closed form of the sequential sweeps,
 //        obs.py:235-273); own cell := carried object (obs.py:207)
-//   P4   lane = cell: cells whose visibility bit is clear become UNSEEN (obs.py:95-100); 3 bytes each into the obs
-//        byte layout in LDS (the rotate/transpose)
+//   P4   lane = cell: cells whose visibility bit is clear become UNSEEN (obs.py:95-100); packed cell -> (type, color, state),
+//        3 bytes each into the obs byte layout in LDS (the rotate/transpose)
 //   P5   ds_read_b128 -> buffer_store_dwordx4 of the (Gw,A,v,v,3) observation bytes
 //
 // Pure integer / byte work: no MFMA.  The roof is HBM bytes; what the kernel is actually bound by is the number of
