@@ -31,6 +31,9 @@ while time.time() < t_end:
                    success_termination_mode=str(r.choice(["any", "all"])),
                    failure_termination_mode=str(r.choice(["any", "all"])))
     B = int(r.choice([1, 2, 3, 7, 33, 64, 65, 255, 1000, 2049, 5000]))
+    if r.random() < 0.06:                       # launches of more than 2048 wavefronts: the throughput instantiations
+        W, H = int(r.integers(3, 13)), int(r.integers(3, 13))
+        B = int(r.integers(30000, 150000))
     if W * H * A * B > 4e7:
         B = max(1, int(4e7 / (W * H * A)))
     T = int(r.integers(3, 14))
