@@ -76,9 +76,24 @@ def random_actions(steps, batch, agents, device, seed):
     return torch.randint(0, 7, (steps, batch, agents), dtype=torch.int8, device=device, generator=g)
 
 
-def capture_steps(env, actions):
-    """One hipGraph holding `len(actions)` consecutive env.step launches."""
-    return env.capture_steps(actions, auto_reset=AUTO_RESET)
+def capture_steps(env, actions, sub_shards=1):
+    """One hipGraph holding `len(actions)` consecutive env.step launches (sub_shards=P: as P parallel chains over P
+    consecutive blocks of the batch, BatchedMultiGridEnv.capture_steps)."""
+    return env.capture_steps(actions, auto_reset=AUTO_RESET, sub_shards=sub_shards)
+
+
+def auto_sub_shards(env) -> int:
+    """Sub-shards for the graph-replay measurement.  A launch that fills the chip first loads (no wave has data to work on),
+    then computes; independent chains of smaller launches on separate streams drift apart and one's loads run under another's
+    compute (tools/interleave_probe.py: C4 20.8 -> 16.3-16.7 us per step of the whole batch as 4 chains, 17.2-17.8 as 2; C5
+    85 -> 69 us as 2, 73 as 4; uneven splits and smaller batches lose).  1 below a full round of wavefronts (4096); 4 when the
+    whole batch is about one round of resident wavefronts (C4), 2 when it is many (C5)."""
+    li = env.backend.launch_info(env.batch)
+    nw = -(-env.batch // max(1, li["envs_per_wavefront"]))
+    if nw < 4096:
+        return 1
+    per_cu = min(20, (160 * 1024 // max(1, li["lds_bytes"])) * (li["threads_per_workgroup"] // 64))
+    return 4 if nw <= 1.5 * 256 * max(1, per_cu) else 2
 
 
 def timed_region(env, run_once, repeats, dist_barrier):
@@ -98,7 +113,7 @@ def timed_region(env, run_once, repeats, dist_barrier):
     return t1 - t0, ev0.elapsed_time(ev1)
 
 
-def measure_steps(env, K, warmup, mode, dist_barrier, seed, min_region_ms=MIN_REGION_MS, agree=None):
+def measure_steps(env, K, warmup, mode, dist_barrier, seed, min_region_ms=MIN_REGION_MS, agree=None, sub_shards=1):
     """W warm-up steps, a calibration pass, then a timed region of whole K-step blocks lasting >= min_region_ms.
     Returns dict(wall_s, event_ms, timed_steps, blocks).  `agree(n)` lets all ranks settle on one repeat count."""
     B, A, dev = env.batch, env.spec.num_agents, env.device
@@ -108,7 +123,7 @@ def measure_steps(env, K, warmup, mode, dist_barrier, seed, min_region_ms=MIN_RE
         env.step(warm[t], auto_reset=AUTO_RESET)
     acts = random_actions(block, B, A, dev, seed)
     if mode == "graph":
-        graph = capture_steps(env, acts)
+        graph = capture_steps(env, acts, sub_shards)
         run_once = graph.replay
     else:
         def run_once():
@@ -154,11 +169,25 @@ def roofline(alg_bytes_per_launch, ms, traffic=None):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
 
 
-def step_roofline(wl_name, spec, B, ms_launch):
-    rf = roofline(B * spec.num_agents * spec.bytes_step(), ms_launch, pmc_traffic(f"{wl_name}_step", B))
-    rf.update(kernel=f"mgx_fused_kernel<{spec.view_size},step,autoreset>", ms_per_launch=round(ms_launch, 5),
-              bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=B * spec.num_agents * spec.bytes_step(),
-              traffic_unit="bytes per launch (rocprofv3 PMC, profiles/traffic.json)")
+def step_roofline(wl_name, spec, B, ms_step, sub_shards=1):
+    """Roofline of the fused step kernel over one step of the batch.  sub_shards=P > 1: a step is P CONCURRENT launches of
+    B/P envs each (parallel chains of one graph); each chain issues its launches back to back, so a launch lasts at most
+    ms_step, and the chip's achieved rate is the sum over the P launches in flight = the step's bytes / ms_step."""
+    P = max(1, sub_shards)
+    alg = B * spec.num_agents * spec.bytes_step()
+    traffic = pmc_traffic(f"{wl_name}_step", B)
+    if P > 1:
+        part = pmc_traffic(f"{wl_name}_part_step", B // P)
+        traffic = part * P if part is not None else traffic
+    rf = roofline(alg, ms_step, traffic)
+    rf.update(kernel=f"mgx_fused_kernel<{spec.view_size},step,autoreset>", ms_per_launch=round(ms_step, 5),
+              bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=alg,
+              traffic_unit="bytes per step of the batch (rocprofv3 PMC, profiles/traffic.json)")
+    if P > 1:
+        rf.update(launches_in_flight=P, launch_batch=B // P, algorithmic_bytes_per_launch=alg // P,
+                  per_launch_achieved=round(alg / P / (ms_step * 1e-3) / 1e9, 1),
+                  note_launches=f"a step = {P} concurrent launches of {B // P} envs (sub-shards on {P} streams); each lasts <= "
+                                "ms_per_launch (its chain is back to back); achieved = their sum = step bytes / step time")
     return rf
 
 
@@ -170,7 +199,8 @@ def config_point(name, device, K, warmup, device_generated=False):
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     if device_generated:
         env.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6)
-    m = measure_steps(env, K, warmup, "graph", lambda: None, seed=4321, min_region_ms=30.0)
+    P = auto_sub_shards(env)
+    m = measure_steps(env, K, warmup, "graph", lambda: None, seed=4321, min_region_ms=30.0, sub_shards=P)
     env.check_errors()
     B, A = wl.batch, wl.spec.num_agents
     ms = m["event_ms"] / m["timed_steps"]
@@ -181,7 +211,11 @@ def config_point(name, device, K, warmup, device_generated=False):
            "layout_pool": "generated on the device in the step's own launch (mgx_step_generate)" if device_generated
                           else int(wl.pool[0].shape[0]),
            "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,
-           "launch": env.backend.launch_info(B), "roofline": step_roofline(name, wl.spec, B, ms)}
+           "sub_shards": P, "launch": env.backend.launch_info(B // P), "roofline": step_roofline(name, wl.spec, B, ms, P)}
+    if P > 1:                                                   # the same steps as ONE chain of whole-batch launches
+        m1 = measure_steps(env, K, 0, "graph", lambda: None, seed=4322, min_region_ms=20.0)
+        ms1 = m1["event_ms"] / m1["timed_steps"]
+        out["single_chain"] = {"ms_per_step": round(ms1, 6), "frac": step_roofline(name, wl.spec, B, ms1)["frac"]}
     del env
     torch.cuda.empty_cache()
     return out
@@ -375,6 +409,9 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: the timed steps are hipGraph replays; eager: Python-level env.step calls")
     ap.add_argument("--no-auto-reset", action="store_true", help="step finished envs on as the reference does (base.py:408-409)")
+    ap.add_argument("--sub-shards", type=int, default=0,
+                    help="graph mode: step the batch as this many independent chains on as many streams (0 = auto: 2 when a "
+                         "launch of the whole batch fills the chip, else 1)")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement + its roofline")
     args = ap.parse_args()
@@ -424,8 +461,9 @@ def main():
     wl = workloads.make(name, batch=B, first_env=first_env, global_batch=G)
     spec, A = wl.spec, wl.spec.num_agents
     env = wl.make_env(device, auto_reset=AUTO_RESET)
+    P = 1 if args.mode != "graph" else (args.sub_shards or int(all_max(float(auto_sub_shards(env)))))
     m = measure_steps(env, args.steps, args.warmup, args.mode, barrier, seed=1234 + rank,
-                      agree=lambda n: int(all_max(float(n))))
+                      agree=lambda n: int(all_max(float(n))), sub_shards=P)
     env.check_errors()
     wall_max = all_max(m["wall_s"])
     S = m["timed_steps"]
@@ -440,7 +478,11 @@ def main():
                    "global_batch": G, "batch_per_gpu": B, "agents": A, "grid": f"{spec.width}x{spec.height}",
                    "view_size": spec.view_size, "mode": args.mode,
                    "parallelism": f"env-sharded x{world} (strong scaling of the global batch), no collective",
-                   "launch": env.backend.launch_info(B),
+                   "sub_shards": P,
+                   "sub_shards_note": ("the batch is stepped as independent chains of launches over consecutive blocks of envs on "
+                                       "separate streams (parallel branches of one hipGraph; BatchedMultiGridEnv.capture_steps); "
+                                       "every env takes exactly the timed steps") if P > 1 else None,
+                   "launch": env.backend.launch_info(B // P),
                    "auto_reset": ("fused into the step launch (mgx_step_autoreset): envs that are done restart from the "
                                   "layout pool before the next step") if AUTO_RESET else False,
                    "layout_pool": int(wl.pool[0].shape[0]),
@@ -451,7 +493,11 @@ def main():
         out["valid"] = False
         out["invalid_reason"] = f"MGX_LIBMGX={_lib.LIB_PATH}: not the product library (profiling / experiment build)"
     if rank == 0:
-        out["roofline"] = step_roofline(name, spec, B, m["event_ms"] / S)
+        out["roofline"] = step_roofline(name, spec, B, m["event_ms"] / S, P)
+        if P > 1 and world == 1:                                # the same steps as ONE chain of whole-batch launches
+            m1 = measure_steps(env, args.steps, 0, "graph", barrier, seed=99, min_region_ms=25.0)
+            ms1 = m1["event_ms"] / m1["timed_steps"]
+            out["single_chain"] = {"ms_per_step": round(ms1, 6), "roofline": step_roofline(name, spec, B, ms1)}
         if B * A * spec.bytes_step() < 200e6:
             out["roofline"]["note"] = ("working set fits the 256 MiB Infinity Cache at this batch: see roofline_large for "
                                        "the HBM-resident regime")

@@ -572,3 +572,50 @@ def test_captured_graph_of_steps_equals_eager_steps():
             assert torch.equal(x, y)
         assert torch.equal(a.grid, b.grid) and torch.equal(a.rng, b.rng) and torch.equal(a.step_count, b.step_count)
     a.check_errors()
+
+
+@pytest.mark.parametrize("case", ["c4_shape", "bup_pool", "bup_generated", "one_hot_ragged"])
+def test_sub_sharded_graph_equals_one_chain(case):
+    """capture_steps(sub_shards=P): the batch stepped as P independent chains of launches on P streams (parallel branches of
+    one hipGraph) == the same steps as one chain: envs are independent, seeds and auto-reset layouts follow the global env
+    index.  Every output of the last step and the whole post-run state are compared, for 2 and 3 sub-shards."""
+    from multigrid_amd import workloads
+    T = 10
+    if case == "c4_shape":
+        wl = workloads.make("c4", batch=20000 + 64, first_env=0, global_batch=65536)
+        mk = lambda: wl.make_env(dev(), auto_reset=True); kw = dict(auto_reset=True)
+    elif case == "bup_pool":
+        wl = workloads.make("c3", batch=3000, first_env=128, global_batch=16384)
+        mk = lambda: wl.make_env(dev(), auto_reset=True); kw = dict(auto_reset=True)
+    elif case == "bup_generated":
+        wl = workloads.make("c3", batch=1500, first_env=0, global_batch=16384)
+
+        def mk():
+            e = wl.make_env(dev(), auto_reset=False)
+            e.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6)
+            e.step_count.fill_(wl.spec.max_steps - 4)                     # every env is regenerated within the run
+            return e
+        kw = dict(auto_reset=True)
+    else:
+        wl = workloads.make("c2", batch=1000 + 7, first_env=0, global_batch=4096)
+        mk = lambda: wl.make_env(dev(), auto_reset=True); kw = dict(auto_reset=True, one_hot=True)
+    B, A = wl.batch, wl.spec.num_agents
+    acts = torch.from_numpy(np.stack([util.random_actions(B, A, seed=300 + t, p_missing=0.0) for t in range(T)])).to(dev())
+    ref = mk()
+    for t in range(T):
+        want = [x.clone() for x in ref.step(acts[t], **kw)]
+    for P in (2, 3):
+        env = mk()
+        shards = env.split(P)
+        assert len(shards) == P and sum(s.batch for s in shards) == B and shards[1].first_env == wl.first_env + shards[0].batch
+        graph = env.capture_steps(acts, sub_shards=P, **kw)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = ((env._one_hot if kw.get("one_hot") else env.obs), env.dir, env.reward, env.terminated, env.truncated)
+        for k, (x, y) in enumerate(zip(got, want)):
+            assert torch.equal(x, y), f"{case} P={P}: output {k}"
+        for f in ("cells", "agents", "rng", "step_count", "aux", "episode", "was_reset"):
+            assert torch.equal(getattr(env, f), getattr(ref, f)), f"{case} P={P}: {f}"
+        if case == "bup_generated":
+            assert torch.equal(env._gen["gen_state"], ref._gen["gen_state"]) and int(env.episode.sum()) >= B
+        env.check_errors()

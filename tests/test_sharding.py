@@ -96,3 +96,32 @@ def test_two_rank_shards_equal_single_process():
             assert a.tobytes() == b.numpy().tobytes()
     assert sharded_grid.tobytes() == grid.numpy().tobytes()
     assert sharded_rng.tobytes() == rng.numpy().tobytes()
+
+
+def test_split_views_step_the_parent():
+    """BatchedMultiGridEnv.split: sub-shards are views (no copies) whose steps, in any interleaving, are the parent's steps
+    -- incl. the auto-reset layout choice, a function of the global env index.  (Oracle backend: host logic only.)"""
+    spec = EnvSpec(8, 8, 2, 7, max_steps=4)
+    B, K = 200, 3
+    pool = util.random_state(spec, K, seed=3, terminated_p=0.0)
+    st = util.random_state(spec, B, seed=4)
+
+    def mk():
+        e = BatchedMultiGridEnv(spec, B, "cpu", first_env=1000, backend=util.OracleBackend(spec))
+        e.load_state(st["grid"], st["agents"], st["rng"], None, st["step_count"] % 4)
+        e.set_layout_pool(pool["grid"], pool["agents"])
+        return e
+    whole, parts = mk(), mk()
+    shards = parts.split(3)
+    assert [s.batch for s in shards] == [128, 64, 8] and [s.first_env for s in shards] == [1000, 1128, 1192]
+    assert shards[1].cells.data_ptr() == parts.cells[128:].data_ptr()                   # views, not copies
+    for t in range(6):
+        act = torch.from_numpy(util.random_actions(B, 2, seed=t, p_missing=0.0))
+        whole.reset_done(); want = [x.clone() for x in whole.step(act)]
+        for s in reversed(shards):                                                       # any order
+            lo, hi = s._range
+            s.reset_done(); s.step(act[lo:hi].contiguous())
+        for x, y in zip((parts.obs, parts.dir, parts.reward, parts.terminated, parts.truncated), want):
+            assert torch.equal(x, y)
+        assert torch.equal(parts.cells, whole.cells) and torch.equal(parts.episode, whole.episode)
+    assert int(whole.episode.sum()) > B

@@ -25,7 +25,8 @@ WARM_LARGE = 250      # the 1M-env point: steady state of the rollout (tools/tim
 
 #: (key, MGX_WORKLOAD, batch, extra env)
 POINTS = [("c2", "c2", 4096, {}), ("c3", "c3", 16384, {}), ("c4", "c4", 65536, {}), ("c5", "c5", 32768, {}),
-          ("c4_share8", "c4", 8192, {}), ("large", "c4", 1 << 20, {"MGX_ONE_HOT_STEP": "1"})]
+          ("c4_share8", "c4", 8192, {}), ("c4_part", "c4", 16384, {}), ("c5_part", "c5", 16384, {}),      # the sub-shard launches of bench.py (C4: 4 chains, C5: 2)
+          ("large", "c4", 1 << 20, {"MGX_ONE_HOT_STEP": "1"})]
 
 
 def kind_of(name: str):
