@@ -130,7 +130,7 @@ def measure_steps(env, K, warmup, mode, dist_barrier, seed, min_region_ms=MIN_RE
             for t in range(block):
                 env.step(acts[t], auto_reset=AUTO_RESET)
     _, cal_ms = timed_region(env, run_once, 2, dist_barrier)    # untimed for the result: clocks settle, gives the estimate
-    repeats = max(1, math.ceil(min_region_ms / max(cal_ms / 2, 1e-3)))
+    repeats = max(1, math.ceil(1.25 * min_region_ms / max(cal_ms / 2, 1e-3)))      # (margin: the calibration pass runs slower)
     if agree is not None:
         repeats = agree(repeats)
     wall_s, ev_ms = timed_region(env, run_once, repeats, dist_barrier)
@@ -169,10 +169,13 @@ def roofline(alg_bytes_per_launch, ms, traffic=None):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
 
 
-def step_roofline(wl_name, spec, B, ms_step, sub_shards=1):
-    """Roofline of the fused step kernel over one step of the batch.  sub_shards=P > 1: a step is P CONCURRENT launches of
-    B/P envs each (parallel chains of one graph); each chain issues its launches back to back, so a launch lasts at most
-    ms_step, and the chip's achieved rate is the sum over the P launches in flight = the step's bytes / ms_step."""
+def step_roofline(wl_name, spec, B, ms_step, sub_shards=1, ms_launch=None):
+    """Roofline of the fused step kernel over one step of the batch.
+    sub_shards=P > 1: a step is P launches of B/P envs each, issued by P independent chains on P streams (parallel branches of
+    one graph), several of them in flight at a time.  `launch` is ONE such launch by the literal definition -- its algorithmic
+    bytes over its own duration `ms_launch` (HIP events over back-to-back launches of one sub-shard; rocprofv3's average
+    duration of that kernel in profiles/ is the same number) -- and the top-level `achieved` is the chip's rate over the step:
+    the step's bytes / the step's time = launch.achieved x mean_launches_in_flight."""
     P = max(1, sub_shards)
     alg = B * spec.num_agents * spec.bytes_step()
     traffic = pmc_traffic(f"{wl_name}_step", B)
@@ -184,11 +187,29 @@ def step_roofline(wl_name, spec, B, ms_step, sub_shards=1):
               bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=alg,
               traffic_unit="bytes per step of the batch (rocprofv3 PMC, profiles/traffic.json)")
     if P > 1:
-        rf.update(launches_in_flight=P, launch_batch=B // P, algorithmic_bytes_per_launch=alg // P,
-                  per_launch_achieved=round(alg / P / (ms_step * 1e-3) / 1e9, 1),
-                  note_launches=f"a step = {P} concurrent launches of {B // P} envs (sub-shards on {P} streams); each lasts <= "
-                                "ms_per_launch (its chain is back to back); achieved = their sum = step bytes / step time")
+        rf["ms_per_launch"] = None if ms_launch is None else round(ms_launch, 5)
+        rf.update(ms_per_step=round(ms_step, 5), launches_per_step=P,
+                  note_launches=f"a step of the batch = {P} launches of {B // P} envs from {P} independent chains on {P} streams, "
+                                "several in flight at a time: `achieved` = step bytes / step time = launch.achieved x "
+                                "mean_launches_in_flight; `launch` = one such launch over its own duration; the same steps as ONE "
+                                "chain of whole-batch launches: `single_chain`")
+        if ms_launch is not None:
+            one = roofline(alg // P, ms_launch)
+            rf["launch"] = {"batch": B // P, "algorithmic_bytes": alg // P, "ms_per_launch": round(ms_launch, 5),
+                            "achieved": one["achieved"], "frac": one["frac"]}
+            rf["mean_launches_in_flight"] = round(P * ms_launch / ms_step, 2)
     return rf
+
+
+def sub_shard_launch_ms(env, P, device):
+    """Duration of one sub-shard launch: HIP events over back-to-back launches of the first of `P` sub-shards, alone."""
+    sh = env.split(P)[0]
+    acts = random_actions(4, sh.batch, env.spec.num_agents, device, 5)
+    i = [0]
+
+    def step():
+        sh.step(acts[i[0] & 3], auto_reset=AUTO_RESET); i[0] += 1
+    return kernel_time_ms(step, 200, device, warm=50)
 
 
 def config_point(name, device, K, warmup, device_generated=False):
@@ -211,7 +232,8 @@ def config_point(name, device, K, warmup, device_generated=False):
            "layout_pool": "generated on the device in the step's own launch (mgx_step_generate)" if device_generated
                           else int(wl.pool[0].shape[0]),
            "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,
-           "sub_shards": P, "launch": env.backend.launch_info(B // P), "roofline": step_roofline(name, wl.spec, B, ms, P)}
+           "sub_shards": P, "launch": env.backend.launch_info(B // P),
+           "roofline": step_roofline(name, wl.spec, B, ms, P, sub_shard_launch_ms(env, P, device) if P > 1 else None)}
     if P > 1:                                                   # the same steps as ONE chain of whole-batch launches
         m1 = measure_steps(env, K, 0, "graph", lambda: None, seed=4322, min_region_ms=20.0)
         ms1 = m1["event_ms"] / m1["timed_steps"]
@@ -493,7 +515,7 @@ def main():
         out["valid"] = False
         out["invalid_reason"] = f"MGX_LIBMGX={_lib.LIB_PATH}: not the product library (profiling / experiment build)"
     if rank == 0:
-        out["roofline"] = step_roofline(name, spec, B, m["event_ms"] / S, P)
+        out["roofline"] = step_roofline(name, spec, B, m["event_ms"] / S, P, sub_shard_launch_ms(env, P, device) if P > 1 else None)
         if P > 1 and world == 1:                                # the same steps as ONE chain of whole-batch launches
             m1 = measure_steps(env, args.steps, 0, "graph", barrier, seed=99, min_region_ms=25.0)
             ms1 = m1["event_ms"] / m1["timed_steps"]

@@ -32,3 +32,12 @@ def test_bench_prints_the_contract_line():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # a full-chip batch is stepped as independent chains of sub-shard launches: the line says so, carries one launch's own
+    # roofline (the number a kernel trace reproduces) and the same steps as one chain of whole-batch launches
+    P = d["config"]["sub_shards"]
+    assert P >= 1
+    if P > 1:
+        one = r["launch"]
+        assert r["launches_per_step"] == P and one["batch"] * P == 65536
+        assert abs(r["achieved"] - one["achieved"] * r["mean_launches_in_flight"]) / r["achieved"] < 0.02
+        assert d["single_chain"]["roofline"]["frac"] <= r["frac"] + 0.05
