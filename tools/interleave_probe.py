@@ -13,6 +13,9 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
 spec = bench.workload_spec()
+if os.environ.get("MGX_G"):                       # needs MGX_LIBMGX=multigrid_amd/lib/libmgx_dbg.so
+    from multigrid_amd import _lib
+    _lib.lib().mgx_debug_set_envs_per_wavefront(int(os.environ["MGX_G"]))
 for B in [int(x) for x in sys.argv[1:]] or [65536]:
     plans = [[B // P + (1 if i < B % P else 0) for i in range(P)] for P in (1, 2, 3, 4)]
     for f in [float(x) for x in os.environ.get("MGX_SPLITS", "").split(",") if x]:      # uneven 2-way splits (first fraction)
