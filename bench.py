@@ -87,11 +87,11 @@ def auto_sub_shards(env) -> int:
     then computes; independent chains of smaller launches on separate streams drift apart and one's loads run under another's
     compute.  Measured (tools/interleave_probe.py, us per step of the whole batch, 1 / 2 / 4 chains): C4 65536 envs 20.8 / 17.2 /
     16.5; C4 shape at 32768 envs 13.5 / 11.0 / 13.7, at 131072 envs 35.9 / 27.1 / 27.9; C5 85 / 69 / 73; but C3 9.4 / 10.9 / 13.3
-    and C2 6.3 / 7.2 / 13.7 -- small launches only lose -- and uneven splits are worse than even ones.  Hence: 1 below 2048
-    wavefronts or 131072 views per launch; 4 when the whole batch is about one round of resident wavefronts; else 2."""
+    and C2 6.3 / 7.2 / 13.7 -- small launches only lose (C4 shape at 16384 envs still gains: 9.3 / 8.7) -- and uneven splits are
+    worse than even ones.  Hence: 1 below 2048 wavefronts or 65536 views per launch; 4 when the whole batch is about one round of resident wavefronts; else 2."""
     li = env.backend.launch_info(env.batch)
     nw = -(-env.batch // max(1, li["envs_per_wavefront"]))
-    if nw < 2048 or env.batch * env.spec.num_agents < 131072:
+    if nw < 2048 or env.batch * env.spec.num_agents < 65536:
         return 1
     per_cu = min(20, (160 * 1024 // max(1, li["lds_bytes"])) * (li["threads_per_workgroup"] // 64))
     rounds = nw / (256.0 * max(1, per_cu))
