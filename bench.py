@@ -538,6 +538,8 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "examples"))
                 import closed_loop
                 out["closed_loop"] = {c: closed_loop.run(c, steps=100, device=str(device)) for c in ("c4", "c2")}
+                # ... and as the double-buffered actor loop: 4 blocks of the batch, each its own [policy -> step] chain
+                out["closed_loop"]["c4_4_blocks"] = closed_loop.run("c4", steps=100, device=str(device), sub_shards=4)
             except Exception as e:                          # an example must not take the bench line down
                 out["closed_loop"] = {"error": repr(e)[:200]}
             from oracle import binding as ob

@@ -18,7 +18,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multigrid_amd import workloads  # noqa: E402
 
 
-def run(workload="c4", batch=None, steps=200, hidden=64, device="cuda:0", one_hot=True):
+def run(workload="c4", batch=None, steps=200, hidden=64, device="cuda:0", one_hot=True, sub_shards=1, iters_per_graph=4):
+    """sub_shards=P > 1: the double-buffered actor loop -- the batch as P independent blocks (BatchedMultiGridEnv.split), each
+    its own chain [policy(block) -> env step(block)] x iters_per_graph on its own stream, P parallel branches of one hipGraph:
+    one block's policy GEMMs run while another block steps."""
     dev = torch.device(device)
     wl = workloads.make(workload, batch=batch, global_batch=max(batch or 0, workloads.GLOBAL_BATCH[workload]))
     env = wl.make_env(dev, auto_reset=True)
@@ -30,29 +33,47 @@ def run(workload="c4", batch=None, steps=200, hidden=64, device="cuda:0", one_ho
     actions = torch.zeros((B, A), dtype=torch.int8, device=dev)
     obs, *_ = env.gen_obs(one_hot=True) if one_hot else env.gen_obs()
     ret = torch.zeros((B, A), dtype=torch.float64, device=dev)
+    P = max(1, int(sub_shards))
+    shards = env.split(P) if P > 1 else [env]
+    P = len(shards)
+    ranges = [getattr(sh, "_range", (0, B)) for sh in shards]
 
-    def iteration():
-        x = obs.view(B * A, feat).to(torch.float16)                       # the env's output buffer, read in place
+    def iteration(i):
+        sh, (lo, hi) = shards[i], ranges[i]
+        n = (hi - lo) * A
+        x = obs[lo:hi].view(n, feat).to(torch.float16)                    # the env's output buffer, read in place
         logits = torch.relu(x @ w1) @ w2
         gumbel = -torch.log(-torch.log(torch.rand_like(logits, dtype=torch.float32).clamp_(1e-6, 1 - 1e-6)))
-        actions.copy_((logits.float() + gumbel).argmax(dim=1).view(B, A).to(torch.int8))
-        o, d, rew, term, trunc = env.step(actions, auto_reset=True, one_hot=one_hot)
-        ret.add_(rew)
+        actions[lo:hi].copy_((logits.float() + gumbel).argmax(dim=1).view(hi - lo, A).to(torch.int8))
+        o, d, rew, term, trunc = sh.step(actions[lo:hi], auto_reset=True, one_hot=one_hot)
+        ret[lo:hi].add_(rew)
 
     for _ in range(5):
-        iteration()
+        for i in range(P):
+            iteration(i)
+    n_it = iters_per_graph if P > 1 else 1
     graph = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream(dev)
+    others = [torch.cuda.Stream(dev) for _ in range(P - 1)]
     s.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(s):
         with torch.cuda.graph(graph, stream=s):
-            iteration()
+            for o in others:
+                o.wait_stream(s)
+            for i in range(P):
+                with torch.cuda.stream(s if i == 0 else others[i - 1]):
+                    for _ in range(n_it):
+                        iteration(i)
+            for o in others:
+                s.wait_stream(o)
     torch.cuda.current_stream(dev).wait_stream(s)
-    for _ in range(10):
+    replays = max(1, steps // n_it)
+    steps = replays * n_it
+    for _ in range(3):
         graph.replay()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(replays):
         graph.replay()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
@@ -65,7 +86,7 @@ def run(workload="c4", batch=None, steps=200, hidden=64, device="cuda:0", one_ho
     e1.record(); torch.cuda.synchronize(dev)
     env_ms = e0.elapsed_time(e1) / steps
     return {"workload": wl.title, "batch": B, "agents": A, "one_hot": one_hot, "policy": f"MLP {feat}-{hidden}-7 fp16, Gumbel sampling",
-            "ms_per_iteration": round(dt * 1e3 / steps, 5), "env_ms_per_step": round(env_ms, 5),
+            "sub_shards": P, "ms_per_iteration": round(dt * 1e3 / steps, 5), "env_ms_per_step": round(env_ms, 5),
             "agent_steps_per_s": round(B * A * steps / dt), "episodes_finished": int(env.episode.sum().item()),
             "mean_return": float(ret.sum().item() / max(1, int(env.episode.sum().item())) / A)}
 
@@ -76,5 +97,6 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--plain-obs", action="store_true", help="3-channel observations instead of one-hot")
+    ap.add_argument("--sub-shards", type=int, default=1, help="double-buffered actor loop over this many blocks of the batch")
     a = ap.parse_args()
-    print(json.dumps(run(a.workload, a.batch, a.steps, one_hot=not a.plain_obs)))
+    print(json.dumps(run(a.workload, a.batch, a.steps, one_hot=not a.plain_obs, sub_shards=a.sub_shards)))
