@@ -13,6 +13,8 @@
 
 `grid` / `pool_grid` are PACKED cells, int16 tensors [B,H,W] holding the MgxCell bit patterns of include/mgx.h (type |
 color << 8 | state << 12 | opaque << 15); pack_grid / unpack_grid convert from / to (type, color, state) bytes on the device.
+The same ops also accept `grid` / `pool_grid` as those bytes, uint8 [B,H,W,3] (packed on the way in and, for the mutating ops,
+unpacked back into the caller's tensor on the way out: two extra streaming kernels per call).
 
 `spec` is the 11-int list of `struct MgxSpec` (include/mgx.h).  Only the CUDA (= HIP on ROCm) dispatch key is
 registered: calling the ops with CPU tensors raises NotImplementedError from the dispatcher -- there is no
@@ -264,6 +266,33 @@ def _unpack_grid_impl(grid):
     return out
 
 
+def _accepts_byte_grids(fn, mutates: bool, pool_pos=None):
+    """The ops take the grid as the device holds it (packed cells, int16).  For callers that hold the reference's form --
+    (type, color, state) bytes, `grid_u8[B,H,W,3]` as SURVEY.md section 8b words the op signatures -- the same ops also accept
+    that: the grid (and a layout pool) is packed on the way in (mgx_pack_grid; unrepresentable values raise) and, for the
+    mutating ops, unpacked back into the caller's tensor on the way out (mgx_unpack_grid).  Two extra streaming kernels per
+    call: the convenience form, not the fast one."""
+    def as_cells(t, name):
+        cells, bad = _pack_grid_impl(t)
+        if int(bad[0]):
+            raise ValueError(f"mgx: `{name}` holds {int(bad[0])} cell(s) outside the packed format (type <= 15, color <= 7, state <= 3)")
+        return cells
+
+    def wrapped(grid, *rest):
+        rest = list(rest)
+        if pool_pos is not None and rest[pool_pos] is not None and rest[pool_pos].dtype == torch.uint8:
+            rest[pool_pos] = as_cells(rest[pool_pos], "pool_grid")
+        if grid.dtype != torch.uint8:
+            return fn(grid, *rest)
+        _want(grid, "grid", torch.uint8)
+        cells = as_cells(grid, "grid")
+        out = fn(cells, *rest)
+        if mutates:
+            grid.copy_(_unpack_grid_impl(cells))
+        return out
+    return wrapped
+
+
 _torch_lib = torch.library.Library("mgx", "DEF")
 _torch_lib.define("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
 _torch_lib.define(
@@ -288,13 +317,13 @@ _torch_lib.define("unpack_grid(Tensor grid) -> Tensor")
 _torch_lib.impl("pack_grid", _pack_grid_impl, "CUDA")
 _torch_lib.impl("unpack_grid", _unpack_grid_impl, "CUDA")
 _torch_lib.impl("one_hot", _one_hot_impl, "CUDA")
-_torch_lib.impl("full_obs", _full_obs_impl, "CUDA")
-_torch_lib.impl("gen_obs", _gen_obs_impl, "CUDA")
-_torch_lib.impl("step", _step_impl, "CUDA")
-_torch_lib.impl("step_autoreset", _step_autoreset_impl, "CUDA")
-_torch_lib.impl("rollout", _rollout_impl, "CUDA")
-_torch_lib.impl("gen_obs_one_hot", _gen_obs_one_hot_impl, "CUDA")
-_torch_lib.impl("step_one_hot", _step_one_hot_impl, "CUDA")
+_torch_lib.impl("full_obs", _accepts_byte_grids(_full_obs_impl, False), "CUDA")
+_torch_lib.impl("gen_obs", _accepts_byte_grids(_gen_obs_impl, False), "CUDA")
+_torch_lib.impl("step", _accepts_byte_grids(_step_impl, True), "CUDA")
+_torch_lib.impl("step_autoreset", _accepts_byte_grids(_step_autoreset_impl, True, pool_pos=6), "CUDA")
+_torch_lib.impl("rollout", _accepts_byte_grids(_rollout_impl, True), "CUDA")
+_torch_lib.impl("gen_obs_one_hot", _accepts_byte_grids(_gen_obs_one_hot_impl, False), "CUDA")
+_torch_lib.impl("step_one_hot", _accepts_byte_grids(_step_one_hot_impl, True, pool_pos=6), "CUDA")
 
 
 class HipBackend:

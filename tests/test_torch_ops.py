@@ -113,3 +113,38 @@ def test_rollout_op_equals_step_op():
             assert torch.equal(x[t], y), f"step {t}"
     for k in ("grid", "agents", "rng", "step_count"):
         assert torch.equal(a[k], b[k]), k
+
+
+def test_ops_accept_the_reference_byte_grids():
+    """SURVEY.md section 8b words the op signatures on `grid_u8[B,H,W,3]` -- the reference's (type, color, state) triples.  The
+    ops take that form too (packed on the way in, unpacked into the caller's tensor on the way out): same results as the
+    packed form and as the oracle, in-place arguments updated; a value the packed cells cannot hold raises."""
+    spec = EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup")
+    B, ints = 333, None
+    st = util.random_state(spec, B, seed=17)
+    st = dict(grid=st["grid"], agents=st["agents"], rng=st["rng"], step_count=st["step_count"], aux=st["target"])
+    ref = {k: v.copy() for k, v in st.items()}
+    d = _dev_state(st, spec)
+    d["grid"] = torch.from_numpy(st["grid"]).to(DEV)                   # bytes, not packed cells
+    ints = ops.spec_to_ints(spec)
+    obs, dirs = torch.ops.mgx.gen_obs(d["grid"], d["agents"], ints)
+    o_ref, d_ref = ob.gen_obs_batch(spec.as_dict(), ref["grid"], ref["agents"])
+    assert obs.cpu().numpy().tobytes() == o_ref.tobytes() and dirs.cpu().numpy().tobytes() == d_ref.tobytes()
+    full = torch.ops.mgx.full_obs(d["grid"], d["agents"], ints)
+    assert torch.equal(full, torch.ops.mgx.full_obs(util.dev_cells(st["grid"], DEV), d["agents"], ints))
+    for t in range(6):
+        act = util.random_actions(B, 2, seed=40 + t)
+        want = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["aux"], nthreads=8)
+        got = torch.ops.mgx.step(d["grid"], d["agents"], d["rng"], d["step_count"], torch.from_numpy(act).to(DEV), d["aux"], d["err"], ints)
+        for g, w in zip(got, want):
+            assert g.cpu().numpy().tobytes() == w.tobytes(), f"step {t}"
+        assert d["grid"].dtype == torch.uint8 and d["grid"].cpu().numpy().tobytes() == ref["grid"].tobytes()      # (a!) as bytes
+    acts = torch.from_numpy(np.stack([util.random_actions(B, 2, seed=60 + t) for t in range(4)])).to(DEV)
+    out = torch.ops.mgx.rollout(d["grid"], d["agents"], d["rng"], d["step_count"], acts, d["aux"], d["err"], ints)
+    for t in range(4):
+        want = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], acts[t].cpu().numpy(), ref["aux"], nthreads=8)
+        assert out[0][t].cpu().numpy().tobytes() == want[0].tobytes()
+    assert d["grid"].cpu().numpy().tobytes() == ref["grid"].tobytes()
+    bad = d["grid"].clone(); bad[0, 2, 2, 0] = 99                                                                  # no such type
+    with pytest.raises((ValueError, RuntimeError)):
+        torch.ops.mgx.gen_obs(bad, d["agents"], ints)
