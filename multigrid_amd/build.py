@@ -30,7 +30,7 @@ UNITS = ([("mgx_kernels", os.path.join(CSRC, "mgx_kernels.hip"), ()), ("mgx_aux"
           ("mgx_layout_gen", os.path.join(CSRC, "mgx_layout_gen.hip"), ())]
          + [(f"mgx_fused_v{v}", os.path.join(CSRC, "mgx_fused_inst.hip"), (f"MGX_INST_V={v}",)) for v in VIEWS])
 SRCS = sorted({u[1] for u in UNITS})
-DEPS = SRCS + [os.path.join(CSRC, "mgx_fused.h"), os.path.join(CSRC, "mgx_layout_gen.h"), os.path.join(CSRC, "mgx_rules.h"),
+DEPS = SRCS + [os.path.join(CSRC, "mgx_fused.h"), os.path.join(CSRC, "mgx_fused_body.inc"), os.path.join(CSRC, "mgx_layout_gen.h"), os.path.join(CSRC, "mgx_rules.h"),
                os.path.join(ROOT, "include", "mgx.h")]
 LIB = os.path.join(HERE, "lib", "libmgx.so")
 LIB_DBG = os.path.join(HERE, "lib", "libmgx_dbg.so")

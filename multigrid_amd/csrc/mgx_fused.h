@@ -443,765 +443,19 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // DMA: the tile is loaded HBM -> LDS by LDS-DMA (small launches: P0).
 template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false, bool DMA = (MGX_LDS_DMA != 0)>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
-    constexpr bool DO_STEP = MODE != 0;
-    const int env_kind = HOOKS ? a.sp.env_kind : (int)MGX_KIND_EMPTY;
-    constexpr bool ROLL = MODE == 2;
-    constexpr int V2 = V * V;
-    constexpr int NW = (V2 + 63) / 64;          // 64-bit mask words per view = lane passes per view
-    constexpr bool HALF = !DMA && MODE == 1;     // cell registers hold two slots' packed cells each (throughput step kernels)
-    constexpr int VPW = (V <= 7 && HALF) ? kSlotsSmallView : 32;   // view slots per wavefront (== slots_per_wave; DMA: kSlotsLatency)
-    extern __shared__ __align__(16) uint8_t lds[];
+#include "mgx_fused_body.inc"
+}
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents;
-    const int HWB = H * W * kCellBytes;                     // bytes of one env's grid (packed cells)
-    const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    const int64_t e0 = wid * a.Gw;
-    if (e0 >= a.batch) return;
-    const int Gc = (int)min((int64_t)a.Gw, a.batch - e0);    // envs of this wavefront
-    const int NVc = Gc * A;                                   // its views (<= VPW)
-    const int64_t v0 = e0 * A;                                // first (env, agent) row
-
-    uint8_t *L = lds + wave * a.wave_lds;
-#if MGX_TIMESTAMPS
-    int stamp_i = 0;
-    MGX_MARK("start");
-    if (lane == 0 && wid < 16384) g_span[2 * wid] = __builtin_amdgcn_s_memrealtime();
-#endif
-    const LdsCarve cv = make_carve(W, H, A, V, a.Gw, a.vpw, ROLL, HOOKS, OH);
-    constexpr int kInAux = STREAM ? MGX_IN_AUX : 0;                           // the small state loads of P0
-    uint64_t *rows = reinterpret_cast<uint64_t *>(L + cv.rows());             // [slot] packed agent rows
-    ViewRec *rec = reinterpret_cast<ViewRec *>(L + cv.rec());                 // [slot]
-    int8_t *acts = reinterpret_cast<int8_t *>(L + cv.act());                  // [slot]
-    uint64_t *rngs = reinterpret_cast<uint64_t *>(L + cv.rng());              // [env][4]
-    uint64_t *rnd = reinterpret_cast<uint64_t *>(L + cv.rnd());               // [slot] 53-bit draws
-    uint8_t *ord = L + cv.ord();                                               // [slot] visiting order per env
-    double *rew = reinterpret_cast<double *>(L + cv.rew());                   // [slot]
-    int32_t *scnt = reinterpret_cast<int32_t *>(L + cv.scnt());               // [env]
-    uint4 *auxl = reinterpret_cast<uint4 *>(L + cv.aux());                    // [env] 16-byte hook state (include/mgx.h)
-    uint64_t *jump = reinterpret_cast<uint64_t *>(L + cv.jump());             // [A+1][4]
-
-    MGX_MARK("P0");
-    // ------------------------------------------------------------------ P0: HBM -> LDS, all loads in flight at once
-    const int64_t g0 = e0 * HWB, g1 = g0 + (int64_t)Gc * HWB;       // byte range of these envs in `grid`
-    const int64_t gtotal = a.batch * (int64_t)HWB;
-    const int64_t ga = g0 & ~(int64_t)15;
-    uint8_t *tile_raw = L + cv.tile();                              // holds global bytes [ga, ...)
-    const int tile_skew = (int)(g0 - ga);
-    uint8_t *tile = tile_raw + tile_skew;                            // env e's cells at tile + e*HWB
-    // Every HBM load of the wavefront is issued here, back to back, into registers; then ONE unconditional
-    // s_waitcnt vmcnt(0); then the LDS stores.  (Waiting under the same lane predicates as the loads makes hipcc's
-    // waitcnt pass believe loads may still be pending and sprinkle vmcnt(0) -- which on CDNA also waits for every
-    // older global STORE -- over the rest of the kernel.)
-    constexpr int U = 8;                                                    // 8 KiB of tile per pass
-    const uint8_t *gsrc = a.grid + ga;
-    const int len = (int)(g1 - ga);
-    const int avail = (int)min(gtotal - ga, (int64_t)INT_MAX);               // bytes readable from gsrc
-    const int grec = MGX_DBG(1) ? 0 : min((len + 15) & ~15, avail);
-    const __amdgpu_buffer_rsrc_t grsrc = make_rsrc(gsrc, grec);
-    const int lane16 = 16 * lane;
-    const int env_of_lane = (lane * a.inv_A) >> 16, agent_of_lane = lane - env_of_lane * A;   // slot `lane` = (env, agent)
-    // (1) what the draws (P1a) need goes out first: this lane's env's PCG64 words and its agent's jump-ahead constants
-    u32x4 in_rngA = {0, 0, 0, 0}, in_rngB = {0, 0, 0, 0};                    // (ROLL: two envs' halves, copied to LDS)
-    u32x4 in_jmpA = {0, 0, 0, 0}, in_jmpB = {0, 0, 0, 0};
-    if (DO_STEP && A > 1) {
-        const __amdgpu_buffer_rsrc_t rr = make_rsrc(a.rng + e0 * 4, Gc * 32);
-        if (ROLL) {                                                              // env-major copy: lane l holds words 2l, 2l+1
-            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, lane16, 0,kInAux);
-            for (int t = lane; t < A * 4; t += 64) jump[t] = kJump.w[1][t];          // constants for k = 1..A, re-read every step
-        } else {                                                                 // same address for the A lanes of an env
-            in_rngA = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32, 0,kInAux);
-            in_rngB = __builtin_amdgcn_raw_buffer_load_b128(rr, env_of_lane * 32 + 16, 0,kInAux);
-            const u32x4 *jk = reinterpret_cast<const u32x4 *>(&kJump.w[1 + agent_of_lane][0]);   // agent k draws k+1 ahead
-            in_jmpA = jk[0]; in_jmpB = jk[1];
-        }
-    }
-    u32x2 in_row = {0, 0};
-    uint32_t in_scnt = 0;
-    u32x4 in_aux = {0, 0, 0, 0};
-    uint8_t in_act = 0;
-    in_row = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(a.agents + v0 * 8, NVc * 8), lane * 8, 0,kInAux);
-    uint32_t in_ep = 0;                                                      // AR: env `lane`'s episode count
-    if (DO_STEP) {
-        if (AR && !ROLL) in_ep = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.episode + e0, Gc * 4), lane * 4, 0, 0);
-        in_scnt = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.step_count + e0, Gc * 4), lane * 4, 0,kInAux);
-        in_act = __builtin_amdgcn_raw_buffer_load_b8(make_rsrc(a.actions + v0, NVc), lane, 0,kInAux);
-        if (cv.has_aux) in_aux = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.aux + e0 * MGX_AUX_BYTES, Gc * MGX_AUX_BYTES), lane16, 0, 0);
-    }
-    // (2) the tile
-    [[maybe_unused]] u32x4 tv[U], tv2[U];
-    const bool big_tile = len > 1024 * U;                                   // e.g. one 64x64 env per wavefront
-    // Cache policy of the tile loads (template flag STREAM, chosen at launch): a grid tensor that fits the 256 MiB Infinity
-    // Cache is re-read from there by the next step and is best left to the default policy; one that does not is a pure
-    // stream and is loaded non-temporal (measured: 1 M envs -3.5 % step / -6.5 % gen_obs and C5 -4 % with nt, C4 +3 %).
-    // (A launch-time branch around the two forms cost 3-4 % everywhere: the loads must stay in the straight-line burst.)
-    constexpr int kTileAux = STREAM ? 2 : MGX_TILE_AUX;
-    // DMA instantiations: the tile goes HBM -> LDS directly (buffer_load_dwordx4 ... lds: wave-uniform LDS base in M0 + 16
-    // bytes per lane, which is exactly the tile's layout): no staging VGPRs (78 instead of 95: the register peak of the
-    // step kernel was this burst), no ds_write pass.  Lanes past the wave's bytes are masked off -- an out-of-range lane
-    // would still write its zeros into LDS.  Shorter for a lone wave (-3..5 % up to 2048 wavefronts), but the LDS-DMA path
-    // has less throughput than loads + ds_write_b128 (+4 % at 65536 envs): chosen at launch by the number of wavefronts.
-    typedef __attribute__((address_space(3))) void *lds_void_ptr;
-#define MGX_TILE_BURST(dst, base)                                                                                     \
-    if constexpr (DMA) {                                                                                              \
-        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                 \
-            if (lane16 + (base) + 1024 * u < len)                                                                     \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void_ptr)(tile_raw + (base) + 1024 * u), 16, lane16, \
-                                                         (base) + 1024 * u, 0, kTileAux);                            \
-    } else {                                                                                                          \
-        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                                 \
-            dst[u] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane16 + 1024 * (u & 3), (base) + 4096 * (u >> 2), kTileAux); \
-    }
-#if !MGX_DRAWS_FIRST
-    MGX_TILE_BURST(tv, 0)
-#endif
-    // (3) P1a of the one-step kernels, while the tile is still on its way: one lane per (env, agent), that agent's draw
-    // by jump-ahead (base.py:399); the env's stream after A draws goes straight back to HBM
-    uint64_t my_rng[4];
-    my_rng[0] = ((uint64_t)in_rngA.y << 32) | in_rngA.x; my_rng[1] = ((uint64_t)in_rngA.w << 32) | in_rngA.z;
-    my_rng[2] = ((uint64_t)in_rngB.y << 32) | in_rngB.x; my_rng[3] = ((uint64_t)in_rngB.w << 32) | in_rngB.z;
-    uint64_t my_draw = 0;
-    if (DO_STEP && !ROLL && A > 1 && !MGX_DBG((2 | 128)) && lane < NVc) {
-        uint64_t jk[4];
-        jk[0] = ((uint64_t)in_jmpA.y << 32) | in_jmpA.x; jk[1] = ((uint64_t)in_jmpA.w << 32) | in_jmpA.z;
-        jk[2] = ((uint64_t)in_jmpB.y << 32) | in_jmpB.x; jk[3] = ((uint64_t)in_jmpB.w << 32) | in_jmpB.z;
-        uint64_t s_lo, s_hi;
-        my_draw = pcg64_draw_at(my_rng, jk, s_lo, s_hi);
-        if (agent_of_lane == A - 1) { uint64_t *dst = a.rng + (e0 + env_of_lane) * 4; dst[0] = s_lo; dst[1] = s_hi; }
-    }
-#if MGX_DRAWS_FIRST
-    asm volatile("" ::: "memory");
-    MGX_TILE_BURST(tv, 0)
-#endif
-    // (3b) big tiles: a second burst under the same wait (requested here, once the draws' inputs are dead, so that the
-    // register peak of P0 stays below that of the gather)
-    if (big_tile) {
-        MGX_TILE_BURST(tv2, 1024 * U)
-    }
-#undef MGX_TILE_BURST
-    // (4) auto-reset test of the one-step kernels, also under the wait (build-defined, include/mgx.h): one lane per env
-    // tests base.py:534-539 on the state the previous step left
-    uint64_t reset_mask0 = 0;
-    if (AR && DO_STEP && !ROLL) {
-        const uint64_t row0 = ((uint64_t)in_row.y << 32) | in_row.x;
-        const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(row0));     // bit = (env, agent) slot
-        bool done = false;
-        if (lane < Gc) {
-            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-            done = (((alive >> mad24(lane, A, 0)) & amask) == 0) | ((int32_t)in_scnt >= a.sp.max_steps);
-            if (a.was_reset) a.was_reset[e0 + lane] = (uint8_t)done;
-        }
-        reset_mask0 = __builtin_amdgcn_ballot_w64(done);
-    }
-    // (5) the small inputs are here long before the tile: their LDS stores go first
-    const uint32_t wall_addr = (uint32_t)(wave * a.wave_lds + cv.wall());
-    if (lane == 0) *reinterpret_cast<uint32_t *>(L + cv.wall()) = CELL16_WALL;
-    if (lane < NVc) {
-        if (DO_STEP && !ROLL && A > 1) rnd[lane] = my_draw;                      // (only the sequential fallback reads the draws)
-        reinterpret_cast<u32x2 *>(rows)[lane] = in_row;
-        rew[lane] = 0.0;                                                         // base.py:393
-        if (DO_STEP) acts[lane] = (int8_t)in_act;
-    }
-    if (DO_STEP) {
-        if (A > 1 && ROLL && lane < Gc * 2) reinterpret_cast<u32x4 *>(rngs)[lane] = in_rngA;
-        if (lane < Gc) { scnt[lane] = (int32_t)in_scnt; if (cv.has_aux) reinterpret_cast<u32x4 *>(auxl)[lane] = in_aux; }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0), for every lane
-    if constexpr (!DMA) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (lane16 + 1024 * u < len) {
-                MGX_CHECK_LDS_PTR(1, tile_raw + lane16 + 1024 * u, 16);
-                *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * u) = tv[u];
-            }
-    }
-    if (big_tile) {
-        if constexpr (!DMA) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (lane16 + 1024 * (U + u) < len) *reinterpret_cast<u32x4 *>(tile_raw + lane16 + 1024 * (U + u)) = tv2[u];
-        }
-        for (int rel = lane16 + 2048 * U; rel < len; rel += 1024)               // tiles larger than two bursts (16 KiB)
-            *reinterpret_cast<u32x4 *>(tile_raw + rel) = __builtin_amdgcn_raw_buffer_load_b128(grsrc, rel, 0, kTileAux);
-    }
-    if (g1 == gtotal && (gtotal & 15)) {                          // last, partial 16-byte vector of the tensor
-        const int64_t t0 = gtotal & ~(int64_t)15;
-        for (int k = lane; k < (int)(gtotal & 15); k += 64) tile_raw[(int)(t0 - ga) + k] = a.grid[t0 + k];
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // (the loops above may have loaded)
-    wave_sync();
-
-    MGX_MARK("P0end");
-    // lane constants: cell k = lane + 64*it  <->  image[i][j], k = j*V + i (depth-row major, so each ballot
-    // word holds whole visibility rows); lateral offset la = i - V/2, forward distance fw = V-1-j.
-    auto lane_consts = [&]() {
-        LaneConst<V, NW> c;
-#pragma unroll
-        for (int it = 0; it < NW; ++it) {
-            const int k = lane + 64 * it;
-            const int j = k / V, i = k - j * V;
-            c.act[it] = k < V2;
-            c.la[it] = i - V / 2;
-            c.fw[it] = V - 1 - j;
-            c.q3[it] = (i * V + j) * 3;
-            c.own[it] = (i == V / 2) && (j == V - 1);
-        }
-        return c;
-    };
-    LaneConst<V, NW> lc_roll;
-    if (ROLL) lc_roll = lane_consts();            // hoisted out of the step loop; the one-step kernels make them late
-
-    const StepCfg cf = make_cfg(a.sp);
-    const int T = ROLL ? a.T : 1;
-    const int64_t BA = a.batch * A;
-    int8_t next_act = 0;                                                     // ROLL: next step's action, in flight
-    if (ROLL && lane < NVc) next_act = a.actions[v0 + lane];
-    for (int t = 0; t < T; ++t) {
-    const int64_t tv0 = (int64_t)t * BA + v0;                                // this step's (env, agent) output rows
-    if (ROLL) {
-        if (lane < NVc) { acts[lane] = next_act; rew[lane] = 0.0; }
-        if (t + 1 < T && lane < NVc) next_act = a.actions[(int64_t)(t + 1) * BA + v0 + lane];
-        wave_sync();
-    }
-    uint32_t ovl_saved = 0;                                                  // ROLL: clean cell under this agent's overlay
-    int ovl_off = -1;
-    // this lane's agent row, carried in registers through the step (one-step kernels have it from P0); re-read from LDS
-    // only after something else may have changed it (a reset, the sequential fallback, an env hook)
-    uint64_t cur_row = ROLL ? (lane < NVc ? rows[lane] : 0ull) : (((uint64_t)in_row.y << 32) | in_row.x);
-    MGX_MARK("AR");
-    uint64_t reset_mask = 0;                                                 // AR: envs (bit = env of the wave) restarted now
-    if (AR && DO_STEP) {
-        // -------------------------------------------------------------- auto-reset: a finished env takes the pool layout
-        // (first_env + b + episode * 7919) mod K, step_count 0, episode + 1 -- the definition mgx_reset_done implements
-        if (ROLL) {
-            const uint64_t alive = __builtin_amdgcn_ballot_w64(lane < NVc && !row_term(cur_row));   // bit = (env, agent) slot
-            bool done = false;
-            if (lane < Gc) {
-                const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-                done = (((alive >> mad24(lane, A, 0)) & amask) == 0) | (scnt[lane] >= cf.max_steps);
-                if (a.was_reset) a.was_reset[(int64_t)t * a.batch + e0 + lane] = (uint8_t)done;
-            }
-            reset_mask = __builtin_amdgcn_ballot_w64(done);
-        } else {
-            reset_mask = reset_mask0;                                            // (tested in P0, under the load wait)
-        }
-        if (reset_mask != 0) {                                                   // rare: a few envs per thousand steps
-            for (uint64_t m = reset_mask; m != 0; m &= m - 1) {
-                const int e = __builtin_ctzll(m);                                // wave-uniform
-                const int64_t b = e0 + e;
-                int32_t *p_ep = MGX_LATE(episode);
-                const int32_t K = MGX_LATE(pool_size);
-                // (one-step kernels fetched the episode counts in P0: no dependent load in front of the copy)
-                const int32_t ep = ROLL ? p_ep[b] : (int32_t)__builtin_amdgcn_readlane(in_ep, e);
-                const int lay = (K == 1) ? 0 : (int)((uint64_t)(MGX_LATE(first_env) + b + (int64_t)ep * 7919) % (uint64_t)K);
-                wave_sync();
-                if (lane == 0) p_ep[b] = ep + 1;
-                const uint8_t *sg = MGX_LATE(pool_grid) + (int64_t)lay * HWB;
-                uint8_t *etile = tile + e * HWB;
-                uint8_t *gg = MGX_LATE(grid) + b * HWB;
-                const uint32_t etile_addr = (uint32_t)(uintptr_t)(lds_u32_ptr)etile;
-                if (((HWB | etile_addr | (uint32_t)reinterpret_cast<uintptr_t>(sg) | (uint32_t)reinterpret_cast<uintptr_t>(gg)) & 3u) == 0) {
-#pragma unroll 4
-                    for (int i = lane; i < HWB / 4; i += 64) {                   // dwords: several loads in flight per lane
-                        const uint32_t v = reinterpret_cast<const uint32_t *>(sg)[i];
-                        reinterpret_cast<uint32_t *>(etile)[i] = v;
-                        if (!ROLL) reinterpret_cast<uint32_t *>(gg)[i] = v;      // (the rollout writes its tile back at the end)
-                    }
-                } else {
-                    for (int i = lane; i < HWB; i += 64) {                       // bytes: layouts of any size / alignment
-                        const uint8_t v = sg[i];
-                        etile[i] = v;
-                        if (!ROLL) gg[i] = v;
-                    }
-                }
-                const uint64_t *sa = reinterpret_cast<const uint64_t *>(MGX_LATE(pool_agents)) + (int64_t)lay * A;
-                for (int j = lane; j < A; j += 64) rows[e * A + j] = sa[j];
-                if (lane == 0) {
-                    scnt[e] = 0;
-                    if (HOOKS) {
-                        const uint4 x = reinterpret_cast<const uint4 *>(MGX_LATE(pool_aux))[lay];
-                        auxl[e] = x;
-                        if (!ROLL) reinterpret_cast<uint4 *>(MGX_LATE(aux))[b] = x;
-                    }
-                }
-            }
-            wave_sync();
-            if (!ROLL && lane < Gc && ((reset_mask >> lane) & 1ull)) in_scnt = 0;
-        }
-    }
-    if (AR && reset_mask != 0 && lane < NVc) cur_row = rows[lane];
-    double my_rew = 0.0;                                                     // this agent's reward (base.py:393), in a register
-    if (DO_STEP && !MGX_DBG(2)) {
-        const bool in = lane < NVc;
-        // (fetched now so that the s_load latency hides behind P1a / P1s)
-        int32_t *const p_step_count = ROLL ? nullptr : MGX_LATE(step_count);
-        uint8_t *const p_truncated = MGX_LATE(truncated);
-        MGX_MARK("P1a");
-        if (ROLL && A > 1 && !MGX_DBG(128)) {
-            // -------------------------------------------------------------- P1a (rollout; the one-step kernels did it in P0):
-            // one lane per (env, agent): its draw
-            if (in) {
-                const int e = env_of_lane, ai = agent_of_lane;
-                uint64_t s_lo, s_hi;
-                rnd[lane] = pcg64_draw_at(rngs + e * 4, jump + ai * 4, s_lo, s_hi);         // base.py:399
-                if (ai == A - 1) { rngs[e * 4 + 0] = s_lo; rngs[e * 4 + 1] = s_hi; }        // (every lane has read it: in-order LDS)
-            }
-        }
-        MGX_MARK("P1s");
-        // ------------------------------------------------------------------ P1s: one lane per (env, agent): order-free
-        // evaluation of every agent's action against the pre-step state (mgx_rules.h: conditions (1)-(3))
-        int32_t *woff = reinterpret_cast<int32_t *>(L + cv.woff());             // [slot]
-        AgentEval ev{};
-        uint8_t *mytile = tile + env_of_lane * HWB;
-        if (in) MGX_CHECK_LDS_PTR(2, mytile, HWB);
-        if (in && !MGX_DBG(64)) {
-            const int so = (env_kind == MGX_KIND_REDBLUEDOORS)
-                               ? stale_offset(cf, reinterpret_cast<const uint8_t *>(auxl + env_of_lane), env_kind) : -1;
-            ev = eval_agent(cf, mytile, rows + env_of_lane * A, ROLL ? (int)acts[lane] : (int)(int8_t)in_act, cur_row, true, so);
-        }
-        // condition (2) needs the cells the other agents write: exchanged through LDS only when somebody writes at all
-        bool conf = false;
-        if (__builtin_amdgcn_ballot_w64(in && ev.writes) != 0) {
-            if (in) woff[lane] = ev.writes ? ev.off : -1;
-            wave_sync();
-            conf = in && spec_cell_conflict(woff + env_of_lane * A, A, agent_of_lane, ev);
-        }
-        // the common step has none of this in the whole wavefront: one ballot decides whether the masks are needed at all
-        bool fb = false, does_act = in;
-        uint64_t m_ends = 0, m_evt = 0, genv = 0;
-        if (__builtin_amdgcn_ballot_w64(in && (ev.bad | conf | ev.used_presence | ev.success | ev.failure)) != 0) {
-            const uint64_t m_bad = __builtin_amdgcn_ballot_w64(in && ev.bad);
-            const uint64_t m_conf = __builtin_amdgcn_ballot_w64(conf);
-            const uint64_t m_pres = __builtin_amdgcn_ballot_w64(in && ev.used_presence);
-            const uint64_t m_moved = __builtin_amdgcn_ballot_w64(in && ev.moved);
-            m_ends = __builtin_amdgcn_ballot_w64(in && event_ends_all(cf, ev));
-            m_evt = __builtin_amdgcn_ballot_w64(in && (ev.success | ev.failure));
-            const uint64_t amask = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-            genv = in ? (amask << (env_of_lane * A)) : 0ull;                     // the lanes of this lane's env
-            fb = in && spec_needs_fallback(m_bad & genv, m_conf & genv, m_pres & genv, m_moved & genv);
-            // an event that ends the episode for every agent: only the agents visited up to it act (mgx_rules.h)
-            does_act = in && !fb;
-            if (A > 1 && m_ends != 0) {                                          // rare, wave-uniform
-                int my_rank = 0;
-                if (in) {
-                    my_rank = draw_rank(rnd + env_of_lane * A, A, agent_of_lane);
-                    ord[env_of_lane * A + my_rank] = (uint8_t)agent_of_lane;
-                }
-                wave_sync();
-                if (in && (m_ends & genv) != 0)
-                    does_act = does_act && my_rank <= event_cutoff(ord + env_of_lane * A, (m_ends & genv) >> (env_of_lane * A), A);
-            }
-        }
-        if (does_act) {                                                              // commit
-            if (ev.go) { rows[lane] = ev.nrow; cur_row = ev.nrow; }
-            if (ev.unstale) reinterpret_cast<uint8_t *>(auxl + env_of_lane)[4] = 0;
-            if (ev.writes) {
-                store_cell(mytile + ev.off, ev.ncell);
-                if (!ROLL) {                                                     // ROLL writes the whole tile back at the end
-                    store_cell(MGX_LATE(grid) + (e0 + env_of_lane) * HWB + ev.off, ev.ncell);
-                }
-            }
-        }
-        if (m_evt != 0) {                                                        // on_success / on_failure of the agents that acted
-            const uint64_t m_succ = __builtin_amdgcn_ballot_w64(does_act && ev.success);
-            if (in && !fb) {
-                if (cf.joint_reward ? (m_succ & genv) != 0 : (does_act && ev.success))
-                    my_rew = reward_value(scnt[env_of_lane] + 1, cf.max_steps);          // base.py:500-507, 598-602
-                if ((does_act && event_ends_self(cf, ev)) || (m_ends & genv) != 0) {          // base.py:478-498, 509-532
-                    cur_row |= 1ull << 32;
-                    rows[lane] = cur_row;
-                }
-            }
-        }
-        MGX_MARK("P1s_end");
-        const uint64_t fbw = __builtin_amdgcn_ballot_w64(fb);                   // envs that need the sequential loop
-        wave_sync();
-        if (fbw != 0) {
-            if (A > 1) {
-                // ---------------------------------------------------------- P1b: argsort by ranking
-                if (in) {
-                    const int e = env_of_lane, ai = agent_of_lane;
-                    ord[e * A + draw_rank(rnd + e * A, A, ai)] = (uint8_t)ai;
-                }
-                wave_sync();
-            }
-            // -------------------------------------------------------------- P1c: one lane per env: the reference's loop
-            const bool mine = lane < Gc && (lane * A < 64) && ((fbw >> (lane * A)) & 1ull);
-            if (mine) {
-                const int e = lane;
-                const int64_t b = e0 + e;
-                uint8_t *etile = tile + e * HWB;
-                uint8_t *ggrid = MGX_LATE(grid) + b * HWB;
-                auto dirty = [=](int off) {
-                    if (!ROLL) store_cell16(ggrid + off, load_cell16(etile + off));
-                };
-                const int rc = handle_actions(cf, etile, rows + e * A, acts + e * A, ord + e * A, rew + e * A,
-                                              scnt[e] + 1, dirty, reinterpret_cast<uint8_t *>(auxl + e), env_kind);
-                int32_t *errp = MGX_LATE(err);
-                if (rc != 0 && errp) { atomicAdd(errp, 1); atomicMin(errp + 1, (int32_t)min(b, (int64_t)INT_MAX)); }
-            }
-            wave_sync();
-        }
-        MGX_MARK("P1hook");
-        // ------------------------------------------------------------------ overlay offsets (pre-hook `terminated`, SURVEY
-        // App. C Q2), then one lane per env: counters + the env subclass' hook on the clean tile, then the overlay itself
-        const int ovl = (in && !MGX_DBG(512)) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
-        if (HOOKS && in && !fb) rew[lane] = my_rew;                              // (the hooks assign to / add onto the base rewards)
-        wave_sync();
-        if (lane < Gc) {
-            const int e = lane;
-            const int64_t b = e0 + e;
-            const int32_t sc = (ROLL ? scnt[e] : (int32_t)in_scnt) + 1;          // base.py:333
-            if (ROLL) scnt[e] = sc; else p_step_count[b] = sc;
-            uint8_t *etile = tile + e * HWB;
-            uint8_t *ggrid = MGX_LATE(grid) + b * HWB;
-            auto dirty = [=](int off) {
-                if (!ROLL) store_cell16(ggrid + off, load_cell16(etile + off));
-            };
-            uint8_t *eaux = reinterpret_cast<uint8_t *>(auxl + e);
-            post_step_hook(cf, env_kind, etile, rows + e * A, acts + e * A, eaux, sc, rew + e * A, dirty);
-            if (!ROLL && cv.has_aux) {                                           // the hook state the step may change
-                uint8_t *gaux = MGX_LATE(aux) + b * MGX_AUX_BYTES;
-                if (env_kind == MGX_KIND_LOCKEDHALLWAY) { gaux[1] = eaux[1]; gaux[2] = eaux[2]; gaux[15] = eaux[15]; }
-                if (env_kind == MGX_KIND_REDBLUEDOORS) gaux[4] = eaux[4];
-            }
-            p_truncated[(int64_t)t * a.batch + b] = (uint8_t)(sc >= cf.max_steps);   // base.py:339
-        }
-        wave_sync();
-        if ((HOOKS || fbw != 0) && in) {                                         // (a hook / the fallback may have terminated it
-            cur_row = rows[lane];                                                // and rewarded it: their results are in LDS)
-            if (HOOKS || fb) my_rew = rew[lane];
-        }
-        if (ROLL && ovl >= 0) ovl_saved = load_cell16(mytile + ovl);
-        ovl_off = ovl;
-        wave_sync();
-        if (ovl >= 0) {
-            MGX_CHECK_LDS_PTR(3, mytile + ovl, 2);
-            store_cell16(mytile + ovl, agent_cell16(cur_row));
-        }
-    } else {
-        const int off = (lane < NVc) ? overlay_offset(cf, rows + env_of_lane * A, agent_of_lane) : -1;
-        wave_sync();
-        if (off >= 0) store_cell16(tile + env_of_lane * HWB + off, agent_cell16(cur_row));
-    }
-    wave_sync();
-
-    MGX_MARK("P1d");
-    // ------------------------------------------------------------------ P1d: one lane per view: geometry + outputs
-    const uint32_t tile_addr = (uint32_t)(wave * a.wave_lds + cv.tile() + tile_skew);   // LDS address of env 0 cell 0
-    uint32_t my_carry = 0;                                                   // slot `lane`: what its agent carries
-    uint32_t inbLo[NW], inbHi[NW];                                           // slot `lane`: its in-bounds lanes (P2 reads them
-#pragma unroll                                                               // with v_readlane; padding slots: none in bounds)
-    for (int k = 0; k < NW; ++k) { inbLo[k] = 0; inbHi[k] = 0; }
-    // (the output pointers are fetched first so that the s_load latency hides behind the geometry arithmetic)
-    uint8_t *const p_dir = MGX_LATE(dir);
-    uint8_t *const p_agents = DO_STEP ? MGX_LATE(agents) : nullptr;
-    double *const p_reward = DO_STEP ? MGX_LATE(reward) : nullptr;
-    uint8_t *const p_term = DO_STEP ? MGX_LATE(terminated) : nullptr;
-    if (lane < NVc) {
-        const int e = env_of_lane;
-        const uint64_t row = cur_row;
-        const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
-        ViewRec r;
-        r.origin = (int32_t)tile_addr + e * HWB + g.origin;
-        r.stepF = g.stepF; r.stepL = g.stepL; r.carry = 0;
-        my_carry = row_carry(row);
-        rec[lane] = r;
-        uint64_t m[NW];
-        inbounds_mask<V, NW>(g, m);
-#pragma unroll
-        for (int k = 0; k < NW; ++k) { inbLo[k] = (uint32_t)m[k]; inbHi[k] = (uint32_t)(m[k] >> 32); }
-        if (DO_STEP) {
-            const u32x2 rowv = {(uint32_t)row, (uint32_t)(row >> 32)};
-            if (!ROLL) __builtin_amdgcn_raw_buffer_store_b64(rowv, make_rsrc(p_agents + v0 * 8, NVc * 8), lane * 8, 0,MGX_OUT_AUX);
-            const uint64_t rbits = __builtin_bit_cast(uint64_t, my_rew);
-            const u32x2 rewv = {(uint32_t)rbits, (uint32_t)(rbits >> 32)};
-            __builtin_amdgcn_raw_buffer_store_b64(rewv, make_rsrc(p_reward + tv0, NVc * 8), lane * 8, 0,MGX_OUT_AUX);
-            const bool forced = env_kind == MGX_KIND_LOCKEDHALLWAY && reinterpret_cast<const uint8_t *>(auxl + e)[15];
-            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row_term(row) | forced),                    // base.py:338 (+ env hook)
-                                                 make_rsrc(p_term + tv0, NVc), lane, 0, MGX_OUT_AUX);
-        }
-        if (p_dir) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)row_dir(row), make_rsrc(p_dir + tv0, NVc), lane, 0,MGX_OUT_AUX);   // base.py:359, 372
-    } else if (lane < ((NVc + kGroup - 1) & ~(kGroup - 1))) {                // padding slots of the last gather group
-        ViewRec r;
-        r.origin = (int32_t)wall_addr; r.stepF = 0; r.stepL = 0; r.carry = 0;
-        rec[lane] = r;
-    }
-    wave_sync();
-
-    MGX_MARK("P2");
-    // ------------------------------------------------------------------ P2: the wavefront renders its views, one lane per cell
-    const LaneConst<V, NW> lc = ROLL ? lc_roll : lane_consts();
-    uint32_t cell[HALF ? VPW / 2 : VPW][NW];     // registers: every slot's packed cells, one per lane (and pass); HALF: slots 2p
-                                                 // and 2p+1 in the halves of one register; P4 reads only the gathered ones (s < NVc)
-    uint32_t sbLo[NW], sbHi[NW];                 // lane s holds the see-behind ballot of slot s
-#pragma unroll
-    for (int k = 0; k < NW; ++k) { sbLo[k] = 0; sbHi[k] = 0; }
-    if (!MGX_DBG(4)) gather_all<V, NW, VPW, HALF>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
-    if (ROLL) {                                                              // take the overlay off again: the tile persists
-        wave_sync();
-        if (ovl_off >= 0) store_cell16(tile + env_of_lane * HWB + ovl_off, ovl_saved);
-    }
-
-    MGX_MARK("P3");
-    // ------------------------------------------------------------------ P3: lane s floods the visibility of slot s
-    const bool masked = !a.sp.see_through_walls;                                // obs.py:95-100
-    uint32_t visLo[NW], visHi[NW];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) { visLo[k] = 0xffffffffu; visHi[k] = 0xffffffffu; }
-    if (masked && !MGX_DBG(8)) {
-        uint64_t sb[NW], vis[NW];
-#pragma unroll
-        for (int k = 0; k < NW; ++k) sb[k] = ((uint64_t)sbHi[k] << 32) | sbLo[k];
-        constexpr int kOwn = (V - 1) * V + V / 2;                               // the agent's own cell: image[V/2][V-1]
-        sb[kOwn >> 6] = (sb[kOwn >> 6] & ~(1ull << (kOwn & 63)))              // ... shows what it carries (obs.py:207)
-                      | ((uint64_t)see_behind(my_carry) << (kOwn & 63));
-        vis_mask<V, NW>(sb, vis);
-#pragma unroll
-        for (int k = 0; k < NW; ++k) { visLo[k] = (uint32_t)vis[k]; visHi[k] = (uint32_t)(vis[k] >> 32); }
-    }
-
-    MGX_MARK("P4");
-    // slot s's packed cell in this lane (HALF: bits 16.. of an even slot's value are the odd slot's cell -- cell_unpack's masks
-    // drop them)
-    auto slot_cell = [&](const int s, const int it) -> uint32_t {
-        if constexpr (HALF) return (s & 1) ? cell[s >> 1][it] >> 16 : cell[s >> 1][it];
-        else return cell[s][it];
-    };
-    if constexpr (OH) {
-        // -------------------------------------------------------------- P4'/P5' (one-hot output) in rounds of kRound slots:
-        // P4' masks each cell and leaves its one-hot bit mask (bit t | bit 11+c | bit 17+s) at its image position in LDS;
-        // P5' turns the masks of the 1-2 cells that each run of 16 output bytes spans into 0/1 bytes and streams them out.
-        constexpr int D = 21;
-        constexpr uint32_t kInvD = 0xFFFFFFFFu / D + 1u;                        // ceil(2^32 / 21): x / 21 exact for x < 2^20
-        const int64_t h0 = tv0 * (int64_t)(V2 * D), h1 = h0 + (int64_t)NVc * V2 * D;
-        const int oh_skew = (int)(h0 & 15);
-        uint32_t *masks = reinterpret_cast<uint32_t *>(L + cv.out()) + 1;      // masks[-1] and masks[cells] are readable pads
-        auto one_hot_mask = [](uint32_t c) -> uint32_t {                        // out-of-range values set no bit (as mgx_one_hot)
-            const uint32_t p0 = min(c & 0xffu, 31u), p1 = min((c >> 8) & 0xffu, 31u), p2 = min((c >> 16) & 0xffu, 31u);
-            return ((1u << p0) & 0x7ffu) | (((1u << p1) & 0x3fu) << 11) | (((1u << p2) & 0xfu) << 17);
-        };
-        if (lane == 0) masks[-1] = 0;
-#pragma unroll
-        for (int r0 = 0; r0 < VPW; r0 += kRound) {
-            if (r0 < NVc) {
-#pragma unroll
-                for (int it = 0; it < NW; ++it) {
-                    if (lc.act[it]) {
-                        uint32_t *d0 = masks + (lc.q3[it] / 3);                  // q3 = 3 * (i*V + j)
-#pragma unroll
-                        for (int g0 = 0; g0 < kRound; g0 += kGroup) {
-                            if (r0 + g0 < NVc) {
-#pragma unroll
-                                for (int sl = g0; sl < g0 + kGroup; ++sl) {
-                                    const int s = r0 + sl;
-                                    const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
-                                                     | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
-                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? slot_cell(s, it) : CELL_UNSEEN);
-                                    MGX_CHECK_LDS_PTR(7, d0 + sl * V2, 4);
-                                    d0[sl * V2] = one_hot_mask(c);
-                                }
-                            }
-                        }
-                    }
-                }
-                wave_sync();
-                if (lane >= r0 && lane < r0 + kRound && lane < NVc)             // own cell := carried object (obs.py:207)
-                    masks[(lane - r0) * V2 + (V / 2) * V + (V - 1)] = one_hot_mask(my_carry);
-                wave_sync();
-                MGX_MARK("P5");
-                const int64_t ro0 = h0 + (int64_t)r0 * (V2 * D);                // this round's output bytes [ro0, ro1)
-                const int rbytes = (int)min((int64_t)kRound * V2 * D, h1 - ro0);
-                const int rlen = oh_skew + rbytes;                              // from the aligned start
-                uint8_t *gdst = MGX_LATE(obs) + (ro0 - oh_skew);
-                const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(gdst, rlen);
-                for (int rel = lane16; rel < rlen; rel += 1024) {
-                    // output bytes [rel, rel + 16) of the aligned run = round bytes x .. x + 15, x = rel - skew (may be < 0:
-                    // shifted by one cell so that the division stays in the positives; masks[-1] is a pad)
-                    const uint32_t xs = (uint32_t)(rel - oh_skew + D);
-                    const uint32_t cq = __umulhi(xs, kInvD);                    // cell + 1
-                    const uint32_t k0 = xs - cq * D;                            // first bit inside that cell: 0..20
-                    MGX_CHECK_LDS_PTR(8, masks + (int)cq - 1, 8);
-                    const uint32_t bits = (masks[(int)cq - 1] >> k0) | (masks[(int)cq] << (D - k0));   // >= 22 valid bits
-                    u32x4 v;
-                    v.x = (((bits >> 0) & 0xfu) * 0x00204081u) & 0x01010101u;   // 4 bits -> 4 bytes of 0/1
-                    v.y = (((bits >> 4) & 0xfu) * 0x00204081u) & 0x01010101u;
-                    v.z = (((bits >> 8) & 0xfu) * 0x00204081u) & 0x01010101u;
-                    v.w = (((bits >> 12) & 0xfu) * 0x00204081u) & 0x01010101u;
-                    if ((rel + 16 <= rlen) & (rel >= oh_skew)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, rel, 0, MGX_OH_AUX);
-                    } else {                                                    // ragged head / tail of the wave's bytes
-                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                        const int lo_b = max(rel, oh_skew), hi_b = min(rel + 16, rlen);
-#pragma clang loop vectorize(disable) unroll(disable)
-                        for (int B = lo_b; B < hi_b; ++B) gdst[B] = (uint8_t)(w[(B - rel) >> 2] >> (8 * ((B - rel) & 3)));
-                    }
-                }
-                wave_sync();
-                MGX_MARK("P5end");
-            }
-        }
-    } else {
-    // ------------------------------------------------------------------ P4/P5 in rounds of kRound slots:
-    // P4 masks each cell and transposes it into the obs byte layout in LDS, P5 streams the round to HBM in 16-byte vectors
-    const int64_t o0 = tv0 * (int64_t)(V2 * 3), o1 = o0 + (int64_t)NVc * V2 * 3;  // this wave's obs bytes (of step t)
-    const int out_skew = (int)(o0 & 15);                                        // the same for every round
-    uint8_t *out_raw = L + cv.out();                                          // obs bytes [oa_r, ...) of round r
-    uint8_t *outb = out_raw + out_skew;
-    constexpr int kRoundBytes = kRound * V2 * 3;                                // multiple of 16
-#pragma unroll
-    for (int r0 = 0; r0 < VPW; r0 += kRound) {
-        if (r0 < NVc) {
-            if (!MGX_DBG(16)) {
-#pragma unroll
-                for (int it = 0; it < NW; ++it) {
-                    if (lc.act[it]) {
-                        uint8_t *d0 = outb + lc.q3[it];
-#if MGX_P4_B16
-                        // A cell's 3 bytes go out as one ALIGNED 2-byte store + one byte store (an LDS store costs the same
-                        // VGPR -> LDS transfer whatever its width, so 2 stores instead of 3).  A view is an odd number of
-                        // bytes, so the parity of a cell's first byte alternates from slot to slot: even slots use [0], odd [1].
-                        const uint32_t par0 = (uint32_t)(out_skew + lc.q3[it]) & 1u;
-                        uint8_t *const d16[2] = {d0 + par0, d0 + (par0 ^ 1u)};                  // the 2-byte part: bytes 0-1 or 1-2
-                        uint8_t *const d8[2] = {d0 + 2u * (par0 ^ 1u), d0 + 2u * par0};         // the other byte: 2 or 0
-                        const uint32_t sh16[2] = {8u * par0, 8u * (par0 ^ 1u)}, sh8[2] = {16u * (par0 ^ 1u), 16u * par0};
-#endif
-                        // whole groups of kGroup slots, like P2 (padding slots write junk into staging space that P5
-                        // never copies): straight-line code whose readlane -> select -> write chains overlap
-#pragma unroll
-                        for (int g0 = 0; g0 < kRound; g0 += kGroup) {
-                            if (r0 + g0 < NVc) {
-#pragma unroll
-                                for (int sl = g0; sl < g0 + kGroup; ++sl) {
-                                    const int s = r0 + sl;
-                                    // (see_through_walls: the masks are all ones -- no branch, it would fence the schedule)
-                                    const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(visHi[it], s) << 32)
-                                                     | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(visLo[it], s);
-                                    // packed cell -> the observation's (type, color, state) bytes
-                                    const uint32_t c = cell_unpack(__builtin_amdgcn_inverse_ballot_w64(m) ? slot_cell(s, it) : CELL_UNSEEN);
-                                    [[maybe_unused]] uint8_t *d = d0 + sl * (V2 * 3);
-                                    MGX_CHECK_LDS_PTR(5, d, 3);
-#if MGX_P4_B16
-                                    *reinterpret_cast<uint16_t *>(d16[sl & 1] + sl * (V2 * 3)) = (uint16_t)(c >> sh16[sl & 1]);
-                                    d8[sl & 1][sl * (V2 * 3)] = (uint8_t)(c >> sh8[sl & 1]);
-#elif MGX_UA_WRITE
-                                    *reinterpret_cast<u16_unaligned *>(d) = (uint16_t)c;    // ds_write_b16 at any byte address
-                                    d[2] = (uint8_t)(c >> 16);                              // ds_write_b8_d16_hi
-#else
-                                    d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
-#endif
-                                }
-                            }
-                        }
-                    }
-                }
-                wave_sync();
-                // lane r0+sl: its agent's own cell shows the carried object (obs.py:207; always visible, obs.py:252)
-                if (lane >= r0 && lane < r0 + kRound && lane < NVc)
-                    store_obs_cell(outb + (lane - r0) * (V2 * 3) + ((V / 2) * V + (V - 1)) * 3, my_carry);
-            }
-            wave_sync();
-            MGX_MARK("P5");
-            if (!MGX_DBG(32)) {
-                const int64_t ro0 = o0 + (int64_t)r0 * (V2 * 3);                // this round's obs bytes [ro0, ro1)
-                const int rlen = out_skew + (int)min((int64_t)kRoundBytes, o1 - ro0);   // staged bytes, from the aligned start
-                uint8_t *gdst = MGX_LATE(obs) + (ro0 - out_skew);
-                const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(gdst, rlen);
-                constexpr int kPasses = (kRoundBytes + 15 + 1023) / 1024;
-#pragma unroll
-                for (int k = 0; k < kPasses; ++k) {
-                    const int rel = lane16 + 1024 * k;
-                    if (rel < rlen) MGX_CHECK_LDS_PTR(6, out_raw + rel, 16);
-                    if ((rel + 16 <= rlen) & (rel >= out_skew)) {
-#if MGX_BUF_STORE
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(out_raw + rel), orsrc, rel, 0, MGX_OBS_AUX);
-#else
-                        *reinterpret_cast<u32x4 *>(gdst + rel) = *reinterpret_cast<const u32x4 *>(out_raw + rel);
-#endif
-                    } else if (rel < rlen) {                                    // ragged head / tail of the wave's bytes
-                        const int lo_b = max(rel, out_skew), hi_b = min(rel + 16, rlen);
-#pragma clang loop vectorize(disable) unroll(disable)
-                        for (int B = lo_b; B < hi_b; ++B) gdst[B] = out_raw[B];
-                    }
-                }
-            }
-            wave_sync();
-            MGX_MARK("P5end");
-        }
-    }
-    }   // if !OH
-    }   // for t
-
-    if constexpr (GEN && MODE == 1) {
-        // -------------------------------------------------------------- the envs whose episode ended with THIS step
-        // (base.py:534-539 on the post-step state, which is still in LDS) start their next one here: Agent.reset + _gen_grid
-        // by the env's lane, straight into the HBM state (every store of the step itself precedes it in program order)
-        bool done_now = false;
-        if (lane < Gc) {
-            bool all_term = true;
-            for (int k = 0; k < A; ++k) all_term &= row_term(rows[lane * A + k]);
-            done_now = all_term | (scnt[lane] + 1 >= cf.max_steps);
-            uint8_t *wr = MGX_LATE(was_reset);
-            if (wr) wr[e0 + lane] = (uint8_t)done_now;
-        }
-        const uint64_t gmask = __builtin_amdgcn_ballot_w64(done_now);
-        if (gmask != 0) {                                                        // rare
-#define MGX_LATE_GEN(f) kernarg_at<decltype(MgxLayoutGen::f)>(offsetof(KernelArgs, gen) + offsetof(MgxLayoutGen, f))
-            MgxLayoutGen gen;
-            gen.kind = MGX_LATE_GEN(kind); gen.room_size = MGX_LATE_GEN(room_size);
-            gen.start_x = MGX_LATE_GEN(start_x); gen.start_y = MGX_LATE_GEN(start_y); gen.start_dir = MGX_LATE_GEN(start_dir);
-            gen.blank = MGX_LATE_GEN(blank); gen.gen_state = MGX_LATE_GEN(gen_state);
-#undef MGX_LATE_GEN
-            mgx_gen::copy_blank(gen, MGX_LATE(grid), e0, HWB, gmask, lane);
-            if (done_now) {
-                const int64_t b = e0 + lane;
-                mgx_gen::NpGen lay, npr;
-                uint64_t *gs = gen.gen_state + b * 6, *rg = MGX_LATE(rng) + b * 4;
-                for (int k = 0; k < 4; ++k) {
-                    lay.s[k] = gs[k];
-                    // (this launch advanced the env's PCG64 words in P0: read them past the L1)
-                    npr.s[k] = __hip_atomic_load(rg + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                lay.buf = gs[4]; npr.buf = gs[5];
-                const uint4 naux = mgx_gen::generate_episode(gen, W, H, A, lay, npr, L + cv.rec() + lane * (2 * A),
-                                                             MGX_LATE(grid) + b * HWB,
-                                                             reinterpret_cast<uint64_t *>(MGX_LATE(agents)) + b * A);
-                if (HOOKS) reinterpret_cast<uint4 *>(MGX_LATE(aux))[b] = naux;
-                for (int k = 0; k < 4; ++k) { gs[k] = lay.s[k]; rg[k] = npr.s[k]; }
-                gs[4] = lay.buf; gs[5] = npr.buf;
-                MGX_LATE(step_count)[b] = 0;                                     // base.py:292
-                MGX_LATE(episode)[b] += 1;
-            }
-        }
-    }
-
-#if MGX_TIMESTAMPS
-    __builtin_amdgcn_s_waitcnt(0);
-    MGX_MARK("end");
-    if (lane == 0 && wid < 16384) g_span[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-    if (ROLL) {
-        // ------------------------------------------------------------------ state write-back, once per launch
-        for (int rel = 16 * lane; rel < len; rel += 16 * 64) {                  // the tile, as it was loaded
-            const int64_t D = ga + rel;
-            if (D >= g0 && D + 16 <= g1) {
-                *reinterpret_cast<uint4 *>(a.grid + D) = *reinterpret_cast<const uint4 *>(tile_raw + rel);
-            } else {
-                const int64_t lo_b = max(D, g0), hi_b = min(D + 16, g1);
-                for (int64_t B = lo_b; B < hi_b; ++B) a.grid[B] = tile_raw[(int)(B - ga)];
-            }
-        }
-        if (lane < NVc) reinterpret_cast<uint64_t *>(a.agents)[v0 + lane] = rows[lane];
-        if (A > 1) {
-            if (lane < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane] = rngs[lane];
-            if (lane + 64 < Gc * 4 && (lane & 3) < 2) a.rng[e0 * 4 + lane + 64] = rngs[lane + 64];
-        }
-        if (lane < Gc) {
-            a.step_count[e0 + lane] = scnt[lane];
-            if (HOOKS && (AR || env_kind >= MGX_KIND_REDBLUEDOORS)) reinterpret_cast<uint4 *>(a.aux)[e0 + lane] = auxl[lane];
-        }
-    }
+// gen_obs for views up to 7x7 is a pure stream and wants the 6th wavefront per SIMD, i.e. <= 80 VGPRs: left to itself the
+// register allocator lands on 78 or 86 depending on unrelated code (measured: 196 vs 204 us at 1M envs).  Its own entry point
+// carries the occupancy request; the step kernels are issue-bound and take the registers they want (forcing them costs
+// spills).  (A shared __device__ function for the body perturbs the other kernels' allocation by ~10 VGPRs: hence the include.)
+template <int V, bool OH, bool STREAM, bool DMA>
+__global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(6)))
+void mgx_obs_kernel(const KernelArgs a) {
+    constexpr int MODE = 0;
+    constexpr bool HOOKS = false, AR = false, GEN = false;
+#include "mgx_fused_body.inc"
 }
 
 // The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
@@ -1218,7 +472,9 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
     const bool ar = MODE != 0 && ka.pool_grid != nullptr;
     constexpr bool S = MODE != 0;
-    if constexpr (GEN) {                                                     // (generation replaces the pool pick-up)
+    if constexpr (MODE == 0 && V <= 7 && !GEN) {
+        kern = mgx_obs_kernel<V, OH, STREAM, DMA>;
+    } else if constexpr (GEN) {                                              // (generation replaces the pool pick-up)
         kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
     } else {
         kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM, DMA> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM, DMA>)

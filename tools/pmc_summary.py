@@ -12,6 +12,8 @@ lines = []
 
 
 def short(n):
+    if "mgx_obs_kernel" in n:
+        return "mgx_fused<gen_obs>"
     m = re.search(r"mgx_fused_kernel<\d+, (\d)", n) or re.search(r"mgx_fused_kernelILi\d+ELi(\d)E", n)
     if m:
         return {"0": "mgx_fused<gen_obs>", "1": "mgx_fused<step>", "2": "mgx_fused<rollout>"}[m.group(1)]

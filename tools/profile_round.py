@@ -30,6 +30,9 @@ POINTS = [("c2", "c2", 4096, {}), ("c3", "c3", 16384, {}), ("c4", "c4", 65536, {
 
 
 def kind_of(name: str):
+    m = re.search(r"mgx_obs_kernel<([^>]*)>", name)
+    if m:                                   # <V, OH, STREAM, DMA>: gen_obs for views up to 7x7 (its own entry point)
+        return "gen_obs" + ("_one_hot" if m.group(1).split(",")[1].strip() == "true" else "")
     m = re.search(r"mgx_fused_kernel<([^>]*)>", name)
     if m:                                   # <V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA>
         t = [x.strip() for x in m.group(1).split(",")] + ["false"] * 8

@@ -19,8 +19,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "mgx_fused" not in k: continue
-        mode = re.search(r"mgx_fused_kernel<\d+, (\d)", k).group(1)
+        if "mgx_fused" not in k and "mgx_obs_kernel" not in k: continue
+        mode = "0" if "mgx_obs_kernel" in k else re.search(r"mgx_fused_kernel<\d+, (\d)", k).group(1)
         name = {"0": "gen_obs", "1": "step", "2": "roll"}[mode]
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, c in acc.items():
