@@ -49,7 +49,8 @@
  *                                                        len(self.rooms) (rooms are keyed by door colour: repeated
  *                                                        colours count once, and that count ends the episode); door k =
  *                                                        (row k/2, side k%2) sits mid-wall at x = side ? 2(rs-1) : rs-1,
- *                                                        y = row (rs-1) + rs/2 (add_door(..., rand_pos=False))
+ *                                                        y = row (rs-1) + (rs-1)/2 (add_door(..., rand_pos=False):
+ *                                                        (top + bottom) // 2, multigrid/core/roomgrid.py:108)
 
  *   obs         u8 [B, A, v, v, 3] image[i][j][c] exactly as multigrid/utils/obs.py:65-102 returns it
  *   dir         u8 [B, A]         obs['direction'] (multigrid/base.py:359, 372)
@@ -68,7 +69,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 5
+#define MGX_ABI_VERSION 6
 
 enum {
     MGX_OK = 0,
@@ -257,6 +258,68 @@ int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar,
                      uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                      uint8_t *obs_one_hot, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                      int32_t *err, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * The general form of the step (ABI 6).  Every mgx_step* / mgx_rollout* entry point above is this call with some of the
+ * options set; options combine freely unless noted.  Replaces multigrid/base.py:303-346 (+ the env subclass' step hook,
+ * + base.py:250-301 reset for finished envs when `auto_reset` / `generate` is given, + wrappers.py:158-190 when `one_hot`).
+ *   steps        1 = one step; T > 1 = T consecutive steps in one launch (mgx_rollout: actions / hook_order / every output and
+ *                was_reset carry a leading [T] axis, the state is written back once)
+ *   one_hot      obs is u8[.., A, v, v, 21] (mgx_step_one_hot)
+ *   auto_reset   finished envs restart from the layout pool BEFORE the step (mgx_step_autoreset), or NULL
+ *   generate     the envs whose episode ends WITH the step are regenerated on the device right after it
+ *                (mgx_step_generate; needs `episode`, optional `was_reset`; not together with `auto_reset`), or NULL
+ *   hook_order   u8[B, A] or NULL: the order in which the env subclass' step hook visits the agents -- the reference's hooks
+ *                iterate `actions.items()`, i.e. the insertion order of the caller's dict (multigrid/envs/redbluedoors.py:176,
+ *                locked_hallway.py:210); row b lists agent indices in that order (a permutation of 0..A-1; agents absent from
+ *                the dict have action -1 and are skipped wherever they are listed).  NULL = ascending index, which is what a
+ *                dict built in agent order gives.  Only RedBlueDoors / LockedHallway read it (BlockedUnlockPickup's hook
+ *                iterates self.agents, blockedunlockpickup.py:170).
+ */
+typedef struct MgxStepArgs {
+    /* state, in/out */
+    MgxCell *grid;
+    uint8_t *agents;
+    uint64_t *rng;               /* may be NULL when A == 1 */
+    int32_t *step_count;
+    uint8_t *aux;                /* may be NULL for MGX_KIND_EMPTY */
+    /* inputs */
+    const int8_t *actions;
+    const uint8_t *hook_order;   /* may be NULL */
+    /* outputs */
+    uint8_t *obs;
+    uint8_t *dir;                /* may be NULL */
+    double *reward;
+    uint8_t *terminated;
+    uint8_t *truncated;
+    int32_t *err;                /* may be NULL */
+    /* options */
+    int32_t steps;
+    int32_t one_hot;
+    const MgxAutoReset *auto_reset;
+    const MgxLayoutGen *generate;
+    int32_t *episode;            /* `generate`: i32[B], in/out */
+    uint8_t *was_reset;          /* `generate`: u8[B] (or [T,B]), may be NULL */
+} MgxStepArgs;
+
+int mgx_step_ex(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, void *stream);
+
+/* Sub-shard stepping.  A launch that fills the chip in one round of wavefronts first loads (no wave has data to work on), then
+ * computes, then drains, and the next step's launch cannot start before the last wave has gone; envs are independent, so the
+ * same step can be issued as `parts` launches over consecutive blocks of the batch on `parts` streams, and consecutive calls
+ * then form `parts` independent CHAINS of launches whose bubbles are filled by the other chains' waves (C4: 20.9 -> 15.7 us per
+ * step of 65536 envs).  Blocks are cut at multiples of 64 envs; per-env seeds, auto-reset layouts and generated episodes follow
+ * the global env index (auto_reset->first_env + block offset), so the results are bit-identical to mgx_step_ex on the whole batch.
+ *   streams      `parts` HIP streams (hipStream_t cast to void*), one per chain
+ *   fork_event   a hipEvent_t (cast to void*) the caller recorded on the stream that produced `actions`, or NULL: every chain's
+ *                stream waits for it before its launch.  The call does NOT join: the outputs of block k are complete when
+ *                streams[k] reaches this point (the caller makes its consumer wait on the streams it needs).
+ * steps must be 1.  mgx_sub_shards() suggests `parts` for (spec, batch, options of `args`) on the current device: 1 when the
+ * launch is less than two wavefronts per SIMD of the chip (splitting only shortens short launches), 4 when the whole batch is
+ * about one round of resident wavefronts (occupancy of the kernel x CUs of the device), else 2.  `args` may be NULL (plain step). */
+int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t parts, void *const *streams,
+                    void *fork_event);
+int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t *parts);
 
 #ifdef __cplusplus
 }

@@ -17,14 +17,15 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
 EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen_obs", "mgx_step",
            "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout", "mgx_step_autoreset",
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
-           "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid")
+           "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid",
+           "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards")
 
 
 class MgxLaunchInfo(C.Structure):
@@ -42,6 +43,17 @@ class MgxLayoutGen(C.Structure):
     """include/mgx.h: struct MgxLayoutGen."""
     _fields_ = [("kind", C.c_int32), ("room_size", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
                 ("start_dir", C.c_int32), ("blank", C.c_void_p), ("gen_state", C.c_void_p)]
+
+
+class MgxStepArgs(C.Structure):
+    """include/mgx.h: struct MgxStepArgs (the general form of the step)."""
+    _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("rng", C.c_void_p), ("step_count", C.c_void_p),
+                ("aux", C.c_void_p), ("actions", C.c_void_p), ("hook_order", C.c_void_p),
+                ("obs", C.c_void_p), ("dir", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
+                ("truncated", C.c_void_p), ("err", C.c_void_p),
+                ("steps", C.c_int32), ("one_hot", C.c_int32),
+                ("auto_reset", C.POINTER(MgxAutoReset)), ("generate", C.POINTER(MgxLayoutGen)),
+                ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
 
 
 GEN_KINDS = {"empty_fixed": 0, "empty_random": 1, "blockedunlockpickup": 2}
@@ -100,6 +112,12 @@ def lib() -> C.CDLL:
     L.mgx_unpack_grid.argtypes = [vp, i64, vp, vp]
     L.mgx_launch_info.restype = C.c_int
     L.mgx_launch_info.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLaunchInfo)]
+    L.mgx_step_ex.restype = C.c_int
+    L.mgx_step_ex.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxStepArgs), vp]
+    L.mgx_step_chains.restype = C.c_int
+    L.mgx_step_chains.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxStepArgs), C.c_int32, C.POINTER(vp), vp]
+    L.mgx_sub_shards.restype = C.c_int
+    L.mgx_sub_shards.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxStepArgs), C.POINTER(C.c_int32)]
     if L.mgx_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {L.mgx_abi_version()} != {ABI_VERSION}; rebuild it")
     _lib = L

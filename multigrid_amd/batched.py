@@ -22,6 +22,21 @@ from .spec import EnvSpec
 INT32_MAX = 2 ** 31 - 1
 
 
+class StepGraph:
+    """A captured hipGraph of env steps (BatchedMultiGridEnv.capture_steps)."""
+
+    def __init__(self, env, graph, sub_shards, keep):
+        self.env, self.graph, self.sub_shards = env, graph, sub_shards
+        self._version = env._layout_version
+        self._keep = keep                # the sub-shards' pre-bound launchers, their streams, the action tensors
+
+    def replay(self):
+        if self.env._layout_version != self._version:
+            raise RuntimeError("this graph was captured before set_layout_pool() / set_layout_generator() replaced the layout "
+                               "tensors it holds pointers to: capture_steps() again")
+        self.graph.replay()
+
+
 class BatchedMultiGridEnv:
     def __init__(self, spec: EnvSpec, batch: int, device="cuda", *, first_env: int = 0, backend=None):
         """
@@ -55,7 +70,11 @@ class BatchedMultiGridEnv:
         self.truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
         self._loaded = False
         self._act_shape = torch.Size((B, A))
-        self._bound = {}                 # (auto_reset, one_hot) -> pre-bound step launcher (ops.HipBackend.bind_step)
+        self._bound = {}                 # (auto_reset, one_hot, generate[, parts]) -> pre-bound step launcher (ops.HipBackend)
+        self._layout_version = 0         # bumped whenever the layout pool / generator tensors are REPLACED: sub-shards and
+        self._parent = None              # captured graphs made before hold pointers into the old ones and refuse to run
+        self._chain_streams = []         # side streams of the eager sub-shard form (step(..., sub_shards=P))
+        self._chains_pending = False
 
     @property
     def grid(self) -> torch.Tensor:
@@ -131,6 +150,7 @@ class BatchedMultiGridEnv:
         one_hot=True: the observation comes out one-hot encoded, u8[B,A,v,v,21] (`OneHotObsWrapper`,
         multigrid/wrappers.py:158-190), written by the same kernel launch; `obs` is not touched."""
         self._need_state()
+        self.join()
         if one_hot:
             self.backend.gen_obs(self.batch, self.cells, self.agents, self._one_hot_buffer(), self.dir, one_hot=True)
             return self._one_hot, self.dir
@@ -149,7 +169,7 @@ class BatchedMultiGridEnv:
             raise RuntimeError("auto_reset needs set_layout_pool() first")
         return (self.first_env, self._pool, self.episode, was_reset)
 
-    def step(self, actions: torch.Tensor, auto_reset: bool = False, one_hot: bool = False):
+    def step(self, actions: torch.Tensor, auto_reset: bool = False, one_hot: bool = False, hook_order=None, sub_shards=1):
         """multigrid/base.py:303-346 for every env.
 
         one_hot=True: the first element returned is the one-hot observation u8[B,A,v,v,21] (what RLlib's default
@@ -160,32 +180,61 @@ class BatchedMultiGridEnv:
         whose episode ended with the previous step first restarts from the layout pool, then takes this step's
         actions; `was_reset` tells which ones did.  Bit-identical to `reset_done(); step(actions)`.
 
-        actions  i8[B,A] on the env's device; `Action` values 0..6, NO_ACTION (-1) = agent not acting
-                 (its key absent from the reference's actions dict, base.py:403-404).
+        actions     i8[B,A] on the env's device; `Action` values 0..6, NO_ACTION (-1) = agent not acting
+                    (its key absent from the reference's actions dict, base.py:403-404).
+        hook_order  u8[B,A] or None: per env, agent indices in the insertion order of the caller's actions dict -- the order
+                    in which the RedBlueDoors / LockedHallway step hooks visit the agents (`for agent_id, action in
+                    actions.items()`, multigrid/envs/redbluedoors.py:176, locked_hallway.py:210).  None = ascending index.
+        sub_shards  1 (default): one launch for the whole batch on the current stream.  P > 1 or "auto" (= what
+                    `sub_shards_hint()` suggests for this device): the step is issued as P launches over consecutive blocks
+                    of the batch on P side streams (mgx_step_chains) and is NOT joined -- consecutive calls form P independent
+                    chains, so one block's load phase runs under another's compute (C4: 20.9 -> ~16 us per step).  The
+                    outputs / state are complete after `join()`; any other method of this object joins first.  Same
+                    results bit for bit (envs are independent; seeds and layouts follow the global env index).
         Returns (obs, dir, reward, terminated, truncated) -- the env's output buffers.
         An unknown action value does not raise here (no device sync on the hot path); it is recorded in
         `err` and surfaced as ValueError by `check_errors()` (multigrid/base.py:473-474).
         """
         if not self._loaded:
             self._need_state()
+        if self._parent is not None:
+            self._check_fresh()
         if actions.dtype is not torch.int8 or actions.shape != self._act_shape or actions.device != self.cells.device \
                 or not actions.is_contiguous():
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {tuple(self._act_shape)} "
                              f"on {self.cells.device}")
+        if hook_order is not None and (hook_order.dtype is not torch.uint8 or hook_order.shape != self._act_shape
+                                       or hook_order.device != self.cells.device or not hook_order.is_contiguous()):
+            raise ValueError(f"hook_order must be a contiguous uint8 tensor of shape {tuple(self._act_shape)} on {self.cells.device}")
         generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
         if generate:
             # on-device generation: the envs whose episode ends with THIS step are regenerated right after it (in the tail
             # of the same launch when the launcher can: mgx_step_generate); `was_reset` = the envs regenerated by this call
             auto_reset = False
-        key = (bool(auto_reset), bool(one_hot), generate and not one_hot)
+        P = 1
+        if sub_shards != 1:
+            P = self.sub_shards_hint(auto_reset or generate, one_hot) if sub_shards == "auto" else int(sub_shards)
+            P = max(1, min(P, self.batch // self.SUB_SHARD_ALIGN))
+            if generate and one_hot:
+                P = 1                                   # (two launches per step: stays on one stream)
+        if P == 1 and self._chains_pending:
+            self.join()
+        key = (bool(auto_reset), bool(one_hot), generate and not one_hot, P)
         fast = self._bound.get(key)
         if fast is None:
             fast = self._bind_step(*key)
+        out = (self._one_hot if one_hot else self.obs), self.dir, self.reward, self.terminated, self.truncated
         if fast is not False:
-            fast(actions)
+            if P > 1:
+                ev = self._fork_event
+                ev.record(torch.cuda.current_stream(self.device))
+                fast(actions, ev.cuda_event, hook_order)
+                self._chains_pending = True
+                return out
+            fast(actions, hook_order)
             if generate and one_hot:
                 self.reset_done()
-            return (self._one_hot if one_hot else self.obs), self.dir, self.reward, self.terminated, self.truncated
+            return out
         # launchers without bind_step (the test-suite's oracle backend)
         sp = self.spec
         ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
@@ -194,6 +243,8 @@ class BatchedMultiGridEnv:
             kw["auto_reset"] = ar
         if one_hot:
             kw["one_hot"] = True
+        if hook_order is not None:
+            kw["hook_order"] = hook_order
         obs = self._one_hot_buffer() if one_hot else self.obs
         self.backend.step(self.batch, self.cells, self.agents, self.rng, self.step_count, actions,
                           self.aux if sp.env_kind != "empty" else None, self.err,
@@ -202,21 +253,55 @@ class BatchedMultiGridEnv:
             self.reset_done()
         return obs, self.dir, self.reward, self.terminated, self.truncated
 
-    def _bind_step(self, auto_reset: bool, one_hot: bool, generate: bool = False):
-        """Resolve every pointer of the step call once (ops.HipBackend.bind_step); False when the launcher cannot."""
-        key = (auto_reset, one_hot, generate)
-        bind = getattr(self.backend, "bind_step", None)
+    def join(self):
+        """Make torch's current stream wait for the sub-shard chains started by `step(..., sub_shards=P)`: afterwards work
+        enqueued on the current stream sees every block's outputs and state.  (No host synchronisation.)"""
+        if self._chains_pending:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self._chain_streams:
+                cur.wait_stream(st)
+            self._chains_pending = False
+
+    def sub_shards_hint(self, auto_reset: bool = False, one_hot: bool = False) -> int:
+        """How many independent chains this env's step is best issued as on its device (mgx_sub_shards: 1 when a launch is
+        less than two wavefronts per SIMD, 4 when the batch is about one round of resident wavefronts, else 2 -- from the
+        kernel's occupancy and the device's CU count, not from constants)."""
+        hint = getattr(self.backend, "sub_shards", None)
+        if hint is None:
+            return 1
+        generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
+        return hint(self.batch, bool(auto_reset), bool(one_hot), generate)
+
+    def _bind_step(self, auto_reset: bool, one_hot: bool, generate: bool = False, parts: int = 1):
+        """Resolve every pointer of the step call once (ops.HipBackend.bind_step / bind_chains); False when the launcher
+        cannot."""
+        key = (auto_reset, one_hot, generate, parts)
+        bind = getattr(self.backend, "bind_step" if parts == 1 else "bind_chains", None)
         if bind is None:
             self._bound[key] = False
             return False
         ar = self._auto_reset_args(auto_reset, getattr(self, "was_reset", None))
-        f = bind(self.batch, self.cells, self.agents, self.rng, self.step_count,
+        head = (self.batch,)
+        if parts > 1:
+            while len(self._chain_streams) < parts:
+                self._chain_streams.append(torch.cuda.Stream(self.device))
+            if getattr(self, "_fork_event", None) is None:
+                self._fork_event = torch.cuda.Event()
+                self._fork_event.record(torch.cuda.current_stream(self.device))     # (creates the handle)
+            head = (self.batch, parts, self._chain_streams[:parts])
+        f = bind(*head, self.cells, self.agents, self.rng, self.step_count,
                  self.aux if self.spec.env_kind != "empty" else None, self.err,
                  self._one_hot_buffer() if one_hot else self.obs, self.dir, self.reward, self.terminated, self.truncated,
                  auto_reset=ar, one_hot=one_hot,
                  **({"generate": (self._gen, self.episode, self.was_reset)} if generate else {}))
         self._bound[key] = f
         return f
+
+    def _check_fresh(self):
+        """A sub-shard (or a captured graph) holds pointers into its parent's layout pool / generator tensors."""
+        if self._parent is not None and self._parent._layout_version != self._made_version:
+            raise RuntimeError("this sub-shard was split off before its parent's set_layout_pool() / set_layout_generator() "
+                               "replaced the layout tensors: split() / capture_steps() again")
 
     # ------------------------------------------------------------------------------------------ sub-shards
     SUB_SHARD_ALIGN = 64         # envs: keeps every sub-shard's tensors 16-byte aligned and its wavefronts' tiles as in the whole
@@ -227,6 +312,7 @@ class BatchedMultiGridEnv:
         sub-shards -- in any interleaving, on any streams -- is stepping this env.  Call it after the state, the layout pool /
         generator and any one-hot use are set up (the views are taken of the tensors as they are now)."""
         self._need_state()
+        self.join()
         B, al = self.batch, self.SUB_SHARD_ALIGN
         parts = max(1, min(int(parts), max(1, B // al)))
         cuts = [0] + [min(B, ((B * i // parts + al - 1) // al) * al) for i in range(1, parts)] + [B]
@@ -240,6 +326,8 @@ class BatchedMultiGridEnv:
                 setattr(c, name, getattr(self, name)[lo:hi])
             c.err = self.err                                                  # (shared: the kernels update it atomically)
             c._loaded, c._act_shape, c._bound = True, torch.Size((hi - lo, self.spec.num_agents)), {}
+            c._parent, c._made_version, c._layout_version = self, self._layout_version, 0
+            c._chain_streams, c._chains_pending = [], False
             c._one_hot = self._one_hot[lo:hi] if getattr(self, "_one_hot", None) is not None else None
             c._pool = getattr(self, "_pool", None)
             c._gen = None
@@ -251,17 +339,26 @@ class BatchedMultiGridEnv:
             out.append(c)
         return out
 
-    def capture_steps(self, actions: torch.Tensor, auto_reset: bool = False, one_hot: bool = False, sub_shards: int = 1):
+    def capture_steps(self, actions: torch.Tensor, auto_reset: bool = False, one_hot: bool = False, sub_shards=1,
+                      hook_order=None):
         """A hipGraph of `len(actions)` consecutive `step` launches reading `actions[t]` (i8[T,B,A], kept by reference: refill
-        it between replays).  `graph.replay()` then costs no Python per step; the outputs of the LAST step are in the env's
-        buffers.  (A policy in the loop is captured the same way: see examples/closed_loop.py.)
+        it between replays; `hook_order` u8[T,B,A] likewise).  `graph.replay()` then costs no Python per step; the outputs of
+        the LAST step are in the env's buffers.  (A policy in the loop is captured the same way: see examples/closed_loop.py.)
 
-        sub_shards=P > 1: the batch is stepped as P independent sub-shards (`split`), each a chain of T launches on its own
-        stream -- P parallel branches of the one graph.  A launch that fills the chip in a single round of wavefronts first
-        loads (no wave has data to work on), then computes; two half-batch chains drift apart and one's loads run under the
-        other's compute (C4: 20.8 -> 17.0 us per step of the whole batch, C5 85 -> 69 us).  Same results: envs are independent.
-        This is the double-buffered actor loop of a closed-loop caller (policy on one half while the other half steps)."""
+        sub_shards=P > 1 or "auto" (`sub_shards_hint()`): the batch is stepped as P independent sub-shards (`split`), each a
+        chain of T launches on its own stream -- P parallel branches of the one graph.  A launch that fills the chip in a
+        single round of wavefronts first loads (no wave has data to work on), then computes, then drains, and the next launch of
+        its chain cannot start before its last wave has gone; the chains drift apart and fill each other's bubbles (C4: 20.9 ->
+        15.7 us per step of the whole batch, C5 85 -> 69 us; in-kernel timestamps of the overlap: profiles/r3_chain_overlap.txt).
+        Same results: envs are independent.  This is the double-buffered actor loop of a closed-loop caller (policy on one block
+        while the others step).  A policy that needs all B observations of step t before step t+1 uses sub_shards=1.
+
+        Returns a StepGraph (`.replay()`, `.graph` = the torch.cuda.CUDAGraph, `.sub_shards`); it refuses to replay once
+        set_layout_pool() / set_layout_generator() have replaced the tensors it captured pointers to."""
         self._need_state()
+        self.join()
+        if sub_shards == "auto":
+            sub_shards = self.sub_shards_hint(auto_reset, one_hot)
         stream = torch.cuda.current_stream(self.device)
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(self.device)
@@ -278,12 +375,13 @@ class BatchedMultiGridEnv:
                     lo, hi = getattr(sh, "_range", (0, self.batch))
                     with torch.cuda.stream(side if i == 0 else others[i - 1]):
                         for t in range(actions.shape[0]):
-                            sh.step(actions[t] if sh is self else actions[t, lo:hi], auto_reset=auto_reset, one_hot=one_hot)
+                            ho = None if hook_order is None else (hook_order[t] if sh is self else hook_order[t, lo:hi])
+                            sh.step(actions[t] if sh is self else actions[t, lo:hi], auto_reset=auto_reset, one_hot=one_hot,
+                                    hook_order=ho)
                 for s in others:                                             # join
                     side.wait_stream(s)
         stream.wait_stream(side)
-        graph._mgx_keep = (shards, others)                                   # (the sub-shards' pre-bound launchers)
-        return graph
+        return StepGraph(self, graph, len(shards), (shards, others, actions, hook_order))
 
     def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False) -> dict:
         """`T` consecutive `step`s in one kernel launch (env state stays in LDS between steps); bit-identical to
@@ -294,6 +392,7 @@ class BatchedMultiGridEnv:
         auto_reset=True: finished envs restart from the layout pool before each step (as `step(auto_reset=True)`);
         the result then also holds 'was_reset': u8[T,B]."""
         self._need_state()
+        self.join()
         sp, B = self.spec, self.batch
         if actions.dtype != torch.int8 or actions.dim() != 3 or tuple(actions.shape[1:]) != (B, sp.num_agents) \
                 or actions.device != self.cells.device or not actions.is_contiguous():
@@ -317,6 +416,7 @@ class BatchedMultiGridEnv:
     # ------------------------------------------------------------------------------------------ either side of the path
     def one_hot_obs(self) -> torch.Tensor:
         """`OneHotObsWrapper` (multigrid/wrappers.py:101-190) applied to the current `obs`: u8[B,A,v,v,21]."""
+        self.join()
         self.backend.one_hot(self.obs, self._one_hot_buffer())
         return self._one_hot
 
@@ -324,6 +424,7 @@ class BatchedMultiGridEnv:
         """`FullyObsWrapper` (multigrid/wrappers.py:17-58): u8[B,W,H,3], the grid in the reference's [x][y]
         orientation with every agent (terminated or not) drawn at its position."""
         self._need_state()
+        self.join()
         if getattr(self, "_full", None) is None:
             self._full = torch.zeros((self.batch, self.spec.width, self.spec.height, 3), dtype=torch.uint8,
                                      device=self.device)
@@ -347,12 +448,23 @@ class BatchedMultiGridEnv:
             t = t.to(self.device).contiguous()
         elif sp.env_kind != "empty":
             raise ValueError(f"env_kind {sp.env_kind!r} needs per-layout aux")
-        self._gen = None
+        self.join()
         cells = torch.from_numpy(layouts.pack_cells(g.numpy()).view(np.int16))
+        old = getattr(self, "_pool", None)
+        if (getattr(self, "_gen", None) is None and old is not None and old[0].shape == cells.shape and old[1].shape == a.shape
+                and (old[2] is None) == (t is None)):
+            # same shapes: refill the tensors in place -- sub-shards, pre-bound launchers and captured graphs stay valid
+            old[0].copy_(cells); old[1].copy_(a)
+            if t is not None:
+                old[2].copy_(t)
+            self.episode.zero_(); self.was_reset.zero_()
+            return
+        self._gen = None
         self._pool = (cells.to(self.device).contiguous(), a.to(self.device).contiguous(), t)
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
         self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
-        self._bound.clear()              # (the pre-bound launchers hold the old pool's pointers)
+        self._bound.clear()              # (the pre-bound launchers hold the old pool's pointers ...
+        self._layout_version += 1        #  ... and so do sub-shards and captured graphs made before: they now refuse to run)
 
     def set_layout_generator(self, kind: str, layout_seed: int = 0, *, room_size: int = 0, start=(1, 1, 0)):
         """Episode starts generated ON THE DEVICE (mgx_reset_generate) instead of picked from a host-made pool: every
@@ -377,6 +489,7 @@ class BatchedMultiGridEnv:
             blank = layouts.empty_blank(sp.width)
         else:
             raise ValueError(f"unknown layout generator {kind!r}")
+        self.join()
         idx = self.first_env + np.arange(self.batch)
         self._gen = {"kind": kind, "room_size": int(room_size), "start": tuple(int(v) for v in start),
                      "blank": torch.from_numpy(layouts.pack_cells(blank).view(np.int16)).to(self.device).contiguous(),
@@ -385,6 +498,7 @@ class BatchedMultiGridEnv:
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
         self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)
         self._bound.clear()
+        self._layout_version += 1        # (sub-shards and captured graphs made before hold the old tensors' pointers)
 
     def reset_done(self) -> torch.Tensor:
         """Vector-env auto-reset (build-defined; the reference leaves `if env.is_done(): env.reset()` to its caller):
@@ -392,6 +506,7 @@ class BatchedMultiGridEnv:
         running as an unseeded `reset()` does.  Returns was_reset u8[B].  Observations of the restarted envs are
         produced by the next `gen_obs()` / `step()`."""
         self._need_state()
+        self.join()
         if getattr(self, "_gen", None) is not None:
             self.backend.reset_generate(self.batch, self._gen, self.cells, self.agents, self.rng, self.step_count,
                                         self.aux if self.spec.env_kind != "empty" else None, self.episode, self.was_reset)
@@ -404,6 +519,7 @@ class BatchedMultiGridEnv:
 
     def check_errors(self):
         """Synchronises and raises ValueError if any env met an unknown action since the last check."""
+        self.join()
         count, first = (int(v) for v in self.err.cpu())
         if count:
             self._reset_err()
@@ -423,6 +539,7 @@ class BatchedMultiGridEnv:
     def state_dict(self) -> dict:
         """Everything a resumed run needs to continue bit-identically: the env state, and -- when auto-reset is in use --
         the layout pool, the per-env episode counters and the last `was_reset`."""
+        self.join()
         sd = {"spec": self.spec.as_dict(), "first_env": self.first_env,
               "grid": self.grid.cpu().clone(), "agents": self.agents.cpu().clone(),
               "rng": self.rng.cpu().clone(), "step_count": self.step_count.cpu().clone(),

@@ -35,6 +35,7 @@ DEPS = SRCS + [os.path.join(CSRC, "mgx_fused.h"), os.path.join(CSRC, "mgx_fused_
 LIB = os.path.join(HERE, "lib", "libmgx.so")
 LIB_DBG = os.path.join(HERE, "lib", "libmgx_dbg.so")
 LIB_CHK = os.path.join(HERE, "lib", "libmgx_chk.so")
+LIB_TS = os.path.join(HERE, "lib", "libmgx_ts.so")
 ARCH = "gfx950"
 
 
@@ -113,10 +114,19 @@ def build_checked_lib(force: bool = False, verbose: bool = False) -> str:
     return build_lib(force, verbose, LIB_CHK, ("MGX_BOUNDS_CHECK=1",))
 
 
+def build_timestamps_lib(force: bool = False, verbose: bool = False) -> str:
+    """lib/libmgx_ts.so: -DMGX_TIMESTAMPS=1 (every wavefront records its begin / end in s_memrealtime ticks, one block of
+    records per launch; one wavefront records the shader clock at every phase marker) + the debug knobs, for
+    tools/span_probe.py, tools/stamp_probe.py and tools/chain_overlap.py.  Built on demand, never by build()."""
+    return build_lib(force, verbose, LIB_TS, ("MGX_DEBUG_KNOBS=1", "MGX_TIMESTAMPS=1", "MGX_SINGLE_TU=1"))
+
+
 if __name__ == "__main__":
     force, verbose = "--force" in sys.argv, True
     extra = tuple(a[2:] for a in sys.argv[1:] if a.startswith("-D"))
-    if "--checked" in sys.argv:
+    if "--timestamps" in sys.argv:
+        print(build_timestamps_lib(force, verbose))
+    elif "--checked" in sys.argv:
         print(build_checked_lib(force, verbose))
     elif "--debug-knobs" in sys.argv:
         print(build_debug_lib(force, verbose, extra))

@@ -12,11 +12,12 @@
 
 #include "mgx_rules.h"
 
+extern "C" void mgx_internal_set_hip_error(int e);      // mgx_kernels.hip: what mgx_last_hip_error() reports
+
 namespace {
 
 using namespace mgx;
 
-int g_aux_hip_error = 0;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void reset_done_kernel(int HWB, int A, int max
 
 int finish_launch() {
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { g_aux_hip_error = (int)e; return MGX_ERR_LAUNCH; }
+    if (e != hipSuccess) { mgx_internal_set_hip_error((int)e); return MGX_ERR_LAUNCH; }
     return MGX_OK;
 }
 

@@ -50,6 +50,7 @@ struct KernelArgs {
     uint64_t *rng;
     int32_t *step_count;
     const int8_t *actions;
+    const uint8_t *hook_order;   // u8[B,A] or null: visiting order of the RedBlueDoors / LockedHallway hooks (include/mgx.h)
     uint8_t *aux;
     uint8_t *obs;
     uint8_t *dir;
@@ -76,6 +77,7 @@ struct KernelArgs {
     uint8_t *was_reset;
     MgxLayoutGen gen;   // mgx_step_generate: finished envs are regenerated in the tail of the launch (template flag GEN)
     int32_t *bounds;    // -DMGX_BOUNDS_CHECK=1 builds: [0] += LDS accesses outside the wavefront's slice, [1] = last site id
+    int32_t span_base;  // -DMGX_TIMESTAMPS=1 builds: first record of this launch in g_span (tools/span_probe.py, tools/chain_overlap.py)
 };
 
 // gfx950's LDS does take a short access at any byte address (hipcc emits ds_write_b16 for an align-1 store), but measured
@@ -272,7 +274,11 @@ static __device__ const JumpTable kJump{};
 #define MGX_MARK(name) asm volatile("; MGX_MARK " name ::: "memory")
 #elif MGX_TIMESTAMPS
 static __device__ unsigned long long g_stamps[64];
-static __device__ unsigned long long g_span[2 * 16384];      // [wave][begin, end] in s_memrealtime ticks (100 MHz), first 16384 waves
+constexpr int kSpanCap = 1 << 18;
+static __device__ unsigned long long g_span[2 * kSpanCap];   // [span_base + wave][begin, end] in s_memrealtime ticks (100 MHz): every
+                                                             // launch gets its own block of records (KernelArgs::span_base, handed out
+                                                             // by the host in launch order -- for a captured graph: capture order), so
+                                                             // a replayed graph of several chains leaves one timeline per node
 static __device__ long long g_stamp_wave = 0;
 #define MGX_MARK(name)                                                                                   \
     do {                                                                                                 \
@@ -461,11 +467,11 @@ void mgx_obs_kernel(const KernelArgs a) {
 // The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
 // failed launch (mgx_last_hip_error).
 template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false>
-inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err) {
+inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
     if constexpr (!STREAM && !DMA && MODE != 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
-        if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
+        if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
         if constexpr (!OH) {
-            if (ka.flags & 2) return launch_mode<V, MODE, OH, GEN, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
+            if (ka.flags & 2) return launch_mode<V, MODE, OH, GEN, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
         }
     }
     void (*kern)(const KernelArgs) = nullptr;
@@ -485,6 +491,12 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
     }
+    if (occupancy) {        // query only (mgx_sub_shards): workgroups of this instantiation that one CU holds at a time
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, reinterpret_cast<const void *>(kern), threads,
+                                                                    (size_t)lds_bytes);
+        if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+        return MGX_OK;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, stream, ka);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
@@ -493,14 +505,14 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
 
 template <int V>
 inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream,
-                       int *hip_err) {
+                       int *hip_err, int *occupancy) {
     switch (mode) {                     // mode | 4: one-hot observations (gen_obs and one step only); | 8: tail generation
-    case 0: return launch_mode<V, 0, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
-    case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
-    case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err);
-    case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
-    case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err);
-    case 9: return launch_mode<V, 1, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err);   // | 8: generate
+    case 0: return launch_mode<V, 0, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    case 9: return launch_mode<V, 1, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);   // | 8: generate
     default: return MGX_ERR_INVALID_ARGUMENT;
     }
 }
@@ -508,7 +520,8 @@ inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_byte
 // One translation unit per view size (mgx_fused_inst.hip, -DMGX_INST_V=<V>) defines its launcher:
 #define MGX_FOR_EACH_VIEW(X) X(3) X(5) X(7) X(9) X(11) X(13) X(15)
 #define MGX_DECLARE_LAUNCHER(V) \
-    int launch_v##V(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err);
+    int launch_v##V(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, \
+                    int *occupancy);
 MGX_FOR_EACH_VIEW(MGX_DECLARE_LAUNCHER)
 #undef MGX_DECLARE_LAUNCHER
 

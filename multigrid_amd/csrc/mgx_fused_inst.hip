@@ -10,8 +10,8 @@
 
 namespace mgx_fused {
 int MGX_CAT(launch_v, MGX_INST_V)(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream,
-                                  int *hip_err) {
-    return launch_view<MGX_INST_V>(mode, ka, threads, lds_bytes, nwg, stream, hip_err);
+                                  int *hip_err, int *occupancy) {
+    return launch_view<MGX_INST_V>(mode, ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
 }
 }  // namespace mgx_fused
 #undef MGX_CAT

@@ -1,5 +1,7 @@
 // mgx_kernels.hip -- the C ABI of libmgx.so (include/mgx.h): argument checks, launch geometry, dispatch to the fused
 // kernel's per-view-size translation units (mgx_fused.h / mgx_fused_inst.hip).
+#include <algorithm>
+
 #include "mgx_fused.h"
 
 #if MGX_SINGLE_TU      // (tools' builds that need the kernels and the host code in one module, e.g. -DMGX_TIMESTAMPS=1)
@@ -32,7 +34,7 @@ using namespace mgx;
 using namespace mgx_fused;
 
 // mode 0: gen_obs, 1: one step, 2: rollout
-int launch(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream);
+int launch(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *occupancy = nullptr);
 
 int g_last_hip_error = 0;
 #if MGX_DEBUG_KNOBS
@@ -46,8 +48,15 @@ constexpr int g_debug_skip = 0, g_debug_G = 0, g_debug_wpb = 0;
 #if MGX_BOUNDS_CHECK
 int32_t *g_bounds = nullptr;        // device: [0] violations, [1] last site (checked build only; allocated on first launch)
 #endif
+#if MGX_TIMESTAMPS
+// launches since mgx_debug_span_reset(): {span_base, wavefronts, batch, first_env} each (tools/chain_overlap.py)
+constexpr int kMaxSpanLaunches = 4096;
+long long g_span_launches[kMaxSpanLaunches][4];
+int g_span_nlaunch = 0;
+int g_span_next = 0;
+#endif
 
-int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_t nwg, hipStream_t stream) {
+int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *occupancy) {
     KernelArgs ka = ka_in;
 #if MGX_BOUNDS_CHECK
     if (!g_bounds) {
@@ -56,8 +65,19 @@ int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_
     }
     ka.bounds = g_bounds;
 #endif
+#if MGX_TIMESTAMPS
+    if (!occupancy) {
+        const long long nwaves = nwg * (threads / 64);
+        ka.span_base = g_span_next;
+        if (g_span_nlaunch < kMaxSpanLaunches) {
+            long long *r = g_span_launches[g_span_nlaunch++];
+            r[0] = g_span_next; r[1] = nwaves; r[2] = ka.batch; r[3] = ka.first_env;
+        }
+        g_span_next = (int)std::min<long long>((long long)kSpanCap, g_span_next + nwaves);
+    }
+#endif
     switch (ka.sp.view_size) {
-#define MGX_CASE(V) case V: return launch_v##V(mode, ka, threads, lds_bytes, nwg, stream, &g_last_hip_error);
+#define MGX_CASE(V) case V: return launch_v##V(mode, ka, threads, lds_bytes, nwg, stream, &g_last_hip_error, occupancy);
     MGX_FOR_EACH_VIEW(MGX_CASE)
 #undef MGX_CASE
     default: return MGX_ERR_UNSUPPORTED;
@@ -147,8 +167,17 @@ int mgx_debug_bounds_violations(int32_t *out2) {
 }
 #endif
 #if MGX_TIMESTAMPS
-int mgx_debug_read_span(unsigned long long *out, int nwaves) {            // [nwaves][2] of the last launch
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * nwaves) == hipSuccess ? 0 : -1;
+// Wave spans: every launch since the last reset owns records [span_base, span_base + wavefronts) of g_span.
+void mgx_debug_span_reset(void) { g_span_next = 0; g_span_nlaunch = 0; }
+int mgx_debug_span_launches(long long *out4, int max_launches) {          // -> number of launches; out4[i] = {base, waves, batch, first_env}
+    const int n = g_span_nlaunch < max_launches ? g_span_nlaunch : max_launches;
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 4; ++k) out4[4 * i + k] = g_span_launches[i][k];
+    return n;
+}
+int mgx_debug_read_span(unsigned long long *out, int first, int count) {  // records [first, first + count), [begin, end] each
+    if (first < 0 || count < 0 || first + count > kSpanCap) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * count,
+                               sizeof(unsigned long long) * 2 * first) == hipSuccess ? 0 : -1;
 }
 int mgx_debug_read_stamps(unsigned long long *out64, long long wave) {   // reads the last launch's stamps, selects the next wave
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
@@ -203,43 +232,55 @@ int mgx_gen_obs_one_hot(const MgxSpec *spec, int64_t batch, const MgxCell *grid,
     return gen_obs_common(true, spec, batch, grid, agents, obs_one_hot, dir, stream);
 }
 
-static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar,
-                       const MgxLayoutGen *gen, int32_t *gen_episode, uint8_t *gen_was_reset,
-                       MgxCell *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
-                       uint8_t *aux, uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated,
-                       uint8_t *truncated, int32_t *err, void *stream) {
+// The one implementation behind every step entry point (include/mgx.h: MgxStepArgs).  `occupancy`: query only (mgx_sub_shards).
+static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa, void *stream, int *occupancy = nullptr) {
+    const bool roll = sa.steps != 1, one_hot = sa.one_hot != 0;
+    const MgxAutoReset *ar = sa.auto_reset;
+    const MgxLayoutGen *gen = sa.generate;
     int rc = check_spec(spec, batch, roll, one_hot);
     if (rc) return rc;
-    if (steps < 0 || (roll && one_hot)) return MGX_ERR_INVALID_ARGUMENT;
-    if (batch == 0 || steps == 0) return MGX_OK;
-    if (!grid || !agents || !step_count || !actions || !obs || !reward || !terminated || !truncated)
-        return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->num_agents > 1 && !rng) return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->env_kind != MGX_KIND_EMPTY && !aux) return MGX_ERR_INVALID_ARGUMENT;
-    if (misaligned(grid, 16) || misaligned(agents, 8) || misaligned(obs, 16) || misaligned(rng, 8)
-        || misaligned(reward, 8) || misaligned(step_count, 4) || misaligned(err, 4) || misaligned(aux, 16))
-        return MGX_ERR_INVALID_ARGUMENT;
+    if (sa.steps < 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (roll && one_hot) return MGX_ERR_UNSUPPORTED;
+    if (batch == 0 || sa.steps == 0) return MGX_OK;
+    if (!occupancy) {
+        if (!sa.grid || !sa.agents || !sa.step_count || !sa.actions || !sa.obs || !sa.reward || !sa.terminated || !sa.truncated)
+            return MGX_ERR_INVALID_ARGUMENT;
+        if (spec->num_agents > 1 && !sa.rng) return MGX_ERR_INVALID_ARGUMENT;
+        if (spec->env_kind != MGX_KIND_EMPTY && !sa.aux) return MGX_ERR_INVALID_ARGUMENT;
+        if (misaligned(sa.grid, 16) || misaligned(sa.agents, 8) || misaligned(sa.obs, 16) || misaligned(sa.rng, 8)
+            || misaligned(sa.reward, 8) || misaligned(sa.step_count, 4) || misaligned(sa.err, 4) || misaligned(sa.aux, 16))
+            return MGX_ERR_INVALID_ARGUMENT;
+    }
     KernelArgs ka{};
     if (ar) {
-        if (ar->pool_size < 1 || ar->first_env < 0 || !ar->pool_grid || !ar->pool_agents || !ar->episode)
-            return MGX_ERR_INVALID_ARGUMENT;
-        if (spec->env_kind != MGX_KIND_EMPTY && !ar->pool_aux) return MGX_ERR_INVALID_ARGUMENT;
-        if (misaligned(ar->pool_agents, 8) || misaligned(ar->pool_aux, 16) || misaligned(ar->episode, 4))
-            return MGX_ERR_INVALID_ARGUMENT;
+        if (!occupancy) {
+            if (ar->pool_size < 1 || ar->first_env < 0 || !ar->pool_grid || !ar->pool_agents || !ar->episode)
+                return MGX_ERR_INVALID_ARGUMENT;
+            if (spec->env_kind != MGX_KIND_EMPTY && !ar->pool_aux) return MGX_ERR_INVALID_ARGUMENT;
+            if (misaligned(ar->pool_agents, 8) || misaligned(ar->pool_aux, 16) || misaligned(ar->episode, 4))
+                return MGX_ERR_INVALID_ARGUMENT;
+        }
         ka.pool_size = ar->pool_size; ka.first_env = ar->first_env; ka.pool_grid = reinterpret_cast<const uint8_t *>(ar->pool_grid);
         ka.pool_agents = ar->pool_agents; ka.pool_aux = ar->pool_aux; ka.episode = ar->episode;
         ka.was_reset = ar->was_reset;
+        if (occupancy && !ka.pool_grid) ka.pool_grid = reinterpret_cast<const uint8_t *>(spec);   // (selects the AR instantiation)
     }
     int threads = 0, lds = 0; int64_t nwg = 0;
     rc = fill_args(ka, spec, batch, threads, lds, nwg, roll, one_hot);
     if (rc) return rc;
-    ka.grid = reinterpret_cast<uint8_t *>(grid); ka.agents = agents; ka.rng = rng; ka.step_count = step_count; ka.actions = actions;
-    ka.aux = aux; ka.obs = obs; ka.dir = dir; ka.reward = reward; ka.terminated = terminated;
-    ka.truncated = truncated; ka.err = err;
-    ka.T = roll ? steps : 1;
+    ka.grid = reinterpret_cast<uint8_t *>(sa.grid); ka.agents = sa.agents; ka.rng = sa.rng; ka.step_count = sa.step_count;
+    ka.actions = sa.actions; ka.hook_order = sa.hook_order;
+    ka.aux = sa.aux; ka.obs = sa.obs; ka.dir = sa.dir; ka.reward = sa.reward; ka.terminated = sa.terminated;
+    ka.truncated = sa.truncated; ka.err = sa.err;
+    ka.T = roll ? sa.steps : 1;
+    int mode = roll ? 2 : (one_hot ? 5 : 1);
     if (gen) {
-        if (roll || one_hot || ar || !gen->blank || !gen->gen_state || !gen_episode || !rng) return MGX_ERR_INVALID_ARGUMENT;
-        if (misaligned(gen->gen_state, 8) || misaligned(gen_episode, 4)) return MGX_ERR_INVALID_ARGUMENT;
+        if (roll || one_hot) return MGX_ERR_UNSUPPORTED;
+        if (ar) return MGX_ERR_INVALID_ARGUMENT;
+        if (!occupancy) {
+            if (!gen->blank || !gen->gen_state || !sa.episode || !sa.rng) return MGX_ERR_INVALID_ARGUMENT;
+            if (misaligned(gen->gen_state, 8) || misaligned(sa.episode, 4)) return MGX_ERR_INVALID_ARGUMENT;
+        }
         if (spec->width > 254 || spec->height > 254) return MGX_ERR_UNSUPPORTED;
         switch (gen->kind) {
         case MGX_GEN_EMPTY_FIXED:
@@ -257,26 +298,44 @@ static int step_common(bool roll, bool one_hot, const MgxSpec *spec, int64_t bat
             break;
         default: return MGX_ERR_UNSUPPORTED;
         }
-        ka.gen = *gen; ka.episode = gen_episode; ka.was_reset = gen_was_reset;
-        return launch(9, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+        ka.gen = *gen; ka.episode = sa.episode; ka.was_reset = sa.was_reset;
+        mode = 9;
     }
-    return launch(roll ? 2 : (one_hot ? 5 : 1), ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+    return launch(mode, ka, threads, lds, nwg, static_cast<hipStream_t>(stream), occupancy);
+}
+
+static MgxStepArgs step_args(MgxCell *grid, uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions,
+                             uint8_t *aux, uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
+                             int32_t *err) {
+    MgxStepArgs sa{};
+    sa.grid = grid; sa.agents = agents; sa.rng = rng; sa.step_count = step_count; sa.aux = aux; sa.actions = actions;
+    sa.obs = obs; sa.dir = dir; sa.reward = reward; sa.terminated = terminated; sa.truncated = truncated; sa.err = err;
+    sa.steps = 1;
+    return sa;
+}
+
+int mgx_step_ex(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, void *stream) {
+    if (!args) return MGX_ERR_INVALID_ARGUMENT;
+    return step_common(spec, batch, *args, stream);
 }
 
 int mgx_step(const MgxSpec *spec, int64_t batch, MgxCell *grid, uint8_t *agents, uint64_t *rng,
              int32_t *step_count, const int8_t *actions, uint8_t *aux,
              uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
              int32_t *err, void *stream) {
-    return step_common(false, false, spec, batch, 1, nullptr, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
-                       terminated, truncated, err, stream);
+    return step_common(spec, batch, step_args(grid, agents, rng, step_count, actions, aux, obs, dir, reward, terminated, truncated, err), stream);
 }
 
 int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, MgxCell *grid, uint8_t *agents, uint64_t *rng,
                 int32_t *step_count, const int8_t *actions, uint8_t *aux,
                 uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                 int32_t *err, void *stream) {
-    return step_common(true, false, spec, batch, steps, nullptr, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
-                       terminated, truncated, err, stream);
+    MgxStepArgs sa = step_args(grid, agents, rng, step_count, actions, aux, obs, dir, reward, terminated, truncated, err);
+    if (steps == 0) return check_spec(spec, batch, true);
+    if (steps < 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (steps == 1) return step_common(spec, batch, sa, stream);          // (one step IS the step kernel: same results)
+    sa.steps = steps;
+    return step_common(spec, batch, sa, stream);
 }
 
 int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, MgxCell *grid, uint8_t *agents,
@@ -284,25 +343,30 @@ int mgx_step_autoreset(const MgxSpec *spec, int64_t batch, const MgxAutoReset *a
                        uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                        int32_t *err, void *stream) {
     if (!ar) return MGX_ERR_INVALID_ARGUMENT;
-    return step_common(false, false, spec, batch, 1, ar, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
-                       terminated, truncated, err, stream);
+    MgxStepArgs sa = step_args(grid, agents, rng, step_count, actions, aux, obs, dir, reward, terminated, truncated, err);
+    sa.auto_reset = ar;
+    return step_common(spec, batch, sa, stream);
 }
 
 int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, const MgxAutoReset *ar, MgxCell *grid,
                           uint8_t *agents, uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                           uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                           int32_t *err, void *stream) {
-    if (!ar) return MGX_ERR_INVALID_ARGUMENT;
-    return step_common(true, false, spec, batch, steps, ar, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs, dir, reward,
-                       terminated, truncated, err, stream);
+    if (!ar || steps < 0) return MGX_ERR_INVALID_ARGUMENT;
+    MgxStepArgs sa = step_args(grid, agents, rng, step_count, actions, aux, obs, dir, reward, terminated, truncated, err);
+    sa.auto_reset = ar;
+    if (steps == 0) return check_spec(spec, batch, true);
+    sa.steps = steps;
+    return step_common(spec, batch, sa, stream);
 }
 
 int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar, MgxCell *grid, uint8_t *agents,
                      uint64_t *rng, int32_t *step_count, const int8_t *actions, uint8_t *aux,
                      uint8_t *obs_one_hot, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                      int32_t *err, void *stream) {
-    return step_common(false, true, spec, batch, 1, ar, nullptr, nullptr, nullptr, grid, agents, rng, step_count, actions, aux, obs_one_hot, dir, reward,
-                       terminated, truncated, err, stream);
+    MgxStepArgs sa = step_args(grid, agents, rng, step_count, actions, aux, obs_one_hot, dir, reward, terminated, truncated, err);
+    sa.auto_reset = ar; sa.one_hot = 1;
+    return step_common(spec, batch, sa, stream);
 }
 
 int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,
@@ -310,8 +374,108 @@ int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *ge
                       uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
                       int32_t *err, int32_t *episode, uint8_t *was_reset, void *stream) {
     if (!gen) return MGX_ERR_INVALID_ARGUMENT;
-    return step_common(false, false, spec, batch, 1, nullptr, gen, episode, was_reset, grid, agents, rng, step_count, actions,
-                       aux, obs, dir, reward, terminated, truncated, err, stream);
+    MgxStepArgs sa = step_args(grid, agents, rng, step_count, actions, aux, obs, dir, reward, terminated, truncated, err);
+    sa.generate = gen; sa.episode = episode; sa.was_reset = was_reset;
+    return step_common(spec, batch, sa, stream);
 }
+
+// ---- sub-shard stepping (include/mgx.h) ------------------------------------------------------------------------------
+static constexpr int64_t kSubShardAlign = 64;      // envs: keeps every block's tensors 16-byte aligned and its wavefronts' tiles as in the whole
+
+static void sub_shard_cuts(int64_t B, int parts, int64_t *cuts /* [parts + 1] */) {
+    cuts[0] = 0;
+    for (int i = 1; i < parts; ++i) {
+        int64_t c = ((B * i / parts + kSubShardAlign - 1) / kSubShardAlign) * kSubShardAlign;
+        cuts[i] = c > B ? B : c;
+    }
+    cuts[parts] = B;
+}
+
+int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t *parts) {
+    if (!parts) return MGX_ERR_INVALID_ARGUMENT;
+    *parts = 1;
+    MgxStepArgs sa{};
+    if (args) sa = *args; else sa.steps = 1;
+    if (sa.steps != 1) return MGX_OK;                                  // rollouts: one launch, nothing to chain
+    int rc = check_spec(spec, batch, false, sa.one_hot != 0);
+    if (rc) return rc;
+    if (batch == 0) return MGX_OK;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGX_ERR_LAUNCH;
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    const int simds = 4 * cus;                                         // CDNA: four SIMDs per CU
+    KernelArgs ka{};
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, sa.one_hot != 0);
+    if (rc) return rc;
+    const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
+    // below two wavefronts per SIMD (or a view per lane of two waves per SIMD) a launch is a lone wave's instruction chain:
+    // splitting it only adds launches
+    if (nwaves < 2 * (int64_t)simds || batch * spec->num_agents < 64 * (int64_t)simds) return MGX_OK;
+    int occ = 0;
+    rc = step_common(spec, batch, sa, nullptr, &occ);                  // workgroups of THIS instantiation resident per CU
+    if (rc) return rc;
+    const int64_t resident = (int64_t)cus * (occ > 0 ? occ : 1) * (threads / 64);
+    const double rounds = (double)nwaves / (double)resident;
+    *parts = (rounds >= 0.75 && rounds <= 1.5) ? 4 : 2;               // about ONE round: load / compute / drain in lock step
+    const int64_t max_parts = batch / kSubShardAlign;
+    if (*parts > max_parts) *parts = (int32_t)(max_parts < 1 ? 1 : max_parts);
+    return MGX_OK;
+}
+
+int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t parts, void *const *streams,
+                    void *fork_event) {
+    if (!args || !spec || parts < 1 || parts > 64 || !streams || args->steps != 1) return MGX_ERR_INVALID_ARGUMENT;
+    if (parts > 1 && batch / kSubShardAlign < parts) return MGX_ERR_INVALID_ARGUMENT;
+    int64_t cuts[65];
+    sub_shard_cuts(batch, parts, cuts);
+    const int64_t A = spec->num_agents, HW = (int64_t)spec->width * spec->height, V2 = (int64_t)spec->view_size * spec->view_size;
+    const int64_t obs_cell = args->one_hot ? 21 : 3;
+    for (int k = 0; k < parts; ++k) {
+        const int64_t lo = cuts[k], n = cuts[k + 1] - lo;
+        if (n <= 0) continue;
+        hipStream_t st = static_cast<hipStream_t>(streams[k]);
+        if (fork_event && hipStreamWaitEvent(st, static_cast<hipEvent_t>(fork_event), 0) != hipSuccess) {
+            g_last_hip_error = (int)hipGetLastError();
+            return MGX_ERR_LAUNCH;
+        }
+        MgxStepArgs sa = *args;
+        MgxAutoReset ar;
+        MgxLayoutGen gen;
+        sa.grid = args->grid ? args->grid + lo * HW : nullptr;
+        sa.agents = args->agents ? args->agents + lo * A * MGX_AGENT_STRIDE : nullptr;
+        sa.rng = args->rng ? args->rng + lo * 4 : nullptr;
+        sa.step_count = args->step_count ? args->step_count + lo : nullptr;
+        sa.aux = args->aux ? args->aux + lo * MGX_AUX_BYTES : nullptr;
+        sa.actions = args->actions ? args->actions + lo * A : nullptr;
+        sa.hook_order = args->hook_order ? args->hook_order + lo * A : nullptr;
+        sa.obs = args->obs ? args->obs + lo * A * V2 * obs_cell : nullptr;
+        sa.dir = args->dir ? args->dir + lo * A : nullptr;
+        sa.reward = args->reward ? args->reward + lo * A : nullptr;
+        sa.terminated = args->terminated ? args->terminated + lo * A : nullptr;
+        sa.truncated = args->truncated ? args->truncated + lo : nullptr;
+        sa.episode = args->episode ? args->episode + lo : nullptr;
+        sa.was_reset = args->was_reset ? args->was_reset + lo : nullptr;
+        if (args->auto_reset) {
+            ar = *args->auto_reset;
+            ar.first_env += lo;
+            ar.episode = ar.episode ? ar.episode + lo : nullptr;
+            ar.was_reset = ar.was_reset ? ar.was_reset + lo : nullptr;
+            sa.auto_reset = &ar;
+        }
+        if (args->generate) {
+            gen = *args->generate;
+            gen.gen_state = gen.gen_state ? gen.gen_state + lo * 6 : nullptr;
+            sa.generate = &gen;
+        }
+        const int rc = step_common(spec, n, sa, st);
+        if (rc) return rc;
+    }
+    return MGX_OK;
+}
+
+void mgx_internal_set_hip_error(int e) { g_last_hip_error = e; }   // (not in include/mgx.h: mgx_layout_gen.hip / mgx_aux.hip report
+                                                                    // their failed launches through mgx_last_hip_error() too)
 
 }  // extern "C"

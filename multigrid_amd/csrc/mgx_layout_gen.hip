@@ -26,6 +26,8 @@
 
 #include "mgx_layout_gen.h"
 
+extern "C" void mgx_internal_set_hip_error(int e);      // mgx_kernels.hip: what mgx_last_hip_error() reports
+
 namespace {
 
 using namespace mgx;
@@ -61,6 +63,10 @@ __global__ __launch_bounds__(64) void reset_generate_kernel(const GenArgs a) {
     const uint64_t mask = __builtin_amdgcn_ballot_w64(done);
     if (mask == 0) return;
     copy_blank(a.gen, a.grid, e0, HWB, mask, lane);                                  // (1) all lanes
+    // (2) overwrites cells that OTHER lanes of this wavefront have just stored: their stores must have left the wave first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                              // vmcnt(0)
+    __builtin_amdgcn_wave_barrier();
     if (!done) return;
     NpGen lay, npr;                                                                  // (2) the owning lane
     uint64_t *gs = a.gen.gen_state + b * 6;
@@ -75,7 +81,6 @@ __global__ __launch_bounds__(64) void reset_generate_kernel(const GenArgs a) {
     a.episode[b] += 1;
 }
 
-int g_gen_hip_error = 0;
 
 inline bool misaligned(const void *p, uintptr_t al) { return (reinterpret_cast<uintptr_t>(p) & (al - 1)) != 0; }
 
@@ -115,7 +120,7 @@ int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *g
     hipLaunchKernelGGL(reset_generate_kernel, dim3((unsigned)blocks), dim3(64), (size_t)(64 * 2 * spec->num_agents),
                        static_cast<hipStream_t>(stream), ga);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { g_gen_hip_error = (int)e; return MGX_ERR_LAUNCH; }
+    if (e != hipSuccess) { mgx_internal_set_hip_error((int)e); return MGX_ERR_LAUNCH; }
     return MGX_OK;
 }
 

@@ -411,11 +411,14 @@ MGX_HD bool spec_needs_fallback(uint64_t m_bad, uint64_t m_conflict, uint64_t m_
 // post-step agent rows; `aux` is the env's 16-byte hook state (include/mgx.h).  The observation is not affected (the
 // reference renders before the hook); `terminated` / `reward` outputs are.
 //   BlockedUnlockPickup  envs/blockedunlockpickup.py:166-175
-//   RedBlueDoors         envs/redbluedoors.py:170-187  (agents in ascending index = a dict built in agent order)
+//   RedBlueDoors         envs/redbluedoors.py:170-187
 //   LockedHallway        envs/locked_hallway.py:203-227
+// `order`: the two hooks above iterate `actions.items()`, i.e. the insertion order of the caller's dict; A agent indices in that
+// order, or nullptr for ascending index (a dict built in agent order).  It matters when two agents toggle the same door in one
+// step (who ends the episode / who is paid for the unlock).  BlockedUnlockPickup iterates self.agents (ascending).
 template <class Dirty>
 MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint64_t *rows, const int8_t *act,
-                           uint8_t *aux, int32_t step_count, double *rew, Dirty dirty) {
+                           uint8_t *aux, int32_t step_count, double *rew, Dirty dirty, const uint8_t *order = nullptr) {
     const int A = cf.A;
     if (env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP) {
         const uint32_t want = (uint32_t)aux[0] | ((uint32_t)aux[1] << 8);
@@ -423,8 +426,9 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             if ((row_carry(rows[a]) & 0xffffu) == want) on_success(cf, rows, a, step_count, rew);
     } else if (env_kind == MGX_KIND_REDBLUEDOORS) {
         const int boff = (aux[1] * cf.W + aux[0]) * kCellBytes, roff = (aux[3] * cf.W + aux[2]) * kCellBytes;
-        for (int a = 0; a < A; ++a) {
-            if (act[a] != ACT_TOGGLE) continue;
+        for (int ko = 0; ko < A; ++ko) {                                        // `for agent_id, action in actions.items()`
+            const int a = order ? (int)order[ko] : ko;
+            if (a >= A || act[a] != ACT_TOGGLE) continue;
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if (fx != aux[0] || fy != aux[1]) continue;                         // fwd_obj == self.blue_door
@@ -439,14 +443,15 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
     } else if (env_kind == MGX_KIND_LOCKEDHALLWAY) {
         // aux[0] < 0x80: the explicit format (n <= 6 doors with their positions); aux[0] & 0x80: the geometric format for
         // more rooms -- doors sit in the middle of their room's wall (add_door(..., rand_pos=False)), so door k = (row k/2,
-        // side k%2) is at x = side ? 2(rs-1) : rs-1, y = row(rs-1) + rs/2; 16-bit unlocked mask in aux[1], aux[2];
+        // side k%2) is at x = side ? 2(rs-1) : rs-1, y = row(rs-1) + (rs-1)/2 (roomgrid.py:108: (top + bottom) // 2); 16-bit unlocked mask in aux[1], aux[2];
         // aux[3] = rs; aux[4] = len(self.rooms) (a dict keyed by colour: < n when colours repeat, include/mgx.h)
         const bool geo = (aux[0] & 0x80) != 0;
         const int nd = aux[0] & 0x7f, rs = aux[3];
         const int target = geo ? (int)aux[4] : nd;
         uint32_t mask = geo ? ((uint32_t)aux[1] | ((uint32_t)aux[2] << 8)) : (uint32_t)aux[1];
-        for (int a = 0; a < A; ++a) {
-            if (act[a] != ACT_TOGGLE) continue;
+        for (int ko = 0; ko < A; ++ko) {                                        // `for agent_id, action in actions.items()`
+            const int a = order ? (int)order[ko] : ko;
+            if (a >= A || act[a] != ACT_TOGGLE) continue;
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;
@@ -455,7 +460,7 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             int k = -1;
             if (geo) {
                 const int side = (fx == 2 * (rs - 1)) ? 1 : ((fx == rs - 1) ? 0 : -1);
-                const int yy = fy - rs / 2;
+                const int yy = fy - (rs - 1) / 2;
                 if (side >= 0 && yy >= 0 && yy % (rs - 1) == 0) k = 2 * (yy / (rs - 1)) + side;
                 if (k >= nd) k = -1;
             } else {

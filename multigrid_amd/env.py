@@ -272,12 +272,20 @@ class MultiGridEnv:
         """multigrid/base.py:303-346.  Returns (observations, rewards, terminations, truncations, infos)."""
         A = self.num_agents
         act = np.full((1, A), NO_ACTION, dtype=np.int8)
+        keys = []
         for i, a in actions.items():
             if isinstance(i, (int, np.integer)) and 0 <= i < A:          # other keys are never visited (base.py:402-404)
                 a = int(a)
                 act[0, i] = a if 0 <= a <= 127 else 127                   # out of range -> "unknown action" on device
+                keys.append(int(i))
         benv = self._benv
-        obs, dirs, rew, term, trunc = benv.step(torch.from_numpy(act).to(benv.device))
+        hook_order = None
+        if self.env_kind in ("redbluedoors", "lockedhallway") and keys != sorted(keys):
+            # the subclass hooks iterate `actions.items()` (redbluedoors.py:176, locked_hallway.py:210): the dict's insertion
+            # order decides who is visited first when two agents toggle the same door in one step
+            order = keys + [i for i in range(A) if i not in keys]        # (absent agents carry NO_ACTION: skipped anyway)
+            hook_order = torch.tensor([order], dtype=torch.uint8).to(benv.device)
+        obs, dirs, rew, term, trunc = benv.step(torch.from_numpy(act).to(benv.device), hook_order=hook_order)
         try:
             benv.check_errors()
         except ValueError:

@@ -396,7 +396,7 @@ def make_aux(kind: str, grid_hwc: np.ndarray, target=None) -> np.ndarray:
                 aux[2 + 2 * k], aux[3 + 2 * k] = x, y
         else:                                                    # geometric format: doors sit mid-wall, two per row of rooms
             rs = min(x for x, _ in doors) + 1
-            want = sorted(((rs - 1) * (1 + side), row * (rs - 1) + rs // 2) for row in range(len(doors) // 2) for side in (0, 1))
+            want = sorted(((rs - 1) * (1 + side), row * (rs - 1) + (rs - 1) // 2) for row in range(len(doors) // 2) for side in (0, 1))
             if doors != want or len(doors) > 16:
                 raise ValueError("LockedHallway with more than 6 doors: they must sit mid-wall, two per row (at most 16)")
             aux[0] = 0x80 | len(doors)

@@ -379,41 +379,86 @@ class HipBackend:
         return _lib.MgxLayoutGen(_lib.GEN_KINDS[gen["kind"]], int(gen.get("room_size", 0)), int(sx), int(sy), int(sd),
                                  gen["blank"].data_ptr(), gen["gen_state"].data_ptr())
 
+    def step_args(self, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
+                  auto_reset=None, one_hot: bool = False, generate=None):
+        """The MgxStepArgs of one env's step (include/mgx.h) with every pointer but `actions` / `hook_order` resolved.
+        Returns (args, keep): `keep` holds the structs `args` points into."""
+        ar = self._auto_reset_struct(auto_reset) if auto_reset is not None else None
+        sa = _lib.MgxStepArgs()
+        sa.grid, sa.agents, sa.rng, sa.step_count = grid.data_ptr(), agents.data_ptr(), _ptr(rng), step_count.data_ptr()
+        sa.aux, sa.err = _ptr(target), _ptr(err)
+        sa.obs, sa.dir, sa.reward = obs.data_ptr(), _ptr(dirs), reward.data_ptr()
+        sa.terminated, sa.truncated = terminated.data_ptr(), truncated.data_ptr()
+        sa.steps, sa.one_hot = 1, int(bool(one_hot))
+        gen = None
+        if ar is not None:
+            sa.auto_reset = C.pointer(ar)
+        if generate is not None:                    # generate = (gen dict, episode, was_reset): mgx_step_generate
+            gd, episode, was_reset = generate
+            gen = self._layout_gen_struct(gd)
+            sa.generate = C.pointer(gen)
+            sa.episode, sa.was_reset = episode.data_ptr(), _ptr(was_reset)
+        return sa, (ar, gen, self.sc)
+
     def bind_step(self, B, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
                   auto_reset=None, one_hot: bool = False, generate=None):
-        """Pre-bound launcher for a policy-in-the-loop caller: every pointer except `actions` is resolved once, so a call
-        costs one ctypes transition + the kernel launch.  The tensors must stay alive and in place (they are the env's
-        own buffers).  Returns f(actions) enqueuing one step on torch's current stream."""
-        L = _lib.lib()
-        ar = self._auto_reset_struct(auto_reset) if auto_reset is not None else None
-        tail = ()
-        if generate is not None:                    # generate = (gen dict, episode, was_reset): mgx_step_generate
-            gen, episode, was_reset = generate
-            ar = self._layout_gen_struct(gen)       # (kept alive below, like the auto-reset struct)
-            fn, head, what = L.mgx_step_generate, (C.byref(self.sc), B, C.byref(ar)), "mgx_step_generate"
-            tail = (episode.data_ptr(), was_reset.data_ptr() if was_reset is not None else None)
-        elif ar is None and not one_hot:
-            fn, head, what = L.mgx_step, (C.byref(self.sc), B), "mgx_step"
-        else:
-            fn = L.mgx_step_one_hot if one_hot else L.mgx_step_autoreset
-            head, what = (C.byref(self.sc), B, C.byref(ar) if ar is not None else None), fn.__name__
-        pre = (grid.data_ptr(), agents.data_ptr(), rng.data_ptr() if rng is not None else None, step_count.data_ptr())
-        post = (target.data_ptr() if target is not None else None, obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(),
-                terminated.data_ptr(), truncated.data_ptr(), err.data_ptr() if err is not None else None) + tail
+        """Pre-bound launcher for a policy-in-the-loop caller: every pointer except `actions` (and the optional `hook_order`)
+        is resolved once into one MgxStepArgs, so a call costs one 4-argument ctypes transition (mgx_step_ex) + the kernel
+        launch.  The tensors must stay alive and in place (they are the env's own buffers).  Returns f(actions, hook_order=None)
+        enqueuing one step on torch's current stream."""
+        fn = _lib.lib().mgx_step_ex
+        sa, keep = self.step_args(grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
+                                  auto_reset, one_hot, generate)
+        spec_ref, args_ref = C.byref(self.sc), C.byref(sa)
         dev, index = grid.device, grid.device.index
-        keep = (ar, self.sc)                                 # the structs the byref()s point into
         current_device, current_stream, device_ctx = torch.cuda.current_device, torch.cuda.current_stream, torch.cuda.device
 
-        def step(actions):
+        def step(actions, hook_order=None):
+            sa.actions = actions.data_ptr()
+            sa.hook_order = hook_order.data_ptr() if hook_order is not None else None
             if current_device() == index:
-                rc = fn(*head, *pre, actions.data_ptr(), *post, current_stream(dev).cuda_stream)
+                rc = fn(spec_ref, B, args_ref, current_stream(dev).cuda_stream)
             else:
                 with device_ctx(dev):
-                    rc = fn(*head, *pre, actions.data_ptr(), *post, current_stream(dev).cuda_stream)
+                    rc = fn(spec_ref, B, args_ref, current_stream(dev).cuda_stream)
             if rc:
-                _lib.check(rc, what)
-        step._keep = keep
+                _lib.check(rc, "mgx_step_ex")
+        step._keep = (sa, keep)
         return step
+
+    def bind_chains(self, B, parts, streams, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated,
+                    truncated, auto_reset=None, one_hot: bool = False, generate=None):
+        """The same step issued as `parts` launches over consecutive blocks of the batch on `streams` (mgx_step_chains): the
+        chains of consecutive calls run independently.  Returns f(actions, fork_event, hook_order=None); nothing is joined."""
+        fn = _lib.lib().mgx_step_chains
+        sa, keep = self.step_args(grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
+                                  auto_reset, one_hot, generate)
+        spec_ref, args_ref = C.byref(self.sc), C.byref(sa)
+        handles = (C.c_void_p * parts)(*[s.cuda_stream for s in streams])
+        dev = grid.device
+
+        def step(actions, fork_event, hook_order=None):
+            sa.actions = actions.data_ptr()
+            sa.hook_order = hook_order.data_ptr() if hook_order is not None else None
+            with torch.cuda.device(dev):
+                rc = fn(spec_ref, B, args_ref, parts, handles, fork_event)
+            if rc:
+                _lib.check(rc, "mgx_step_chains")
+        step._keep = (sa, keep, handles, streams)
+        return step
+
+    def sub_shards(self, B, auto_reset: bool = False, one_hot: bool = False, generate: bool = False) -> int:
+        """mgx_sub_shards: how many independent chains the step of `B` envs is best issued as on this device."""
+        sa = _lib.MgxStepArgs()
+        sa.steps, sa.one_hot = 1, int(bool(one_hot))
+        ar = _lib.MgxAutoReset()
+        if auto_reset and not generate:
+            sa.auto_reset = C.pointer(ar)            # (only its presence matters: it selects the kernel instantiation)
+        out = C.c_int32(1)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mgx_sub_shards(C.byref(self.sc), B, C.byref(sa), C.byref(out))
+        _lib.check(rc, "mgx_sub_shards")
+        return int(out.value)
 
     def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
                 truncated, auto_reset=None):

@@ -105,8 +105,11 @@ class RefEnv:
         return gen_obs_ref(self.grid_state, self.agent_state, self.spec.view_size,
                            bool(self.spec.see_through_walls))
 
-    def step(self, actions):
+    def step(self, actions, hook_order=None):
+        """hook_order: agent indices in the insertion order of the caller's actions dict (None = ascending)."""
         A, v = self.spec.num_agents, self.spec.view_size
+        ho = None if hook_order is None else np.ascontiguousarray(hook_order, dtype=np.uint8)
+        assert ho is None or ho.shape == (A,)
         act = np.ascontiguousarray(actions, dtype=np.int8)
         obs = np.empty((A, v, v, 3), dtype=np.int64)
         direction = np.empty(A, dtype=np.int64)
@@ -118,7 +121,8 @@ class RefEnv:
             C.byref(self.spec), _p(self.grid_state, C.c_int64), _p(self.agent_state, C.c_int64),
             _p(self.rng, C.c_uint64), _p(self.step_count, C.c_int64), _p(act, C.c_int8),
             _p(self.target, C.c_int64), _p(obs, C.c_int64), _p(direction, C.c_int64), _p(reward, C.c_double),
-            _p(terminated, C.c_uint8), _p(truncated, C.c_uint8), _p(order, C.c_int))
+            _p(terminated, C.c_uint8), _p(truncated, C.c_uint8), _p(order, C.c_int),
+            _p(ho, C.c_uint8) if ho is not None else None)
         if rc == ERR_UNKNOWN_ACTION:
             raise ValueError("Unknown action")
         if rc:
@@ -134,9 +138,10 @@ def step_outputs(spec: dict, B: int):
             np.zeros((B, A), dtype=np.uint8), np.zeros((B,), dtype=np.uint8))
 
 
-def step_batch(spec: dict, grid, agents, rng, step_count, actions, target=None, nthreads: int = 1, out=None):
+def step_batch(spec: dict, grid, agents, rng, step_count, actions, target=None, nthreads: int = 1, out=None, hook_order=None):
     """Product-layout batched step on numpy arrays (modified in place; `target` = aux u8[B,16], include/mgx.h).
-    Returns (obs, dir, reward, terminated, truncated) -- the arrays of `out` (step_outputs) when given."""
+    Returns (obs, dir, reward, terminated, truncated) -- the arrays of `out` (step_outputs) when given.
+    hook_order u8[B,A] | None: the env hooks' visiting order (the caller's dict order; None = ascending index)."""
     sp = make_spec(spec)
     B = grid.shape[0]
     A, v = sp.num_agents, sp.view_size
@@ -156,7 +161,7 @@ def step_batch(spec: dict, grid, agents, rng, step_count, actions, target=None, 
         C.byref(sp), C.c_int64(B), _p(grid, C.c_uint8), _p(agents, C.c_uint8), _p(rng, C.c_uint64),
         _p(step_count, C.c_int32), _p(actions, C.c_int8), tgt, _p(obs, C.c_uint8), _p(d, C.c_uint8),
         _p(reward, C.c_double), _p(terminated, C.c_uint8), _p(truncated, C.c_uint8), C.byref(err_env),
-        int(nthreads))
+        int(nthreads), _p(np.ascontiguousarray(hook_order, dtype=np.uint8), C.c_uint8) if hook_order is not None else None)
     if rc == ERR_UNKNOWN_ACTION:
         raise ValueError(f"Unknown action (env {err_env.value})")
     if rc:

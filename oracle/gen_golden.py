@@ -21,6 +21,9 @@ Array conventions in the .npz files (reference layouts, narrowed to the smallest
     grid         (T,W,H,3), agents (T,A,9)  post-step state
     rng_final    (4,) u64
     spec_json    JSON: constructor-level parameters needed to rebuild the EnvSpec
+    hook_order   (T,A) u8, only in the *_dictorder fixtures: the insertion order of the keys of the actions dict handed to
+                 step() at step t (the RedBlueDoors / LockedHallway hooks iterate actions.items(), redbluedoors.py:176,
+                 locked_hallway.py:210); every other fixture builds its dict in ascending agent order
 """
 from __future__ import annotations
 
@@ -113,7 +116,7 @@ def door_pos(env, color):
     return int(x), int(y)
 
 
-def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, script=None, note=""):
+def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, script=None, note="", dict_orders=None):
     obs0, _ = env.reset(seed=seed)
     if edit is not None:
         edit(env)
@@ -137,7 +140,8 @@ def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, scri
     log = {k: [] for k in keys}
     for t in range(T):
         log["order"].append(clone_order(env.np_random, A))
-        act = {i: int(actions[t, i]) for i in range(A) if actions[t, i] >= 0}
+        key_order = range(A) if dict_orders is None else [int(i) for i in dict_orders[t]]
+        act = {i: int(actions[t, i]) for i in key_order if actions[t, i] >= 0}
         obs, rew, term, trunc, _ = env.step(act)
         log["obs"].append(np.stack([obs[i]["image"] for i in range(A)]))
         log["direction"].append([int(obs[i]["direction"]) for i in range(A)])
@@ -148,6 +152,8 @@ def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, scri
         log["grid"].append(env.grid.state.copy())
         log["agents"].append(np.asarray(env.agent_states).copy())
     rec["actions"] = actions
+    if dict_orders is not None:
+        rec["hook_order"] = np.asarray(dict_orders, dtype=np.uint8)[:T]
     for k in keys:
         arr = np.asarray(log[k])
         rec[k] = arr.astype(np.float64) if k == "reward" else narrow(arr)
@@ -276,6 +282,7 @@ def main():
     record_layouts()
     record_wrappers()
     record_hook_envs()
+    record_dict_order()
 
 
 def face(env, i, target_xy, carrying=None):
@@ -342,6 +349,74 @@ def record_hook_envs():
            script=[[N] * 8, [T] + [N] * 7, [T] * 8, [T] * 8, [F] * 8, [T] * 8, [L] * 8, [T] * 8] +
                   np.random.default_rng(6).integers(0, 7, size=(30, 8)).tolist(),
            note="8 rooms, 6 colours: rooms dict keyed by colour; every agent unlocks a door")
+
+
+def record_dict_order():
+    """The env hooks visit the agents in the insertion order of the caller's dict (redbluedoors.py:176, locked_hallway.py:210).
+    Cases where that order decides the result, plus random rollouts with a random key order every step."""
+    from multigrid.core.world_object import Key
+    T, L, R, F, P, D, N = 5, 0, 1, 2, 3, 4, 6
+
+    # RedBlueDoors, failure 'all', three agents stacked in front of the CLOSED blue door, all toggle in one step: the door
+    # goes closed -> open -> closed -> open in handle_actions, then the hook fails the FIRST toggler in dict order only (it
+    # closes the blue door object, so the next ones find it closed)
+    def rbd_three(env):
+        face(env, 0, door_pos(env, "blue"))
+        for i in (1, 2):
+            env.agents[i].state.pos = env.agents[0].state.pos
+            env.agents[i].state.dir = env.agents[0].state.dir
+    for tag, orders in (("rev", [[2, 1, 0]] * 6), ("mid", [[1, 2, 0], [1, 0, 2], [2, 0, 1], [0, 2, 1], [1, 2, 0], [2, 1, 0]])):
+        record(f"rbd_a3_dictorder_{tag}",
+               make_env("MultiGrid-RedBlueDoors-8x8-v0", agents=3, failure_termination_mode="all"), "redbluedoors", 91, None, None,
+               edit=rbd_three, script=[[T, T, T], [N, N, N], [T, T, T], [T, N, T], [T, T, N], [T, T, T]], dict_orders=orders,
+               note="three togglers of the blue door in one step: the first in DICT order fails (failure 'all')")
+
+    # LockedHallway, own rewards: agent 0 (with the key) and agent 1 face the same locked door from the hallway and both toggle:
+    # whoever comes first in dict order is paid for the unlock
+    def lh_two(env):
+        doors = sorted((int(x), int(y)) for x, y in np.argwhere(env.grid.state[..., 0] == 4))
+        colors = ["red", "green", "blue", "purple", "yellow", "grey"]
+        x, y = doors[0]
+        face(env, 0, (x, y), carrying=Key(colors[int(env.grid.state[x, y, 1])]))
+        env.agents[1].state.pos = env.agents[0].state.pos
+        env.agents[1].state.dir = env.agents[0].state.dir
+    for tag, orders in (("rev", [[1, 0]] * 8), ("fwd", [[0, 1]] * 8)):
+        record(f"lh_2rooms_a2_dictorder_{tag}", make_env("MultiGrid-LockedHallway-2Rooms-v0", agents=2, joint_reward=False),
+               "lockedhallway", 92, None, None, edit=lh_two,
+               script=[[N, N], [T, T], [T, T], [T, N], [N, T], [T, T], [F, F], [T, T]], dict_orders=orders,
+               note="two togglers of one door in one step: the first in DICT order is paid (joint_reward=False)")
+
+    # random rollouts, a random permutation of the keys every step, agents kept near the doors by a biased action mix
+    def perm_orders(T_, A, seed):
+        r = np.random.default_rng(seed)
+        return np.stack([r.permutation(A) for _ in range(T_)]).astype(np.uint8)
+
+    def rbd_near(env):
+        face(env, 0, door_pos(env, "blue")); face(env, 1, door_pos(env, "red"))
+        env.agents[2].state.pos = env.agents[0].state.pos; env.agents[2].state.dir = env.agents[0].state.dir
+    tog = np.random.default_rng(94).choice([T, T, T, L, R, F, N], size=(200, 3)).astype(np.int8)
+    record("rbd_a3_random_dictorder",
+           make_env("MultiGrid-RedBlueDoors-6x6-v0", agents=3, failure_termination_mode="all", success_termination_mode="all"),
+           "redbluedoors", 93, None, None, edit=rbd_near, script=tog, dict_orders=perm_orders(200, 3, 95),
+           note="toggle-heavy random rollout, random dict order every step")
+    record("lh_4rooms_a3_random_dictorder", make_env("MultiGrid-LockedHallway-4Rooms-v0", agents=3, joint_reward=False),
+           "lockedhallway", 96, 300, np.random.default_rng(397), p_missing=0.05, dict_orders=perm_orders(300, 3, 98),
+           note="random rollout, random dict order every step")
+
+    # ADVICE r2: more than 6 rooms with an EVEN room size -- the doors sit at (top + bottom) // 2 = row (rs-1) + (rs-1)//2
+    def lh_unlock(env):
+        doors = sorted((int(x), int(y)) for x, y in np.argwhere(env.grid.state[..., 0] == 4))
+        colors = ["red", "green", "blue", "purple", "yellow", "grey"]
+        for i, (x, y) in enumerate(doors[:env.num_agents]):
+            face(env, i, (x, y), carrying=Key(colors[int(env.grid.state[x, y, 1])]))
+    for rs in (4, 6):
+        _MAKE_COUNT[0] += 1
+        ref_envs.LockedHallwayEnv._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
+        record(f"lh_8rooms_rs{rs}_a4", ref_envs.LockedHallwayEnv(num_rooms=8, room_size=rs, agents=4, joint_reward=True),
+               "lockedhallway", 99, None, None, edit=lh_unlock,
+               script=[[N] * 4, [T] + [N] * 3, [T] * 4, [T] * 4, [F] * 4, [T] * 4, [L] * 4, [T] * 4] +
+                      np.random.default_rng(7).integers(0, 7, size=(30, 4)).tolist(),
+               note=f"8 rooms of even size {rs}: mid-wall doors at (top + bottom) // 2")
 
 
 def record_wrappers():

@@ -329,11 +329,15 @@ static int handle_actions(const MgoSpec *sp, int64_t *grid_state, int64_t *agent
 }
 
 /* base.py:303-346 step (+ envs/blockedunlockpickup.py:166-175 post-step hook).  Single env, reference
- * layout.  target: (3,) encoding of the BlockedUnlockPickup target box (ignored for KIND_EMPTY). */
+ * layout.  target: (3,) encoding of the BlockedUnlockPickup target box (ignored for KIND_EMPTY).
+ * hook_order: the order in which the RedBlueDoors / LockedHallway hooks visit the agents = the insertion order of the
+ * caller's `actions` dict (`for agent_id, action in actions.items()`, redbluedoors.py:176, locked_hallway.py:210): A agent
+ * indices, or NULL for ascending index (a dict built in agent order).  Agents absent from the dict carry action -1 and are
+ * skipped wherever they are listed. */
 int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, uint64_t rng[4],
                  int64_t *step_count, const int8_t *actions, int64_t *target /* aux[MGO_AUX] */,
                  int64_t *obs, int64_t *direction, double *rewards, uint8_t *terminated, uint8_t *truncated,
-                 int *order_out) {
+                 int *order_out, const uint8_t *hook_order) {
     const int A = sp->num_agents;
     if (A < 1 || A > MGO_MAX_AGENTS) return -1;
     *step_count += 1;                                                  /* base.py:333 */
@@ -363,8 +367,9 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
     if (sp->env_kind == KIND_REDBLUEDOORS) {                           /* redbluedoors.py:170-187 */
         int64_t *aux = target;
         const int W = sp->width, H = sp->height;
-        for (int a = 0; a < A; ++a) {                                  /* `for agent_id, action in actions.items()` */
-            if (actions[a] != A_TOGGLE) continue;                      /* absent (-1) or another action */
+        for (int k = 0; k < A; ++k) {                                  /* `for agent_id, action in actions.items()` */
+            const int a = hook_order ? hook_order[k] : k;
+            if (a >= A || actions[a] != A_TOGGLE) continue;            /* absent (-1) or another action */
             const int64_t *s = agent_state + (size_t)a * AS_DIM;
             int64_t fx = s[AS_X], fy = s[AS_Y];
             if (s[AS_DIR] >= 0 && s[AS_DIR] < 4) { fx += DIR_TO_VEC[s[AS_DIR]][0]; fy += DIR_TO_VEC[s[AS_DIR]][1]; }
@@ -387,15 +392,17 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
     if (sp->env_kind == KIND_LOCKEDHALLWAY) {                          /* locked_hallway.py:203-227 */
         int64_t *aux = target;
         const int H = sp->height;
-        /* aux[0] & 0x80: the geometric door format for more than 6 rooms (the doors sit mid-wall: add_door(rand_pos=False)):
+        /* aux[0] & 0x80: the geometric door format for more than 6 rooms (the doors sit mid-wall: add_door(rand_pos=False),
+         * Room.set_door_pos: y = (top + bottom) // 2 = row (rs-1) + (rs-1) // 2, roomgrid.py:104-108, 116-118):
          * mask in aux[1] | aux[2] << 8, aux[3] = room_size, aux[4] = len(self.rooms) -- a dict keyed by colour, so
          * fewer than the number of doors when colours repeat (locked_hallway.py:166-176) */
         const int geo = ((int)aux[0] & 0x80) != 0;
         const int nd = (int)aux[0] & 0x7f, rs = (int)aux[3];
         const int n_rooms = geo ? (int)aux[4] : nd;
         int64_t mask = geo ? (aux[1] | (aux[2] << 8)) : aux[1];
-        for (int a = 0; a < A; ++a) {
-            if (actions[a] != A_TOGGLE) continue;
+        for (int ko = 0; ko < A; ++ko) {                               /* `for agent_id, action in actions.items()` */
+            const int a = hook_order ? hook_order[ko] : ko;
+            if (a >= A || actions[a] != A_TOGGLE) continue;
             const int64_t *s = agent_state + (size_t)a * AS_DIM;
             int64_t fx = s[AS_X], fy = s[AS_Y];
             if (s[AS_DIR] >= 0 && s[AS_DIR] < 4) { fx += DIR_TO_VEC[s[AS_DIR]][0]; fy += DIR_TO_VEC[s[AS_DIR]][1]; }
@@ -405,7 +412,7 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
             int d = -1;
             if (geo) {
                 for (int k = 0; k < nd; ++k) {
-                    const int64_t dx = (k & 1) ? 2 * (rs - 1) : rs - 1, dy = (int64_t)(k >> 1) * (rs - 1) + rs / 2;
+                    const int64_t dx = (k & 1) ? 2 * (rs - 1) : rs - 1, dy = (int64_t)(k >> 1) * (rs - 1) + (rs - 1) / 2;   /* roomgrid.py:108: (top + bottom) // 2 */
                     if (dx == fx && dy == fy) { d = k; break; }
                 }
             } else {
@@ -506,7 +513,7 @@ int mgo_max_threads(void) {
 int mgo_step_batch(const MgoSpec *sp, int64_t B, uint8_t *grid, uint8_t *agents, uint64_t *rng,
                    int32_t *step_count, const int8_t *actions, const uint8_t *target,
                    uint8_t *obs, uint8_t *dir, double *reward, uint8_t *terminated, uint8_t *truncated,
-                   int64_t *err_env, int nthreads) {
+                   int64_t *err_env, int nthreads, const uint8_t *hook_order /* u8[B,A] or NULL */) {
     const int W = sp->width, H = sp->height, A = sp->num_agents, v = sp->view_size;
     const size_t gsz = (size_t)W * H * 3, osz = (size_t)A * v * v * 3;
     int64_t bad = -1;
@@ -523,7 +530,8 @@ int mgo_step_batch(const MgoSpec *sp, int64_t B, uint8_t *grid, uint8_t *agents,
             int64_t sc = step_count[b];
             for (int k = 0; k < MGO_AUX; ++k) tgt[k] = target ? target[b * MGO_AUX + k] : 0;
             int rc = mgo_step_ref(sp, gs, as, rng + b * 4, &sc, actions + (size_t)b * A, tgt, ob, dirs,
-                                  reward + (size_t)b * A, terminated + (size_t)b * A, truncated + b, NULL);
+                                  reward + (size_t)b * A, terminated + (size_t)b * A, truncated + b, NULL,
+                                  hook_order ? hook_order + (size_t)b * A : NULL);
             step_count[b] = (int32_t)sc;
             pack_env(sp, gs, as, grid + b * gsz, agents + (size_t)b * A * 8);
             if (sp->env_kind == KIND_LOCKEDHALLWAY && target) {

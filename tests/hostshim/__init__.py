@@ -38,7 +38,7 @@ def _layouts():
     return layouts
 
 
-def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=False):
+def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=False, hook_order=None):
     """tile u8[H,W,3], rows8 u8[A,8], act i8[A], rng4 u64[4], target = aux u8[16]; all updated in place.
     Returns dict(obs, reward, terminated, truncated, order, rc, n_dirty)."""
     sc = spec.to_c()
@@ -52,7 +52,8 @@ def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=Fals
     rc = lib().shim_step_env(C.byref(sc), _p(tile, C.c_uint8), _p(over, C.c_uint8), _p(rows, C.c_uint64),
                              _p(act, C.c_int8), _p(rng4, C.c_uint64), C.byref(scnt), _p(target, C.c_uint8),
                              _p(rew, C.c_double), _p(term, C.c_uint8), _p(trunc, C.c_uint8), _p(order, C.c_uint8),
-                             C.byref(nd), int(force_serial))
+                             C.byref(nd), int(force_serial),
+                             _p(np.ascontiguousarray(hook_order, dtype=np.uint8), C.c_uint8) if hook_order is not None else None)
     obs = np.empty((A, v, v, 3), np.uint8)
     assert lib().shim_obs_env(C.byref(sc), _p(over, C.c_uint8), _p(rows, C.c_uint64), _p(obs, C.c_uint8)) == 0
     assert np.array_equal(_layouts().pack_cells(_layouts().unpack_cells(tile)), tile), "opaque bits out of date"

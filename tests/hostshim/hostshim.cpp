@@ -21,7 +21,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
                              uint64_t *rows /* A, updated */, const int8_t *act, uint64_t *rng /* 4, updated */,
                              int32_t *step_count, uint8_t *aux /* 16, updated */, double *rew /* A out */,
                              uint8_t *terminated /* A out */, uint8_t *truncated, uint8_t *order_out,
-                             int32_t *n_dirty, int force_serial) {
+                             int32_t *n_dirty, int force_serial, const uint8_t *hook_order /* A, or NULL */) {
     const StepCfg cf = make_cfg(*sp);
     const int A = cf.A, HWB = cf.H * cf.W * kCellBytes;
     std::vector<uint64_t> rnd(A);
@@ -86,7 +86,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
     for (int ai = 0; ai < A; ++ai) ovl[ai] = overlay_offset(cf, rows, ai);
 
     for (int a = 0; a < A; ++a) terminated[a] = 0;
-    post_step_hook(cf, sp->env_kind, tile, rows, act, aux, sc, rew, dirty);       // on the clean tile, like the kernel
+    post_step_hook(cf, sp->env_kind, tile, rows, act, aux, sc, rew, dirty, hook_order);   // on the clean tile, like the kernel
     const bool forced = sp->env_kind == MGX_KIND_LOCKEDHALLWAY && aux[15];
     for (int a = 0; a < A; ++a) terminated[a] = (uint8_t)(row_term(rows[a]) | forced);
     std::memcpy(tile_overlaid, tile, HWB);

@@ -67,6 +67,44 @@ def test_dict_api_replays_reference_from_reset(path):
     assert isinstance(info, dict)
 
 
+@pytest.mark.parametrize("path", [p for p in util.GOLDEN if "_dictorder" in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_dict_api_hooks_follow_the_dict_insertion_order(path):
+    """RedBlueDoors / LockedHallway visit the agents in the insertion order of the caller's dict (redbluedoors.py:176,
+    locked_hallway.py:210): the dict API must hand that order down (fixtures recorded from the reference with such dicts)."""
+    import torch
+    from multigrid_amd import layouts
+    z, d, spec = util.load_golden(path)
+    A = spec.num_agents
+    if d["env_kind"] == "redbluedoors":
+        env = mg.RedBlueDoorsEnv(size=spec.height, agents=A, failure_termination_mode=d["failure_termination_mode"],
+                                 success_termination_mode=d["success_termination_mode"], device="cpu", _backend=backend_factory)
+    else:
+        env = mg.LockedHallwayEnv(num_rooms=len(d["doors"]), agents=A, joint_reward=d["joint_reward"], device="cpu",
+                                  _backend=backend_factory)
+    env.reset(seed=0)
+    assert env.spec == spec
+    env._benv.load_state(layouts.grid_to_product(z["grid0"]), layouts.pack_agents(z["agents0"]),
+                         rng=util.rng_words_lohi(z["rng0"]), aux=util.golden_aux(d))
+    for t in range(z["actions"].shape[0]):
+        act = {int(i): int(z["actions"][t, i]) for i in z["hook_order"][t] if z["actions"][t, i] >= 0}
+        obs, rew, term, trunc, _ = env.step(act)
+        for i in range(A):
+            assert rew[i] == z["reward"][t][i], (t, i)
+            assert term[i] == bool(z["terminated"][t][i]), (t, i)
+            np.testing.assert_array_equal(obs[i]["image"], z["obs"][t][i])
+
+
+@pytest.mark.parametrize("room_size", [4, 5, 6, 7])
+def test_lockedhallway_eight_rooms_resets_for_even_and_odd_room_sizes(room_size):
+    """More than 6 rooms use the geometric door format (include/mgx.h): doors at (top + bottom) // 2 = row (rs-1) + (rs-1)//2
+    (multigrid/core/roomgrid.py:108) -- for even room sizes that is not rs // 2."""
+    env = mg.LockedHallwayEnv(num_rooms=8, room_size=room_size, agents=2, device="cpu", _backend=backend_factory)
+    env.reset(seed=3)
+    aux = env._benv.aux[0].numpy()
+    assert aux[0] == (0x80 | 8) and aux[3] == room_size
+    env.step({0: 5, 1: 2})
+
+
 def test_missing_agents_are_skipped_and_unknown_actions_raise():
     env = make("MultiGrid-Empty-8x8-v0", agents=3)
     env.reset(seed=1)

@@ -33,7 +33,10 @@ def test_golden_replay(path, replicas):
     T = z["actions"].shape[0]
     for t in range(T):
         act = torch.from_numpy(np.repeat(z["actions"][t][None], replicas, 0)).to(dev())
-        obs, dirs, rew, term, trunc = env.step(act)
+        ho = None
+        if "hook_order" in z.files:                          # the dict order the reference was stepped with
+            ho = torch.from_numpy(np.repeat(z["hook_order"][t][None], replicas, 0)).to(dev())
+        obs, dirs, rew, term, trunc = env.step(act, hook_order=ho)
         ctx = f"step {t}"
         for b in (0, replicas - 1):
             np.testing.assert_array_equal(obs[b].cpu().numpy(), z["obs"][t], err_msg=ctx)

@@ -40,7 +40,9 @@ def test_oracle_replays_reference(path):
     np.testing.assert_array_equal(env.gen_obs(), z["obs0"].astype(np.int64))
     T = z["actions"].shape[0]
     for t in range(T):
-        obs, direction, reward, terminated, truncated, order = env.step(z["actions"][t])
+        # (*_dictorder fixtures: the reference was stepped with a dict whose keys were inserted in this order)
+        obs, direction, reward, terminated, truncated, order = env.step(
+            z["actions"][t], hook_order=z["hook_order"][t] if "hook_order" in z.files else None)
         ctx = f"{os.path.basename(path)} step {t}"
         np.testing.assert_array_equal(order, z["order"][t], err_msg=ctx)
         np.testing.assert_array_equal(obs, z["obs"][t].astype(np.int64), err_msg=ctx)
@@ -51,6 +53,24 @@ def test_oracle_replays_reference(path):
         np.testing.assert_array_equal(env.grid_state, z["grid"][t].astype(np.int64), err_msg=ctx)
         np.testing.assert_array_equal(env.agent_state, z["agents"][t].astype(np.int64), err_msg=ctx)
     np.testing.assert_array_equal(env.rng, rng_lohi(z["rng_final"]))
+
+
+def test_dict_order_fixtures_pin_the_hook_visiting_order():
+    """The *_dictorder fixtures must be cases where the visiting order of the env hooks (the caller's dict order,
+    redbluedoors.py:176 / locked_hallway.py:210) changes the result: replayed with ascending order the oracle must DIFFER."""
+    from tests import util
+    differs = 0
+    for path in GOLDEN:
+        if "_dictorder_" not in path:
+            continue
+        z, spec = load(path)
+        env = ob.RefEnv(spec, z["grid0"], z["agents0"], rng_lohi(z["rng0"]), target=[int(v) for v in util.golden_aux(spec)])
+        for t in range(z["actions"].shape[0]):
+            _, _, reward, terminated, _, _ = env.step(z["actions"][t])          # ascending
+            if reward.tobytes() != z["reward"][t].tobytes() or not np.array_equal(terminated, z["terminated"][t].astype(bool)):
+                differs += 1
+                break
+    assert differs >= 2
 
 
 def test_goldens_cover_the_dynamics():

@@ -68,7 +68,8 @@ def test_rules_replay_goldens(path):
     rng = util.rng_words_lohi(z["rng0"]); target = util.golden_target(d); sc = 0
     np.testing.assert_array_equal(hostshim.obs_env(spec, tile, rows), z["obs0"])
     for t in range(z["actions"].shape[0]):
-        out = hostshim.step_env(spec, tile, rows, np.ascontiguousarray(z["actions"][t]), rng, sc, target)
+        out = hostshim.step_env(spec, tile, rows, np.ascontiguousarray(z["actions"][t]), rng, sc, target,
+                                hook_order=z["hook_order"][t] if "hook_order" in z.files else None)
         sc = out["step_count"]
         ctx = f"step {t}"
         np.testing.assert_array_equal(out["order"][:spec.num_agents] if spec.num_agents > 1 else [0],

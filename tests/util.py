@@ -158,12 +158,14 @@ class OracleBackend:
         if dirs is not None:
             dirs.copy_(torch.from_numpy(d))
 
-    def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated):
+    def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated,
+             hook_order=None):
         g3 = self._g3(grid)
         try:
             o, d, r, te, tr = ob.step_batch(
                 self.d, g3, agents.numpy(), rng.numpy().view(np.uint64), step_count.numpy(),
-                actions.numpy(), target.numpy() if target is not None else None, self.nthreads)
+                actions.numpy(), target.numpy() if target is not None else None, self.nthreads,
+                hook_order=None if hook_order is None else hook_order.numpy())
         except ValueError:
             err[0] += 1
             err[1] = 0

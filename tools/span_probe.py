@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""When do the wavefronts of one fused-step launch begin and end (s_memrealtime, 10 ns ticks)?  Needs a library built with
--DMGX_TIMESTAMPS=1 in place (tools/with_altlib.sh).  Shows the launch ramp, the per-wave duration and the tail."""
+"""When do the wavefronts of one fused-step launch begin and end (s_memrealtime, 10 ns ticks)?  Needs
+MGX_LIBMGX=multigrid_amd/lib/libmgx_ts.so (`python -m multigrid_amd.build --timestamps`).  Shows the launch ramp, the per-wave
+duration and the tail.  (Several chains of launches in one graph: tools/chain_overlap.py.)"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -8,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from multigrid_amd import _lib
 lib = _lib.lib()
+lib.mgx_debug_span_launches.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+lib.mgx_debug_read_span.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int, ctypes.c_int]
 dev = torch.device("cuda", 0)
 spec = bench.workload_spec()
 if os.environ.get("MGX_WPB"):
@@ -20,7 +23,7 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
     env = bench.make_env(spec, B, dev, 0)
     acts = bench.random_actions(64, B, spec.num_agents, dev, 7)
     li = env.backend.launch_info(B)
-    nw = min(16384, (B + li["envs_per_wavefront"] - 1) // li["envs_per_wavefront"])
+    nw = (B + li["envs_per_wavefront"] - 1) // li["envs_per_wavefront"]
     for t in range(30):
         env.step(acts[t], auto_reset=bench.AUTO_RESET)
     torch.cuda.synchronize()
@@ -28,6 +31,7 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
     rows = []
     graph = None
     if os.environ.get("MGX_GRAPH"):                        # the last launch of a replayed graph of 20 steps
+        lib.mgx_debug_span_reset()
         graph = torch.cuda.CUDAGraph()
         s_ = torch.cuda.Stream(dev); s_.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s_):
@@ -39,9 +43,12 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
         if graph is not None:
             graph.replay()
         else:
+            lib.mgx_debug_span_reset()
             env.step(acts[30 + r], auto_reset=bench.AUTO_RESET)
         torch.cuda.synchronize()
-        lib.mgx_debug_read_span(buf, nw)
+        tab = (ctypes.c_longlong * (4 * 64))()
+        nl = lib.mgx_debug_span_launches(tab, 64)
+        lib.mgx_debug_read_span(buf, int(tab[4 * (nl - 1)]), nw)
         a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 2).astype(np.int64)
         t0 = a[:, 0].min()
         b, e = (a[:, 0] - t0) * 10, (a[:, 1] - t0) * 10          # ns
