@@ -15,10 +15,19 @@ number of K-step blocks is replayed until the region is >= 50 ms (a K-step regio
 driver's K = 20); `ms_per_step` = region / steps in it, `timed_steps` says how many that was.  The region is bracketed by
 barrier + torch.cuda.synchronize() on both sides, max over ranks.
 
+`value` is the LOCK-STEP path: one launch of the fused kernel per step of the whole per-GPU batch, step t+1 enqueued behind step
+t (what a policy that needs all B observations of step t before step t+1 gets; the reference's own semantics).  Beside it,
+`pipelined`: the same steps issued as independent chains of sub-shard launches (BatchedMultiGridEnv.capture_steps(sub_shards=
+"auto"), the product's own policy: mgx_sub_shards) -- valid for open-loop actions or a double-buffered actor loop.
+
 Prints ONE JSON line on rank 0.  Extra objects (N=1 only, except `roofline`):
-  roofline            the fused kernel on the timed workload: algorithmic bytes per launch / average launch
-                      duration from HIP events over the timed region on the launch stream; `traffic` = HBM bytes per
-                      launch from the committed rocprofv3 PMC passes (profiles/traffic.json)
+  roofline            the fused kernel on the timed workload, by the literal definition: algorithmic bytes per launch (SURVEY.md
+                      8d) / average launch duration from HIP events over the timed region on the launch stream (one launch per
+                      step, back to back; rocprofv3's average for the kernel: profiles/); `traffic` = HBM bytes per launch from the
+                      committed rocprofv3 PMC passes (profiles/traffic.json)
+  pipelined           the sub-sharded variant: value, ms_per_step, `step_frac` (the step's bytes / the step's time: an aggregate over
+                      several launches in flight) and `launch` (ONE sub-shard launch over its own duration: the literal per-launch
+                      fraction); the overlap itself is shown by in-kernel timestamps in profiles/r3_chain_overlap.txt
   configs             the other BASELINE.json GPU configurations (C2, C3 with its layout pool + hook, C5 with occluders),
                       each timed the same way, each with its own roofline
   eager               the same step called from Python once per step (policy-in-the-loop cost: ctypes + launch)
@@ -80,22 +89,6 @@ def capture_steps(env, actions, sub_shards=1):
     """One hipGraph holding `len(actions)` consecutive env.step launches (sub_shards=P: as P parallel chains over P
     consecutive blocks of the batch, BatchedMultiGridEnv.capture_steps)."""
     return env.capture_steps(actions, auto_reset=AUTO_RESET, sub_shards=sub_shards)
-
-
-def auto_sub_shards(env) -> int:
-    """Sub-shards for the graph-replay measurement.  A launch that fills the chip first loads (no wave has data to work on),
-    then computes; independent chains of smaller launches on separate streams drift apart and one's loads run under another's
-    compute.  Measured (tools/interleave_probe.py, us per step of the whole batch, 1 / 2 / 4 chains): C4 65536 envs 20.8 / 17.2 /
-    16.5; C4 shape at 32768 envs 13.5 / 11.0 / 13.7, at 131072 envs 35.9 / 27.1 / 27.9; C5 85 / 69 / 73; but C3 9.4 / 10.9 / 13.3
-    and C2 6.3 / 7.2 / 13.7 -- small launches only lose (C4 shape at 16384 envs still gains: 9.3 / 8.7) -- and uneven splits are
-    worse than even ones.  Hence: 1 below 2048 wavefronts or 65536 views per launch; 4 when the whole batch is about one round of resident wavefronts; else 2."""
-    li = env.backend.launch_info(env.batch)
-    nw = -(-env.batch // max(1, li["envs_per_wavefront"]))
-    if nw < 2048 or env.batch * env.spec.num_agents < 65536:
-        return 1
-    per_cu = min(20, (160 * 1024 // max(1, li["lds_bytes"])) * (li["threads_per_workgroup"] // 64))
-    rounds = nw / (256.0 * max(1, per_cu))
-    return 4 if 0.75 <= rounds <= 1.5 else 2
 
 
 def timed_region(env, run_once, repeats, dist_barrier):
@@ -171,36 +164,36 @@ def roofline(alg_bytes_per_launch, ms, traffic=None):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
 
 
-def step_roofline(wl_name, spec, B, ms_step, sub_shards=1, ms_launch=None):
-    """Roofline of the fused step kernel over one step of the batch.
-    sub_shards=P > 1: a step is P launches of B/P envs each, issued by P independent chains on P streams (parallel branches of
-    one graph), several of them in flight at a time.  `launch` is ONE such launch by the literal definition -- its algorithmic
-    bytes over its own duration `ms_launch` (HIP events over back-to-back launches of one sub-shard; rocprofv3's average
-    duration of that kernel in profiles/ is the same number) -- and the top-level `achieved` is the chip's rate over the step:
-    the step's bytes / the step's time = launch.achieved x mean_launches_in_flight."""
-    P = max(1, sub_shards)
+def step_roofline(wl_name, spec, B, ms_launch):
+    """Roofline of the fused step kernel, literal definition: one launch of B envs over its own duration."""
     alg = B * spec.num_agents * spec.bytes_step()
-    traffic = pmc_traffic(f"{wl_name}_step", B)
-    if P > 1:
-        part = pmc_traffic(f"{wl_name}_part_step", B // P)
-        traffic = part * P if part is not None else traffic
-    rf = roofline(alg, ms_step, traffic)
-    rf.update(kernel=f"mgx_fused_kernel<{spec.view_size},step,autoreset>", ms_per_launch=round(ms_step, 5),
+    rf = roofline(alg, ms_launch, pmc_traffic(f"{wl_name}_step", B))
+    rf.update(kernel=f"mgx_fused_kernel<{spec.view_size},step,autoreset>", ms_per_launch=round(ms_launch, 5),
               bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=alg,
-              traffic_unit="bytes per step of the batch (rocprofv3 PMC, profiles/traffic.json)")
-    if P > 1:
-        rf["ms_per_launch"] = None if ms_launch is None else round(ms_launch, 5)
-        rf.update(ms_per_step=round(ms_step, 5), launches_per_step=P,
-                  note_launches=f"a step of the batch = {P} launches of {B // P} envs from {P} independent chains on {P} streams, "
-                                "several in flight at a time: `achieved` = step bytes / step time = launch.achieved x "
-                                "mean_launches_in_flight; `launch` = one such launch over its own duration; the same steps as ONE "
-                                "chain of whole-batch launches: `single_chain`")
-        if ms_launch is not None:
-            one = roofline(alg // P, ms_launch)
-            rf["launch"] = {"batch": B // P, "algorithmic_bytes": alg // P, "ms_per_launch": round(ms_launch, 5),
-                            "achieved": one["achieved"], "frac": one["frac"]}
-            rf["mean_launches_in_flight"] = round(P * ms_launch / ms_step, 2)
+              traffic_unit="bytes per launch (rocprofv3 PMC, profiles/traffic.json)")
     return rf
+
+
+def pipelined_point(wl_name, spec, env, K, device, barrier, seed, P, wall_scale=None, min_region_ms=30.0, agree=None, G=None):
+    """The same steps as P independent chains of sub-shard launches (capture_steps(sub_shards=P))."""
+    B, A = env.batch, spec.num_agents
+    m = measure_steps(env, K, 0, "graph", barrier, seed=seed, min_region_ms=min_region_ms, sub_shards=P, agree=agree)
+    ms_step = m["event_ms"] / m["timed_steps"]
+    ms_launch = sub_shard_launch_ms(env, P, device)
+    alg = B * A * spec.bytes_step()
+    part = pmc_traffic(f"{wl_name}_part_step", B // P)
+    one = roofline(alg // P, ms_launch, part)
+    return m, {"sub_shards": P, "ms_per_step": round(ms_step, 6), "timed_steps": m["timed_steps"],
+               "step_frac": round(alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "step_achieved_GBs": round(alg / (ms_step * 1e-3) / 1e9, 1),
+               "launch": {"batch": B // P, "algorithmic_bytes": alg // P, "ms_per_launch": round(ms_launch, 5),
+                          "achieved": one["achieved"], "frac": one["frac"], "traffic": part},
+               "mean_launches_in_flight": round(P * ms_launch / ms_step, 2),
+               "note": f"a step of the batch = {P} launches of {B // P} envs from {P} independent chains on {P} streams (parallel "
+                       "branches of one hipGraph), several in flight at a time; `step_frac` = the step's algorithmic bytes / the "
+                       "step's time (an aggregate: launch.frac x launches in flight, computed), `launch` = one such launch over its "
+                       "own duration, alone on the chip; the overlap OBSERVED with in-kernel timestamps: profiles/r3_chain_overlap.txt "
+                       "(rocprofv3 serialises the chains).  Open-loop actions or a double-buffered actor loop only."}
 
 
 def sub_shard_launch_ms(env, P, device):
@@ -215,15 +208,15 @@ def sub_shard_launch_ms(env, P, device):
 
 
 def config_point(name, device, K, warmup, device_generated=False):
-    """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline.
+    """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline (lock-step: one launch per
+    step); `pipelined` beside it when the product's policy suggests sub-shards for it.
     device_generated: episode starts are generated ON THE DEVICE (the reference's _gen_grid with numpy-exact draws, in the
     tail of the step's own launch: mgx_step_generate) instead of picked from the host-made layout pool."""
     wl = workloads.make(name)
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     if device_generated:
         env.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6)
-    P = auto_sub_shards(env)
-    m = measure_steps(env, K, warmup, "graph", lambda: None, seed=4321, min_region_ms=30.0, sub_shards=P)
+    m = measure_steps(env, K, warmup, "graph", lambda: None, seed=4321, min_region_ms=30.0)
     env.check_errors()
     B, A = wl.batch, wl.spec.num_agents
     ms = m["event_ms"] / m["timed_steps"]
@@ -234,32 +227,36 @@ def config_point(name, device, K, warmup, device_generated=False):
            "layout_pool": "generated on the device in the step's own launch (mgx_step_generate)" if device_generated
                           else int(wl.pool[0].shape[0]),
            "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,
-           "sub_shards": P, "launch": env.backend.launch_info(B // P),
-           "roofline": step_roofline(name, wl.spec, B, ms, P, sub_shard_launch_ms(env, P, device) if P > 1 else None)}
-    if P > 1:                                                   # the same steps as ONE chain of whole-batch launches
-        m1 = measure_steps(env, K, 0, "graph", lambda: None, seed=4322, min_region_ms=20.0)
-        ms1 = m1["event_ms"] / m1["timed_steps"]
-        out["single_chain"] = {"ms_per_step": round(ms1, 6), "frac": step_roofline(name, wl.spec, B, ms1)["frac"]}
+           "launch": env.backend.launch_info(B),
+           "roofline": step_roofline(name, wl.spec, B, ms)}
+    P = env.sub_shards_hint(AUTO_RESET)
+    if P > 1:
+        m2, pp = pipelined_point(name, wl.spec, env, K, device, lambda: None, 4322, P, min_region_ms=20.0)
+        pp["value"] = round(B * A * m2["timed_steps"] / m2["wall_s"])
+        out["pipelined"] = pp
     del env
     torch.cuda.empty_cache()
     return out
 
 
-def eager_point(wl, device, steps=2000):
-    """env.step called from Python once per step (what an RL loop that cannot capture its policy pays)."""
+def eager_point(wl, device, steps=2000, sub_shards=1):
+    """env.step called from Python once per step (what an RL loop that cannot capture its policy pays).
+    sub_shards="auto": the eager sub-shard form (mgx_step_chains on the env's side streams, joined once at the end)."""
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     B, A = wl.batch, wl.spec.num_agents
     acts = random_actions(64, B, A, device, 77)
     for t in range(200):
-        env.step(acts[t & 63], auto_reset=AUTO_RESET)
+        env.step(acts[t & 63], auto_reset=AUTO_RESET, sub_shards=sub_shards)
+    env.join()
     stream = torch.cuda.current_stream(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     ev0.record(stream)
     for t in range(steps):
-        env.step(acts[t & 63], auto_reset=AUTO_RESET)
+        env.step(acts[t & 63], auto_reset=AUTO_RESET, sub_shards=sub_shards)
     t_host = time.perf_counter() - t0
+    env.join()
     ev1.record(stream)
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
@@ -267,7 +264,9 @@ def eager_point(wl, device, steps=2000):
     out = {"workload": wl.name, "batch": B, "steps": steps, "ms_per_step": round(wall * 1e3 / steps, 6),
            "host_ms_per_call": round(t_host * 1e3 / steps, 6), "event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 6),
            "value": round(B * A * steps / wall), "unit": "agent-steps/s",
-           "note": "BatchedMultiGridEnv.step from Python per step (ctypes -> mgx_step_autoreset); no graph"}
+           "sub_shards": env.sub_shards_hint(AUTO_RESET) if sub_shards == "auto" else sub_shards,
+           "note": "BatchedMultiGridEnv.step from Python per step (one ctypes call: mgx_step_ex"
+                   + (" / mgx_step_chains, the chains joined once after the last step" if sub_shards != 1 else "") + "); no graph"}
     del env
     return out
 
@@ -433,9 +432,10 @@ def main():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: the timed steps are hipGraph replays; eager: Python-level env.step calls")
     ap.add_argument("--no-auto-reset", action="store_true", help="step finished envs on as the reference does (base.py:408-409)")
-    ap.add_argument("--sub-shards", type=int, default=0,
-                    help="graph mode: step the batch as this many independent chains on as many streams (0 = auto: 2 when a "
-                         "launch of the whole batch fills the chip, else 1)")
+    ap.add_argument("--sub-shards", type=int, default=1,
+                    help="graph mode: the chains the HEADLINE steps the batch as (default 1: lock-step, one launch per step; 0 = "
+                         "the product's policy, BatchedMultiGridEnv.sub_shards_hint).  The pipelined variant is reported "
+                         "beside the headline either way")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement + its roofline")
     args = ap.parse_args()
@@ -485,7 +485,8 @@ def main():
     wl = workloads.make(name, batch=B, first_env=first_env, global_batch=G)
     spec, A = wl.spec, wl.spec.num_agents
     env = wl.make_env(device, auto_reset=AUTO_RESET)
-    P = 1 if args.mode != "graph" else (args.sub_shards or int(all_max(float(auto_sub_shards(env)))))
+    hint = int(all_max(float(env.sub_shards_hint(AUTO_RESET))))          # the product's policy (mgx_sub_shards), same on all ranks
+    P = 1 if args.mode != "graph" else (args.sub_shards or hint)
     m = measure_steps(env, args.steps, args.warmup, args.mode, barrier, seed=1234 + rank,
                       agree=lambda n: int(all_max(float(n))), sub_shards=P)
     env.check_errors()
@@ -503,9 +504,9 @@ def main():
                    "view_size": spec.view_size, "mode": args.mode,
                    "parallelism": f"env-sharded x{world} (strong scaling of the global batch), no collective",
                    "sub_shards": P,
-                   "sub_shards_note": ("the batch is stepped as independent chains of launches over consecutive blocks of envs on "
-                                       "separate streams (parallel branches of one hipGraph; BatchedMultiGridEnv.capture_steps); "
-                                       "every env takes exactly the timed steps") if P > 1 else None,
+                   "semantics": ("lock-step: one launch of the fused kernel per step of the whole per-GPU batch, step t+1 behind "
+                                 "step t" if P == 1 else
+                                 "pipelined: independent chains of sub-shard launches (see `pipelined.note`)"),
                    "launch": env.backend.launch_info(B // P),
                    "auto_reset": ("fused into the step launch (mgx_step_autoreset): envs that are done restart from the "
                                   "layout pool before the next step") if AUTO_RESET else False,
@@ -517,11 +518,18 @@ def main():
         out["valid"] = False
         out["invalid_reason"] = f"MGX_LIBMGX={_lib.LIB_PATH}: not the product library (profiling / experiment build)"
     if rank == 0:
-        out["roofline"] = step_roofline(name, spec, B, m["event_ms"] / S, P, sub_shard_launch_ms(env, P, device) if P > 1 else None)
-        if P > 1 and world == 1:                                # the same steps as ONE chain of whole-batch launches
-            m1 = measure_steps(env, args.steps, 0, "graph", barrier, seed=99, min_region_ms=25.0)
-            ms1 = m1["event_ms"] / m1["timed_steps"]
-            out["single_chain"] = {"ms_per_step": round(ms1, 6), "roofline": step_roofline(name, spec, B, ms1)}
+        if P == 1:
+            out["roofline"] = step_roofline(name, spec, B, m["event_ms"] / S)
+        else:                                                   # (--sub-shards: the literal per-launch number stays the `frac`)
+            out["roofline"] = step_roofline(name, spec, B // P, sub_shard_launch_ms(env, P, device))
+            out["roofline"]["step_frac"] = round(B * A * spec.bytes_step() / (m["event_ms"] / S * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if P == 1 and hint > 1 and args.mode == "graph":            # the pipelined variant beside the lock-step headline (all ranks)
+        m2, pp = pipelined_point(name, spec, env, args.steps, device, barrier, 99 + rank, hint, min_region_ms=25.0,
+                                 agree=lambda n: int(all_max(float(n))))
+        pp["value"] = round(G * A * m2["timed_steps"] / all_max(m2["wall_s"]))
+        if rank == 0:
+            out["pipelined"] = pp
+    if rank == 0:
         if B * A * spec.bytes_step() < 200e6:
             out["roofline"]["note"] = ("working set fits the 256 MiB Infinity Cache at this batch: see roofline_large for "
                                        "the HBM-resident regime")
@@ -531,6 +539,7 @@ def main():
             out["configs"] = {c: config_point(c, device, 256, 50) for c in ("c2", "c3", "c5") if c != name}
             out["configs"]["c3_device_generated"] = config_point("c3", device, 256, 50, device_generated=True)
             out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}
+            out["eager"]["c4_chains"] = eager_point(workloads.make("c4"), device, sub_shards="auto")
             out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)
             out.update(large_batch_points(device, args.large_batch))
             out["device_generation"] = generation_point(device)

@@ -112,6 +112,7 @@ typedef struct MgxLaunchInfo {
     int32_t threads_per_workgroup;
     int32_t workgroups;
     int32_t lds_bytes;
+    int32_t slots_per_group;     /* view slots a wavefront gathers / stages as one block: 16, or 4 / 8 in the latency regime */
 } MgxLaunchInfo;
 
 int mgx_abi_version(void);

@@ -30,7 +30,7 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
 
 class MgxLaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("envs_per_wavefront", "envs_per_workgroup", "threads_per_workgroup", "workgroups",
-                                          "lds_bytes")]
+                                          "lds_bytes", "slots_per_group")]
 
 
 class MgxAutoReset(C.Structure):

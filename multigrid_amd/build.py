@@ -36,6 +36,7 @@ LIB = os.path.join(HERE, "lib", "libmgx.so")
 LIB_DBG = os.path.join(HERE, "lib", "libmgx_dbg.so")
 LIB_CHK = os.path.join(HERE, "lib", "libmgx_chk.so")
 LIB_TS = os.path.join(HERE, "lib", "libmgx_ts.so")
+LIB_SPANS = os.path.join(HERE, "lib", "libmgx_spans.so")
 ARCH = "gfx950"
 
 
@@ -104,6 +105,52 @@ def build_lib(force: bool = False, verbose: bool = False, lib: str = LIB, define
     return lib
 
 
+LIB_TORCH = os.path.join(HERE, "lib", "libmgx_torch.so")
+TORCH_SRC = os.path.join(CSRC, "mgx_torch.cpp")
+
+
+def _torch_build_cmd(out: str) -> list[str]:
+    import torch
+    from torch.utils import cpp_extension as ce
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", TORCH_SRC, "-o", out]
+    cmd += [f"-L{p}" for p in ce.library_paths()] + ["-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip",
+                                                      f"-L{os.path.dirname(LIB)}", "-lmgx", "-Wl,-rpath,$ORIGIN"]
+    cmd += [f"-Wl,-rpath,{p}" for p in ce.library_paths()]      # (a C++ host that dlopen()s the library finds torch's own)
+    return cmd
+
+
+def build_torch_lib(force: bool = False, verbose: bool = False) -> str:
+    """lib/libmgx_torch.so: the compiled TORCH_LIBRARY(mgx) / TORCH_LIBRARY_IMPL(mgx, CUDA) operator library
+    (csrc/mgx_torch.cpp: host code only, g++ against the installed torch's headers) over libmgx.so, which it finds beside
+    itself ($ORIGIN).  Staleness by content: the source, include/mgx.h, the compile command and the torch version."""
+    import torch
+    build_lib()                                                    # (links against libmgx.so)
+    h = hashlib.sha256()
+    h.update((" ".join(_torch_build_cmd("out")) + torch.__version__).encode())
+    for d in (TORCH_SRC, os.path.join(ROOT, "include", "mgx.h")):
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    digest = h.hexdigest()
+    try:
+        with open(LIB_TORCH + ".srchash") as fh:
+            fresh = os.path.exists(LIB_TORCH) and fh.read().strip() == digest
+    except OSError:
+        fresh = False
+    if fresh and not force:
+        return LIB_TORCH
+    cmd = _torch_build_cmd(LIB_TORCH + ".tmp")
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB_TORCH + ".tmp", LIB_TORCH)
+    with open(LIB_TORCH + ".srchash", "w") as fh:
+        fh.write(digest + "\n")
+    return LIB_TORCH
+
+
 def build_debug_lib(force: bool = False, verbose: bool = False, extra_defines=()) -> str:
     return build_lib(force, verbose, LIB_DBG, ("MGX_DEBUG_KNOBS=1", *extra_defines))
 
@@ -121,10 +168,21 @@ def build_timestamps_lib(force: bool = False, verbose: bool = False) -> str:
     return build_lib(force, verbose, LIB_TS, ("MGX_DEBUG_KNOBS=1", "MGX_TIMESTAMPS=1", "MGX_SINGLE_TU=1"))
 
 
+def build_spans_lib(force: bool = False, verbose: bool = False, only_v: int = 7) -> str:
+    """lib/libmgx_spans.so: the PRODUCT kernels + two s_memrealtime reads and two stores per wavefront (-DMGX_SPANS=1; no debug
+    knobs, no phase stamps, no extra waits), for tools/chain_overlap.py: the launches' timelines as the kernels themselves saw
+    them.  One view size only (a single translation unit: the records are a kernel-side global)."""
+    return build_lib(force, verbose, LIB_SPANS, ("MGX_SPANS=1", "MGX_SINGLE_TU=1", f"MGX_ONLY_V={only_v}"))
+
+
 if __name__ == "__main__":
     force, verbose = "--force" in sys.argv, True
     extra = tuple(a[2:] for a in sys.argv[1:] if a.startswith("-D"))
-    if "--timestamps" in sys.argv:
+    if "--torch" in sys.argv:
+        print(build_torch_lib(force, verbose))
+    elif "--spans" in sys.argv:
+        print(build_spans_lib(force, verbose))
+    elif "--timestamps" in sys.argv:
         print(build_timestamps_lib(force, verbose))
     elif "--checked" in sys.argv:
         print(build_checked_lib(force, verbose))

@@ -66,6 +66,7 @@ struct KernelArgs {
     // per-wavefront LDS slice: its stride and the slot count its carve is derived from (LdsCarve below)
     int32_t wave_lds;
     int32_t vpw;
+    int32_t grp;        // slots per gather / staging group of the instantiation to launch: 16, or 4 / 8 (small-group latency family)
     int32_t inv_A;      // ceil(2^16 / A): (lane * inv_A) >> 16 == lane / A for lane < 64
     // fused auto-reset (mgx_step_autoreset / mgx_rollout_autoreset; include/mgx.h: MgxAutoReset)
     int32_t pool_size;
@@ -168,6 +169,9 @@ constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 #ifndef MGX_OBS_AUX
 #define MGX_OBS_AUX 2       // nt: the observation is written once and read by another kernel (C4 -4.6 %, C3 -2 %, C5 -1.7 %)
 #endif
+#ifndef MGX_OBS_AUX_CACHED
+#define MGX_OBS_AUX_CACHED MGX_OBS_AUX   // ... of the instantiations whose grid tensor fits the Infinity Cache (!STREAM)
+#endif
 #ifndef MGX_OH_AUX
 #define MGX_OH_AUX 0        // one-hot observation stores: default policy (nt measured 6 % slower on this 7x larger write stream)
 #endif
@@ -233,22 +237,25 @@ struct LdsCarve {
 };
 
 // one_hot: the round's staging holds one 32-bit one-hot mask per cell (+ a pad dword either side) instead of 3 obs bytes
+// `round`: slots staged per P4/P5 round (kRound, or the group size of a small-group latency instantiation)
 __host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
-                                               bool one_hot = false) {
-    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * kCellBytes, one_hot ? kRound * V * V * 4 + 16 : kRound * V * V * 3,
+                                               bool one_hot = false, int round = kRound) {
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * kCellBytes, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
                     roll, has_aux};
 }
 
-inline int slots_in_use(const MgxSpec &sp, int Gw, bool narrow = false) {
-    int vpw = (Gw * sp.num_agents + 15) & ~15;     // (the kernel is compiled for slots_per_wave(V) slots)
+// `grp`: the group size the launch's instantiation is compiled for (16, or 4 / 8: KernelArgs::grp)
+inline int slots_in_use(const MgxSpec &sp, int Gw, bool narrow = false, int grp = 16) {
+    int vpw = (Gw * sp.num_agents + grp - 1) / grp * grp;     // (the kernel is compiled for slots_per_wave(V) slots)
     return vpw > slots_per_wave(sp.view_size, narrow) ? slots_per_wave(sp.view_size, narrow) : vpw;
 }
 
-inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false, bool one_hot = false, bool obs_only = false) {
-    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw, roll || obs_only), roll,
-                      sp.env_kind != MGX_KIND_EMPTY, one_hot).total();
+inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false, bool one_hot = false, bool obs_only = false, int grp = 16) {
+    return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw, roll || obs_only, grp), roll,
+                      sp.env_kind != MGX_KIND_EMPTY, one_hot, grp).total();
 }
 
+constexpr int kGroupSlots = 16;           // (== kGroup, defined with the gather below)
 constexpr int kLdsPerCU = 160 * 1024;
 #ifndef MGX_LDS_WAVE_BUDGET
 #define MGX_LDS_WAVE_BUDGET (12 * 1024)
@@ -261,24 +268,41 @@ inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false, bool o
     int Gw = slots_per_wave(sp.view_size, roll || obs_only) / sp.num_agents;
     if (Gw < 1) Gw = 1;
     while (Gw > 1 && wave_lds_bytes(sp, Gw, roll, one_hot, obs_only) > kLdsWaveBudget) --Gw;
-    while (Gw > 4 && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;      // measured: 4 envs/wave is the latency optimum
-    while (Gw > 1 && (batch + Gw - 1) / Gw < 512) Gw = (Gw + 1) / 2;       // tiny batches: spread over the chip
+    // latency regime (fewer than two wavefronts per SIMD): one full group of 16 view slots per wave is the optimum whatever the
+    // batch -- fewer slots per wave means more waves, each paying the fixed per-wave phases again (tools/group_sweep.py, round 3:
+    // C2 shape at 1024 envs: 4 envs per wave 5.92 us, 2: 6.45, 1: 6.54; BlockedUnlockPickup at 8192 envs: 8 envs per wave 8.58 us,
+    // 4: 10.05; more than 16 slots only once every SIMD has its two waves: C2 shape at 4096 envs, 8 envs per wave: 7.53 vs 6.27)
+    while (Gw * sp.num_agents > kGroupSlots && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;
     return Gw;
+}
+
+// Group size of the latency family (mgx_fused_body.inc: GRP): 16 = the ordinary instantiations -- always, see has_small_groups
+// below; the tools' build overrides it with mgx_debug_set_group().
+inline int choose_group(const MgxSpec &sp, int64_t batch) {
+    (void)sp; (void)batch;
+    return 16;
 }
 
 static __device__ const JumpTable kJump{};
 
 // -DMGX_MARKERS=1 (tools/isa_phase_count.py): comment lines in the assembly that delimit the phases
-// -DMGX_TIMESTAMPS=1 (tools/stamp_probe.py): wavefront `g_stamp_wave` records the shader clock at every marker
-#if MGX_MARKERS
-#define MGX_MARK(name) asm volatile("; MGX_MARK " name ::: "memory")
-#elif MGX_TIMESTAMPS
-static __device__ unsigned long long g_stamps[64];
+// -DMGX_TIMESTAMPS=1 (tools/stamp_probe.py): wavefront `g_stamp_wave` records the shader clock at every marker; implies MGX_SPANS
+// -DMGX_SPANS=1 (tools/chain_overlap.py, tools/span_probe.py): every wavefront records s_memrealtime at its first and after its
+//   last instruction -- two scalar clock reads and two stores per wave, nothing else changes (lib/libmgx_spans.so)
+#ifndef MGX_SPANS
+#define MGX_SPANS (MGX_TIMESTAMPS + 0)
+#endif
+#if MGX_SPANS
 constexpr int kSpanCap = 1 << 18;
 static __device__ unsigned long long g_span[2 * kSpanCap];   // [span_base + wave][begin, end] in s_memrealtime ticks (100 MHz): every
                                                              // launch gets its own block of records (KernelArgs::span_base, handed out
                                                              // by the host in launch order -- for a captured graph: capture order), so
                                                              // a replayed graph of several chains leaves one timeline per node
+#endif
+#if MGX_MARKERS
+#define MGX_MARK(name) asm volatile("; MGX_MARK " name ::: "memory")
+#elif MGX_TIMESTAMPS
+static __device__ unsigned long long g_stamps[64];
 static __device__ long long g_stamp_wave = 0;
 #define MGX_MARK(name)                                                                                   \
     do {                                                                                                 \
@@ -421,15 +445,15 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
 #endif
 constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as one straight-line block
 
-template <int V, int NW, int VPW, bool HALF, int S0 = 0>
+template <int V, int NW, int VPW, bool HALF, int G, int S0 = 0>
 __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, int NVc, const uint32_t wall_addr, const ViewRec *rec,
                                            const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
-        if (S0 < NVc) gather_group<V, NW, S0, kGroup, VPW, HALF>(a, wave, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
-        gather_all<V, NW, VPW, HALF, S0 + kGroup>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        if (S0 < NVc) gather_group<V, NW, S0, G, VPW, HALF>(a, wave, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, HALF, G, S0 + G>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
     }
 }
 
@@ -447,7 +471,8 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // after the step: the reference's _gen_grid on the device, mgx_layout_gen.h).
 // STREAM: the grid tensor is larger than the Infinity Cache can keep between steps: non-temporal tile loads.
 // DMA: the tile is loaded HBM -> LDS by LDS-DMA (small launches: P0).
-template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false, bool DMA = (MGX_LDS_DMA != 0)>
+template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false, bool DMA = (MGX_LDS_DMA != 0),
+          int GRP = kGroup>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
 #include "mgx_fused_body.inc"
 }
@@ -459,21 +484,39 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 template <int V, bool OH, bool STREAM, bool DMA>
 __global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(6)))
 void mgx_obs_kernel(const KernelArgs a) {
-    constexpr int MODE = 0;
+    constexpr int MODE = 0, GRP = kGroup;
     constexpr bool HOOKS = false, AR = false, GEN = false;
 #include "mgx_fused_body.inc"
 }
 
 // The kernel instantiation for (V, mode, hooks, auto-reset) and its launch.  `hip_err` receives the HIP error code of a
 // failed launch (mgx_last_hip_error).
-template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false>
+// The small-group latency instantiations (GRP 4 / 8: a wavefront owns ONE group of 4 or 8 view slots) exist only in the tools'
+// build (-DMGX_DEBUG_KNOBS=1, lib/libmgx_dbg.so; mgx_debug_set_group), for the step kernel of views up to 9x9.  Measured
+// (tools/group_sweep.py, profiles/r3_small_group_sweep.txt): they do NOT pay -- every additional wavefront on a SIMD costs its
+// whole instruction stream in issue slots (~1.5 us per 1024 wavefronts of this kernel), so halving a wave's slots and doubling
+// the wavefronts only moves the work: C2 6.27 us (4 envs per wave, 16 slots) vs 6.80 (2 envs, group of 8) vs 8.80 (1 env, group
+// of 4); only below one 4-slot wave per SIMD (1024 envs of C2 shape) is the group of 4 ahead, by 0.1 us.  The product library
+// does not carry them.
+constexpr bool has_small_groups(int V, int MODE, bool OH, bool GEN) {
+    return MGX_DEBUG_KNOBS != 0 && MODE == 1 && V <= 9 && !OH && !GEN;
+}
+
+template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false, int GRP = kGroup>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
     if constexpr (!STREAM && !DMA && MODE != 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
         if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
         if constexpr (!OH) {
-            if (ka.flags & 2) return launch_mode<V, MODE, OH, GEN, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+            if (ka.flags & 2) {
+                if constexpr (has_small_groups(V, MODE, OH, GEN)) {
+                    if (ka.grp == 4) return launch_mode<V, MODE, OH, GEN, false, true, 4>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+                    if (ka.grp == 8) return launch_mode<V, MODE, OH, GEN, false, true, 8>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+                }
+                return launch_mode<V, MODE, OH, GEN, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+            }
         }
     }
+    if (ka.grp != GRP) return MGX_ERR_INVALID_ARGUMENT;       // (the host-side carve was made for another group size)
     void (*kern)(const KernelArgs) = nullptr;
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
     const bool ar = MODE != 0 && ka.pool_grid != nullptr;
@@ -483,8 +526,8 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
     } else if constexpr (GEN) {                                              // (generation replaces the pool pick-up)
         kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
     } else {
-        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM, DMA> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM, DMA>)
-                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH, false, STREAM, DMA> : mgx_fused_kernel<V, MODE, false, false, OH, false, STREAM, DMA>);
+        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM, DMA, GRP> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM, DMA, GRP>)
+                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH, false, STREAM, DMA, GRP> : mgx_fused_kernel<V, MODE, false, false, OH, false, STREAM, DMA, GRP>);
     }
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

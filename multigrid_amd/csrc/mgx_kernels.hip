@@ -4,28 +4,44 @@
 
 #include "mgx_fused.h"
 
-#if MGX_SINGLE_TU      // (tools' builds that need the kernels and the host code in one module, e.g. -DMGX_TIMESTAMPS=1)
+#if MGX_SINGLE_TU      // (tools' builds that need the kernels and the host code in one module, e.g. -DMGX_SPANS=1: kernel-side
+                       // globals); -DMGX_ONLY_V=<v> keeps just that view size (a third of the build time)
+#define MGX_TU_HAS(v) (!defined(MGX_ONLY_V) || MGX_ONLY_V == (v))
+#if MGX_TU_HAS(3)
 #define MGX_INST_V 3
 #include "mgx_fused_inst.hip"
 #undef MGX_INST_V
+#endif
+#if MGX_TU_HAS(5)
 #define MGX_INST_V 5
 #include "mgx_fused_inst.hip"
 #undef MGX_INST_V
+#endif
+#if MGX_TU_HAS(7)
 #define MGX_INST_V 7
 #include "mgx_fused_inst.hip"
 #undef MGX_INST_V
+#endif
+#if MGX_TU_HAS(9)
 #define MGX_INST_V 9
 #include "mgx_fused_inst.hip"
 #undef MGX_INST_V
+#endif
+#if MGX_TU_HAS(11)
 #define MGX_INST_V 11
 #include "mgx_fused_inst.hip"
 #undef MGX_INST_V
+#endif
+#if MGX_TU_HAS(13)
 #define MGX_INST_V 13
 #include "mgx_fused_inst.hip"
 #undef MGX_INST_V
+#endif
+#if MGX_TU_HAS(15)
 #define MGX_INST_V 15
 #include "mgx_fused_inst.hip"
 #undef MGX_INST_V
+#endif
 #endif
 
 namespace {
@@ -41,14 +57,15 @@ int g_last_hip_error = 0;
 int g_debug_skip = 0;
 int g_debug_G = 0;
 int g_debug_wpb = 0;
+int g_debug_grp = 0;
 #else
-constexpr int g_debug_skip = 0, g_debug_G = 0, g_debug_wpb = 0;
+constexpr int g_debug_skip = 0, g_debug_G = 0, g_debug_wpb = 0, g_debug_grp = 0;
 #endif
 
 #if MGX_BOUNDS_CHECK
 int32_t *g_bounds = nullptr;        // device: [0] violations, [1] last site (checked build only; allocated on first launch)
 #endif
-#if MGX_TIMESTAMPS
+#if MGX_SPANS
 // launches since mgx_debug_span_reset(): {span_base, wavefronts, batch, first_env} each (tools/chain_overlap.py)
 constexpr int kMaxSpanLaunches = 4096;
 long long g_span_launches[kMaxSpanLaunches][4];
@@ -65,7 +82,7 @@ int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_
     }
     ka.bounds = g_bounds;
 #endif
-#if MGX_TIMESTAMPS
+#if MGX_SPANS
     if (!occupancy) {
         const long long nwaves = nwg * (threads / 64);
         ka.span_base = g_span_next;
@@ -78,7 +95,13 @@ int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_
 #endif
     switch (ka.sp.view_size) {
 #define MGX_CASE(V) case V: return launch_v##V(mode, ka, threads, lds_bytes, nwg, stream, &g_last_hip_error, occupancy);
+#if defined(MGX_ONLY_V)
+#define MGX_CASE_ONLY2(V) MGX_CASE(V)
+#define MGX_CASE_ONLY(V) MGX_CASE_ONLY2(V)
+    MGX_CASE_ONLY(MGX_ONLY_V)
+#else
     MGX_FOR_EACH_VIEW(MGX_CASE)
+#endif
 #undef MGX_CASE
     default: return MGX_ERR_UNSUPPORTED;
     }
@@ -96,8 +119,10 @@ int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot
     return MGX_OK;
 }
 
+// `step_plain`: the launch is the plain one-step kernel (mode 1 without one-hot / generation): the only one the small-group
+// latency instantiations exist for (mgx_fused.h: has_small_groups)
 int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg,
-              bool roll = false, bool one_hot = false, bool obs_only = false) {
+              bool roll = false, bool one_hot = false, bool obs_only = false, bool step_plain = false) {
     ka.sp = *sp;
     ka.batch = batch;
     ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll, one_hot, obs_only);
@@ -105,12 +130,19 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     if (ka.Gw > max_gw) ka.Gw = max_gw;
     if (ka.Gw < 1) ka.Gw = 1;
     while (ka.Gw > 1 && wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only) > kLdsPerCU) --ka.Gw;
+    ka.grp = kGroup;
+    // latency regime: a wavefront that owns ONE small group of view slots (4 or 8) -- fewer slots of P2/P4/P5 on each wave's
+    // instruction chain, more wavefronts per SIMD to run them side by side (mgx_fused.h: choose_group)
+    if (step_plain && has_small_groups(sp->view_size, 1, false, false) && sp->num_agents <= 8) {
+        const int g = g_debug_grp > 0 ? g_debug_grp : (g_debug_G > 0 ? kGroup : choose_group(*sp, batch));
+        if (g < kGroup && sp->num_agents <= g) { ka.grp = g; ka.Gw = g / sp->num_agents; }
+    }
     ka.dbg = g_debug_skip;
     // a grid tensor beyond half of the 256 MiB Infinity Cache is streamed (nt tile loads): mgx_fused.h, P0
     ka.flags = (batch * (int64_t)sp->width * sp->height * kCellBytes > (int64_t)128 << 20) ? 1 : 0;
-    ka.vpw = slots_in_use(*sp, ka.Gw, roll || obs_only);
+    ka.vpw = slots_in_use(*sp, ka.Gw, roll || obs_only, ka.grp);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
-    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only);
+    ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only, ka.grp);
     struct { int total; } p{ka.wave_lds};
     // wavefronts bundled per workgroup: 2 packs a CU's 160 KiB of LDS tighter than 4 once the chip is full (measured
     // 403 vs 425 us at 1M envs); below that, fewer and larger workgroups launch faster (9.9 vs 10.5 us at 4096 envs)
@@ -121,7 +153,8 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     lds_bytes = wpb * p.total;
     const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
     // latency regime: LDS-DMA tile loads, 32 view slots with unpacked cell registers (mgx_fused.h: DMA instantiations)
-    if (nwaves <= 2048 && !(ka.flags & 1) && ka.Gw * sp->num_agents <= kSlotsLatency) ka.flags |= 2;
+    if ((nwaves <= 2048 || ka.grp < kGroup) && !(ka.flags & 1) && ka.Gw * sp->num_agents <= kSlotsLatency) ka.flags |= 2;
+    if (!(ka.flags & 2) && ka.grp < kGroup) return MGX_ERR_UNSUPPORTED;     // (cannot happen: small groups imply a small grid tensor)
     nwg = (nwaves + wpb - 1) / wpb;
     if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
     return MGX_OK;
@@ -154,6 +187,7 @@ int mgx_last_hip_error(void) { return g_last_hip_error; }
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
+void mgx_debug_set_group(int g) { g_debug_grp = g; }               // 4 / 8: force the small-group latency instantiation, 16: forbid it
 #endif
 #if MGX_BOUNDS_CHECK
 // Checked build only: LDS accesses of the fused kernel that fell outside their wavefront's slice since the last call
@@ -166,7 +200,7 @@ int mgx_debug_bounds_violations(int32_t *out2) {
     return hipMemset(g_bounds, 0, 8) == hipSuccess ? 0 : -1;
 }
 #endif
-#if MGX_TIMESTAMPS
+#if MGX_SPANS
 // Wave spans: every launch since the last reset owns records [span_base, span_base + wavefronts) of g_span.
 void mgx_debug_span_reset(void) { g_span_next = 0; g_span_nlaunch = 0; }
 int mgx_debug_span_launches(long long *out4, int max_launches) {          // -> number of launches; out4[i] = {base, waves, batch, first_env}
@@ -179,6 +213,8 @@ int mgx_debug_read_span(unsigned long long *out, int first, int count) {  // rec
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * count,
                                sizeof(unsigned long long) * 2 * first) == hipSuccess ? 0 : -1;
 }
+#endif
+#if MGX_TIMESTAMPS
 int mgx_debug_read_stamps(unsigned long long *out64, long long wave) {   // reads the last launch's stamps, selects the next wave
     if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
     unsigned long long zero[64] = {0};
@@ -193,13 +229,14 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     if (!out) return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, false, false, true);     // (the plain step's geometry)
     if (rc) return rc;
     out->envs_per_wavefront = ka.Gw;
     out->envs_per_workgroup = ka.Gw * (threads / 64);
     out->threads_per_workgroup = threads;
     out->workgroups = (int32_t)nwg;
     out->lds_bytes = lds;
+    out->slots_per_group = ka.grp;
     return MGX_OK;
 }
 
@@ -266,7 +303,7 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
         if (occupancy && !ka.pool_grid) ka.pool_grid = reinterpret_cast<const uint8_t *>(spec);   // (selects the AR instantiation)
     }
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg, roll, one_hot);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, roll, one_hot, false, !roll && !one_hot && !gen);
     if (rc) return rc;
     ka.grid = reinterpret_cast<uint8_t *>(sa.grid); ka.agents = sa.agents; ka.rng = sa.rng; ka.step_count = sa.step_count;
     ka.actions = sa.actions; ka.hook_order = sa.hook_order;
@@ -407,8 +444,9 @@ int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, 
     const int simds = 4 * cus;                                         // CDNA: four SIMDs per CU
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, sa.one_hot != 0);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, sa.one_hot != 0, false, !sa.one_hot && !sa.generate);
     if (rc) return rc;
+    if (ka.grp < kGroup) return MGX_OK;                                // the latency regime: one launch
     const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
     // below two wavefronts per SIMD (or a view per lane of two waves per SIMD) a launch is a lone wave's instruction chain:
     // splitting it only adds launches

@@ -1,0 +1,290 @@
+// mgx_torch.cpp -- the compiled PyTorch-ROCm operator library over the C ABI of libmgx.so (include/mgx.h):
+//     TORCH_LIBRARY(mgx, ...)  +  TORCH_LIBRARY_IMPL(mgx, CUDA, ...)        (CUDA dispatch key = HIP on ROCm)
+// built in-tree as multigrid_amd/lib/libmgx_torch.so (multigrid_amd/build.py: build_torch_lib) and loaded by
+// multigrid_amd/ops.py with torch.ops.load_library -- or by any C++ program that links libtorch: the ops are in the dispatcher
+// without a Python interpreter.  No device code here: every op validates its tensors, allocates its outputs and calls ONE entry
+// point of libmgx.so on torch's current HIP stream of the tensors' device.  Only the CUDA key is registered: CPU tensors raise
+// from the dispatcher (there is no CPU implementation to fall back to).
+//
+// The seam these ops replace in the reference (ini/multigrid): multigrid/base.py:361-366 (gen_obs_grid_encoding call) and
+// multigrid/base.py:333-340 (the body of MultiGridEnv.step); wrappers: multigrid/wrappers.py:48-58, 158-190.
+//
+// `grid` / `pool_grid` are packed cells (int16 [B,H,W], MgxCell bit patterns).  The same ops accept the reference's form,
+// (type, color, state) bytes uint8 [B,H,W,3]: packed on the way in (mgx_pack_grid) and, for the mutating ops, unpacked back into
+// the caller's tensor on the way out (mgx_unpack_grid) -- two more streaming kernels, NO host synchronisation (values the packed
+// format cannot hold are stored truncated; torch.ops.mgx.pack_grid reports their count for callers who want to check).
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/library.h>
+
+#include <optional>
+#include <tuple>
+#include <vector>
+
+#include "../../include/mgx.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+MgxSpec spec_from(at::IntArrayRef v) {
+    TORCH_CHECK(v.size() == 11, "mgx: spec must have 11 ints (struct MgxSpec, include/mgx.h), got ", v.size());
+    MgxSpec s;
+    s.width = (int32_t)v[0]; s.height = (int32_t)v[1]; s.num_agents = (int32_t)v[2]; s.view_size = (int32_t)v[3];
+    s.max_steps = (int32_t)v[4]; s.see_through_walls = (int32_t)v[5]; s.allow_agent_overlap = (int32_t)v[6];
+    s.joint_reward = (int32_t)v[7]; s.success_any = (int32_t)v[8]; s.failure_any = (int32_t)v[9]; s.env_kind = (int32_t)v[10];
+    return s;
+}
+
+void want(const Tensor &t, const char *name, at::ScalarType dtype, at::IntArrayRef shape = {}, bool check_shape = false) {
+    TORCH_CHECK(t.is_cuda(), "mgx: `", name, "` must live on a HIP device (got ", t.device(), "); there is no CPU path");
+    TORCH_CHECK_TYPE(t.scalar_type() == dtype, "mgx: `", name, "` must be ", dtype, ", got ", t.scalar_type());
+    TORCH_CHECK_VALUE(t.is_contiguous(), "mgx: `", name, "` must be contiguous");
+    if (check_shape) TORCH_CHECK_VALUE(t.sizes() == shape, "mgx: `", name, "` must have shape ", shape, ", got ", t.sizes());
+}
+
+void check(int rc, const char *what) {
+    TORCH_CHECK(rc == MGX_OK, what, ": ", mgx_error_string(rc), " (code ", rc, ", hip error ", mgx_last_hip_error(), ")");
+}
+
+void *stream_of(const Tensor &t) { return (void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
+
+struct DeviceGuard {
+    c10::hip::HIPGuardMasqueradingAsCUDA g;
+    explicit DeviceGuard(const Tensor &t) : g(t.device()) {}
+};
+
+template <class T> T *ptr(const Tensor &t) { return reinterpret_cast<T *>(t.data_ptr()); }
+template <class T> T *ptr(const OptTensor &t) { return t.has_value() ? reinterpret_cast<T *>(t->data_ptr()) : nullptr; }
+
+// ---- grid format ------------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor> pack_grid(const Tensor &cells3) {
+    want(cells3, "cells3", at::kByte);
+    TORCH_CHECK_VALUE(cells3.dim() >= 1 && cells3.size(-1) == 3, "mgx: pack_grid expects (type, color, state) bytes in the last axis");
+    DeviceGuard g(cells3);
+    auto shape = cells3.sizes().vec(); shape.pop_back();
+    Tensor out = at::empty(shape, cells3.options().dtype(at::kShort));
+    Tensor bad = at::zeros({1}, cells3.options().dtype(at::kInt));
+    check(mgx_pack_grid(ptr<const uint8_t>(cells3), out.numel(), ptr<MgxCell>(out), ptr<int32_t>(bad), stream_of(cells3)), "mgx_pack_grid");
+    return {out, bad};
+}
+
+Tensor unpack_grid(const Tensor &grid) {
+    want(grid, "grid", at::kShort);
+    DeviceGuard g(grid);
+    auto shape = grid.sizes().vec(); shape.push_back(3);
+    Tensor out = at::empty(shape, grid.options().dtype(at::kByte));
+    check(mgx_unpack_grid(ptr<const MgxCell>(grid), grid.numel(), ptr<uint8_t>(out), stream_of(grid)), "mgx_unpack_grid");
+    return out;
+}
+
+// the grid as the device wants it: packed cells.  A byte grid is packed here (no host sync); `bytes` tells the caller whether it
+// has to unpack the result back into the caller's tensor.
+Tensor as_cells(const Tensor &grid, const char *name, bool &bytes) {
+    bytes = grid.scalar_type() == at::kByte;
+    if (!bytes) return grid;
+    want(grid, name, at::kByte);
+    TORCH_CHECK_VALUE(grid.dim() == 4 && grid.size(-1) == 3, "mgx: a byte `", name, "` must be uint8 [B,H,W,3]");
+    auto shape = grid.sizes().vec(); shape.pop_back();
+    Tensor out = at::empty(shape, grid.options().dtype(at::kShort));
+    check(mgx_pack_grid(ptr<const uint8_t>(grid), out.numel(), ptr<MgxCell>(out), nullptr, stream_of(grid)), "mgx_pack_grid");
+    return out;
+}
+
+void cells_back(const Tensor &cells, const Tensor &grid_bytes) {
+    check(mgx_unpack_grid(ptr<const MgxCell>(cells), cells.numel(), ptr<uint8_t>(grid_bytes), stream_of(cells)), "mgx_unpack_grid");
+}
+
+int64_t check_state(const MgxSpec &sc, const Tensor &cells, const Tensor &agents) {
+    const int64_t B = cells.dim() > 0 ? cells.size(0) : 0;
+    want(cells, "grid", at::kShort, {B, sc.height, sc.width}, true);
+    want(agents, "agents", at::kByte, {B, sc.num_agents, 8}, true);
+    return B;
+}
+
+// ---- gen_obs ---------------------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor> gen_obs_any(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec, bool one_hot) {
+    const MgxSpec sc = spec_from(spec);
+    DeviceGuard g(grid);
+    bool bytes;
+    const Tensor cells = as_cells(grid, "grid", bytes);
+    const int64_t B = check_state(sc, cells, agents);
+    const int64_t A = sc.num_agents, v = sc.view_size;
+    Tensor obs = at::empty({B, A, v, v, one_hot ? 21 : 3}, agents.options());
+    Tensor dirs = at::empty({B, A}, agents.options());
+    if (one_hot)
+        check(mgx_gen_obs_one_hot(&sc, B, ptr<const MgxCell>(cells), ptr<const uint8_t>(agents), ptr<uint8_t>(obs), ptr<uint8_t>(dirs),
+                                  stream_of(cells)), "mgx_gen_obs_one_hot");
+    else
+        check(mgx_gen_obs(&sc, B, ptr<const MgxCell>(cells), ptr<const uint8_t>(agents), ptr<uint8_t>(obs), ptr<uint8_t>(dirs),
+                          stream_of(cells)), "mgx_gen_obs");
+    return {obs, dirs};
+}
+std::tuple<Tensor, Tensor> gen_obs(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec) { return gen_obs_any(grid, agents, spec, false); }
+std::tuple<Tensor, Tensor> gen_obs_one_hot(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec) { return gen_obs_any(grid, agents, spec, true); }
+
+// ---- step family: one implementation over MgxStepArgs / mgx_step_ex ----------------------------------------------------
+struct StepOut { Tensor obs, dirs, reward, terminated, truncated, was_reset; };
+
+StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, const Tensor &step_count, const Tensor &actions,
+                 const OptTensor &aux, const Tensor &err, at::IntArrayRef spec, int64_t T /* 0 = one step */, bool one_hot,
+                 const OptTensor &pool_grid, const OptTensor &pool_agents, const OptTensor &pool_aux, const OptTensor &episode,
+                 int64_t first_env, const OptTensor &hook_order, const char *what) {
+    const MgxSpec sc = spec_from(spec);
+    DeviceGuard g(grid);
+    bool bytes, pool_bytes = false;
+    const Tensor cells = as_cells(grid, "grid", bytes);
+    const int64_t B = check_state(sc, cells, agents);
+    const int64_t A = sc.num_agents, v = sc.view_size;
+    want(rng, "rng", at::kLong, {B, 4}, true);
+    want(step_count, "step_count", at::kInt, {B}, true);
+    if (T > 0) want(actions, "actions", at::kChar, {T, B, A}, true);
+    else want(actions, "actions", at::kChar, {B, A}, true);
+    want(err, "err", at::kInt, {2}, true);
+    if (aux.has_value()) want(*aux, "aux", at::kByte, {B, 16}, true);
+    else TORCH_CHECK_VALUE(sc.env_kind == MGX_KIND_EMPTY, "mgx: this env kind needs `aux` (the env subclass' hook state, include/mgx.h)");
+    if (hook_order.has_value()) {
+        if (T > 0) want(*hook_order, "hook_order", at::kByte, {T, B, A}, true);
+        else want(*hook_order, "hook_order", at::kByte, {B, A}, true);
+    }
+    std::vector<int64_t> lead = T > 0 ? std::vector<int64_t>{T, B} : std::vector<int64_t>{B};
+    auto shape = [&](std::initializer_list<int64_t> tail) { auto s = lead; s.insert(s.end(), tail); return s; };
+    StepOut o;
+    o.obs = at::empty(shape({A, v, v, one_hot ? 21 : 3}), agents.options());
+    o.dirs = at::empty(shape({A}), agents.options());
+    o.reward = at::empty(shape({A}), agents.options().dtype(at::kDouble));
+    o.terminated = at::empty(shape({A}), agents.options());
+    o.truncated = at::empty(lead, agents.options());
+    MgxStepArgs sa{};
+    sa.grid = ptr<MgxCell>(cells); sa.agents = ptr<uint8_t>(agents); sa.rng = ptr<uint64_t>(rng); sa.step_count = ptr<int32_t>(step_count);
+    sa.aux = ptr<uint8_t>(aux); sa.actions = ptr<const int8_t>(actions); sa.hook_order = ptr<const uint8_t>(hook_order);
+    sa.obs = ptr<uint8_t>(o.obs); sa.dir = ptr<uint8_t>(o.dirs); sa.reward = ptr<double>(o.reward);
+    sa.terminated = ptr<uint8_t>(o.terminated); sa.truncated = ptr<uint8_t>(o.truncated); sa.err = ptr<int32_t>(err);
+    sa.steps = T > 0 ? (int32_t)T : 1;
+    sa.one_hot = one_hot ? 1 : 0;
+    MgxAutoReset ar{};
+    Tensor pool_cells;
+    if (pool_grid.has_value()) {
+        pool_cells = as_cells(*pool_grid, "pool_grid", pool_bytes);
+        const int64_t K = pool_cells.dim() > 0 ? pool_cells.size(0) : 0;
+        want(pool_cells, "pool_grid", at::kShort, {K, sc.height, sc.width}, true);
+        TORCH_CHECK_VALUE(pool_agents.has_value() && episode.has_value(), "mgx: auto-reset needs pool_agents and episode");
+        want(*pool_agents, "pool_agents", at::kByte, {K, A, 8}, true);
+        if (pool_aux.has_value()) want(*pool_aux, "pool_aux", at::kByte, {K, 16}, true);
+        want(*episode, "episode", at::kInt, {B}, true);
+        o.was_reset = at::empty(lead, agents.options());
+        ar.first_env = first_env; ar.pool_size = (int32_t)K; ar.pool_grid = ptr<const MgxCell>(pool_cells);
+        ar.pool_agents = ptr<const uint8_t>(*pool_agents); ar.pool_aux = ptr<const uint8_t>(pool_aux);
+        ar.episode = ptr<int32_t>(*episode); ar.was_reset = ptr<uint8_t>(o.was_reset);
+        sa.auto_reset = &ar;
+    } else {
+        o.was_reset = at::zeros(lead, agents.options());
+    }
+    check(mgx_step_ex(&sc, B, &sa, stream_of(cells)), what);
+    if (bytes) cells_back(cells, grid);
+    return o;
+}
+
+using Out5 = std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>;
+using Out6 = std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>;
+
+Out5 step(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+          at::IntArrayRef spec) {
+    StepOut o = step_any(grid, agents, rng, step_count, actions, aux, err, spec, 0, false, {}, {}, {}, {}, 0, {}, "mgx_step");
+    return {o.obs, o.dirs, o.reward, o.terminated, o.truncated};
+}
+
+Out5 step_ordered(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, const Tensor &hook_order,
+                  OptTensor aux, Tensor err, at::IntArrayRef spec) {
+    StepOut o = step_any(grid, agents, rng, step_count, actions, aux, err, spec, 0, false, {}, {}, {}, {}, 0, hook_order, "mgx_step");
+    return {o.obs, o.dirs, o.reward, o.terminated, o.truncated};
+}
+
+Out6 step_autoreset(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+                    const Tensor &pool_grid, const Tensor &pool_agents, const OptTensor &pool_aux, Tensor episode,
+                    int64_t first_env, at::IntArrayRef spec) {
+    StepOut o = step_any(grid, agents, rng, step_count, actions, aux, err, spec, 0, false, pool_grid, pool_agents, pool_aux, episode,
+                         first_env, {}, "mgx_step_autoreset");
+    return {o.obs, o.dirs, o.reward, o.terminated, o.truncated, o.was_reset};
+}
+
+Out5 rollout(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+             at::IntArrayRef spec) {
+    TORCH_CHECK_VALUE(actions.dim() == 3, "mgx: rollout expects actions[T, B, A]");
+    StepOut o = step_any(grid, agents, rng, step_count, actions, aux, err, spec, actions.size(0), false, {}, {}, {}, {}, 0, {},
+                         "mgx_rollout");
+    return {o.obs, o.dirs, o.reward, o.terminated, o.truncated};
+}
+
+Out6 step_one_hot(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+                  const OptTensor &pool_grid, const OptTensor &pool_agents, const OptTensor &pool_aux, OptTensor episode,
+                  int64_t first_env, at::IntArrayRef spec) {
+    StepOut o = step_any(grid, agents, rng, step_count, actions, aux, err, spec, 0, true, pool_grid, pool_agents, pool_aux, episode,
+                         first_env, {}, "mgx_step_one_hot");
+    return {o.obs, o.dirs, o.reward, o.terminated, o.truncated, o.was_reset};
+}
+
+// ---- either side of the path ---------------------------------------------------------------------------------------------
+Tensor one_hot(const Tensor &cells, at::IntArrayRef dim_sizes) {
+    want(cells, "cells", at::kByte);
+    TORCH_CHECK_VALUE(cells.dim() >= 1 && cells.size(-1) == 3 && dim_sizes.size() == 3, "mgx: one_hot expects cells[..., 3] and three dim sizes");
+    DeviceGuard g(cells);
+    const int32_t ds[3] = {(int32_t)dim_sizes[0], (int32_t)dim_sizes[1], (int32_t)dim_sizes[2]};
+    auto shape = cells.sizes().vec(); shape.back() = (int64_t)ds[0] + ds[1] + ds[2];
+    Tensor out = at::empty(shape, cells.options());
+    check(mgx_one_hot(ptr<const uint8_t>(cells), cells.numel() / 3, ds, ptr<uint8_t>(out), stream_of(cells)), "mgx_one_hot");
+    return out;
+}
+
+Tensor full_obs(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec) {
+    const MgxSpec sc = spec_from(spec);
+    DeviceGuard g(grid);
+    bool bytes;
+    const Tensor cells = as_cells(grid, "grid", bytes);
+    const int64_t B = check_state(sc, cells, agents);
+    Tensor out = at::empty({B, sc.width, sc.height, 3}, agents.options());
+    check(mgx_full_obs(&sc, B, ptr<const MgxCell>(cells), ptr<const uint8_t>(agents), ptr<uint8_t>(out), stream_of(cells)), "mgx_full_obs");
+    return out;
+}
+
+int64_t abi_version() { return mgx_abi_version(); }
+
+}  // namespace
+
+TORCH_LIBRARY(mgx, m) {
+    m.def("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)");
+    m.def("step(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("step_ordered(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor hook_order, Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("step_autoreset(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor(f!)? aux, Tensor(e!) err, Tensor pool_grid, Tensor pool_agents, Tensor? pool_aux, Tensor(g!) episode, "
+          "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("rollout(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("gen_obs_one_hot(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)");
+    m.def("step_one_hot(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor(f!)? aux, Tensor(e!) err, Tensor? pool_grid, Tensor? pool_agents, Tensor? pool_aux, Tensor(g!)? episode, "
+          "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("one_hot(Tensor cells, int[] dim_sizes) -> Tensor");
+    m.def("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor");
+    m.def("pack_grid(Tensor cells3) -> (Tensor, Tensor)");
+    m.def("unpack_grid(Tensor grid) -> Tensor");
+    m.def("abi_version() -> int", &abi_version);
+}
+
+TORCH_LIBRARY_IMPL(mgx, CUDA, m) {
+    m.impl("gen_obs", &gen_obs);
+    m.impl("step", &step);
+    m.impl("step_ordered", &step_ordered);
+    m.impl("step_autoreset", &step_autoreset);
+    m.impl("rollout", &rollout);
+    m.impl("gen_obs_one_hot", &gen_obs_one_hot);
+    m.impl("step_one_hot", &step_one_hot);
+    m.impl("one_hot", &one_hot);
+    m.impl("full_obs", &full_obs);
+    m.impl("pack_grid", &pack_grid);
+    m.impl("unpack_grid", &unpack_grid);
+}

@@ -1,8 +1,10 @@
-"""PyTorch-ROCm custom ops over the C ABI of libmgx.so.
+"""PyTorch-ROCm custom ops over the C ABI of libmgx.so -- compiled (csrc/mgx_torch.cpp, lib/libmgx_torch.so), loaded here.
 
     torch.ops.mgx.gen_obs(grid, agents, spec) -> (obs, dir)
     torch.ops.mgx.step(grid!, agents!, rng!, step_count!, actions, aux!?, err!, spec)
                                                -> (obs, dir, reward, terminated, truncated)
+    torch.ops.mgx.step_ordered(grid!, agents!, rng!, step_count!, actions, hook_order, aux!?, err!, spec)   (hook_order u8[B,A]: the
+                                               env hooks' visiting order = the caller's dict order, include/mgx.h)
     torch.ops.mgx.step_autoreset(grid!, agents!, rng!, step_count!, actions, aux!?, err!, pool_grid, pool_agents,
                                  pool_aux?, episode!, first_env, spec)
                                                -> (obs, dir, reward, terminated, truncated, was_reset)
@@ -14,7 +16,8 @@
 `grid` / `pool_grid` are PACKED cells, int16 tensors [B,H,W] holding the MgxCell bit patterns of include/mgx.h (type |
 color << 8 | state << 12 | opaque << 15); pack_grid / unpack_grid convert from / to (type, color, state) bytes on the device.
 The same ops also accept `grid` / `pool_grid` as those bytes, uint8 [B,H,W,3] (packed on the way in and, for the mutating ops,
-unpacked back into the caller's tensor on the way out: two extra streaming kernels per call).
+unpacked back into the caller's tensor on the way out: two extra streaming kernels per call, no host synchronisation; cells the
+packed format cannot hold are stored truncated -- pack_grid reports their count).
 
 `spec` is the 11-int list of `struct MgxSpec` (include/mgx.h).  Only the CUDA (= HIP on ROCm) dispatch key is
 registered: calling the ops with CPU tensors raises NotImplementedError from the dispatcher -- there is no
@@ -26,6 +29,7 @@ device; nothing synchronises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -38,23 +42,6 @@ _SPEC_FIELDS = [n for n, _ in MgxSpecC._fields_]
 def spec_to_ints(spec: EnvSpec) -> list[int]:
     c = spec.to_c()
     return [int(getattr(c, n)) for n in _SPEC_FIELDS]
-
-
-def _spec_from_ints(ints) -> MgxSpecC:
-    if len(ints) != len(_SPEC_FIELDS):
-        raise ValueError(f"spec must have {len(_SPEC_FIELDS)} ints")
-    return MgxSpecC(*[int(v) for v in ints])
-
-
-def _want(t: torch.Tensor, name: str, dtype, shape=None):
-    if not t.is_cuda:
-        raise RuntimeError(f"mgx: `{name}` must live on a HIP device (got {t.device}); there is no CPU path")
-    if t.dtype != dtype:
-        raise TypeError(f"mgx: `{name}` must be {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
-        raise ValueError(f"mgx: `{name}` must be contiguous")
-    if shape is not None and tuple(t.shape) != tuple(shape):
-        raise ValueError(f"mgx: `{name}` must have shape {tuple(shape)}, got {tuple(t.shape)}")
 
 
 def _stream(device) -> int:
@@ -80,135 +67,8 @@ def _step_into(sc: MgxSpecC, B, grid, agents, rng, step_count, actions, target, 
     _lib.check(rc, "mgx_step")
 
 
-def _check_state(sc: MgxSpecC, grid, agents):
-    B = grid.shape[0]
-    _want(grid, "grid", torch.int16, (B, sc.height, sc.width))
-    _want(agents, "agents", torch.uint8, (B, sc.num_agents, 8))
-    return B
-
-
-def _gen_obs_impl(grid, agents, spec):
-    sc = _spec_from_ints(spec)
-    B = _check_state(sc, grid, agents)
-    A, v = sc.num_agents, sc.view_size
-    obs = torch.empty((B, A, v, v, 3), dtype=torch.uint8, device=grid.device)
-    dirs = torch.empty((B, A), dtype=torch.uint8, device=grid.device)
-    _gen_obs_into(sc, B, grid, agents, obs, dirs)
-    return obs, dirs
-
-
-def _step_impl(grid, agents, rng, step_count, actions, aux, err, spec):
-    sc = _spec_from_ints(spec)
-    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err)
-    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, grid.device)
-    _step_into(sc, B, grid, agents, rng, step_count, actions, aux, err, obs, dirs, reward, terminated, truncated)
-    return obs, dirs, reward, terminated, truncated
-
-
-def _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err, T=None):
-    B = _check_state(sc, grid, agents)
-    A = sc.num_agents
-    _want(rng, "rng", torch.int64, (B, 4))
-    _want(step_count, "step_count", torch.int32, (B,))
-    _want(actions, "actions", torch.int8, (B, A) if T is None else (T, B, A))
-    _want(err, "err", torch.int32, (2,))
-    if aux is not None:
-        _want(aux, "aux", torch.uint8, (B, 16))
-    elif sc.env_kind != 0:
-        raise ValueError("mgx: this env kind needs `aux` (the env subclass' hook state, include/mgx.h)")
-    return B
-
-
-def _alloc_outputs(sc, B, dev, T=None, channels=3):
-    A, v = sc.num_agents, sc.view_size
-    lead = (B,) if T is None else (T, B)
-    return (torch.empty(lead + (A, v, v, channels), dtype=torch.uint8, device=dev),
-            torch.empty(lead + (A,), dtype=torch.uint8, device=dev),
-            torch.empty(lead + (A,), dtype=torch.float64, device=dev),
-            torch.empty(lead + (A,), dtype=torch.uint8, device=dev),
-            torch.empty(lead, dtype=torch.uint8, device=dev))
-
-
 def _ptr(t):
     return t.data_ptr() if t is not None else None
-
-
-def _step_autoreset_impl(grid, agents, rng, step_count, actions, aux, err, pool_grid, pool_agents, pool_aux, episode,
-                         first_env, spec):
-    sc = _spec_from_ints(spec)
-    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err)
-    K = pool_grid.shape[0]
-    _want(pool_grid, "pool_grid", torch.int16, (K, sc.height, sc.width))
-    _want(pool_agents, "pool_agents", torch.uint8, (K, sc.num_agents, 8))
-    if pool_aux is not None:
-        _want(pool_aux, "pool_aux", torch.uint8, (K, 16))
-    _want(episode, "episode", torch.int32, (B,))
-    dev = grid.device
-    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, dev)
-    was_reset = torch.empty((B,), dtype=torch.uint8, device=dev)
-    ar = _lib.MgxAutoReset(int(first_env), K, pool_grid.data_ptr(), pool_agents.data_ptr(), _ptr(pool_aux),
-                           episode.data_ptr(), was_reset.data_ptr())
-    with torch.cuda.device(dev):
-        rc = _lib.lib().mgx_step_autoreset(
-            C.byref(sc), B, C.byref(ar), grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
-            actions.data_ptr(), _ptr(aux), obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(),
-            truncated.data_ptr(), err.data_ptr(), _stream(dev))
-    _lib.check(rc, "mgx_step_autoreset")
-    return obs, dirs, reward, terminated, truncated, was_reset
-
-
-def _rollout_impl(grid, agents, rng, step_count, actions, aux, err, spec):
-    sc = _spec_from_ints(spec)
-    if actions.dim() != 3:
-        raise ValueError("mgx: rollout expects actions[T, B, A]")
-    T = actions.shape[0]
-    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err, T=T)
-    dev = grid.device
-    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, dev, T=T)
-    with torch.cuda.device(dev):
-        rc = _lib.lib().mgx_rollout(
-            C.byref(sc), B, T, grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
-            actions.data_ptr(), _ptr(aux), obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(),
-            truncated.data_ptr(), err.data_ptr(), _stream(dev))
-    _lib.check(rc, "mgx_rollout")
-    return obs, dirs, reward, terminated, truncated
-
-
-def _gen_obs_one_hot_impl(grid, agents, spec):
-    sc = _spec_from_ints(spec)
-    B = _check_state(sc, grid, agents)
-    A, v = sc.num_agents, sc.view_size
-    obs = torch.empty((B, A, v, v, 21), dtype=torch.uint8, device=grid.device)
-    dirs = torch.empty((B, A), dtype=torch.uint8, device=grid.device)
-    _gen_obs_into(sc, B, grid, agents, obs, dirs, one_hot=True)
-    return obs, dirs
-
-
-def _step_one_hot_impl(grid, agents, rng, step_count, actions, aux, err, pool_grid, pool_agents, pool_aux, episode,
-                       first_env, spec):
-    """pool_grid None = no auto-reset (then pool_agents / pool_aux / episode are ignored)."""
-    sc = _spec_from_ints(spec)
-    B = _check_step_args(sc, grid, agents, rng, step_count, actions, aux, err)
-    dev = grid.device
-    obs, dirs, reward, terminated, truncated = _alloc_outputs(sc, B, dev, channels=21)
-    was_reset = torch.zeros((B,), dtype=torch.uint8, device=dev)
-    ar = None
-    if pool_grid is not None:
-        K = pool_grid.shape[0]
-        _want(pool_grid, "pool_grid", torch.int16, (K, sc.height, sc.width))
-        _want(pool_agents, "pool_agents", torch.uint8, (K, sc.num_agents, 8))
-        if pool_aux is not None:
-            _want(pool_aux, "pool_aux", torch.uint8, (K, 16))
-        _want(episode, "episode", torch.int32, (B,))
-        ar = C.byref(_lib.MgxAutoReset(int(first_env), K, pool_grid.data_ptr(), pool_agents.data_ptr(), _ptr(pool_aux),
-                                       episode.data_ptr(), was_reset.data_ptr()))
-    with torch.cuda.device(dev):
-        rc = _lib.lib().mgx_step_one_hot(
-            C.byref(sc), B, ar, grid.data_ptr(), agents.data_ptr(), rng.data_ptr(), step_count.data_ptr(),
-            actions.data_ptr(), _ptr(aux), obs.data_ptr(), dirs.data_ptr(), reward.data_ptr(), terminated.data_ptr(),
-            truncated.data_ptr(), err.data_ptr(), _stream(dev))
-    _lib.check(rc, "mgx_step_one_hot")
-    return obs, dirs, reward, terminated, truncated, was_reset
 
 
 ONE_HOT_DIMS = (11, 6, 4)      # len(Type), len(Color), max(len(State), len(Direction))  (multigrid/wrappers.py:139-140)
@@ -221,15 +81,6 @@ def _one_hot_into(cells, out, dim_sizes=ONE_HOT_DIMS):
     _lib.check(rc, "mgx_one_hot")
 
 
-def _one_hot_impl(cells, dim_sizes):
-    _want(cells, "cells", torch.uint8)
-    if cells.shape[-1] != 3 or len(dim_sizes) != 3:
-        raise ValueError("mgx: one_hot expects cells[..., 3] and three dim sizes")
-    out = torch.empty(tuple(cells.shape[:-1]) + (int(sum(dim_sizes)),), dtype=torch.uint8, device=cells.device)
-    _one_hot_into(cells, out, tuple(int(d) for d in dim_sizes))
-    return out
-
-
 def _full_obs_into(sc: MgxSpecC, B, grid, agents, out):
     with torch.cuda.device(grid.device):
         rc = _lib.lib().mgx_full_obs(C.byref(sc), B, grid.data_ptr(), agents.data_ptr(), out.data_ptr(),
@@ -237,93 +88,23 @@ def _full_obs_into(sc: MgxSpecC, B, grid, agents, out):
     _lib.check(rc, "mgx_full_obs")
 
 
-def _full_obs_impl(grid, agents, spec):
-    sc = _spec_from_ints(spec)
-    B = _check_state(sc, grid, agents)
-    out = torch.empty((B, sc.width, sc.height, 3), dtype=torch.uint8, device=grid.device)
-    _full_obs_into(sc, B, grid, agents, out)
-    return out
+# The operators themselves are COMPILED: csrc/mgx_torch.cpp -> lib/libmgx_torch.so, TORCH_LIBRARY(mgx) + TORCH_LIBRARY_IMPL(mgx,
+# CUDA), in the dispatcher without any Python (a C++ program that links libtorch loads the same file).  Loading it here is what
+# makes `torch.ops.mgx.*` exist; a missing library is an ImportError, never a Python fallback.
+TORCH_LIB_PATH = os.path.join(os.path.dirname(_lib.PRODUCT_LIB_PATH), "libmgx_torch.so")
 
 
-def _pack_grid_impl(cells3):
-    _want(cells3, "cells3", torch.uint8)
-    if cells3.shape[-1] != 3:
-        raise ValueError("mgx: pack_grid expects (type, color, state) bytes in the last axis")
-    out = torch.empty(tuple(cells3.shape[:-1]), dtype=torch.int16, device=cells3.device)
-    bad = torch.zeros((1,), dtype=torch.int32, device=cells3.device)
-    with torch.cuda.device(cells3.device):
-        rc = _lib.lib().mgx_pack_grid(cells3.data_ptr(), out.numel(), out.data_ptr(), bad.data_ptr(), _stream(cells3.device))
-    _lib.check(rc, "mgx_pack_grid")
-    return out, bad
+def _load_compiled_ops():
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise ImportError(f"{TORCH_LIB_PATH} is missing: the compiled operator library has not been built. Run "
+                          "`python -m multigrid_amd.build --torch` (or __graft_entry__.build()).")
+    _lib.lib()                                       # libmgx.so first (the operator library links against it)
+    torch.ops.load_library(TORCH_LIB_PATH)
+    if int(torch.ops.mgx.abi_version()) != _lib.ABI_VERSION:
+        raise ImportError(f"{TORCH_LIB_PATH} was built against ABI {int(torch.ops.mgx.abi_version())}, libmgx.so is {_lib.ABI_VERSION}")
 
 
-def _unpack_grid_impl(grid):
-    _want(grid, "grid", torch.int16)
-    out = torch.empty(tuple(grid.shape) + (3,), dtype=torch.uint8, device=grid.device)
-    with torch.cuda.device(grid.device):
-        rc = _lib.lib().mgx_unpack_grid(grid.data_ptr(), grid.numel(), out.data_ptr(), _stream(grid.device))
-    _lib.check(rc, "mgx_unpack_grid")
-    return out
-
-
-def _accepts_byte_grids(fn, mutates: bool, pool_pos=None):
-    """The ops take the grid as the device holds it (packed cells, int16).  For callers that hold the reference's form --
-    (type, color, state) bytes, `grid_u8[B,H,W,3]` as SURVEY.md section 8b words the op signatures -- the same ops also accept
-    that: the grid (and a layout pool) is packed on the way in (mgx_pack_grid; unrepresentable values raise) and, for the
-    mutating ops, unpacked back into the caller's tensor on the way out (mgx_unpack_grid).  Two extra streaming kernels per
-    call: the convenience form, not the fast one."""
-    def as_cells(t, name):
-        cells, bad = _pack_grid_impl(t)
-        if int(bad[0]):
-            raise ValueError(f"mgx: `{name}` holds {int(bad[0])} cell(s) outside the packed format (type <= 15, color <= 7, state <= 3)")
-        return cells
-
-    def wrapped(grid, *rest):
-        rest = list(rest)
-        if pool_pos is not None and rest[pool_pos] is not None and rest[pool_pos].dtype == torch.uint8:
-            rest[pool_pos] = as_cells(rest[pool_pos], "pool_grid")
-        if grid.dtype != torch.uint8:
-            return fn(grid, *rest)
-        _want(grid, "grid", torch.uint8)
-        cells = as_cells(grid, "grid")
-        out = fn(cells, *rest)
-        if mutates:
-            grid.copy_(_unpack_grid_impl(cells))
-        return out
-    return wrapped
-
-
-_torch_lib = torch.library.Library("mgx", "DEF")
-_torch_lib.define("gen_obs(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
-_torch_lib.define(
-    "step(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
-    "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
-_torch_lib.define(
-    "step_autoreset(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
-    "Tensor(f!)? aux, Tensor(e!) err, Tensor pool_grid, Tensor pool_agents, Tensor? pool_aux, Tensor(g!) episode, "
-    "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
-_torch_lib.define(
-    "rollout(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
-    "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
-_torch_lib.define("gen_obs_one_hot(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)")
-_torch_lib.define(
-    "step_one_hot(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
-    "Tensor(f!)? aux, Tensor(e!) err, Tensor? pool_grid, Tensor? pool_agents, Tensor? pool_aux, Tensor(g!)? episode, "
-    "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
-_torch_lib.define("one_hot(Tensor cells, int[] dim_sizes) -> Tensor")
-_torch_lib.define("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor")
-_torch_lib.define("pack_grid(Tensor cells3) -> (Tensor, Tensor)")
-_torch_lib.define("unpack_grid(Tensor grid) -> Tensor")
-_torch_lib.impl("pack_grid", _pack_grid_impl, "CUDA")
-_torch_lib.impl("unpack_grid", _unpack_grid_impl, "CUDA")
-_torch_lib.impl("one_hot", _one_hot_impl, "CUDA")
-_torch_lib.impl("full_obs", _accepts_byte_grids(_full_obs_impl, False), "CUDA")
-_torch_lib.impl("gen_obs", _accepts_byte_grids(_gen_obs_impl, False), "CUDA")
-_torch_lib.impl("step", _accepts_byte_grids(_step_impl, True), "CUDA")
-_torch_lib.impl("step_autoreset", _accepts_byte_grids(_step_autoreset_impl, True, pool_pos=6), "CUDA")
-_torch_lib.impl("rollout", _accepts_byte_grids(_rollout_impl, True), "CUDA")
-_torch_lib.impl("gen_obs_one_hot", _accepts_byte_grids(_gen_obs_one_hot_impl, False), "CUDA")
-_torch_lib.impl("step_one_hot", _accepts_byte_grids(_step_one_hot_impl, True, pool_pos=6), "CUDA")
+_load_compiled_ops()
 
 
 class HipBackend:

@@ -14,7 +14,8 @@
 // the oracle's batch entry points (oracle/mgx_oracle.c); its spec struct has the layout of MgxSpec
 extern "C" int mgo_step_batch(const MgxSpec *sp, int64_t B, uint8_t *grid, uint8_t *agents, uint64_t *rng,
                               int32_t *step_count, const int8_t *actions, const uint8_t *target, uint8_t *obs, uint8_t *dir,
-                              double *reward, uint8_t *terminated, uint8_t *truncated, int64_t *err_env, int nthreads);
+                              double *reward, uint8_t *terminated, uint8_t *truncated, int64_t *err_env, int nthreads,
+                              const uint8_t *hook_order);
 extern "C" int mgo_gen_obs_batch(const MgxSpec *sp, int64_t B, const uint8_t *grid, const uint8_t *agents, uint8_t *obs,
                                  uint8_t *dir, int nthreads);
 
@@ -93,7 +94,7 @@ int main(int argc, char **argv) {
         HIP_OK(hipStreamSynchronize(stream));
         int64_t bad = -1;
         if (mgo_step_batch(&sp, B, grid.data(), agents.data(), rng.data(), sc.data(), act.data(), nullptr, o_obs.data(), o_dir.data(),
-                           o_rew.data(), o_term.data(), o_trunc.data(), &bad, 8)) return 6;
+                           o_rew.data(), o_term.data(), o_trunc.data(), &bad, 8, nullptr)) return 6;
         HIP_OK((hipError_t)d_obs.down(h_obs)); HIP_OK((hipError_t)d_dir.down(h_dir)); HIP_OK((hipError_t)d_rew.down(h_rew)); HIP_OK((hipError_t)d_term.down(h_term));
         MGX_OK_(mgx_unpack_grid(d_grid.p, B * (int64_t)W * H, d_cells3.p, stream));
         HIP_OK(hipStreamSynchronize(stream));

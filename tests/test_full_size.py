@@ -83,6 +83,76 @@ def test_c4_full_size_vs_oracle():
     run_vs_oracle(wl, T=24, seed=4)
 
 
+@pytest.mark.parametrize("form", ["graph", "eager_chains"])
+def test_c4_full_size_four_chains_vs_oracle(form):
+    """EXACTLY what bench.py times as the pipelined headline: C4 at 65 536 envs stepped as 4 independent chains of 16 384-env
+    launches (capture_steps(sub_shards=4): four parallel branches of one hipGraph; or step(..., sub_shards=4): mgx_step_chains on
+    four streams), auto-reset fused in -- against the ORACLE, every output and the whole state:
+      * a one-step 4-chain graph replayed per step with fresh actions: every step's outputs and post-step state;
+      * then a 12-step 4-chain graph replayed once (the chains free to drift apart, as in the bench): the last step's outputs
+        and the whole state after the run."""
+    wl = workloads.make("c4")
+    assert wl.batch == 65536
+    spec, B, A = wl.spec, wl.batch, wl.spec.num_agents
+    env = wl.make_env(DEV, auto_reset=True)
+    assert env.sub_shards_hint(auto_reset=True) == 4                     # (what sub_shards="auto" resolves to on an MI355X)
+    ref = dict(grid=wl.grid.copy(), agents=wl.agents.copy(), rng=wl.rng.copy(), step_count=np.zeros(B, np.int32), aux=None)
+    episode = np.zeros(B, np.int32)
+    sd, nt = spec.as_dict(), ob.max_threads()
+    r = np.random.default_rng(44)
+
+    def oracle_step(act):
+        was = oracle_reset_done(wl, ref, episode)
+        return was, ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, None, nthreads=nt)
+
+    def check(ctx, was_ref, outs_ref):
+        torch.cuda.synchronize()
+        o_ref, d_ref, r_ref, te_ref, tr_ref = outs_ref
+        np.testing.assert_array_equal(env.was_reset.cpu().numpy(), was_ref, err_msg=ctx)
+        assert env.obs.cpu().numpy().tobytes() == o_ref.tobytes(), ctx + ": obs"
+        np.testing.assert_array_equal(env.dir.cpu().numpy(), d_ref, err_msg=ctx)
+        assert env.reward.cpu().numpy().tobytes() == r_ref.tobytes(), ctx + ": reward"
+        np.testing.assert_array_equal(env.terminated.cpu().numpy(), te_ref, err_msg=ctx)
+        np.testing.assert_array_equal(env.truncated.cpu().numpy(), tr_ref, err_msg=ctx)
+        assert env.grid.cpu().numpy().tobytes() == ref["grid"].tobytes(), ctx + ": grid"
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"], err_msg=ctx)
+        np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref["step_count"], err_msg=ctx)
+        np.testing.assert_array_equal(env.rng.cpu().numpy().view(np.uint64), ref["rng"], err_msg=ctx)
+        np.testing.assert_array_equal(env.episode.cpu().numpy(), episode, err_msg=ctx)
+
+    T1, T2 = 6, 12
+    if form == "graph":
+        buf = torch.zeros((1, B, A), dtype=torch.int8, device=DEV)
+        g1 = env.capture_steps(buf, auto_reset=True, sub_shards="auto")
+        assert g1.sub_shards == 4
+        for t in range(T1):
+            act = r.integers(0, 7, size=(B, A)).astype(np.int8)
+            was, outs = oracle_step(act)
+            buf[0].copy_(torch.from_numpy(act).to(DEV))
+            g1.replay()
+            check(f"one-step 4-chain graph, step {t}", was, outs)
+        acts = r.integers(0, 7, size=(T2, B, A)).astype(np.int8)
+        g12 = env.capture_steps(torch.from_numpy(acts).to(DEV), auto_reset=True, sub_shards=4)
+        for t in range(T2):
+            was, outs = oracle_step(acts[t])
+        g12.replay()
+        check("12-step 4-chain graph", was, outs)
+    else:
+        acts = r.integers(0, 7, size=(T1 + T2, B, A)).astype(np.int8)
+        dacts = torch.from_numpy(acts).to(DEV)
+        for t in range(T1):                                              # joined after every step
+            was, outs = oracle_step(acts[t])
+            env.step(dacts[t], auto_reset=True, sub_shards=4)
+            env.join()
+            check(f"eager 4 chains, step {t}", was, outs)
+        for t in range(T1, T1 + T2):                                     # free-running chains, joined once
+            was, outs = oracle_step(acts[t])
+            env.step(dacts[t], auto_reset=True, sub_shards="auto")
+        env.join()
+        check("eager 4 chains, 12 steps unjoined", was, outs)
+    env.check_errors()
+
+
 def test_c2_with_auto_reset_through_goals_vs_oracle():
     """Agents biased to walk (forward 55 %): goals are reached, envs restart, the run continues -- all vs the oracle."""
     wl = workloads.make("c2")

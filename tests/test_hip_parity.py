@@ -622,3 +622,81 @@ def test_sub_sharded_graph_equals_one_chain(case):
         if case == "bup_generated":
             assert torch.equal(env._gen["gen_state"], ref._gen["gen_state"]) and int(env.episode.sum()) >= B
         env.check_errors()
+
+
+@pytest.mark.parametrize("kind", ["redbluedoors", "lockedhallway"])
+def test_hook_visiting_order_random_vs_oracle(kind):
+    """hook_order (the caller's dict order, redbluedoors.py:176 / locked_hallway.py:210): many envs with agents stacked in front
+    of a door and toggle-heavy actions, a random permutation per env and step -- HIP vs the oracle, every output and the state;
+    the orders must matter (the same run with ascending order gives different results)."""
+    from multigrid_amd import layouts
+    A, B, T = 3, 600, 12
+    r = np.random.default_rng(17)
+    grids, agents, auxs = [], [], []
+    if kind == "redbluedoors":
+        spec = EnvSpec(16, 8, A, 7, max_steps=1280, joint_reward=True, success_termination_mode="any",
+                       failure_termination_mode="all", env_kind="redbluedoors")
+        for k in range(16):
+            g, a = layouts.redbluedoors_layout(8, A, np.random.default_rng(100 + k))
+            grids.append(g); agents.append(a); auxs.append(layouts.make_aux("redbluedoors", g))
+    else:
+        spec = EnvSpec(13, 9, A, 7, max_steps=3200, joint_reward=False, env_kind="lockedhallway")
+        for k in range(16):
+            g, a = layouts.lockedhallway_layout(4, 5, 1, 2, A, np.random.default_rng(200 + k), np.random.default_rng(300 + k))
+            grids.append(g); agents.append(a); auxs.append(layouts.make_aux("lockedhallway", g))
+    pick = r.integers(0, 16, size=B)
+    grid = np.stack([grids[k] for k in pick]); ag = np.stack([agents[k] for k in pick]); aux = np.stack([auxs[k] for k in pick])
+    for b in range(B):                                   # stack every agent in front of a door, facing it; agent 0 holds its key
+        ys, xs = np.nonzero(grid[b, :, :, 0] == 4)
+        j = r.integers(0, len(xs)); dx_, dy_ = int(xs[j]), int(ys[j])
+        # the side of the door the agents stand on: the middle room of RedBlueDoors, the hallway of LockedHallway
+        side = (1 if dx_ < 8 else -1) if kind == "redbluedoors" else (1 if dx_ < 6 else -1)
+        ag[b, :, 2], ag[b, :, 3], ag[b, :, 1] = dx_ + side, dy_, 2 if side == 1 else 0
+        assert grid[b, dy_, dx_ + side, 0] in (1, 5), grid[b, dy_, dx_ + side]
+        grid[b, dy_, dx_ + side] = (1, 0, 0)
+        if kind == "lockedhallway":
+            ag[b, 0, 5:8] = (5, grid[b, dy_, dx_, 1], 0)
+    rng = np.random.default_rng(5).integers(0, 2 ** 63, size=(B, 4), dtype=np.int64).astype(np.uint64); rng[:, 2] |= np.uint64(1)
+    env = BatchedMultiGridEnv(spec, B, dev())
+    env.load_state(grid, ag, rng, aux)
+    ref = dict(grid=grid.copy(), agents=ag.copy(), rng=rng.copy(), step_count=np.zeros(B, np.int32), aux=aux.copy())
+    asc = {k: v.copy() for k, v in ref.items()}
+    sd = spec.as_dict()
+    mattered = 0
+    for t in range(T):
+        act = r.choice([5, 5, 5, 0, 1, 6, -1], size=(B, A)).astype(np.int8)
+        order = np.stack([r.permutation(A) for _ in range(B)]).astype(np.uint8)
+        want = ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["aux"], nthreads=8,
+                             hook_order=order)
+        plain = ob.step_batch(sd, asc["grid"], asc["agents"], asc["rng"], asc["step_count"], act, asc["aux"], nthreads=8)
+        mattered += int(want[2].tobytes() != plain[2].tobytes() or not np.array_equal(want[3], plain[3]))
+        got = env.step(torch.from_numpy(act).to(dev()), hook_order=torch.from_numpy(order).to(dev()))
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert g.cpu().numpy().tobytes() == w.tobytes(), f"{kind} step {t}: output {k}"
+        assert env.grid.cpu().numpy().tobytes() == ref["grid"].tobytes()
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"])
+        np.testing.assert_array_equal(env.aux.cpu().numpy(), ref["aux"])
+    assert mattered >= 1, "the visiting order never mattered: the test is hollow"
+    env.check_errors()
+
+
+def test_layout_tensors_replaced_after_split_or_capture_is_refused():
+    """sub-shards and captured graphs hold raw pointers into the layout pool; replacing it must not leave them
+    launching on freed memory -- same-shape pools are refilled in place, anything else makes the old objects refuse to run."""
+    from multigrid_amd import workloads
+    wl = workloads.make("c3", batch=512, first_env=0, global_batch=16384)
+    env = wl.make_env(dev(), auto_reset=True)
+    acts = torch.from_numpy(np.stack([util.random_actions(512, 2, seed=t, p_missing=0.0) for t in range(3)])).to(dev())
+    graph = env.capture_steps(acts, auto_reset=True, sub_shards=2)
+    shards = env.split(2)
+    pg, pa, pt = wl.pool                                  # numpy: u8[K,H,W,3], u8[K,A,8], u8[K,16]
+    env.set_layout_pool(pg, pa, pt)                       # same shapes: in place, everything stays valid
+    graph.replay(); shards[0].step(acts[0, :shards[0].batch].contiguous(), auto_reset=True)
+    env.set_layout_pool(pg[:100], pa[:100], pt[:100])     # another pool size: new tensors
+    with pytest.raises(RuntimeError, match="capture_steps"):
+        graph.replay()
+    with pytest.raises(RuntimeError, match="split"):
+        shards[0].step(acts[0, :shards[0].batch].contiguous(), auto_reset=True)
+    env.step(acts[0], auto_reset=True)                    # the env itself re-binds
+    torch.cuda.synchronize()
+    env.check_errors()

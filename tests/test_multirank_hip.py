@@ -22,23 +22,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(args, extra_env=None, timeout=900):
+def _torchrun(args, extra_env=None, timeout=900, nproc=2):
     env = dict(os.environ, MGX_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
 
 
-@pytest.mark.parametrize("name,G,T", [("c4", 65536, 12), ("c3", 16384, 12), ("c5", 2048, 6)])
-def test_two_hip_ranks_equal_single_process(tmp_path, name, G, T):
-    out = _torchrun([os.path.join(ROOT, "tests", "shard_worker.py"), name, str(G), str(T), str(tmp_path)])
+@pytest.mark.parametrize("name,G,T,N", [("c4", 65536, 12, 2), ("c3", 16384, 12, 2), ("c5", 2048, 6, 2), ("c4", 65536, 8, 8)])
+def test_hip_ranks_equal_single_process(tmp_path, name, G, T, N):
+    """N ranks (2, and the 8 of the named 8-GPU target: 8192 envs of C4 each) == one process stepping the whole batch."""
+    out = _torchrun([os.path.join(ROOT, "tests", "shard_worker.py"), name, str(G), str(T), str(tmp_path)], nproc=N)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from tests.shard_worker import run_shard
     whole = run_shard(name, G, T, 0, G, torch.device("cuda", 0))
-    shards = [np.load(os.path.join(tmp_path, f"shard{r}.npz")) for r in range(2)]
+    shards = [np.load(os.path.join(tmp_path, f"shard{r}.npz")) for r in range(N)]
     assert int(shards[0]["first"]) == 0 and int(shards[1]["first"]) == int(shards[0]["count"])
-    assert int(shards[0]["count"]) + int(shards[1]["count"]) == G
+    assert sum(int(s["count"]) for s in shards) == G and all(int(s["count"]) == G // N for s in shards)
     for k, v in whole.items():
         cat = np.concatenate([s[k] for s in shards])
         assert cat.tobytes() == v.tobytes(), k
@@ -53,3 +54,17 @@ def test_bench_under_two_ranks_prints_strong_scaling_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 32768
     assert "roofline" in d and "configs" not in d and "cpu_baseline" not in d      # extras are N=1 only
+
+
+def test_bench_under_eight_ranks_prints_the_8_gpu_line():
+    """`bench.py --gpus 8` as the driver launches it (one rank per GPU; here all eight on device 0): the first real SCALE run
+    must not fail on plumbing.  8192 envs of C4 per rank, lock-step, no pipelined variant at that size."""
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], nproc=8, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 8192 and d["config"]["sub_shards"] == 1
+    assert "roofline" in d and d["roofline"]["algorithmic_bytes"] == 8192 * 4 * 339 and "pipelined" not in d
+    assert abs(d["value"] - 65536 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01

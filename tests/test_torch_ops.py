@@ -118,7 +118,8 @@ def test_rollout_op_equals_step_op():
 def test_ops_accept_the_reference_byte_grids():
     """SURVEY.md section 8b words the op signatures on `grid_u8[B,H,W,3]` -- the reference's (type, color, state) triples.  The
     ops take that form too (packed on the way in, unpacked into the caller's tensor on the way out): same results as the
-    packed form and as the oracle, in-place arguments updated; a value the packed cells cannot hold raises."""
+    packed form and as the oracle, in-place arguments updated.  No host synchronisation on that path: a value the packed cells
+    cannot hold is stored truncated, and torch.ops.mgx.pack_grid reports the count for callers who want to check."""
     spec = EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup")
     B, ints = 333, None
     st = util.random_state(spec, B, seed=17)
@@ -146,5 +147,32 @@ def test_ops_accept_the_reference_byte_grids():
         assert out[0][t].cpu().numpy().tobytes() == want[0].tobytes()
     assert d["grid"].cpu().numpy().tobytes() == ref["grid"].tobytes()
     bad = d["grid"].clone(); bad[0, 2, 2, 0] = 99                                                                  # no such type
-    with pytest.raises((ValueError, RuntimeError)):
-        torch.ops.mgx.gen_obs(bad, d["agents"], ints)
+    cells, n_bad = torch.ops.mgx.pack_grid(bad)
+    assert int(n_bad[0]) == 1 and int(torch.ops.mgx.pack_grid(d["grid"])[1][0]) == 0
+    torch.ops.mgx.gen_obs(bad, d["agents"], ints)                                                                  # (no sync, no raise)
+
+
+def test_ops_are_the_compiled_library_and_step_ordered_follows_the_dict_order():
+    """torch.ops.mgx.* come from lib/libmgx_torch.so (TORCH_LIBRARY, csrc/mgx_torch.cpp), not from Python registrations; the
+    hook-order form of the step (redbluedoors.py:176: `for agent_id, action in actions.items()`) against the reference's own
+    fixture recorded with a reversed dict."""
+    import os
+    from multigrid_amd import layouts
+    assert os.path.basename(ops.TORCH_LIB_PATH) == "libmgx_torch.so" and int(torch.ops.mgx.abi_version()) == 6
+    with open(f"/proc/{os.getpid()}/maps") as fh:
+        assert "libmgx_torch.so" in fh.read()
+    z, d_, spec = util.load_golden([p for p in util.GOLDEN if "rbd_a3_dictorder_rev" in p][0])
+    ints = ops.spec_to_ints(spec)
+    grid = util.dev_cells(layouts.grid_to_product(z["grid0"])[None], DEV)
+    agents = torch.from_numpy(layouts.pack_agents(z["agents0"])[None]).to(DEV)
+    rng = torch.from_numpy(util.rng_words_lohi(z["rng0"]).view(np.int64)[None].copy()).to(DEV)
+    sc = torch.zeros(1, dtype=torch.int32, device=DEV)
+    aux = torch.from_numpy(util.golden_aux(d_)[None]).to(DEV)
+    err = torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32, device=DEV)
+    for t in range(z["actions"].shape[0]):
+        out = torch.ops.mgx.step_ordered(grid, agents, rng, sc, torch.from_numpy(z["actions"][t][None]).to(DEV),
+                                         torch.from_numpy(z["hook_order"][t][None]).to(DEV), aux, err, ints)
+        np.testing.assert_array_equal(out[0][0].cpu().numpy(), z["obs"][t])
+        assert out[2][0].cpu().numpy().tobytes() == z["reward"][t].tobytes()
+        np.testing.assert_array_equal(out[3][0].cpu().numpy(), z["terminated"][t])
+    assert int(err[0]) == 0

@@ -3,14 +3,14 @@
 bench.py's timers and of rocprofv3 (whose instrumentation serialises the chains: one launch in flight, 38.7 us per step of
 C4 where the uninstrumented run takes 15.7).
 
-Needs lib/libmgx_ts.so (`python -m multigrid_amd.build --timestamps`, -DMGX_TIMESTAMPS=1): lane 0 of every wavefront stores
-s_memrealtime (100 MHz, one clock for the whole device) at its first and after its last instruction into a block of records
-that belongs to its launch (KernelArgs::span_base, handed out in capture order).  A graph of K steps x P chains is captured
-and replayed; the records of the last replay give, per graph node (chain c, step t): begin = first wavefront's first
-instruction, end = last wavefront's last store retired.  From those: the timeline, the number of launches in flight over
-time, and the step period.
+Needs lib/libmgx_spans.so (`python -m multigrid_amd.build --spans`, -DMGX_SPANS=1: the product kernels + this, nothing else):
+lane 0 of every wavefront stores s_memrealtime (100 MHz, one clock for the whole device) at its first and after its last
+instruction into a block of records that belongs to its launch (KernelArgs::span_base, handed out in capture order).  A graph
+of K steps x P chains is captured and replayed; the records of the last replay give, per graph node (chain c, step t): begin =
+first wavefront's first instruction, end = last wavefront's last instruction issued.  From those: the timeline, the number of
+launches in flight over time, and the step period.
 
-    MGX_LIBMGX=multigrid_amd/lib/libmgx_ts.so MGX_WORKLOAD=c4 python tools/chain_overlap.py [batch] [P ...]  > profiles/r3_chain_overlap.txt
+    MGX_LIBMGX=multigrid_amd/lib/libmgx_spans.so MGX_WORKLOAD=c4 python tools/chain_overlap.py [batch] [P ...]  > profiles/r3_chain_overlap.txt
 """
 import ctypes
 import os
@@ -25,20 +25,23 @@ from multigrid_amd import _lib  # noqa: E402
 
 lib = _lib.lib()
 if not hasattr(lib, "mgx_debug_span_reset"):
-    sys.exit("needs MGX_LIBMGX=multigrid_amd/lib/libmgx_ts.so (python -m multigrid_amd.build --timestamps)")
+    sys.exit("needs MGX_LIBMGX=multigrid_amd/lib/libmgx_spans.so (python -m multigrid_amd.build --spans)")
 lib.mgx_debug_span_launches.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
 lib.mgx_debug_read_span.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int, ctypes.c_int]
 dev = torch.device("cuda", 0)
 spec = bench.workload_spec()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 PS = [int(x) for x in sys.argv[2:]] or [1, 4]
-K = int(os.environ.get("MGX_K", "16"))
+K = int(os.environ.get("MGX_K", "48"))
 SHOW = int(os.environ.get("MGX_SHOW_STEPS", "4"))
 
 print(f"# tools/chain_overlap.py: {bench.tool_workload()} at {B} envs, graph of K={K} steps, in-kernel s_memrealtime spans (10 ns ticks)")
-print("# (the timestamp build adds two s_memrealtime + one store per wavefront and an s_waitcnt before the end stamp)")
+print("# (the spans build = the product kernels + two s_memrealtime reads and two 8-byte stores per wavefront)")
+K_ASKED = K
 for P in PS:
     env = bench.make_env(spec, B, dev, 0)
+    nw_launch = -(-(B // P) // env.backend.launch_info(B // P)["envs_per_wavefront"])
+    K = max(8, min(K_ASKED, (1 << 18) // (P * nw_launch)))          # the records of a replay must fit the 2^18-entry buffer
     acts = bench.random_actions(K, B, spec.num_agents, dev, 7)
     for t in range(K):
         env.step(acts[t], auto_reset=bench.AUTO_RESET)
@@ -83,7 +86,14 @@ for P in PS:
     inflight = ((begins[None, :] <= grid[:, None]) & (grid[:, None] < ends[None, :])).sum(axis=1)
     print(f"\n== {P} chain(s) x {K} steps, {B // P} envs per launch ({nodes[0][5].shape[0]} wavefronts) ==")
     print(f"   graph replay, HIP events over 8 replays: {ev_us:.2f} us per step of the batch")
-    print(f"   in-kernel: first wavefront begins at 0, last wavefront ends at {total} ns -> {period / 1e3:.2f} us per step of the batch")
+    # steady state: per chain, (begin of its last step - begin of its step K/4) / steps between -- no fork ramp, no tail
+    steady = []
+    for f in firsts:
+        idx = [i for i, x in enumerate(nodes) if x[0] == f]
+        steady.append((begins[idx[-1]] - begins[idx[K // 4]]) / (len(idx) - 1 - K // 4))
+    print(f"   in-kernel: first wavefront begins at 0, last wavefront ends at {total} ns -> {period / 1e3:.2f} us per step of the batch "
+          f"over the whole replay (fork ramp and tail included); steady state (per chain, begin of step {K // 4} -> begin of step {K - 1}): "
+          f"{np.mean(steady) / 1e3:.2f} us per step")
     print(f"   launch duration (first wave begin -> last wave end): median {np.median(ends - begins) / 1e3:.2f} us, "
           f"min {(ends - begins).min() / 1e3:.2f}, max {(ends - begins).max() / 1e3:.2f}; median wavefront lives {np.median([x[4] for x in nodes]) * 10 / 1e3:.2f} us")
     print(f"   launches in flight: mean {busy / total:.2f} over the replay (sum of launch durations / replay span); "
