@@ -222,9 +222,12 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
  * Kinds:  MGX_GEN_EMPTY_FIXED          EmptyEnv with agent_start_pos / agent_start_dir (empty.py:164-167): no draws
  *         MGX_GEN_EMPTY_RANDOM         EmptyEnv with agent_start_pos=None: place_agent over the whole grid (empty.py:168-169)
  *         MGX_GEN_BLOCKEDUNLOCKPICKUP  multigrid/envs/blockedunlockpickup.py:142-164 (room_size; also writes aux[0..2])
+ *         MGX_GEN_REDBLUEDOORS         multigrid/envs/redbluedoors.py:142-168 (grid 2*size x size: agents placed in the middle
+ *                                      room, then the red and the blue door rows drawn; writes aux[0..4]; `blank` = the outer
+ *                                      walls + the room's walls, multigrid_amd.layouts.redbluedoors_blank)
  * Given generators in the same state the result is byte-identical to the reference's reset() (pinned through
  * multigrid_amd/layouts.py and the reference's reset fixtures).  step_count := 0, episode += 1, was_reset (may be NULL). */
-enum { MGX_GEN_EMPTY_FIXED = 0, MGX_GEN_EMPTY_RANDOM = 1, MGX_GEN_BLOCKEDUNLOCKPICKUP = 2 };
+enum { MGX_GEN_EMPTY_FIXED = 0, MGX_GEN_EMPTY_RANDOM = 1, MGX_GEN_BLOCKEDUNLOCKPICKUP = 2, MGX_GEN_REDBLUEDOORS = 3 };
 
 typedef struct MgxLayoutGen {
     int32_t kind;
@@ -269,7 +272,8 @@ int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar,
  *   one_hot      obs is u8[.., A, v, v, 21] (mgx_step_one_hot)
  *   auto_reset   finished envs restart from the layout pool BEFORE the step (mgx_step_autoreset), or NULL
  *   generate     the envs whose episode ends WITH the step are regenerated on the device right after it
- *                (mgx_step_generate; needs `episode`, optional `was_reset`; not together with `auto_reset`), or NULL
+ *                (mgx_step_generate; needs `episode`, optional `was_reset`; not together with `auto_reset`; steps == 1:
+ *                a rollout restarts its finished envs from the layout pool), or NULL
  *   hook_order   u8[B, A] or NULL: the order in which the env subclass' step hook visits the agents -- the reference's hooks
  *                iterate `actions.items()`, i.e. the insertion order of the caller's dict (multigrid/envs/redbluedoors.py:176,
  *                locked_hallway.py:210); row b lists agent indices in that order (a permutation of 0..A-1; agents absent from

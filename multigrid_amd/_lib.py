@@ -56,7 +56,7 @@ class MgxStepArgs(C.Structure):
                 ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
 
 
-GEN_KINDS = {"empty_fixed": 0, "empty_random": 1, "blockedunlockpickup": 2}
+GEN_KINDS = {"empty_fixed": 0, "empty_random": 1, "blockedunlockpickup": 2, "redbluedoors": 3}
 
 
 class MgxError(RuntimeError):

@@ -203,6 +203,11 @@ class BatchedMultiGridEnv:
                 or not actions.is_contiguous():
             raise ValueError(f"actions must be a contiguous int8 tensor of shape {tuple(self._act_shape)} "
                              f"on {self.cells.device}")
+        if sub_shards == 1 and hook_order is None and not self._chains_pending:      # the hot path: one dict lookup, one call
+            fast = self._bound.get((auto_reset, one_hot))
+            if fast is not None:
+                fast[0](actions)
+                return fast[1]
         if hook_order is not None and (hook_order.dtype is not torch.uint8 or hook_order.shape != self._act_shape
                                        or hook_order.device != self.cells.device or not hook_order.is_contiguous()):
             raise ValueError(f"hook_order must be a contiguous uint8 tensor of shape {tuple(self._act_shape)} on {self.cells.device}")
@@ -215,11 +220,9 @@ class BatchedMultiGridEnv:
         if sub_shards != 1:
             P = self.sub_shards_hint(auto_reset or generate, one_hot) if sub_shards == "auto" else int(sub_shards)
             P = max(1, min(P, self.batch // self.SUB_SHARD_ALIGN))
-            if generate and one_hot:
-                P = 1                                   # (two launches per step: stays on one stream)
         if P == 1 and self._chains_pending:
             self.join()
-        key = (bool(auto_reset), bool(one_hot), generate and not one_hot, P)
+        key = (bool(auto_reset), bool(one_hot), generate, P)
         fast = self._bound.get(key)
         if fast is None:
             fast = self._bind_step(*key)
@@ -231,9 +234,9 @@ class BatchedMultiGridEnv:
                 fast(actions, ev.cuda_event, hook_order)
                 self._chains_pending = True
                 return out
+            if isinstance(auto_reset, bool) and isinstance(one_hot, bool):
+                self._bound[(auto_reset or generate, one_hot)] = (fast, out)       # (the hot path's entry: cleared with _bound)
             fast(actions, hook_order)
-            if generate and one_hot:
-                self.reset_done()
             return out
         # launchers without bind_step (the test-suite's oracle backend)
         sp = self.spec
@@ -383,14 +386,15 @@ class BatchedMultiGridEnv:
         stream.wait_stream(side)
         return StepGraph(self, graph, len(shards), (shards, others, actions, hook_order))
 
-    def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False) -> dict:
+    def rollout(self, actions: torch.Tensor, out: dict | None = None, auto_reset: bool = False, one_hot: bool = False) -> dict:
         """`T` consecutive `step`s in one kernel launch (env state stays in LDS between steps); bit-identical to
         calling `step(actions[t])` for t = 0..T-1.  For open-loop action sequences (random / scripted policies).
 
         actions  i8[T,B,A].  Returns {'obs': u8[T,B,A,v,v,3], 'dir', 'reward', 'terminated': [T,B,A],
         'truncated': u8[T,B]} (pass `out` to reuse buffers).  The env's own `obs`... buffers are not touched.
         auto_reset=True: finished envs restart from the layout pool before each step (as `step(auto_reset=True)`);
-        the result then also holds 'was_reset': u8[T,B]."""
+        the result then also holds 'was_reset': u8[T,B].  one_hot=True: 'obs' is the one-hot observation u8[T,B,A,v,v,21]
+        (multigrid/wrappers.py:158-190), written by the same launch."""
         self._need_state()
         self.join()
         sp, B = self.spec, self.batch
@@ -399,7 +403,7 @@ class BatchedMultiGridEnv:
             raise ValueError(f"actions must be a contiguous int8 tensor of shape (T, {B}, {sp.num_agents}) on {self.cells.device}")
         T, A, v, dev = actions.shape[0], sp.num_agents, sp.view_size, self.device
         if out is None:
-            out = {"obs": torch.empty((T, B, A, v, v, 3), dtype=torch.uint8, device=dev),
+            out = {"obs": torch.empty((T, B, A, v, v, 21 if one_hot else 3), dtype=torch.uint8, device=dev),
                    "dir": torch.empty((T, B, A), dtype=torch.uint8, device=dev),
                    "reward": torch.empty((T, B, A), dtype=torch.float64, device=dev),
                    "terminated": torch.empty((T, B, A), dtype=torch.uint8, device=dev),
@@ -410,7 +414,7 @@ class BatchedMultiGridEnv:
         self.backend.rollout(B, T, self.cells, self.agents, self.rng, self.step_count, actions,
                              self.aux if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],
                              out["reward"], out["terminated"], out["truncated"],
-                             **({"auto_reset": ar} if ar is not None else {}))
+                             **({"auto_reset": ar} if ar is not None else {}), **({"one_hot": True} if one_hot else {}))
         return out
 
     # ------------------------------------------------------------------------------------------ either side of the path
@@ -472,7 +476,7 @@ class BatchedMultiGridEnv:
         kernel, one lane per env.
 
         kind         'empty_fixed' (EmptyEnv, agents at `start` = (x, y, dir)), 'empty_random' (EmptyEnv with
-                     agent_start_pos=None) or 'blockedunlockpickup' (`room_size`)
+                     agent_start_pos=None), 'blockedunlockpickup' (`room_size`) or 'redbluedoors' (the spec's 2*size x size grid)
         layout_seed  seeds every env's placement generator: Generator(PCG64(SeedSequence([layout_seed, global index])))
         `reset_done()` then regenerates every finished env; `step(auto_reset=True)` regenerates the envs whose episode ends
         with that step right after it -- in the tail of the step's own launch (mgx_step_generate), so the returned
@@ -483,6 +487,10 @@ class BatchedMultiGridEnv:
             if sp.env_kind != "blockedunlockpickup" or (sp.width, sp.height) != (2 * room_size - 1, room_size):
                 raise ValueError("blockedunlockpickup generator: the spec must be a BlockedUnlockPickup grid of (2*room_size-1) x room_size")
             blank = layouts.roomgrid_blank(room_size, 1, 2)
+        elif kind == "redbluedoors":
+            if sp.env_kind != "redbluedoors" or sp.width != 2 * sp.height:
+                raise ValueError("redbluedoors generator: the spec must be a RedBlueDoors grid of (2*size) x size")
+            blank = layouts.redbluedoors_blank(sp.height)
         elif kind in ("empty_fixed", "empty_random"):
             if sp.env_kind != "empty" or sp.width != sp.height:
                 raise ValueError("empty generator: the spec must be a square Empty grid")

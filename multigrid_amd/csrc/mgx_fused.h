@@ -268,11 +268,14 @@ inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false, bool o
     int Gw = slots_per_wave(sp.view_size, roll || obs_only) / sp.num_agents;
     if (Gw < 1) Gw = 1;
     while (Gw > 1 && wave_lds_bytes(sp, Gw, roll, one_hot, obs_only) > kLdsWaveBudget) --Gw;
+    // a power of two: otherwise the tile's 16-byte vectors and the output rows stop lining up with the wave's lanes (round 2:
+    // C4 at 14 envs per wave 30.4 us, 12: 22.1, 16: 20.8)
+    while (Gw > 2 && (Gw & (Gw - 1)) != 0) Gw &= Gw - 1;
     // latency regime (fewer than two wavefronts per SIMD): one full group of 16 view slots per wave is the optimum whatever the
     // batch -- fewer slots per wave means more waves, each paying the fixed per-wave phases again (tools/group_sweep.py, round 3:
     // C2 shape at 1024 envs: 4 envs per wave 5.92 us, 2: 6.45, 1: 6.54; BlockedUnlockPickup at 8192 envs: 8 envs per wave 8.58 us,
     // 4: 10.05; more than 16 slots only once every SIMD has its two waves: C2 shape at 4096 envs, 8 envs per wave: 7.53 vs 6.27)
-    while (Gw * sp.num_agents > kGroupSlots && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;
+    while (Gw > 1 && Gw * sp.num_agents > kGroupSlots && (batch + Gw - 1) / Gw < 2048) Gw = (Gw + 1) / 2;
     return Gw;
 }
 
@@ -549,13 +552,15 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
 template <int V>
 inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream,
                        int *hip_err, int *occupancy) {
-    switch (mode) {                     // mode | 4: one-hot observations (gen_obs and one step only); | 8: tail generation
+    switch (mode) {                     // mode | 4: one-hot observations; | 8: tail generation (one step only)
     case 0: return launch_mode<V, 0, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    case 6: return launch_mode<V, 2, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 9: return launch_mode<V, 1, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);   // | 8: generate
+    case 13: return launch_mode<V, 1, true, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     default: return MGX_ERR_INVALID_ARGUMENT;
     }
 }

@@ -277,7 +277,6 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
     int rc = check_spec(spec, batch, roll, one_hot);
     if (rc) return rc;
     if (sa.steps < 0) return MGX_ERR_INVALID_ARGUMENT;
-    if (roll && one_hot) return MGX_ERR_UNSUPPORTED;
     if (batch == 0 || sa.steps == 0) return MGX_OK;
     if (!occupancy) {
         if (!sa.grid || !sa.agents || !sa.step_count || !sa.actions || !sa.obs || !sa.reward || !sa.terminated || !sa.truncated)
@@ -310,9 +309,9 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
     ka.aux = sa.aux; ka.obs = sa.obs; ka.dir = sa.dir; ka.reward = sa.reward; ka.terminated = sa.terminated;
     ka.truncated = sa.truncated; ka.err = sa.err;
     ka.T = roll ? sa.steps : 1;
-    int mode = roll ? 2 : (one_hot ? 5 : 1);
+    int mode = (roll ? 2 : 1) | (one_hot ? 4 : 0);
     if (gen) {
-        if (roll || one_hot) return MGX_ERR_UNSUPPORTED;
+        if (roll) return MGX_ERR_UNSUPPORTED;             // (a rollout regenerates from the layout pool: auto_reset)
         if (ar) return MGX_ERR_INVALID_ARGUMENT;
         if (!occupancy) {
             if (!gen->blank || !gen->gen_state || !sa.episode || !sa.rng) return MGX_ERR_INVALID_ARGUMENT;
@@ -333,10 +332,14 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
                 || spec->width != 2 * gen->room_size - 1 || spec->height != gen->room_size)
                 return MGX_ERR_INVALID_ARGUMENT;
             break;
+        case MGX_GEN_REDBLUEDOORS:
+            if (spec->env_kind != MGX_KIND_REDBLUEDOORS || spec->width != 2 * spec->height || spec->width < 8)
+                return MGX_ERR_INVALID_ARGUMENT;
+            break;
         default: return MGX_ERR_UNSUPPORTED;
         }
         ka.gen = *gen; ka.episode = sa.episode; ka.was_reset = sa.was_reset;
-        mode = 9;
+        mode |= 8;
     }
     return launch(mode, ka, threads, lds, nwg, static_cast<hipStream_t>(stream), occupancy);
 }

@@ -59,9 +59,12 @@ struct Placer {
     __device__ int type_at(int x, int y) const {
         // the blank layout (what copy_blank wrote): RoomGrid walls (roomgrid.py:203-218: rooms of rs x rs sharing walls) for
         // BlockedUnlockPickup; border walls + the goal at (W-2, H-2) for EmptyEnv (empty.py:156-162)
+        // ... and for RedBlueDoors the walls of the middle room, wall_rect(W/4, 0, W/2, H) (redbluedoors.py:148-153)
         const bool border = (x == 0) | (y == 0) | (x == W - 1) | (y == H - 1);
-        int t = border | ((kind == MGX_GEN_BLOCKEDUNLOCKPICKUP) & (x == rs - 1)) ? (int)T_WALL : (int)T_EMPTY;
-        if (kind != MGX_GEN_BLOCKEDUNLOCKPICKUP && x == W - 2 && y == H - 2) t = T_GOAL;
+        const bool inner = ((kind == MGX_GEN_BLOCKEDUNLOCKPICKUP) & (x == rs - 1))
+                         | ((kind == MGX_GEN_REDBLUEDOORS) & ((x == W / 4) | (x == W / 4 + W / 2 - 1)));
+        int t = (border | inner) ? (int)T_WALL : (int)T_EMPTY;
+        if ((kind == MGX_GEN_EMPTY_FIXED || kind == MGX_GEN_EMPTY_RANDOM) && x == W - 2 && y == H - 2) t = T_GOAL;
         const uint32_t p = (uint32_t)x | ((uint32_t)y << 8);
 #pragma unroll
         for (int k = 0; k < kMaxObjects; ++k) t = (k < n_obj && obj_pos[k] == p) ? (int)(obj_cell[k] & 0xff) : t;
@@ -116,6 +119,20 @@ __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W
             P.apos[2 * i] = (uint8_t)p; P.apos[2 * i + 1] = (uint8_t)(p >> 8);
             write_row(i, p & 0xff, p >> 8, np_integers(lay, 0, 4));
         }
+    } else if (gen.kind == MGX_GEN_REDBLUEDOORS) {                                   // redbluedoors.py:142-168
+        const int rx0 = W / 4, rw = W / 2;                                           // room_top = (width // 4, 0), size (width // 2, height)
+        for (int i = 0; i < A; ++i) { P.apos[2 * i] = 0xff; P.apos[2 * i + 1] = 0xff; }   // Agent.reset: pos = (-1, -1)
+        for (int i = 0; i < A; ++i) {                                                // place_agent(agent, top=room_top, size=room_size)
+            const uint32_t p = P.place(lay, rx0, 0, rw, H, false);
+            P.apos[2 * i] = (uint8_t)p; P.apos[2 * i + 1] = (uint8_t)(p >> 8);
+            write_row(i, p & 0xff, p >> 8, np_integers(lay, 0, 4));
+        }
+        const int ry = np_integers(lay, 1, H - 1);                                   // red door, left wall of the room
+        const int by = np_integers(lay, 1, H - 1);                                   // blue door, right wall
+        const int bx = rx0 + rw - 1;
+        store_cell(grid + (ry * W + rx0) * kCellBytes, (uint32_t)T_DOOR | (0u << 8) | ((uint32_t)S_CLOSED << 16));     // Color.red
+        store_cell(grid + (by * W + bx) * kCellBytes, (uint32_t)T_DOOR | (2u << 8) | ((uint32_t)S_CLOSED << 16));      // Color.blue
+        aux.x = (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)rx0 << 16) | ((uint32_t)ry << 24);   // include/mgx.h: blue, red; [4] = 0
     } else {                                                                         // blockedunlockpickup.py:142-164
         const int rs = gen.room_size;
         for (int i = 0; i < A; ++i) { P.apos[2 * i] = (uint8_t)((rs - 1) + rs / 2); P.apos[2 * i + 1] = (uint8_t)(rs / 2); }   // roomgrid.py:232-236

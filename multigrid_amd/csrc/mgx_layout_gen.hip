@@ -111,6 +111,10 @@ int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *g
         if (gen->room_size < 4 || spec->width != 2 * gen->room_size - 1 || spec->height != gen->room_size || !aux)
             return MGX_ERR_INVALID_ARGUMENT;
         break;
+    case MGX_GEN_REDBLUEDOORS:
+        if (spec->env_kind != MGX_KIND_REDBLUEDOORS || spec->width != 2 * spec->height || spec->width < 8 || !aux)
+            return MGX_ERR_INVALID_ARGUMENT;
+        break;
     default:
         return MGX_ERR_UNSUPPORTED;
     }

@@ -218,6 +218,14 @@ Out5 rollout(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Te
     return {o.obs, o.dirs, o.reward, o.terminated, o.truncated};
 }
 
+Out5 rollout_one_hot(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+                     at::IntArrayRef spec) {
+    TORCH_CHECK_VALUE(actions.dim() == 3, "mgx: rollout_one_hot expects actions[T, B, A]");
+    StepOut o = step_any(grid, agents, rng, step_count, actions, aux, err, spec, actions.size(0), true, {}, {}, {}, {}, 0, {},
+                         "mgx_rollout (one-hot)");
+    return {o.obs, o.dirs, o.reward, o.terminated, o.truncated};
+}
+
 Out6 step_one_hot(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
                   const OptTensor &pool_grid, const OptTensor &pool_agents, const OptTensor &pool_aux, OptTensor episode,
                   int64_t first_env, at::IntArrayRef spec) {
@@ -264,6 +272,8 @@ TORCH_LIBRARY(mgx, m) {
           "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("rollout(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
           "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("rollout_one_hot(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor(f!)? aux, Tensor(e!) err, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("gen_obs_one_hot(Tensor grid, Tensor agents, int[] spec) -> (Tensor, Tensor)");
     m.def("step_one_hot(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
           "Tensor(f!)? aux, Tensor(e!) err, Tensor? pool_grid, Tensor? pool_agents, Tensor? pool_aux, Tensor(g!)? episode, "
@@ -281,6 +291,7 @@ TORCH_LIBRARY_IMPL(mgx, CUDA, m) {
     m.impl("step_ordered", &step_ordered);
     m.impl("step_autoreset", &step_autoreset);
     m.impl("rollout", &rollout);
+    m.impl("rollout_one_hot", &rollout_one_hot);
     m.impl("gen_obs_one_hot", &gen_obs_one_hot);
     m.impl("step_one_hot", &step_one_hot);
     m.impl("one_hot", &one_hot);

@@ -419,6 +419,16 @@ def playground_layout(room_size, num_rows, num_cols, num_agents, layout_rng, np_
     return rg.result()
 
 
+def redbluedoors_blank(size: int) -> np.ndarray:
+    """RedBlueDoors before agents and doors are placed (multigrid/envs/redbluedoors.py:144-153): the outer walls and the walls
+    of the middle room, u8[H,W,3] -- the template of the on-device generator (mgx_reset_generate, MGX_GEN_REDBLUEDOORS)."""
+    width, height = 2 * size, size
+    grid = _Grid(width, height)
+    grid.wall_rect(0, 0, width, height)
+    grid.wall_rect(width // 4, 0, width // 2, height)
+    return grid.to_product()
+
+
 # ---- multigrid/envs/redbluedoors.py:142-168 -----------------------------------------------------------------------------
 def redbluedoors_layout(size, num_agents, layout_rng):
     width, height = 2 * size, size

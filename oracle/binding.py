@@ -235,3 +235,11 @@ def empty_random_layout(A: int, lay_words: np.ndarray, blank: np.ndarray):
     agents = np.zeros((A, 8), np.uint8)
     lib().mgo_empty_random_layout(W, H, A, _p(lay_words, C.c_uint64), _p(grid, C.c_uint8), _p(agents, C.c_uint8))
     return grid, agents
+
+
+def rbd_layout(size: int, A: int, lay_words: np.ndarray, blank: np.ndarray):
+    """blank: u8[H,W,3] (outer walls + the middle room's walls).  Returns (grid, agents u8[A,8], aux u8[16])."""
+    grid = np.ascontiguousarray(blank, dtype=np.uint8).copy()
+    agents = np.zeros((A, 8), np.uint8); aux = np.zeros(16, np.uint8)
+    lib().mgo_rbd_layout(size, A, _p(lay_words, C.c_uint64), _p(grid, C.c_uint8), _p(agents, C.c_uint8), _p(aux, C.c_uint8))
+    return grid, agents, aux

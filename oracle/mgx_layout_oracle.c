@@ -130,6 +130,28 @@ int mgo_bup_layout(int room_size, int A, uint64_t lay_rng[5], uint64_t np_rng[5]
     return 0;
 }
 
+/* redbluedoors.py:142-168.  `grid` comes in as the blank layout (outer walls + the walls of the middle room), u8[H][W][3],
+ * W = 2 * size, H = size.  All draws come from the construction-time generator. */
+int mgo_rbd_layout(int size, int A, uint64_t lay_rng[5], uint8_t *grid, uint8_t *agents, uint8_t *aux) {
+    Lay L; L.W = 2 * size; L.H = size; L.A = A; L.grid = grid;
+    const int rx0 = L.W / 4, rw = L.W / 2;                                     /* room_top = (width // 4, 0), room_size = (width // 2, height) */
+    for (int a = 0; a < A; ++a) { L.adir[a] = -1; L.ax[a] = -1; L.ay[a] = -1; }   /* Agent.reset */
+    for (int a = 0; a < A; ++a) {                                               /* place_agent(agent, top=room_top, size=room_size) */
+        int x, y;
+        lay_place(&L, lay_rng, rx0, 0, rw, L.H, 0, &x, &y);
+        L.ax[a] = x; L.ay[a] = y;
+        L.adir[a] = (int)lay_integers(lay_rng, 0, 4);
+    }
+    const int ry = (int)lay_integers(lay_rng, 1, L.H - 1);                      /* red door in the left wall */
+    lay_set(&L, rx0, ry, LT_DOOR, 0 /* red */, 1 /* closed */);
+    const int bx = rx0 + rw - 1, by = (int)lay_integers(lay_rng, 1, L.H - 1);   /* blue door in the right wall */
+    lay_set(&L, bx, by, LT_DOOR, 2 /* blue */, 1);
+    lay_pack_agents(&L, agents);
+    memset(aux, 0, 16);
+    aux[0] = (uint8_t)bx; aux[1] = (uint8_t)by; aux[2] = (uint8_t)rx0; aux[3] = (uint8_t)ry;
+    return 0;
+}
+
 /* empty.py:151-170 with agent_start_pos=None: place_agent over the whole grid.  `grid` = walls + goal. */
 int mgo_empty_random_layout(int W, int H, int A, uint64_t lay_rng[5], uint8_t *grid, uint8_t *agents) {
     Lay L; L.W = W; L.H = H; L.A = A; L.grid = grid;

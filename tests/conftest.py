@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a hung kernel or a host-side loop must fail ONE test, not eat the GPU box's time limit (pytest-timeout, when installed)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900
 
 
 @pytest.fixture(scope="session")

@@ -49,6 +49,18 @@ def test_layout_oracle_equals_layouts_py():
         np.testing.assert_array_equal(g, g_ref); np.testing.assert_array_equal(a, a_ref)
         np.testing.assert_array_equal(aux[:3], t_ref[:3])
         np.testing.assert_array_equal(lw, ob.gen_words(lg)); np.testing.assert_array_equal(nw, ob.gen_words(ng))
+    for seed in range(200):                                                    # RedBlueDoors (redbluedoors.py:142-168)
+        size = int(r.integers(4, 11))
+        A = int(r.integers(1, min(6, (size - 2) ** 2)))                      # (the room's interior must hold the agents)
+        lg = np.random.default_rng(7000 + seed)
+        if seed % 4 == 0:
+            lg.integers(0, 9)                                                  # a buffered 32-bit half
+        lw = ob.gen_words(lg)
+        g_ref, a_ref = layouts.redbluedoors_layout(size, A, lg)
+        g, a, aux = ob.rbd_layout(size, A, lw, layouts.redbluedoors_blank(size))
+        np.testing.assert_array_equal(g, g_ref); np.testing.assert_array_equal(a, a_ref)
+        np.testing.assert_array_equal(aux, layouts.make_aux("redbluedoors", g_ref))
+        np.testing.assert_array_equal(lw, ob.gen_words(lg))
     for seed in range(100):
         A, size = int(r.integers(1, 6)), int(r.integers(5, 12))
         lg = np.random.default_rng(5000 + seed); lw = ob.gen_words(lg)
@@ -66,6 +78,10 @@ CASES = [
     ("empty_random_9_a3", EnvSpec(9, 9, 3, 7, max_steps=6), dict(kind="empty_random"), 2000),
     ("empty_random_5_a6", EnvSpec(5, 5, 6, 5, max_steps=4), dict(kind="empty_random"), 515),
     ("empty_fixed_16_a4", EnvSpec(16, 16, 4, 7, max_steps=5), dict(kind="empty_fixed", start=(1, 1, 0)), 4099),
+    ("rbd_8_a3", EnvSpec(16, 8, 3, 7, max_steps=6, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors"),
+     dict(kind="redbluedoors"), 2500),
+    ("rbd_6_a2", EnvSpec(12, 6, 2, 5, max_steps=4, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors"),
+     dict(kind="redbluedoors"), 777),
 ]
 
 
@@ -84,6 +100,9 @@ def _make(spec, gen, B, dev, backend=None):
     if spec.env_kind == "blockedunlockpickup":
         g0, a0, t0 = layouts.blockedunlockpickup_layout(gen["room_size"], spec.num_agents, np.random.default_rng(1), np.random.default_rng(2))
         env.load_state(g0, a0, aux=layouts.make_aux("blockedunlockpickup", g0, target=t0))
+    elif spec.env_kind == "redbluedoors":
+        g0, a0 = layouts.redbluedoors_layout(spec.height, spec.num_agents, np.random.default_rng(1))
+        env.load_state(g0, a0, aux=layouts.make_aux("redbluedoors", g0))
     else:
         g0, a0 = layouts.empty_layout(spec.width, spec.num_agents)
         env.load_state(g0, a0)

@@ -112,3 +112,72 @@ def test_one_hot_torch_ops():
     for x, w in zip(got[1:5], want[1:]):
         assert x.cpu().numpy().tobytes() == w.tobytes()
     assert util.grid3(g).tobytes() == ref["grid"].tobytes()
+
+
+@pytest.mark.parametrize("kind", ["bup", "empty_random"])
+def test_one_hot_with_device_generation_in_one_launch(kind):
+    """OH x GEN (the production combination: RLlib's default registration one-hots every env, rllib/__init__.py:110-111, and
+    episodes restart through reset, base.py:250-301): the step with one-hot output AND the regeneration of the envs it finished,
+    in ONE launch == mgx_step_generate followed by mgx_one_hot of its observation; every output, the whole state, the generators."""
+    if kind == "bup":
+        wl = workloads.make("c3", batch=3000, first_env=0, global_batch=16384)
+        gen = dict(kind="blockedunlockpickup", room_size=6)
+    else:
+        wl = workloads.make("c2", batch=2500, first_env=64, global_batch=4096)
+        gen = dict(kind="empty_random")
+    B, A = wl.batch, wl.spec.num_agents
+
+    def mk():
+        e = wl.make_env(DEV, auto_reset=False)
+        e.set_layout_generator(gen["kind"], layout_seed=11, room_size=gen.get("room_size", 0))
+        e.step_count.fill_(wl.spec.max_steps - 3)                         # every env is regenerated within the run
+        return e
+    a, b = mk(), mk()
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    for t in range(8):
+        act = torch.randint(0, 7, (B, A), dtype=torch.int8, device=DEV, generator=g)
+        want = [x.clone() for x in a.step(act, auto_reset=True)]
+        want_oh = a.one_hot_obs().clone()
+        got = b.step(act, auto_reset=True, one_hot=True)
+        assert torch.equal(got[0], want_oh), f"{kind} step {t}: one-hot observation"
+        for x, y in zip(got[1:], want[1:]):
+            assert torch.equal(x, y), f"{kind} step {t}"
+        assert torch.equal(a.was_reset, b.was_reset)
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    assert torch.equal(a._gen["gen_state"], b._gen["gen_state"]) and int(b.episode.sum()) >= B
+    b.check_errors()
+
+
+@pytest.mark.parametrize("name,B,T", [("c2", 1000, 9), ("c3", 2048, 7), ("c5", 100, 4)])
+def test_rollout_with_one_hot_output_equals_steps(name, B, T):
+    """mgx_rollout with one-hot observations (T steps, one launch, u8[T,B,A,v,v,21]) == T x mgx_step_one_hot, with the fused
+    auto-reset on the way; also through torch.ops.mgx.rollout_one_hot vs the oracle."""
+    wl = workloads.make(name, batch=B)
+    a, b = wl.make_env(DEV), wl.make_env(DEV)
+    if name != "c5":
+        a.step_count.fill_(wl.spec.max_steps - 3); b.step_count.fill_(wl.spec.max_steps - 3)
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    acts = torch.randint(0, 7, (T, B, wl.spec.num_agents), dtype=torch.int8, device=DEV, generator=g)
+    out = b.rollout(acts, auto_reset=True, one_hot=True)
+    assert tuple(out["obs"].shape) == (T, B, wl.spec.num_agents, wl.spec.view_size, wl.spec.view_size, 21)
+    for t in range(T):
+        want = [x.clone() for x in a.step(acts[t], auto_reset=True, one_hot=True)]
+        for k, key in enumerate(("obs", "dir", "reward", "terminated", "truncated")):
+            assert torch.equal(out[key][t], want[k]), f"{name} step {t}: {key}"
+        assert torch.equal(out["was_reset"][t], a.was_reset)
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    if name == "c2":
+        spec = wl.spec
+        st = util.random_state(spec, 300, seed=21)
+        ints = ops.spec_to_ints(spec)
+        gd = util.dev_cells(st["grid"], DEV); ad = torch.from_numpy(st["agents"]).to(DEV)
+        rng = torch.from_numpy(st["rng"].view(np.int64)).to(DEV); sc = torch.from_numpy(st["step_count"]).to(DEV)
+        err = torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32, device=DEV)
+        act3 = np.stack([util.random_actions(300, 4, seed=70 + t) for t in range(3)])
+        got = torch.ops.mgx.rollout_one_hot(gd, ad, rng, sc, torch.from_numpy(act3).to(DEV), None, err, ints)
+        ref = {k: v.copy() for k, v in st.items()}
+        for t in range(3):
+            w = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act3[t], None, nthreads=8)
+            assert got[0][t].cpu().numpy().tobytes() == ob.one_hot(w[0]).tobytes(), t

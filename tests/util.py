@@ -218,6 +218,9 @@ class OracleBackend:
             if gen["kind"] == "blockedunlockpickup":
                 g, a, x = ob.bup_layout(gen["room_size"], A, lay, npw, blank)
                 aux[b] = torch.from_numpy(x)
+            elif gen["kind"] == "redbluedoors":
+                g, a, x = ob.rbd_layout(self.spec.height, A, lay, blank)
+                aux[b] = torch.from_numpy(x)
             elif gen["kind"] == "empty_random":
                 g, a = ob.empty_random_layout(A, lay, blank)
             else:
