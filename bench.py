@@ -244,7 +244,7 @@ def eager_point(wl, device, steps=2000, sub_shards=1):
     sub_shards="auto": the eager sub-shard form (mgx_step_chains on the env's side streams, joined once at the end)."""
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     B, A = wl.batch, wl.spec.num_agents
-    acts = random_actions(64, B, A, device, 77)
+    acts = list(random_actions(64, B, A, device, 77))           # (64 action tensors: a policy hands over a tensor, not a slice)
     for t in range(200):
         env.step(acts[t & 63], auto_reset=AUTO_RESET, sub_shards=sub_shards)
     env.join()

@@ -222,17 +222,26 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
  * Kinds:  MGX_GEN_EMPTY_FIXED          EmptyEnv with agent_start_pos / agent_start_dir (empty.py:164-167): no draws
  *         MGX_GEN_EMPTY_RANDOM         EmptyEnv with agent_start_pos=None: place_agent over the whole grid (empty.py:168-169)
  *         MGX_GEN_BLOCKEDUNLOCKPICKUP  multigrid/envs/blockedunlockpickup.py:142-164 (room_size; also writes aux[0..2])
+ *         MGX_GEN_LOCKEDHALLWAY        multigrid/envs/locked_hallway.py:152-201 (room_size, max_hallway_keys, max_keys_per_room; the grid
+ *                                      is 3 columns of rooms x num_rooms / 2 rows, num_rooms <= 16; numpy's Generator.shuffle for
+ *                                      _rand_perm; writes the whole aux; `blank` = multigrid_amd.layouts.lockedhallway_blank)
+ *         MGX_GEN_PLAYGROUND           multigrid/envs/playground.py:122-137 (room_size; rooms x rooms from the grid size, at most 64
+ *                                      rooms; connect_all's doors are placed with env.np_random, roomgrid.py:104-124; `blank` =
+ *                                      multigrid_amd.layouts.roomgrid_blank; spec->env_kind = MGX_KIND_EMPTY: no hook)
  *         MGX_GEN_REDBLUEDOORS         multigrid/envs/redbluedoors.py:142-168 (grid 2*size x size: agents placed in the middle
  *                                      room, then the red and the blue door rows drawn; writes aux[0..4]; `blank` = the outer
  *                                      walls + the room's walls, multigrid_amd.layouts.redbluedoors_blank)
  * Given generators in the same state the result is byte-identical to the reference's reset() (pinned through
  * multigrid_amd/layouts.py and the reference's reset fixtures).  step_count := 0, episode += 1, was_reset (may be NULL). */
-enum { MGX_GEN_EMPTY_FIXED = 0, MGX_GEN_EMPTY_RANDOM = 1, MGX_GEN_BLOCKEDUNLOCKPICKUP = 2, MGX_GEN_REDBLUEDOORS = 3 };
+enum { MGX_GEN_EMPTY_FIXED = 0, MGX_GEN_EMPTY_RANDOM = 1, MGX_GEN_BLOCKEDUNLOCKPICKUP = 2, MGX_GEN_REDBLUEDOORS = 3,
+       MGX_GEN_LOCKEDHALLWAY = 4, MGX_GEN_PLAYGROUND = 5 };
 
 typedef struct MgxLayoutGen {
     int32_t kind;
-    int32_t room_size;                    /* MGX_GEN_BLOCKEDUNLOCKPICKUP */
+    int32_t room_size;                    /* MGX_GEN_BLOCKEDUNLOCKPICKUP, MGX_GEN_LOCKEDHALLWAY, MGX_GEN_PLAYGROUND */
     int32_t start_x, start_y, start_dir;  /* MGX_GEN_EMPTY_FIXED */
+    int32_t max_hallway_keys;             /* MGX_GEN_LOCKEDHALLWAY (locked_hallway.py:107) */
+    int32_t max_keys_per_room;            /* MGX_GEN_LOCKEDHALLWAY (locked_hallway.py:108) */
     const MgxCell *blank;
     uint64_t *gen_state;
 } MgxLayoutGen;

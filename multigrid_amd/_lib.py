@@ -42,7 +42,8 @@ class MgxAutoReset(C.Structure):
 class MgxLayoutGen(C.Structure):
     """include/mgx.h: struct MgxLayoutGen."""
     _fields_ = [("kind", C.c_int32), ("room_size", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
-                ("start_dir", C.c_int32), ("blank", C.c_void_p), ("gen_state", C.c_void_p)]
+                ("start_dir", C.c_int32), ("max_hallway_keys", C.c_int32), ("max_keys_per_room", C.c_int32),
+                ("blank", C.c_void_p), ("gen_state", C.c_void_p)]
 
 
 class MgxStepArgs(C.Structure):
@@ -56,7 +57,7 @@ class MgxStepArgs(C.Structure):
                 ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
 
 
-GEN_KINDS = {"empty_fixed": 0, "empty_random": 1, "blockedunlockpickup": 2, "redbluedoors": 3}
+GEN_KINDS = {"empty_fixed": 0, "empty_random": 1, "blockedunlockpickup": 2, "redbluedoors": 3, "lockedhallway": 4, "playground": 5}
 
 
 class MgxError(RuntimeError):

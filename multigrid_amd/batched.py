@@ -470,13 +470,16 @@ class BatchedMultiGridEnv:
         self._bound.clear()              # (the pre-bound launchers hold the old pool's pointers ...
         self._layout_version += 1        #  ... and so do sub-shards and captured graphs made before: they now refuse to run)
 
-    def set_layout_generator(self, kind: str, layout_seed: int = 0, *, room_size: int = 0, start=(1, 1, 0)):
+    def set_layout_generator(self, kind: str, layout_seed: int = 0, *, room_size: int = 0, start=(1, 1, 0),
+                             max_hallway_keys: int = 1, max_keys_per_room: int = 2):
         """Episode starts generated ON THE DEVICE (mgx_reset_generate) instead of picked from a host-made pool: every
         finished env runs the reference's own `_gen_grid` (rejection-sampling placement with numpy-compatible draws) in a
         kernel, one lane per env.
 
         kind         'empty_fixed' (EmptyEnv, agents at `start` = (x, y, dir)), 'empty_random' (EmptyEnv with
-                     agent_start_pos=None), 'blockedunlockpickup' (`room_size`) or 'redbluedoors' (the spec's 2*size x size grid)
+                     agent_start_pos=None), 'blockedunlockpickup' (`room_size`), 'redbluedoors' (the spec's 2*size x size grid),
+                     'lockedhallway' (`room_size`, `max_hallway_keys`, `max_keys_per_room`; at most 16 rooms) or 'playground'
+                     (`room_size`; at most 16 rooms) -- every env class of the reference
         layout_seed  seeds every env's placement generator: Generator(PCG64(SeedSequence([layout_seed, global index])))
         `reset_done()` then regenerates every finished env; `step(auto_reset=True)` regenerates the envs whose episode ends
         with that step right after it -- in the tail of the step's own launch (mgx_step_generate), so the returned
@@ -491,6 +494,16 @@ class BatchedMultiGridEnv:
             if sp.env_kind != "redbluedoors" or sp.width != 2 * sp.height:
                 raise ValueError("redbluedoors generator: the spec must be a RedBlueDoors grid of (2*size) x size")
             blank = layouts.redbluedoors_blank(sp.height)
+        elif kind == "lockedhallway":
+            rs = int(room_size)
+            if sp.env_kind != "lockedhallway" or rs < 4 or sp.width != 3 * (rs - 1) + 1 or (sp.height - 1) % (rs - 1):
+                raise ValueError("lockedhallway generator: the spec must be 3 columns of `room_size` rooms")
+            blank = layouts.lockedhallway_blank(2 * ((sp.height - 1) // (rs - 1)), rs)
+        elif kind == "playground":
+            rs = int(room_size)
+            if sp.env_kind != "empty" or rs < 4 or (sp.width - 1) % (rs - 1) or (sp.height - 1) % (rs - 1):
+                raise ValueError("playground generator: the spec must be a hook-free grid of `room_size` rooms")
+            blank = layouts.roomgrid_blank(rs, (sp.height - 1) // (rs - 1), (sp.width - 1) // (rs - 1))
         elif kind in ("empty_fixed", "empty_random"):
             if sp.env_kind != "empty" or sp.width != sp.height:
                 raise ValueError("empty generator: the spec must be a square Empty grid")
@@ -500,6 +513,7 @@ class BatchedMultiGridEnv:
         self.join()
         idx = self.first_env + np.arange(self.batch)
         self._gen = {"kind": kind, "room_size": int(room_size), "start": tuple(int(v) for v in start),
+                     "max_hallway_keys": int(max_hallway_keys), "max_keys_per_room": int(max_keys_per_room),
                      "blank": torch.from_numpy(layouts.pack_cells(blank).view(np.int16)).to(self.device).contiguous(),
                      "gen_state": torch.from_numpy(rnglib.layout_gen_state(layout_seed, idx).view(np.int64)).to(self.device)}
         self._pool = None
@@ -554,6 +568,7 @@ class BatchedMultiGridEnv:
               "aux": self.aux.cpu().clone()}
         if getattr(self, "_gen", None) is not None:
             sd["generator"] = {"kind": self._gen["kind"], "room_size": self._gen["room_size"], "start": self._gen["start"],
+                               "max_hallway_keys": self._gen["max_hallway_keys"], "max_keys_per_room": self._gen["max_keys_per_room"],
                                "gen_state": self._gen["gen_state"].cpu().clone()}
             sd["episode"] = self.episode.cpu().clone()
             sd["was_reset"] = self.was_reset.cpu().clone()
@@ -574,7 +589,8 @@ class BatchedMultiGridEnv:
         self.load_state(sd["grid"], sd["agents"], sd["rng"], sd["aux"], sd["step_count"], validate=True)
         if sd.get("generator") is not None:
             g = sd["generator"]
-            self.set_layout_generator(g["kind"], 0, room_size=g["room_size"], start=g["start"])
+            self.set_layout_generator(g["kind"], 0, room_size=g["room_size"], start=g["start"],
+                                      max_hallway_keys=g.get("max_hallway_keys", 1), max_keys_per_room=g.get("max_keys_per_room", 2))
             self._gen["gen_state"].copy_(g["gen_state"])
             self.episode.copy_(sd["episode"])
             self.was_reset.copy_(sd["was_reset"])

@@ -318,26 +318,8 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
             if (misaligned(gen->gen_state, 8) || misaligned(sa.episode, 4)) return MGX_ERR_INVALID_ARGUMENT;
         }
         if (spec->width > 254 || spec->height > 254) return MGX_ERR_UNSUPPORTED;
-        switch (gen->kind) {
-        case MGX_GEN_EMPTY_FIXED:
-            if (spec->env_kind != MGX_KIND_EMPTY || gen->start_x < 0 || gen->start_x >= spec->width || gen->start_y < 0
-                || gen->start_y >= spec->height || gen->start_dir < 0 || gen->start_dir > 3)
-                return MGX_ERR_INVALID_ARGUMENT;
-            break;
-        case MGX_GEN_EMPTY_RANDOM:
-            if (spec->env_kind != MGX_KIND_EMPTY) return MGX_ERR_INVALID_ARGUMENT;
-            break;
-        case MGX_GEN_BLOCKEDUNLOCKPICKUP:
-            if (spec->env_kind != MGX_KIND_BLOCKEDUNLOCKPICKUP || gen->room_size < 4
-                || spec->width != 2 * gen->room_size - 1 || spec->height != gen->room_size)
-                return MGX_ERR_INVALID_ARGUMENT;
-            break;
-        case MGX_GEN_REDBLUEDOORS:
-            if (spec->env_kind != MGX_KIND_REDBLUEDOORS || spec->width != 2 * spec->height || spec->width < 8)
-                return MGX_ERR_INVALID_ARGUMENT;
-            break;
-        default: return MGX_ERR_UNSUPPORTED;
-        }
+        rc = mgx_gen::check_layout_gen(spec, gen);
+        if (rc) return rc;
         ka.gen = *gen; ka.episode = sa.episode; ka.was_reset = sa.was_reset;
         mode |= 8;
     }

@@ -11,6 +11,39 @@ namespace mgx_gen {
 
 using namespace mgx;
 
+// Is (spec, gen) a combination the generators implement?  Shared by mgx_reset_generate and the fused step (MGX_OK or an error).
+inline int check_layout_gen(const MgxSpec *spec, const MgxLayoutGen *gen) {
+    const int W = spec->width, H = spec->height, rs = gen->room_size;
+    switch (gen->kind) {
+    case MGX_GEN_EMPTY_FIXED:
+        if (spec->env_kind != MGX_KIND_EMPTY || gen->start_x < 0 || gen->start_x >= W || gen->start_y < 0 || gen->start_y >= H
+            || gen->start_dir < 0 || gen->start_dir > 3)
+            return MGX_ERR_INVALID_ARGUMENT;
+        return MGX_OK;
+    case MGX_GEN_EMPTY_RANDOM:
+        return spec->env_kind == MGX_KIND_EMPTY ? MGX_OK : MGX_ERR_INVALID_ARGUMENT;
+    case MGX_GEN_BLOCKEDUNLOCKPICKUP:
+        return (spec->env_kind == MGX_KIND_BLOCKEDUNLOCKPICKUP && rs >= 4 && W == 2 * rs - 1 && H == rs) ? MGX_OK : MGX_ERR_INVALID_ARGUMENT;
+    case MGX_GEN_REDBLUEDOORS:
+        return (spec->env_kind == MGX_KIND_REDBLUEDOORS && W == 2 * H && W >= 8) ? MGX_OK : MGX_ERR_INVALID_ARGUMENT;
+    case MGX_GEN_LOCKEDHALLWAY: {
+        if (spec->env_kind != MGX_KIND_LOCKEDHALLWAY || rs < 4 || W != 3 * (rs - 1) + 1 || (H - 1) % (rs - 1) != 0)
+            return MGX_ERR_INVALID_ARGUMENT;
+        const int rows = (H - 1) / (rs - 1);
+        if (rows < 1 || gen->max_hallway_keys < 1 || gen->max_keys_per_room < 1) return MGX_ERR_INVALID_ARGUMENT;
+        return rows <= 8 ? MGX_OK : MGX_ERR_UNSUPPORTED;                 // at most 16 rooms (the hook's 16-bit door mask)
+    }
+    case MGX_GEN_PLAYGROUND: {
+        if (spec->env_kind != MGX_KIND_EMPTY || rs < 4 || (W - 1) % (rs - 1) != 0 || (H - 1) % (rs - 1) != 0)
+            return MGX_ERR_INVALID_ARGUMENT;
+        const int rooms = ((W - 1) / (rs - 1)) * ((H - 1) / (rs - 1));
+        return (rooms >= 1 && rooms <= 16) ? MGX_OK : MGX_ERR_UNSUPPORTED;
+    }
+    default:
+        return MGX_ERR_UNSUPPORTED;
+    }
+}
+
 // numpy PCG64 + its next_uint32 buffer: s = {state_lo, state_hi, inc_lo, inc_hi}, buf = has_uint32 << 32 | uinteger
 struct NpGen {
     uint64_t s[4];
@@ -44,6 +77,44 @@ __device__ __forceinline__ int np_integers(NpGen &g, int lo, int hi) {
     return lo + (int)(m >> 32);
 }
 
+// distributions.c random_interval (max <= 0xffffffff): masked rejection over next_uint32 -- what Generator.shuffle draws
+__device__ __forceinline__ uint32_t np_interval(NpGen &g, uint32_t max) {
+    if (max == 0) return 0;
+    uint32_t mask = max, value;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    do { value = np_next32(g) & mask; } while (value > max);
+    return value;
+}
+
+// numpy Generator.shuffle of a Python list of n <= 21 colours (RandomMixin._rand_perm, multigrid/utils/random.py:75-83: the
+// untyped path, `for i in reversed(range(1, n)): j = random_interval(bitgen, i); x[i], x[j] = x[j], x[i]`), the list kept as 3-bit
+// fields of ONE 64-bit register (field k = bits [3k, 3k+3)): no per-lane array, no scratch memory
+__device__ __forceinline__ uint32_t field3(uint64_t seq, int k) { return (uint32_t)(seq >> (3 * k)) & 7u; }
+__device__ __forceinline__ uint64_t np_shuffle3(NpGen &g, uint64_t seq, int n) {
+    for (int i = n - 1; i >= 1; --i) {
+        const int j = (int)np_interval(g, (uint32_t)i);
+        const uint64_t d = (uint64_t)(field3(seq, i) ^ field3(seq, j));
+        seq ^= (d << (3 * i)) ^ (d << (3 * j));                       // swap fields i and j (i == j: d ^ d = 0)
+    }
+    return seq;
+}
+
+// The env's grid in memory, for the generators whose objects do not fit a handful of registers (LockedHallway: up to 16 doors +
+// 16 keys; Playground: 12 doors + 12 objects): the lane reads back what it (and copy_blank, before the fence) wrote -- past the
+// L1, with its own stores retired first.
+struct GridIO {
+    uint8_t *grid;
+    int W;
+    __device__ int type_at(int x, int y) const {
+        const uint16_t *p = reinterpret_cast<const uint16_t *>(grid + (y * W + x) * kCellBytes);
+        return (int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfu);
+    }
+    __device__ void set(int x, int y, uint32_t cell) const {
+        store_cell(grid + (y * W + x) * kCellBytes, cell);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): a later type_at of this cell must see it
+    }
+};
+
 constexpr int kMaxObjects = 4;
 
 // What the owning lane knows about its env while placing: the blank template (global, read-only), the objects placed so
@@ -76,6 +147,24 @@ struct Placer {
         for (int k = 0; k < kMaxObjects; ++k)
             if (k == n_obj) { obj_pos[k] = p; obj_cell[k] = cell; }
         ++n_obj;
+    }
+    // the same against the grid in memory (GridIO) instead of the closed form + register objects
+    __device__ uint32_t place_io(NpGen &g, const GridIO &io, int tx, int ty, int sw, int sh, bool next_to) const {
+        tx = max(tx, 0); ty = max(ty, 0);
+        const int xhi = min(tx + sw, W), yhi = min(ty + sh, H);
+        for (;;) {
+            const int x = np_integers(g, tx, xhi), y = np_integers(g, ty, yhi);
+            if (io.type_at(x, y) != T_EMPTY) continue;
+            bool bad = false;
+            for (int a = 0; a < A; ++a) {
+                const int ax = apos[2 * a] == 0xff ? -1 : apos[2 * a], ay = apos[2 * a + 1] == 0xff ? -1 : apos[2 * a + 1];
+                const int dx = x - ax, dy = y - ay;
+                bad |= (dx == 0) & (dy == 0);
+                bad |= next_to & (dx * dx + dy * dy <= 1);
+            }
+            if (bad) continue;
+            return (uint32_t)x | ((uint32_t)y << 8);
+        }
     }
     // base.py:604-669 place_obj: returns the position as x | y << 8
     __device__ uint32_t place(NpGen &g, int tx, int ty, int sw, int sh, bool next_to) const {
@@ -133,6 +222,112 @@ __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W
         store_cell(grid + (ry * W + rx0) * kCellBytes, (uint32_t)T_DOOR | (0u << 8) | ((uint32_t)S_CLOSED << 16));     // Color.red
         store_cell(grid + (by * W + bx) * kCellBytes, (uint32_t)T_DOOR | (2u << 8) | ((uint32_t)S_CLOSED << 16));      // Color.blue
         aux.x = (uint32_t)bx | ((uint32_t)by << 8) | ((uint32_t)rx0 << 16) | ((uint32_t)ry << 24);   // include/mgx.h: blue, red; [4] = 0
+    } else if (gen.kind == MGX_GEN_LOCKEDHALLWAY) {                                  // locked_hallway.py:152-201
+        const GridIO io{grid, W};
+        const int rs = gen.room_size, nrows = (H - 1) / (rs - 1), n = 2 * nrows;
+        for (int i = 0; i < A; ++i) {                                                // roomgrid.py:232-236: all agents in the middle
+            P.apos[2 * i] = (uint8_t)((rs - 1) + rs / 2); P.apos[2 * i + 1] = (uint8_t)((nrows / 2) * (rs - 1) + rs / 2);
+        }
+        const int Lc = 6 * ((n + 5) / 6);
+        uint64_t seq = 0;
+        for (int k = 0; k < Lc; ++k) seq |= (uint64_t)(k % 6) << (3 * k);            // list(Color) * ceil(n / 6)
+        seq = np_shuffle3(lay, seq, Lc);                                             // _rand_perm(...)[:num_rooms]
+        uint64_t doors = np_shuffle3(lay, n >= 21 ? seq : (seq & ((1ull << (3 * n)) - 1ull)), n);   // door_colors = _rand_perm(color_sequence)
+        uint32_t room_of_color = 0xffffffu, distinct = 0;                            // 4-bit field per colour: row * 2 + side
+        int top = n;
+        for (int row = 0; row < nrows; ++row)
+            for (int side = 0; side < 2; ++side) {                                   // (LEFT, right), (RIGHT, left)
+                const uint32_t color = field3(doors, --top);                         // door_colors.pop()
+                room_of_color = (room_of_color & ~(0xfu << (4 * color))) | ((uint32_t)(row * 2 + side) << (4 * color));
+                distinct |= 1u << color;
+                io.set(side ? 2 * (rs - 1) : rs - 1, row * (rs - 1) + (rs - 1) / 2,
+                       (uint32_t)T_DOOR | (color << 8) | ((uint32_t)S_LOCKED << 16));
+            }
+        const int nhk = np_integers(lay, 1, gen.max_hallway_keys + 1);
+        for (int t = 0; t < nhk && t < n; ++t) {                                     // keys in the hallway (column 1, whole height)
+            const uint32_t p = P.place_io(lay, io, rs - 1, 0, rs, H, false);
+            io.set(p & 0xff, p >> 8, (uint32_t)T_KEY | (field3(seq, t) << 8));
+        }
+        int ki = nhk;
+        while (ki < n) {                                                             // keys in the rooms
+            const uint32_t r = (room_of_color >> (4 * field3(seq, ki - 1))) & 0xfu;
+            const int row = (int)(r >> 1), side = (int)(r & 1u);
+            const int nrk = np_integers(lay, 1, gen.max_keys_per_room + 1);
+            const int stop = min(ki + nrk, n);                                       // color_sequence[ki : ki + nrk]
+            for (int t = ki; t < stop; ++t) {
+                const uint32_t p = P.place_io(lay, io, side ? 2 * (rs - 1) : 0, row * (rs - 1), rs, rs, false);
+                io.set(p & 0xff, p >> 8, (uint32_t)T_KEY | (field3(seq, t) << 8));
+                ++ki;
+            }
+        }
+        for (int i = 0; i < A; ++i) {                                                // MultiGridEnv.place_agent in the hallway
+            P.apos[2 * i] = 0xff; P.apos[2 * i + 1] = 0xff;
+            const uint32_t p = P.place_io(lay, io, rs - 1, 0, rs, H, false);
+            P.apos[2 * i] = (uint8_t)p; P.apos[2 * i + 1] = (uint8_t)(p >> 8);
+            write_row(i, p & 0xff, p >> 8, np_integers(lay, 0, 4));
+        }
+        if (n <= 6) {                                                                // include/mgx.h: explicit door positions, sorted by (x, y)
+            uint64_t lo = (uint64_t)n, hi = 0;                                       // bytes 0..7 / 8..15 (no indexed array: no scratch)
+            for (int k = 0; k < n; ++k) {
+                const int side = k / nrows, row = k % nrows, b0 = 2 + 2 * k;
+                const uint64_t xy = (uint64_t)(side ? 2 * (rs - 1) : rs - 1) | ((uint64_t)(row * (rs - 1) + (rs - 1) / 2) << 8);
+                if (b0 < 8) lo |= xy << (8 * b0); else hi |= xy << (8 * (b0 - 8));   // (b0 is even: a pair never straddles)
+            }
+            aux.x = (uint32_t)lo; aux.y = (uint32_t)(lo >> 32); aux.z = (uint32_t)hi; aux.w = (uint32_t)(hi >> 32);
+        } else {                                                                     // geometric format: room_size, len(self.rooms)
+            aux.x = (uint32_t)(0x80 | n) | ((uint32_t)rs << 24);
+            aux.y = (uint32_t)__builtin_popcount(distinct);
+        }
+    } else if (gen.kind == MGX_GEN_PLAYGROUND) {                                     // playground.py:122-137 over roomgrid.py:203-452
+        const GridIO io{grid, W};
+        const int rs = gen.room_size, ncols = (W - 1) / (rs - 1), nrows = (H - 1) / (rs - 1), R = nrows * ncols;
+        for (int i = 0; i < A; ++i) {
+            P.apos[2 * i] = (uint8_t)((ncols / 2) * (rs - 1) + rs / 2); P.apos[2 * i + 1] = (uint8_t)((nrows / 2) * (rs - 1) + rs / 2);
+        }
+        uint64_t dbits = 0;                                   // bit 16 d + r: room r (<= 16 rooms) has a door in direction d
+        const uint32_t all = (1u << R) - 1u;
+        for (int itr = 0; itr < 5000; ++itr) {                                       // connect_all (roomgrid.py:406-452)
+            uint32_t seen = 1u;                                                      // bfs from room (0, 0): rooms reachable through doors
+            for (int pass = 0; pass < R; ++pass) {
+                const uint32_t nx = seen | ((seen & (uint32_t)(dbits & 0xffff)) << 1) | ((seen & (uint32_t)((dbits >> 16) & 0xffff)) << ncols)
+                                  | ((seen & (uint32_t)((dbits >> 32) & 0xffff)) >> 1) | ((seen & (uint32_t)((dbits >> 48) & 0xffff)) >> ncols);
+                if (nx == seen) break;
+                seen = nx;
+            }
+            if ((seen & all) == all) break;
+            const int col = np_integers(lay, 0, ncols), row = np_integers(lay, 0, nrows), d = np_integers(lay, 0, 4);
+            const int ncol = col + dir_dx(d), nrow = row + dir_dy(d), r = row * ncols + col;
+            if (ncol < 0 || ncol >= ncols || nrow < 0 || nrow >= nrows || ((dbits >> (16 * d + r)) & 1ull)) continue;
+            const uint32_t color = (uint32_t)np_integers(lay, 0, 6);                 // _rand_elem(door_colors)
+            const int left = col * (rs - 1), topy = row * (rs - 1), right = left + rs - 1, bottom = topy + rs - 1;
+            int dx, dy;                                                              // Room.set_door_pos(dir, random=env.np_random)
+            if (d == 0) { dx = right; dy = np_integers(npr, topy + 1, bottom); }
+            else if (d == 1) { dx = np_integers(npr, left + 1, right); dy = bottom; }
+            else if (d == 2) { dx = left; dy = np_integers(npr, topy + 1, bottom); }
+            else { dx = np_integers(npr, left + 1, right); dy = topy; }
+            io.set(dx, dy, (uint32_t)T_DOOR | (color << 8) | ((uint32_t)S_CLOSED << 16));
+            dbits |= 1ull << (16 * d + r);
+            dbits |= 1ull << (16 * ((d + 2) & 3) + nrow * ncols + ncol);
+        }
+        for (int k = 0; k < 12; ++k) {                                               // 12 random objects, each in a random room
+            const int col = np_integers(lay, 0, ncols), row = np_integers(lay, 0, nrows);
+            const uint32_t kind = (uint32_t)T_KEY + (uint32_t)np_integers(lay, 0, 3);      // ['key', 'ball', 'box']
+            const uint32_t color = (uint32_t)np_integers(lay, 0, 6);
+            const uint32_t p = P.place_io(lay, io, col * (rs - 1), row * (rs - 1), rs, rs, true);   // place_in_room: reject_next_to
+            io.set(p & 0xff, p >> 8, kind | (color << 8));
+        }
+        for (int i = 0; i < A; ++i) {                                                // RoomGrid.place_agent: a random room
+            const int col = np_integers(lay, 0, ncols), row = np_integers(lay, 0, nrows);
+            for (;;) {
+                P.apos[2 * i] = 0xff; P.apos[2 * i + 1] = 0xff;
+                const uint32_t p = P.place_io(lay, io, col * (rs - 1), row * (rs - 1), rs, rs, false);
+                const int x = (int)(p & 0xff), y = (int)(p >> 8);
+                P.apos[2 * i] = (uint8_t)x; P.apos[2 * i + 1] = (uint8_t)y;
+                const int d = np_integers(lay, 0, 4);
+                const int t = io.type_at(x + dir_dx(d), y + dir_dy(d));
+                if (t == T_EMPTY || t == T_WALL) { write_row(i, x, y, d); break; }
+            }
+        }
     } else {                                                                         // blockedunlockpickup.py:142-164
         const int rs = gen.room_size;
         for (int i = 0; i < A; ++i) { P.apos[2 * i] = (uint8_t)((rs - 1) + rs / 2); P.apos[2 * i + 1] = (uint8_t)(rs / 2); }   // roomgrid.py:232-236

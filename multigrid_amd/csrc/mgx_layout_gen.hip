@@ -99,25 +99,9 @@ int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *g
     if (misaligned(agents, 8) || misaligned(rng, 8) || misaligned(gen->gen_state, 8) || misaligned(aux, 16)
         || misaligned(step_count, 4) || misaligned(episode, 4))
         return MGX_ERR_INVALID_ARGUMENT;
-    switch (gen->kind) {
-    case MGX_GEN_EMPTY_FIXED:
-        if (gen->start_x < 0 || gen->start_x >= spec->width || gen->start_y < 0 || gen->start_y >= spec->height
-            || gen->start_dir < 0 || gen->start_dir > 3)
-            return MGX_ERR_INVALID_ARGUMENT;
-        break;
-    case MGX_GEN_EMPTY_RANDOM:
-        break;
-    case MGX_GEN_BLOCKEDUNLOCKPICKUP:
-        if (gen->room_size < 4 || spec->width != 2 * gen->room_size - 1 || spec->height != gen->room_size || !aux)
-            return MGX_ERR_INVALID_ARGUMENT;
-        break;
-    case MGX_GEN_REDBLUEDOORS:
-        if (spec->env_kind != MGX_KIND_REDBLUEDOORS || spec->width != 2 * spec->height || spec->width < 8 || !aux)
-            return MGX_ERR_INVALID_ARGUMENT;
-        break;
-    default:
-        return MGX_ERR_UNSUPPORTED;
-    }
+    const int rc = check_layout_gen(spec, gen);
+    if (rc) return rc;
+    if (spec->env_kind != MGX_KIND_EMPTY && !aux) return MGX_ERR_INVALID_ARGUMENT;
     const int64_t blocks = (batch + 63) / 64;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     GenArgs ga{*spec, batch, *gen, reinterpret_cast<uint8_t *>(grid), agents, rng, step_count, aux, episode, was_reset};

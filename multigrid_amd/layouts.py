@@ -419,6 +419,15 @@ def playground_layout(room_size, num_rows, num_cols, num_agents, layout_rng, np_
     return rg.result()
 
 
+def lockedhallway_blank(num_rooms: int, room_size: int) -> np.ndarray:
+    """LockedHallway before doors, keys and agents are placed (multigrid/envs/locked_hallway.py:155-166): the walls of 3 columns
+    of rooms with the hallway's inner walls removed -- the template of the on-device generator (MGX_GEN_LOCKEDHALLWAY)."""
+    rg = _RoomGrid(room_size, num_rooms // 2, 3, 1, None, None)
+    for row in range(num_rooms // 2 - 1):
+        rg.remove_wall(1, row, 1)
+    return rg.grid.to_product()
+
+
 def redbluedoors_blank(size: int) -> np.ndarray:
     """RedBlueDoors before agents and doors are placed (multigrid/envs/redbluedoors.py:144-153): the outer walls and the walls
     of the middle room, u8[H,W,3] -- the template of the on-device generator (mgx_reset_generate, MGX_GEN_REDBLUEDOORS)."""

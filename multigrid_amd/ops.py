@@ -166,6 +166,7 @@ class HipBackend:
     def _layout_gen_struct(gen):
         sx, sy, sd = gen.get("start", (0, 0, 0))
         return _lib.MgxLayoutGen(_lib.GEN_KINDS[gen["kind"]], int(gen.get("room_size", 0)), int(sx), int(sy), int(sd),
+                                 int(gen.get("max_hallway_keys", 1)), int(gen.get("max_keys_per_room", 2)),
                                  gen["blank"].data_ptr(), gen["gen_state"].data_ptr())
 
     def step_args(self, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,

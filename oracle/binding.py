@@ -243,3 +243,29 @@ def rbd_layout(size: int, A: int, lay_words: np.ndarray, blank: np.ndarray):
     agents = np.zeros((A, 8), np.uint8); aux = np.zeros(16, np.uint8)
     lib().mgo_rbd_layout(size, A, _p(lay_words, C.c_uint64), _p(grid, C.c_uint8), _p(agents, C.c_uint8), _p(aux, C.c_uint8))
     return grid, agents, aux
+
+
+def np_shuffle(words5: np.ndarray, items) -> list:
+    """numpy's Generator.shuffle of a Python list, restated (oracle/mgx_layout_oracle.c lay_shuffle); words advanced in place."""
+    x = np.asarray(list(items), dtype=np.int64)
+    lib().mgo_np_shuffle(_p(words5, C.c_uint64), _p(x, C.c_int64), C.c_int64(len(x)))
+    return [int(v) for v in x]
+
+
+def lh_layout(num_rooms: int, room_size: int, max_hallway_keys: int, max_keys_per_room: int, A: int, lay_words: np.ndarray,
+              blank: np.ndarray):
+    """blank: u8[H,W,3] (room walls, hallway opened).  Returns (grid, agents u8[A,8], aux u8[16])."""
+    grid = np.ascontiguousarray(blank, dtype=np.uint8).copy()
+    agents = np.zeros((A, 8), np.uint8); aux = np.zeros(16, np.uint8)
+    lib().mgo_lh_layout(num_rooms, room_size, max_hallway_keys, max_keys_per_room, A, _p(lay_words, C.c_uint64),
+                        _p(grid, C.c_uint8), _p(agents, C.c_uint8), _p(aux, C.c_uint8))
+    return grid, agents, aux
+
+
+def playground_layout(room_size: int, num_rows: int, num_cols: int, A: int, lay_words: np.ndarray, np_words: np.ndarray,
+                      blank: np.ndarray):
+    grid = np.ascontiguousarray(blank, dtype=np.uint8).copy()
+    agents = np.zeros((A, 8), np.uint8)
+    lib().mgo_playground_layout(room_size, num_rows, num_cols, A, _p(lay_words, C.c_uint64), _p(np_words, C.c_uint64),
+                                _p(grid, C.c_uint8), _p(agents, C.c_uint8))
+    return grid, agents

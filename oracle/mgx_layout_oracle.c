@@ -152,6 +152,145 @@ int mgo_rbd_layout(int size, int A, uint64_t lay_rng[5], uint8_t *grid, uint8_t 
     return 0;
 }
 
+/* numpy Generator.shuffle on a Python list (the untyped path of _generator.pyx: `for i in reversed(range(1, n)): j =
+ * random_interval(bitgen, i); x[i], x[j] = x[j], x[i]`) with distributions.c random_interval: masked rejection over next_uint32
+ * (max <= 0xffffffff).  RandomMixin._rand_perm, multigrid/utils/random.py:75-83. */
+static uint32_t lay_interval(uint64_t s[5], uint32_t max) {
+    if (max == 0) return 0;
+    uint32_t mask = max, value;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    while ((value = (lay_next32(s) & mask)) > max) {}
+    return value;
+}
+static void lay_shuffle(uint64_t s[5], int *x, int n) {
+    for (int i = n - 1; i >= 1; --i) {
+        const int j = (int)lay_interval(s, (uint32_t)i);
+        const int t = x[i]; x[i] = x[j]; x[j] = t;
+    }
+}
+void mgo_np_shuffle(uint64_t s[5], int64_t *x, int64_t n) {            /* (test hook: against numpy itself) */
+    int tmp[64];
+    for (int i = 0; i < n; ++i) tmp[i] = (int)x[i];
+    lay_shuffle(s, tmp, (int)n);
+    for (int i = 0; i < n; ++i) x[i] = tmp[i];
+}
+
+/* base.py:671-697 place_agent: pos = (-1,-1); place_obj(None, top, size); optional random direction */
+static void lay_place_agent(Lay *L, uint64_t *rng, int a, int tx, int ty, int sw, int sh) {
+    int x, y;
+    L->ax[a] = -1; L->ay[a] = -1;
+    lay_place(L, rng, tx, ty, sw, sh, 0, &x, &y);
+    L->ax[a] = x; L->ay[a] = y;
+    L->adir[a] = (int)lay_integers(rng, 0, 4);
+}
+
+/* locked_hallway.py:152-201.  `grid` comes in as the blank layout: the RoomGrid walls (3 columns of rooms, num_rooms / 2
+ * rows) with the hallway's inner walls removed (remove_wall, roomgrid.py:333-374).  All draws come from the construction-time
+ * generator (the doors sit mid-wall: rand_pos=False).  aux = the hook state of include/mgx.h. */
+int mgo_lh_layout(int num_rooms, int room_size, int max_hallway_keys, int max_keys_per_room, int A, uint64_t lay_rng[5],
+                  uint8_t *grid, uint8_t *agents, uint8_t *aux) {
+    const int rs = room_size, rows = num_rooms / 2, n = num_rooms;
+    Lay L; L.W = 3 * (rs - 1) + 1; L.H = rows * (rs - 1) + 1; L.A = A; L.grid = grid;
+    for (int a = 0; a < A; ++a) { L.adir[a] = 0; L.ax[a] = (rs - 1) + rs / 2; L.ay[a] = (rows / 2) * (rs - 1) + rs / 2; }   /* roomgrid.py:232-236 */
+    int seq[24], doors[16], room_of_color[6] = {-1, -1, -1, -1, -1, -1};
+    const int Lc = 6 * ((n + 5) / 6);
+    for (int k = 0; k < Lc; ++k) seq[k] = k % 6;                                /* list(Color) * ceil(n / 6) */
+    lay_shuffle(lay_rng, seq, Lc);                                              /* _rand_perm(...)[:num_rooms] */
+    for (int k = 0; k < n; ++k) doors[k] = seq[k];
+    lay_shuffle(lay_rng, doors, n);                                             /* door_colors = _rand_perm(color_sequence) */
+    int top = n;
+    for (int row = 0; row < rows; ++row)
+        for (int side = 0; side < 2; ++side) {                                  /* (LEFT, right), (RIGHT, left) */
+            const int color = doors[--top];                                     /* door_colors.pop() */
+            room_of_color[color] = row * 2 + side;                              /* self.rooms[color] = room (later rooms overwrite) */
+            lay_set(&L, side ? 2 * (rs - 1) : rs - 1, row * (rs - 1) + (rs - 1) / 2, LT_DOOR, color, LS_LOCKED);
+        }
+    const int nhk = (int)lay_integers(lay_rng, 1, max_hallway_keys + 1);
+    int x, y;
+    for (int t = 0; t < nhk && t < n; ++t) {                                    /* keys in the hallway: column 1, the whole height */
+        lay_place(&L, lay_rng, rs - 1, 0, rs, L.H, 0, &x, &y);
+        lay_set(&L, x, y, LT_KEY, seq[t], 0);
+    }
+    int ki = nhk;
+    while (ki < n) {                                                            /* keys in the rooms */
+        const int r = room_of_color[seq[ki - 1]], row = r >> 1, side = r & 1;
+        const int nrk = (int)lay_integers(lay_rng, 1, max_keys_per_room + 1);
+        const int stop = ki + nrk < n ? ki + nrk : n;                           /* color_sequence[ki : ki + nrk] */
+        for (int t = ki; t < stop; ++t) {
+            lay_place(&L, lay_rng, side ? 2 * (rs - 1) : 0, row * (rs - 1), rs, rs, 0, &x, &y);
+            lay_set(&L, x, y, LT_KEY, seq[t], 0);
+            ++ki;
+        }
+    }
+    for (int a = 0; a < A; ++a) lay_place_agent(&L, lay_rng, a, rs - 1, 0, rs, L.H);   /* MultiGridEnv.place_agent in the hallway */
+    lay_pack_agents(&L, agents);
+    memset(aux, 0, 16);
+    if (n <= 6) {                                                               /* explicit door positions, sorted by (x, y) */
+        aux[0] = (uint8_t)n;
+        for (int k = 0; k < n; ++k) {
+            const int side = k / rows, row = k % rows;
+            aux[2 + 2 * k] = (uint8_t)(side ? 2 * (rs - 1) : rs - 1); aux[3 + 2 * k] = (uint8_t)(row * (rs - 1) + (rs - 1) / 2);
+        }
+    } else {
+        int distinct = 0;
+        for (int c = 0; c < 6; ++c) distinct += room_of_color[c] >= 0;
+        aux[0] = (uint8_t)(0x80 | n); aux[3] = (uint8_t)rs; aux[4] = (uint8_t)distinct;   /* len(self.rooms) */
+    }
+    return 0;
+}
+
+/* playground.py:122-137 over RoomGrid (roomgrid.py:203-452).  `grid` = the walls of num_rows x num_cols rooms.  Door positions
+ * come from env.np_random (Room.set_door_pos, roomgrid.py:104-124), everything else from the construction-time generator. */
+int mgo_playground_layout(int room_size, int num_rows, int num_cols, int A, uint64_t lay_rng[5], uint64_t np_rng[5],
+                          uint8_t *grid, uint8_t *agents) {
+    const int rs = room_size, R = num_rows * num_cols;
+    Lay L; L.W = num_cols * (rs - 1) + 1; L.H = num_rows * (rs - 1) + 1; L.A = A; L.grid = grid;
+    for (int a = 0; a < A; ++a) { L.adir[a] = 0; L.ax[a] = (num_cols / 2) * (rs - 1) + rs / 2; L.ay[a] = (num_rows / 2) * (rs - 1) + rs / 2; }
+    unsigned char door[64][4];
+    memset(door, 0, sizeof door);
+    static const int NDX[4] = {1, 0, -1, 0}, NDY[4] = {0, 1, 0, -1};
+    for (int itr = 0; itr < 5000; ++itr) {                                      /* connect_all, roomgrid.py:406-452 */
+        unsigned long long seen = 1ull;                                         /* bfs from room (0, 0) over the doors */
+        for (int pass = 0; pass < R; ++pass)
+            for (int r = 0; r < R; ++r)
+                if ((seen >> r) & 1ull)
+                    for (int d = 0; d < 4; ++d)
+                        if (door[r][d]) seen |= 1ull << ((r / num_cols + NDY[d]) * num_cols + (r % num_cols + NDX[d]));
+        if (seen == ((R >= 64) ? ~0ull : ((1ull << R) - 1ull))) break;
+        const int col = (int)lay_integers(lay_rng, 0, num_cols), row = (int)lay_integers(lay_rng, 0, num_rows);
+        const int d = (int)lay_integers(lay_rng, 0, 4);
+        const int ncol = col + NDX[d], nrow = row + NDY[d], r = row * num_cols + col;
+        if (ncol < 0 || ncol >= num_cols || nrow < 0 || nrow >= num_rows || door[r][d]) continue;
+        const int color = (int)lay_integers(lay_rng, 0, 6);                     /* _rand_elem(door_colors) */
+        const int left = col * (rs - 1), top = row * (rs - 1), right = left + rs - 1, bottom = top + rs - 1;
+        int dx, dy;                                                             /* Room.set_door_pos(dir, random=np_random) */
+        if (d == 0) { dx = right; dy = (int)lay_integers(np_rng, top + 1, bottom); }
+        else if (d == 1) { dx = (int)lay_integers(np_rng, left + 1, right); dy = bottom; }
+        else if (d == 2) { dx = left; dy = (int)lay_integers(np_rng, top + 1, bottom); }
+        else { dx = (int)lay_integers(np_rng, left + 1, right); dy = top; }
+        lay_set(&L, dx, dy, LT_DOOR, color, 1 /* closed */);
+        door[r][d] = 1; door[nrow * num_cols + ncol][(d + 2) % 4] = 1;
+    }
+    int x, y;
+    for (int k = 0; k < 12; ++k) {                                              /* 12 random objects */
+        const int col = (int)lay_integers(lay_rng, 0, num_cols), row = (int)lay_integers(lay_rng, 0, num_rows);
+        const int kind = LT_KEY + (int)lay_integers(lay_rng, 0, 3);             /* ['key', 'ball', 'box'] */
+        const int color = (int)lay_integers(lay_rng, 0, 6);
+        lay_place(&L, lay_rng, col * (rs - 1), row * (rs - 1), rs, rs, 1, &x, &y);   /* place_in_room: reject_next_to */
+        lay_set(&L, x, y, kind, color, 0);
+    }
+    for (int a = 0; a < A; ++a) {                                               /* RoomGrid.place_agent: a random room */
+        const int col = (int)lay_integers(lay_rng, 0, num_cols), row = (int)lay_integers(lay_rng, 0, num_rows);
+        for (;;) {
+            lay_place_agent(&L, lay_rng, a, col * (rs - 1), row * (rs - 1), rs, rs);
+            const int t = lay_type(&L, L.ax[a] + LDX[L.adir[a]], L.ay[a] + LDY[L.adir[a]]);
+            if (t == LT_EMPTY || t == LT_WALL) break;
+        }
+    }
+    lay_pack_agents(&L, agents);
+    return 0;
+}
+
 /* empty.py:151-170 with agent_start_pos=None: place_agent over the whole grid.  `grid` = walls + goal. */
 int mgo_empty_random_layout(int W, int H, int A, uint64_t lay_rng[5], uint8_t *grid, uint8_t *agents) {
     Lay L; L.W = W; L.H = H; L.A = A; L.grid = grid;

@@ -82,6 +82,12 @@ CASES = [
      dict(kind="redbluedoors"), 2500),
     ("rbd_6_a2", EnvSpec(12, 6, 2, 5, max_steps=4, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors"),
      dict(kind="redbluedoors"), 777),
+    ("lh_4rooms_a2", EnvSpec(13, 9, 2, 7, max_steps=6, joint_reward=True, env_kind="lockedhallway"),
+     dict(kind="lockedhallway", room_size=5, max_hallway_keys=1, max_keys_per_room=2), 1500),
+    ("lh_8rooms_rs6_a3", EnvSpec(16, 21, 3, 7, max_steps=5, joint_reward=False, env_kind="lockedhallway"),
+     dict(kind="lockedhallway", room_size=6, max_hallway_keys=2, max_keys_per_room=3), 600),
+    ("playground_3x3_a3", EnvSpec(19, 19, 3, 7, max_steps=5), dict(kind="playground", room_size=7), 1000),
+    ("playground_2x3_rs6_a2", EnvSpec(16, 11, 2, 5, max_steps=4), dict(kind="playground", room_size=6), 400),
 ]
 
 
@@ -103,6 +109,16 @@ def _make(spec, gen, B, dev, backend=None):
     elif spec.env_kind == "redbluedoors":
         g0, a0 = layouts.redbluedoors_layout(spec.height, spec.num_agents, np.random.default_rng(1))
         env.load_state(g0, a0, aux=layouts.make_aux("redbluedoors", g0))
+    elif spec.env_kind == "lockedhallway":
+        rs = gen["room_size"]
+        g0, a0 = layouts.lockedhallway_layout(2 * ((spec.height - 1) // (rs - 1)), rs, 1, 2, spec.num_agents,
+                                              np.random.default_rng(1), np.random.default_rng(2))
+        env.load_state(g0, a0, aux=layouts.make_aux("lockedhallway", g0))
+    elif gen["kind"] == "playground":
+        rs = gen["room_size"]
+        g0, a0 = layouts.playground_layout(rs, (spec.height - 1) // (rs - 1), (spec.width - 1) // (rs - 1), spec.num_agents,
+                                           np.random.default_rng(1), np.random.default_rng(2))
+        env.load_state(g0, a0)
     else:
         g0, a0 = layouts.empty_layout(spec.width, spec.num_agents)
         env.load_state(g0, a0)
@@ -187,3 +203,46 @@ def test_generator_state_round_trip_on_cpu():
         for x, y in zip(want[t - 6], b.step(acts[t], auto_reset=True)):
             assert torch.equal(x, y)
     assert torch.equal(a.grid, b.grid) and torch.equal(a._gen["gen_state"], b._gen["gen_state"])
+
+
+def test_oracle_shuffle_equals_numpy():
+    """numpy's Generator.shuffle of a Python list (RandomMixin._rand_perm, multigrid/utils/random.py:75-83) restated."""
+    r = np.random.default_rng(5)
+    for trial in range(300):
+        g = np.random.Generator(np.random.PCG64(int(r.integers(0, 2 ** 40))))
+        if r.random() < 0.5:
+            g.integers(0, 5)                                   # leaves a buffered 32-bit half behind
+        w = ob.gen_words(g)
+        n = int(r.integers(1, 25))
+        items = [int(v) for v in r.integers(0, 6, size=n)]
+        want = list(items); g.shuffle(want)
+        assert ob.np_shuffle(w, items) == want
+        np.testing.assert_array_equal(w, ob.gen_words(g))
+
+
+def test_layout_oracle_equals_layouts_py_lockedhallway_and_playground():
+    r = np.random.default_rng(9)
+    for seed in range(250):
+        # (feasible parameters only: the hallway must hold its keys and the agents, a room its keys -- the reference's rejection
+        # sampling loops forever otherwise, base.py:640-669 with max_tries = inf)
+        n = int(r.choice([2, 4, 6, 8, 12, 16])); rs = int(r.integers(5, 8)); A = int(r.integers(1, 4))
+        mhk, mkr = int(r.integers(1, 3)), int(r.integers(1, 4))
+        lg = np.random.default_rng(8000 + seed)
+        if seed % 3 == 0:
+            lg.integers(0, 7)
+        lw = ob.gen_words(lg)
+        g_ref, a_ref = layouts.lockedhallway_layout(n, rs, mhk, mkr, A, lg, np.random.default_rng(1))
+        g, a, aux = ob.lh_layout(n, rs, mhk, mkr, A, lw, layouts.lockedhallway_blank(n, rs))
+        np.testing.assert_array_equal(g, g_ref, err_msg=f"seed {seed} n {n} rs {rs}"); np.testing.assert_array_equal(a, a_ref)
+        np.testing.assert_array_equal(aux, layouts.make_aux("lockedhallway", g_ref))
+        np.testing.assert_array_equal(lw, ob.gen_words(lg))
+    for seed in range(150):
+        rs, rows, cols, A = int(r.integers(6, 9)), int(r.integers(2, 4)), int(r.integers(2, 4)), int(r.integers(1, 5))
+        lg, ng = np.random.default_rng(9000 + seed), np.random.default_rng(9500 + seed)
+        if seed % 3 == 0:
+            ng.integers(0, 7)
+        lw, nw = ob.gen_words(lg), ob.gen_words(ng)
+        g_ref, a_ref = layouts.playground_layout(rs, rows, cols, A, lg, ng)
+        g, a = ob.playground_layout(rs, rows, cols, A, lw, nw, layouts.roomgrid_blank(rs, rows, cols))
+        np.testing.assert_array_equal(g, g_ref, err_msg=f"seed {seed}"); np.testing.assert_array_equal(a, a_ref)
+        np.testing.assert_array_equal(lw, ob.gen_words(lg)); np.testing.assert_array_equal(nw, ob.gen_words(ng))

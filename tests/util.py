@@ -218,6 +218,14 @@ class OracleBackend:
             if gen["kind"] == "blockedunlockpickup":
                 g, a, x = ob.bup_layout(gen["room_size"], A, lay, npw, blank)
                 aux[b] = torch.from_numpy(x)
+            elif gen["kind"] == "lockedhallway":
+                rs = gen["room_size"]
+                g, a, x = ob.lh_layout(2 * ((self.spec.height - 1) // (rs - 1)), rs, gen["max_hallway_keys"], gen["max_keys_per_room"],
+                                       A, lay, blank)
+                aux[b] = torch.from_numpy(x)
+            elif gen["kind"] == "playground":
+                rs = gen["room_size"]
+                g, a = ob.playground_layout(rs, (self.spec.height - 1) // (rs - 1), (self.spec.width - 1) // (rs - 1), A, lay, npw, blank)
             elif gen["kind"] == "redbluedoors":
                 g, a, x = ob.rbd_layout(self.spec.height, A, lay, blank)
                 aux[b] = torch.from_numpy(x)

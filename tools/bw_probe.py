@@ -25,7 +25,5 @@ for gb in (1.2, 4.3):
     print(f"{gb} GB fill_ (write only):        {ms:7.3f} ms  {n / ms / 1e6:7.1f} GB/s written")
     ms = t_ms(lambda: bi.copy_(ai))
     print(f"{gb} GB copy_ (read + write):      {ms:7.3f} ms  {2 * n / ms / 1e6:7.1f} GB/s moved")
-    src = a[: n // 7].view(torch.int32)
-    ms = t_ms(lambda: torch.add(src.repeat(7)[: bi.numel()], 1, out=bi)) if False else 0
     del a, b
     torch.cuda.empty_cache()
