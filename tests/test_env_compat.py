@@ -299,6 +299,28 @@ def test_seed_streams_do_not_alias_across_seeds_or_shards():
     np.testing.assert_array_equal(w0[0].view(np.uint64), rnglib.words_from_seed(0))   # env 0 == gym reset(seed=0)
 
 
+def test_vectorised_seeding_equals_numpy_seed_sequence():
+    """rng.words_from_seed_and_index / words_from_seeds / layout_gen_state restate numpy's SeedSequence -> PCG64 seeding over
+    the whole batch at once: every env's words equal PCG64(SeedSequence(...)).state of numpy itself."""
+    from multigrid_amd import rng as rnglib
+    idx = np.array([0, 1, 2, 3, 77, 65535, 1 << 20, (1 << 32) - 1, (1 << 32) + 9])
+    for seed in (0, 1, 7, 123, 1 << 31, (1 << 32) - 1, (1 << 32) + 5, (1 << 70) + 3):
+        got = rnglib.words_from_seed_and_index(seed, idx[:-1])
+        big = rnglib.words_from_seed_and_index(seed, idx)                       # (an index beyond 2^32: the per-env path)
+        np.testing.assert_array_equal(big[:-1], got)
+        lay = rnglib.layout_gen_state(seed, idx[:-1])
+        for b, g in enumerate(idx[:-1]):
+            want = rnglib.words_from_seed(int(seed) if g == 0 else [int(seed), int(g)])
+            np.testing.assert_array_equal(got[b], want)
+            np.testing.assert_array_equal(lay[b, :4], rnglib.words_from_seed([int(seed), int(g)]))
+            assert not lay[b, 4:].any()
+    seeds = np.random.default_rng(0).integers(0, 1 << 32, 300)
+    got = rnglib.words_from_seeds(seeds)
+    for b in range(len(seeds)):
+        np.testing.assert_array_equal(got[b], rnglib.words_from_seed(int(seeds[b])))
+    assert rnglib.words_from_seed_and_index(3, np.zeros(0, dtype=np.int64)).shape == (0, 4)
+
+
 def test_agents_given_as_agent_objects():
     """MultiGridEnv(agents=[Agent(...), ...]) (multigrid/base.py:170-177): sorted by index, agents[0]'s view applies to all
     (base.py:364-365), and the trajectory equals the agents=<int> env's."""

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda", 0)
 spec = bench.workload_spec()
+if os.environ.get("MGX_SKIP"):          # tools' build only (MGX_LIBMGX=lib/libmgx_dbg.so): mgx_debug_skip_phases bit mask
+    from multigrid_amd import _lib
+    _lib.lib().mgx_debug_skip_phases(int(os.environ["MGX_SKIP"]))
 out = []
 for B in [int(x) for x in sys.argv[1:]] or [4096, 1 << 20]:
     env = bench.make_env(spec, B, dev, 0)

@@ -39,8 +39,16 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
             lib.mgx_debug_read_stamps(buf, wave)
             st = [int(x) for x in buf if x]
             d = [st[i + 1] - st[i] for i in range(len(st) - 1)]
-            acc = d if acc is None else [min(x, y) for x, y in zip(acc, d)]     # min over launches: least disturbed
-        labels = names[:len(acc)]
+            if acc is None:
+                acc, tot_all, all_d = d, [], []
+            acc = [min(x, y) for x, y in zip(acc, d)]     # min over launches: least disturbed
+            tot_all.append(st[-1] - st[0])
+            all_d.append(d)
+        # (the marker sequence after "P4" is one ("P5", "P5end") pair per staging round of 16 slots, then "end")
+        labels = (names[:12] + ["P5", "P5end"] * 8)[:len(acc) - 0]
+        labels = labels[:len(acc)] + ["?"] * (len(acc) - len(labels))
         tot = sum(acc)
-        print(f"  wave {wave}: total {tot} clk  " + "  ".join(f"{labels[i]}>{acc[i]}" for i in range(len(acc))))
+        print(f"  wave {wave}: sum of per-phase minima {tot} clk; whole wave: min {min(tot_all)} median {sorted(tot_all)[len(tot_all) // 2]} max {max(tot_all)} clk  " + "  ".join(f"{labels[i]}>{acc[i]}" for i in range(len(acc))))
+        med = [sorted(x[i] for x in all_d if len(x) == len(acc))[len(all_d) // 2] for i in range(len(acc))]
+        print("      medians over launches: " + "  ".join(f"{labels[i]}>{med[i]}" for i in range(len(acc))))
     del env
