@@ -22,6 +22,15 @@
  *                                 convert from / to u8[B,H,W,3] (type, color, state) bytes on the device; values the 16 bits
  *                                 cannot hold (type > 15, color > 7, state > 3 -- the reference has types 0-10, colors 0-5,
  *                                 states 0-2 and directions 0-3) are reported by mgx_pack_grid.
+ *                                 PRECONDITION: the outer ring of cells (x = 0, x = W-1, y = 0, y = H-1) of every env is the
+ *                                 reference's WALL = (wall, grey, 0) (multigrid/utils/obs.py:14).  Every env of the reference
+ *                                 starts from Grid.wall_rect(0, 0, W, H) (multigrid/core/grid.py:183-218; envs/empty.py:158,
+ *                                 core/roomgrid.py:203-218) and no action can change a wall, so it holds for every reachable
+ *                                 state.  The kernels use it twice: a front cell outside the grid never has to be tested
+ *                                 (the agent cannot stand on the ring), and a view cell outside the grid -- which
+ *                                 obs.py:199-202 shows as WALL -- is read from the ring cell next to it (the gather clamps its
+ *                                 coordinates instead of carrying an in-bounds mask per view).  The host side checks it on
+ *                                 import (multigrid_amd/layouts.py: check_walled).
  *   agents      u8 [B, A, 8]      packed AgentState row (multigrid/core/agent.py:222-232, 72 B -> 8 B):
  *                                 [0]=color [1]=dir [2]=x [3]=y [4]=terminated [5]=carry.type [6]=carry.color
  *                                 [7]=carry.state ; "carrying nothing" = the empty cell (1,0,0) (agent.py:337-346).

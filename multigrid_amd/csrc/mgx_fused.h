@@ -153,7 +153,8 @@ __device__ __forceinline__ T kernarg_at(size_t offset) {
 #endif
 
 // per-view record written by P1d and read (broadcast) by the wavefront in P2
-struct ViewRec { int32_t origin, stepF, stepL; uint32_t carry; };     // 16 bytes
+// origin: LDS address of the agent's own cell; steps / lo / hi: mgx_rules.h ViewClamp (packed i16 pairs, low half = forward)
+struct alignas(16) ViewRec { int32_t origin; uint32_t steps, lo, hi; };           // 16 bytes
 
 typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
 typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
@@ -369,7 +370,8 @@ __device__ __forceinline__ uint64_t state_is_open(uint32_t c) {
 
 template <int V, int NIT>
 struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V + i
-    int la[NIT], fw[NIT], q3[NIT];
+    uint32_t pk[NIT];       // (fw, la) as an i16 pair: forward distance V-1-j in the low half, lateral offset i - V/2 in the high
+    int q3[NIT];
     bool act[NIT], own[NIT];
 };
 
@@ -378,36 +380,35 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 // shows the grid here; lane s patches the carried object in afterwards (P3: its see-behind bit, P4: its bytes).
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
 template <int V, int NW, int S0, int N, int VPW, bool HALF>
-__device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave, const uint32_t wall_addr, const ViewRec *rec,
-                                             const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
+__device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave, const ViewRec *rec,
                                              const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
                                              uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     constexpr int V2 = V * V;
-    ViewRec r[N];
-    uint64_t inbm[N][NW];
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        r[n] = rec[S0 + n];                                                  // broadcast reads
-#pragma unroll
-        for (int it = 0; it < NW; ++it)                                      // lane S0+n made this slot's mask in P1d
-            inbm[n][it] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbHi[it], S0 + n) << 32)
-                        | (uint64_t)(uint32_t)__builtin_amdgcn_readlane(inbLo[it], S0 + n);
-    }
+    // (the records are fetched half a group at a time: all N of them at once would hold 4 N registers across the block)
+    constexpr int NH = N >= 16 ? N / 2 : N;
     uint32_t raw[N][NW];
-    bool inb[N][NW];
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
+    for (int h0 = 0; h0 < N; h0 += NH) {
+        ViewRec r[NH];
 #pragma unroll
-        for (int it = 0; it < NW; ++it) {
-            inb[n][it] = __builtin_amdgcn_inverse_ballot_w64(inbm[n][it]);
-            // world cell seen at image[i][j]: pos + fw*forward + la*right; lanes looking outside the grid read the
-            // wavefront's WALL cell instead (obs.py:199-202)
-            const int off = mad24(lc.fw[it], r[n].stepF, mad24(lc.la[it], r[n].stepL, r[n].origin));
-            const uint32_t addr = inb[n][it] ? (uint32_t)off : wall_addr;
-            if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr, 2);
-            // one aligned 16-bit read per cell (ds_read_u16)
-            raw[n][it] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+        for (int n = 0; n < NH; ++n) r[n] = rec[S0 + h0 + n];                // broadcast reads
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                // world cell seen at image[i][j]: pos + fw*forward + la*right, with (fw, la) clamped to the part of the view
+                // that lies inside the grid -- a cell outside it reads the border WALL cell next to it, which is what
+                // obs.py:199-202 shows there (mgx_rules.h: ViewClamp).  Three VALU instructions per cell, no per-view lane mask.
+                uint32_t t, addr;
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(lc.pk[it]), "v"(r[n].lo));
+                asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(r[n].hi));
+                asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "v"(r[n].steps), "v"(r[n].origin));
+                if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr, 2);
+                // one aligned 16-bit read per cell (ds_read_u16)
+                raw[h0 + n][it] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+            }
         }
+        if (h0 + NH < N) __builtin_amdgcn_sched_barrier(0);
     }
     // obs.py:46-63 see_behind as a lane mask: the cell's opaque bit is the sign of its 16 bits -- ONE compare per cell, whose
     // SGPR pair goes straight into lane s of sbLo / sbHi.  HARDWARE HAZARD (found on gfx950, not in the ISA manual's table,
@@ -449,14 +450,13 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
 constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as one straight-line block
 
 template <int V, int NW, int VPW, bool HALF, int G, int S0 = 0>
-__device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, int NVc, const uint32_t wall_addr, const ViewRec *rec,
-                                           const uint32_t (&inbLo)[NW], const uint32_t (&inbHi)[NW],
+__device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, int NVc, const ViewRec *rec,
                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
-        if (S0 < NVc) gather_group<V, NW, S0, G, VPW, HALF>(a, wave, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
-        gather_all<V, NW, VPW, HALF, G, S0 + G>(a, wave, NVc, wall_addr, rec, inbLo, inbHi, lc, cell, sbLo, sbHi);
+        if (S0 < NVc) gather_group<V, NW, S0, G, VPW, HALF>(a, wave, rec, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, HALF, G, S0 + G>(a, wave, NVc, rec, lc, cell, sbLo, sbHi);
     }
 }
 

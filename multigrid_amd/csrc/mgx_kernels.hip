@@ -1,6 +1,7 @@
 // mgx_kernels.hip -- the C ABI of libmgx.so (include/mgx.h): argument checks, launch geometry, dispatch to the fused
 // kernel's per-view-size translation units (mgx_fused.h / mgx_fused_inst.hip).
 #include <algorithm>
+#include <vector>
 
 #include "mgx_fused.h"
 
@@ -210,8 +211,20 @@ int mgx_debug_span_launches(long long *out4, int max_launches) {          // -> 
 }
 int mgx_debug_read_span(unsigned long long *out, int first, int count) {  // records [first, first + count), [begin, end] each
     if (first < 0 || count < 0 || first + count > kSpanCap) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * count,
-                               sizeof(unsigned long long) * 2 * first) == hipSuccess ? 0 : -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * count,
+                            sizeof(unsigned long long) * 2 * first) != hipSuccess) return -1;
+    for (int i = 0; i < count; ++i) out[2 * i + 1] &= 0x0fffffffffffffffull;   // (bits 60..: the wave's path flags, below)
+    return 0;
+}
+// which rare paths the wavefronts of records [first, first + count) took: 1 = auto-reset, 2 = sequential fallback, 4 = success /
+// failure events, 8 = cell writes (mgx_fused_body.inc: MGX_SPAN_FLAG)
+int mgx_debug_read_span_flags(unsigned char *out, int first, int count) {
+    if (first < 0 || count < 0 || first + count > kSpanCap) return -1;
+    std::vector<unsigned long long> tmp(2 * (size_t)count);
+    if (hipMemcpyFromSymbol(tmp.data(), HIP_SYMBOL(g_span), sizeof(unsigned long long) * 2 * count,
+                            sizeof(unsigned long long) * 2 * first) != hipSuccess) return -1;
+    for (int i = 0; i < count; ++i) out[i] = (unsigned char)(tmp[2 * i + 1] >> 60);
+    return 0;
 }
 #endif
 #if MGX_TIMESTAMPS

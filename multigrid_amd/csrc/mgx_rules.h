@@ -537,6 +537,38 @@ MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d) {
     return g;
 }
 
+// The same rectangle for the CLAMPED gather (round 3).  Every env's outer ring of cells is WALL = (wall, grey, 0) -- the
+// reference's envs all start from Grid.wall_rect(0, 0, W, H) (core/grid.py:183-218) and nothing can change a wall, a
+// precondition of include/mgx.h that layouts.check_walled enforces on import -- and WALL is exactly what obs.py:199-202 shows
+// for a world cell outside the grid.  A view cell outside the grid may therefore read the nearest cell INSIDE it: clamp
+// (fw, la) to the rectangle, one packed-i16 max + min per cell instead of a 64-bit mask per view (two v_readlane + a select
+// per cell), and the tile offset is one dot product with the packed steps:
+//     off = origin + dot2((fw', la'), (stepF, stepL)),   (fw', la') = min(max((fw, la), lo), hi)
+// all three as i16 pairs, low half = forward.  An agent that stands outside the grid (no valid state has one) sees only walls:
+// `valid` is false and the caller points the view at its WALL cell.
+struct ViewClamp { uint32_t steps, lo, hi; bool valid; };
+
+template <int V>
+MGX_HD ViewClamp view_clamp(const ViewGeom &g, int W, int H, int x, int y) {
+    constexpr int h = V / 2;
+    ViewClamp c;
+    const int fhi = g.fmax > V - 1 ? V - 1 : g.fmax;
+    c.steps = ((uint32_t)g.stepF & 0xffffu) | ((uint32_t)g.stepL << 16);
+    c.lo = (uint32_t)(g.imin - h) << 16;                                     // forward: from 0
+    c.hi = ((uint32_t)fhi & 0xffffu) | ((uint32_t)(g.imax - h) << 16);
+    c.valid = (x < W) & (y < H) & (g.fmax >= 0) & (g.imax >= g.imin);
+    return c;
+}
+
+// (host restatement of the three instructions, for tests/hostshim: v_pk_max_i16, v_pk_min_i16, v_dot2_i32_i16)
+MGX_HD int clamped_offset(int origin, const ViewClamp &c, int fw, int la) {
+    auto lo16 = [](uint32_t v) { return (int)(int16_t)(v & 0xffffu); };
+    auto hi16 = [](uint32_t v) { return (int)(int16_t)(v >> 16); };
+    int f = fw > lo16(c.lo) ? fw : lo16(c.lo), l = la > hi16(c.lo) ? la : hi16(c.lo);
+    f = f < lo16(c.hi) ? f : lo16(c.hi); l = l < hi16(c.hi) ? l : hi16(c.hi);
+    return origin + f * lo16(c.steps) + l * hi16(c.steps);
+}
+
 // in-bounds bit mask in lane order k = j*V + i
 template <int V, int NW>
 MGX_HD void inbounds_mask(const ViewGeom &g, uint64_t (&m)[NW]) {

@@ -491,10 +491,14 @@ def lockedhallway_layout(num_rooms, room_size, max_hallway_keys, max_keys_per_ro
 
 
 def check_walled(grid_hwc: np.ndarray):
-    """The kernels treat an out-of-bounds front cell as impassable; every shipped env has wall borders
-    (SURVEY.md App. A.2), which is what makes that equivalent to the reference.  Checked on import."""
+    """The precondition of include/mgx.h: the outer ring of every grid is the reference's WALL = (wall, grey, 0)
+    (multigrid/utils/obs.py:14) -- every shipped env starts from Grid.wall_rect(0, 0, W, H).  The kernels
+    rely on it twice: an out-of-bounds front cell is never tested, and a view cell outside the grid is read from the ring cell
+    next to it (the clamped gather).  Checked on import."""
     g = np.asarray(grid_hwc)
-    border = np.concatenate([g[..., 0, :, 0].ravel(), g[..., -1, :, 0].ravel(),
-                             g[..., :, 0, 0].ravel(), g[..., :, -1, 0].ravel()])
-    if not (border == Type.wall).all():
+    ring = np.concatenate([g[..., 0, :, :].reshape(-1, 3), g[..., -1, :, :].reshape(-1, 3),
+                           g[..., :, 0, :].reshape(-1, 3), g[..., :, -1, :].reshape(-1, 3)])
+    if not (ring[:, 0] == Type.wall).all():
         raise ValueError("grid borders must be walls")
+    if not ((ring[:, 1] == Color.grey) & (ring[:, 2] == 0)).all():
+        raise ValueError("grid borders must be the reference's WALL cells (wall, grey, 0): multigrid/utils/obs.py:14")

@@ -7,6 +7,7 @@
 //   shim_obs_env  : P1d (view geometry, in-bounds mask) + P2 (gather, see-behind bits) + P3 (visibility flood)
 //                   + P4 (mask) + byte packing
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -110,13 +111,16 @@ static void obs_env(const MgxSpec *sp, const uint8_t *tile, const uint64_t *rows
         const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
         uint64_t inb[NW], sb[NW], vis[NW];
         inbounds_mask<V, NW>(g, inb);
+        const ViewClamp vc = view_clamp<V>(g, W, H, row_x(row), row_y(row));   // what the kernel's P2 gathers with
         uint32_t cells[V2];
         for (int k = 0; k < NW; ++k) sb[k] = 0;
         for (int k = 0; k < V2; ++k) {                       // "lane" k
             const int j = k / V, i = k - j * V, la = i - V / 2, fw = V - 1 - j;
             const bool in = (inb[k >> 6] >> (k & 63)) & 1;
-            uint32_t c = CELL_WALL;
-            if (in) c = load_cell(tile + g.origin + fw * g.stepF + la * g.stepL);
+            // (the kernel: the clamped offset, or the WALL cell for an agent outside the grid; must agree with the mask form)
+            uint32_t c = vc.valid ? load_cell(tile + clamped_offset(g.origin, vc, fw, la)) : (uint32_t)CELL_WALL;
+            const uint32_t c_mask = in ? load_cell(tile + g.origin + fw * g.stepF + la * g.stepL) : (uint32_t)CELL_WALL;
+            if (c != c_mask) std::abort();
             if (i == V / 2 && j == V - 1) c = row_carry(row);
             if (see_behind(c)) sb[k >> 6] |= 1ull << (k & 63);
             cells[i * V + j] = c;

@@ -62,6 +62,11 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, unsigned long long *cyc,
         if (OP == 38) {  REP8(asm volatile("v_add_co_u32_e32 %0, vcc, %0, %8\n v_add_co_u32_e32 %1, vcc, %1, %8\n v_add_co_u32_e32 %2, vcc, %2, %8\n v_add_co_u32_e32 %3, vcc, %3, %8\n v_add_co_u32_e32 %4, vcc, %4, %8\n v_add_co_u32_e32 %5, vcc, %5, %8\n v_add_co_u32_e32 %6, vcc, %6, %8\n v_add_co_u32_e32 %7, vcc, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");) }
         if (OP == 39) {  REP8(asm volatile("v_cmp_eq_u32_e32 vcc, %0, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cmp_eq_u32_e32 vcc, %1, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cmp_eq_u32_e32 vcc, %2, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cmp_eq_u32_e32 vcc, %3, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cmp_eq_u32_e32 vcc, %4, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cmp_eq_u32_e32 vcc, %5, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cmp_eq_u32_e32 vcc, %6, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cmp_eq_u32_e32 vcc, %7, %8\n v_add_u32 %9, %9, %8\n v_add_u32 %9, %9, %8\n v_cndmask_b32_e32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");) }
         if (OP == 40) { asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc"); REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n s_nop 4\n v_cndmask_b32_e32 %1, %1, %8, vcc\n s_nop 4\n v_cndmask_b32_e32 %2, %2, %8, vcc\n s_nop 4\n v_cndmask_b32_e32 %3, %3, %8, vcc\n s_nop 4\n v_cndmask_b32_e32 %4, %4, %8, vcc\n s_nop 4\n v_cndmask_b32_e32 %5, %5, %8, vcc\n s_nop 4\n v_cndmask_b32_e32 %6, %6, %8, vcc\n s_nop 4\n v_cndmask_b32_e32 %7, %7, %8, vcc\n s_nop 4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");) }
+        if (OP == 41) {  REP8(asm volatile("v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n v_pk_max_i16 %2, %2, %8\n v_pk_max_i16 %3, %3, %8\n v_pk_max_i16 %4, %4, %8\n v_pk_max_i16 %5, %5, %8\n v_pk_max_i16 %6, %6, %8\n v_pk_max_i16 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (OP == 42) {  REP8(asm volatile("v_dot2_i32_i16 %0, %0, %8, %9\n v_dot2_i32_i16 %1, %1, %8, %9\n v_dot2_i32_i16 %2, %2, %8, %9\n v_dot2_i32_i16 %3, %3, %8, %9\n v_dot2_i32_i16 %4, %4, %8, %9\n v_dot2_i32_i16 %5, %5, %8, %9\n v_dot2_i32_i16 %6, %6, %8, %9\n v_dot2_i32_i16 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (OP == 43) {  REP8(asm volatile("v_mad_i32_i16 %0, %0, %8, %9\n v_mad_i32_i16 %1, %1, %8, %9\n v_mad_i32_i16 %2, %2, %8, %9\n v_mad_i32_i16 %3, %3, %8, %9\n v_mad_i32_i16 %4, %4, %8, %9\n v_mad_i32_i16 %5, %5, %8, %9\n v_mad_i32_i16 %6, %6, %8, %9\n v_mad_i32_i16 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (OP == 44) {  REP8(asm volatile("v_med3_i32 %0, %0, %8, %9\n v_med3_i32 %1, %1, %8, %9\n v_med3_i32 %2, %2, %8, %9\n v_med3_i32 %3, %3, %8, %9\n v_med3_i32 %4, %4, %8, %9\n v_med3_i32 %5, %5, %8, %9\n v_med3_i32 %6, %6, %8, %9\n v_med3_i32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+        if (OP == 45) {  REP8(asm volatile("v_pk_min_i16 %0, %0, %8\n v_pk_min_i16 %1, %1, %8\n v_pk_min_i16 %2, %2, %8\n v_pk_min_i16 %3, %3, %8\n v_pk_min_i16 %4, %4, %8\n v_pk_min_i16 %5, %5, %8\n v_pk_min_i16 %6, %6, %8\n v_pk_min_i16 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -121,5 +126,10 @@ int main(int argc, char **argv) {
     run<30>("v_min_u32", 8);
     run<31>("v_mul_u32_u24", 8);
     run<32>("v_add_u32 x2 lit", 8);
+    run<41>("v_pk_max_i16", 8);
+    run<45>("v_pk_min_i16", 8);
+    run<42>("v_dot2_i32_i16", 8);
+    run<43>("v_mad_i32_i16", 8);
+    run<44>("v_med3_i32", 8);
     return 0;
 }
