@@ -71,6 +71,7 @@ struct KernelArgs {
     // fused auto-reset (mgx_step_autoreset / mgx_rollout_autoreset; include/mgx.h: MgxAutoReset)
     int32_t pool_size;
     int64_t first_env;
+    uint64_t pool_magic;    // ceil(2^64 / pool_size): x mod pool_size for 32-bit x without a division (pool_index below)
     const uint8_t *pool_grid;
     const uint8_t *pool_agents;
     const uint8_t *pool_aux;

@@ -309,7 +309,8 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
             if (misaligned(ar->pool_agents, 8) || misaligned(ar->pool_aux, 16) || misaligned(ar->episode, 4))
                 return MGX_ERR_INVALID_ARGUMENT;
         }
-        ka.pool_size = ar->pool_size; ka.first_env = ar->first_env; ka.pool_grid = reinterpret_cast<const uint8_t *>(ar->pool_grid);
+        ka.pool_size = ar->pool_size; ka.first_env = ar->first_env;
+        ka.pool_magic = ar->pool_size > 1 ? ~0ull / (uint64_t)ar->pool_size + 1ull : 0ull; ka.pool_grid = reinterpret_cast<const uint8_t *>(ar->pool_grid);
         ka.pool_agents = ar->pool_agents; ka.pool_aux = ar->pool_aux; ka.episode = ar->episode;
         ka.was_reset = ar->was_reset;
         if (occupancy && !ka.pool_grid) ka.pool_grid = reinterpret_cast<const uint8_t *>(spec);   // (selects the AR instantiation)

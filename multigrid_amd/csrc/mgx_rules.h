@@ -342,22 +342,33 @@ MGX_HD int stale_offset(const StepCfg &cf, const uint8_t *aux, int env_kind) {
     return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.W + aux[0]) * kCellBytes : -1;
 }
 
+// ONE iteration of that loop: agent `i` takes its turn against the CURRENT tile and rows and its effects are committed.
+// Returns true for an unknown action (base.py:473-474).  `alive` = no unknown action has been met earlier in the visiting order
+// (the reference has raised by then).  The kernel's fallback runs it with one lane per env whose turn it is (mgx_fused_body.inc,
+// P1c); handle_actions below is the same loop on one thread.
+template <class Dirty>
+MGX_HD bool agent_turn(const StepCfg &cf, uint8_t *tile, uint64_t *rows, int i, int action, bool alive, double *rew,
+                       int32_t step_count, Dirty dirty, uint8_t *aux = nullptr, int env_kind = MGX_KIND_EMPTY) {
+    const int so = aux ? stale_offset(cf, aux, env_kind) : -1;
+    const AgentEval ev = eval_agent(cf, tile, rows, action, rows[i], alive, so);
+    if (ev.go) rows[i] = ev.nrow;
+    if (ev.unstale) aux[4] = 0;
+    if (ev.writes) { store_cell(tile + ev.off, ev.ncell); dirty(ev.off); }
+    if (ev.success) on_success(cf, rows, i, step_count, rew);                // base.py:433-434
+    if (ev.failure) set_terminated(rows, cf.A, i, cf.failure_any);           // base.py:435-436, 509-532
+    return ev.bad;
+}
+
 template <class Dirty>
 MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, const int8_t *act,
                           const uint8_t *ord, double *rew, int32_t step_count, Dirty dirty,
-                          uint8_t *aux = nullptr, int env_kind = MGX_KIND_EMPTY) {
+                          uint8_t *aux = nullptr, int env_kind = MGX_KIND_EMPTY, int k0 = 0) {
     const int A = cf.A;
     int rc = 0;
-    for (int k = 0; k < A; ++k) {
+    for (int k = k0; k < A; ++k) {                   // k0 = 1: the first visited agent's turn has been committed by the caller
         const int i = (A == 1) ? 0 : ord[k];
-        const int so = aux ? stale_offset(cf, aux, env_kind) : -1;
-        const AgentEval ev = eval_agent(cf, tile, rows, act[i], rows[i], rc == 0, so);   // after an unknown action the reference has raised
-        if (ev.bad) rc = MGX_ERR_UNKNOWN_ACTION;
-        if (ev.go) rows[i] = ev.nrow;
-        if (ev.unstale) aux[4] = 0;
-        if (ev.writes) { store_cell(tile + ev.off, ev.ncell); dirty(ev.off); }
-        if (ev.success) on_success(cf, rows, i, step_count, rew);                // base.py:433-434
-        if (ev.failure) set_terminated(rows, A, i, cf.failure_any);              // base.py:435-436, 509-532
+        // (after an unknown action the reference has raised: the later agents do nothing)
+        if (agent_turn(cf, tile, rows, i, act[i], rc == 0, rew, step_count, dirty, aux, env_kind)) rc = MGX_ERR_UNKNOWN_ACTION;
     }
     return rc;
 }
@@ -510,6 +521,27 @@ MGX_HD int overlay_offset(const StepCfg &cf, const uint64_t *rows, int ai) {
     const int x = row_x(r), y = row_y(r);
     if (row_term(r) | shadowed | (x >= cf.W) | (y >= cf.H)) return -1;
     return (y * cf.W + x) * kCellBytes;
+}
+
+// Layout of a restarting env (include/mgx.h: MgxAutoReset): (first_env + b + episode * 7919) mod K.  The 64-bit remainder costs
+// ~150 scalar instructions on the ONE wavefront of the launch that restarts an env -- and a launch lasts as long as its slowest
+// wavefront -- so the common case (pool of at most 2^19 layouts, env index below 2^32) takes three exact 32-bit remainders by
+// multiplication instead (Lemire, "Faster remainder by direct computation", 2019: a mod d = hi64(((M * a) mod 2^64) * d),
+// M = ceil(2^64 / d), exact for every 32-bit a and d); anything else takes the division.
+MGX_HD uint32_t fastmod_u32(uint32_t a, uint64_t M, uint32_t d) {
+    const uint64_t low = M * a;                                             // mod 2^64
+    const uint64_t hi_part = (low >> 32) * d, lo_part = (low & 0xffffffffull) * d;
+    return (uint32_t)((hi_part + (lo_part >> 32)) >> 32);
+}
+MGX_HD int pool_index(int64_t first_env, int64_t b, int32_t ep, int32_t K, uint64_t M) {
+    if (K == 1) return 0;
+    const uint64_t g = (uint64_t)(first_env + b);
+    if (K <= (1 << 19) && (g >> 32) == 0 && ep >= 0) {
+        const uint32_t k = (uint32_t)K;
+        const uint32_t x = fastmod_u32((uint32_t)g, M, k) + fastmod_u32((uint32_t)ep, M, k) * (7919u % k);   // < 2^32 (K <= 2^19)
+        return (int)fastmod_u32(x, M, k);
+    }
+    return (int)((uint64_t)(first_env + b + (int64_t)ep * 7919) % (uint64_t)K);
 }
 
 // ---------------------------------------------------------------------------------------------------

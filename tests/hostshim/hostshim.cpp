@@ -155,3 +155,10 @@ extern "C" int shim_overlay(const MgxSpec *sp, uint8_t *tile, const uint64_t *ro
     overlay_agents(make_cfg(*sp), tile, rows);
     return 0;
 }
+
+// the restart's layout index (mgx_rules.h: pool_index -- exact remainders by multiplication) for the test against big-int Python
+extern "C" int shim_pool_index(int64_t first_env, int64_t b, int32_t ep, int32_t K) {
+    const uint64_t M = K > 1 ? ~0ull / (uint64_t)K + 1ull : 0ull;
+    return pool_index(first_env, b, ep, K, M);
+}
+

@@ -81,3 +81,25 @@ def test_rules_replay_goldens(path):
         np.testing.assert_array_equal(layouts.grid_from_product(tile), z["grid"][t].astype(np.int64), err_msg=ctx)
         np.testing.assert_array_equal(layouts.unpack_agents(rows), z["agents"][t].astype(np.int64), err_msg=ctx)
     np.testing.assert_array_equal(rng, util.rng_words_lohi(z["rng_final"]))
+
+
+def test_pool_index_by_multiplication_is_the_exact_remainder():
+    """The restart's layout index (mgx_rules.h: pool_index) takes three 32-bit remainders by multiplication when the pool has at
+    most 2^19 layouts and the env index is below 2^32, the 64-bit division otherwise: both must equal the definition of
+    include/mgx.h (MgxAutoReset), (first_env + b + episode * 7919) mod K, computed here in Python integers."""
+    import ctypes as C
+    L = hostshim.lib()
+    L.shim_pool_index.restype = C.c_int
+    L.shim_pool_index.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int32]
+    r = np.random.default_rng(11)
+    ks = [1, 2, 3, 7, 64, 255, 256, 1000, 7918, 7919, 7920, 65535, 65536, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, (1 << 31) - 1]
+    ks += [int(x) for x in r.integers(1, 1 << 19, 40)] + [int(x) for x in r.integers(1 << 19, (1 << 31) - 1, 10)]
+    cases = 0
+    for K in ks:
+        firsts = [0, 1, K - 1, K, (1 << 32) - 2, (1 << 32) - 1, 1 << 32, (1 << 40) + 5] + [int(x) for x in r.integers(0, 1 << 33, 6)]
+        for first in firsts:
+            for b in (0, 1, 63, 65535, int(r.integers(0, 1 << 20))):
+                for ep in (0, 1, 2, 542_000, (1 << 31) - 1, int(r.integers(0, 1 << 31))):
+                    assert L.shim_pool_index(first, b, ep, K) == (first + b + ep * 7919) % K, (first, b, ep, K)
+                    cases += 1
+    assert cases > 20000

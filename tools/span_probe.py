@@ -54,13 +54,16 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
         a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 2).astype(np.int64)
         t0 = a[:, 0].min()
         b, e = (a[:, 0] - t0) * 10, (a[:, 1] - t0) * 10          # ns
-        if r == 9 and hasattr(lib, "mgx_debug_read_span_flags"):  # which rare paths the waves took, and what that cost them
+        if hasattr(lib, "mgx_debug_read_span_flags"):  # which rare paths the waves took, and what that cost them
             fl = (ctypes.c_ubyte * nw)()
             lib.mgx_debug_read_span_flags(fl, int(tab[4 * (nl - 1)]), nw)
-            fl = np.frombuffer(fl, dtype=np.uint8)
-            d = e - b
+            acc_f = np.concatenate([acc_f, np.frombuffer(fl, dtype=np.uint8).copy()]) if r else np.frombuffer(fl, dtype=np.uint8).copy()
+            acc_d = np.concatenate([acc_d, e - b]) if r else (e - b)
+        if r == 9 and hasattr(lib, "mgx_debug_read_span_flags"):  # (over the last launch of all ten runs)
+            fl, d = acc_f, acc_d
+            nw_all = len(d)
             pc = lambda x: " ".join(f"{int(np.percentile(x, q)):6d}" for q in (1, 10, 25, 50, 75, 90, 99, 100))
-            print(f"   wave durations (ns) p1 p10 p25 p50 p75 p90 p99 max, all {nw} waves: {pc(d)}")
+            print(f"   wave durations (ns) p1 p10 p25 p50 p75 p90 p99 max, all {nw_all} waves of 10 launches: {pc(d)}")
             for bit, name in ((1, "auto-reset"), (2, "sequential fallback"), (4, "success/failure events"), (8, "cell writes")):
                 m_ = (fl & bit) != 0
                 if m_.any():
@@ -68,9 +71,6 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
             m_ = fl == 0
             if m_.any():
                 print(f"     none of those            {int(m_.sum()):5d} waves: {pc(d[m_])}")
-            wv = np.arange(nw) % (li["threads_per_workgroup"] // 64)
-            for k in range(li["threads_per_workgroup"] // 64):
-                print(f"     wave {k} of its workgroup          : {pc(d[wv == k])}   begins {pc(b[wv == k])}")
         rows.append((b.max(), np.median(e - b), (e - b).max(), e.max(), np.percentile(e, 50), np.percentile(e, 99)))
         wpb_ = li["threads_per_workgroup"] // 64
         wg = np.arange(nw) // wpb_
