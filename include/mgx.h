@@ -290,8 +290,9 @@ int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar,
  *   one_hot      obs is u8[.., A, v, v, 21] (mgx_step_one_hot)
  *   auto_reset   finished envs restart from the layout pool BEFORE the step (mgx_step_autoreset), or NULL
  *   generate     the envs whose episode ends WITH the step are regenerated on the device right after it
- *                (mgx_step_generate; needs `episode`, optional `was_reset`; not together with `auto_reset`; steps == 1:
- *                a rollout restarts its finished envs from the layout pool), or NULL
+ *                (mgx_step_generate; needs `episode`, optional `was_reset`; not together with `auto_reset`), or NULL.  With
+ *                steps = T the call enqueues T launches of the step kernel over the [t] slices (generation writes the state in
+ *                device memory, which the one-launch rollout keeps in LDS between its steps): same results as T calls
  *   hook_order   u8[B, A] or NULL: the order in which the env subclass' step hook visits the agents -- the reference's hooks
  *                iterate `actions.items()`, i.e. the insertion order of the caller's dict (multigrid/envs/redbluedoors.py:176,
  *                locked_hallway.py:210); row b lists agent indices in that order (a permutation of 0..A-1; agents absent from

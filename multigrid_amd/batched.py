@@ -393,7 +393,9 @@ class BatchedMultiGridEnv:
         actions  i8[T,B,A].  Returns {'obs': u8[T,B,A,v,v,3], 'dir', 'reward', 'terminated': [T,B,A],
         'truncated': u8[T,B]} (pass `out` to reuse buffers).  The env's own `obs`... buffers are not touched.
         auto_reset=True: finished envs restart from the layout pool before each step (as `step(auto_reset=True)`);
-        the result then also holds 'was_reset': u8[T,B].  one_hot=True: 'obs' is the one-hot observation u8[T,B,A,v,v,21]
+        the result then also holds 'was_reset': u8[T,B].  With a layout generator set (`set_layout_generator`) the envs whose
+        episode ends with a step are regenerated on the device right after it instead, and the call is T launches of the
+        step kernel (as T calls of `step(auto_reset=True)`).  one_hot=True: 'obs' is the one-hot observation u8[T,B,A,v,v,21]
         (multigrid/wrappers.py:158-190), written by the same launch."""
         self._need_state()
         self.join()
@@ -410,6 +412,13 @@ class BatchedMultiGridEnv:
                    "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev)}
         if auto_reset and "was_reset" not in out:
             out["was_reset"] = torch.empty((T, B), dtype=torch.uint8, device=dev)
+        generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
+        if generate:        # episode starts generated on the device: the envs whose episode ends with step t are regenerated
+            self.backend.rollout(B, T, self.cells, self.agents, self.rng, self.step_count, actions,          # right after it
+                                 self.aux if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],
+                                 out["reward"], out["terminated"], out["truncated"],
+                                 generate=(self._gen, self.episode, out["was_reset"]), **({"one_hot": True} if one_hot else {}))
+            return out
         ar = self._auto_reset_args(auto_reset, out.get("was_reset"))
         self.backend.rollout(B, T, self.cells, self.agents, self.rng, self.step_count, actions,
                              self.aux if sp.env_kind != "empty" else None, self.err, out["obs"], out["dir"],

@@ -184,7 +184,7 @@ int mgx_last_hip_error(void) { return g_last_hip_error; }
 
 #if MGX_DEBUG_KNOBS
 // Profiling aid, only in the tools' build (lib/libmgx_dbg.so; never in libmgx.so): bit p set = the fused kernel skips
-// phase Pp.  Results are then meaningless; tools/phase_probe.py uses it to attribute kernel time to phases.
+// phase Pp.  Results are then meaningless; tools/graph_phase.py uses it to attribute kernel time to phases.
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
@@ -325,8 +325,29 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
     ka.T = roll ? sa.steps : 1;
     int mode = (roll ? 2 : 1) | (one_hot ? 4 : 0);
     if (gen) {
-        if (roll) return MGX_ERR_UNSUPPORTED;             // (a rollout regenerates from the layout pool: auto_reset)
         if (ar) return MGX_ERR_INVALID_ARGUMENT;
+        if (roll) {
+            // steps = T with generation: T launches of the one-step kernel over the [t] slices.  (Generation writes the HBM state;
+            // the one-launch rollout keeps the state in LDS between its steps, so the two do not combine into a single launch --
+            // a rollout in one launch restarts its finished envs from the layout pool: auto_reset.)  Same results as T calls.
+            if (occupancy) { MgxStepArgs one = sa; one.steps = 1; return step_common(spec, batch, one, stream, occupancy); }
+            const int64_t BA = batch * spec->num_agents, V2 = (int64_t)spec->view_size * spec->view_size * (one_hot ? 21 : 3);
+            for (int32_t t = 0; t < sa.steps; ++t) {
+                MgxStepArgs one = sa;
+                one.steps = 1;
+                one.actions = sa.actions + t * BA;
+                one.hook_order = sa.hook_order ? sa.hook_order + t * BA : nullptr;
+                one.obs = sa.obs + t * BA * V2;
+                one.dir = sa.dir ? sa.dir + t * BA : nullptr;
+                one.reward = sa.reward + t * BA;
+                one.terminated = sa.terminated + t * BA;
+                one.truncated = sa.truncated + t * batch;
+                one.was_reset = sa.was_reset ? sa.was_reset + t * batch : nullptr;
+                rc = step_common(spec, batch, one, stream, nullptr);
+                if (rc) return rc;
+            }
+            return MGX_OK;
+        }
         if (!occupancy) {
             if (!gen->blank || !gen->gen_state || !sa.episode || !sa.rng) return MGX_ERR_INVALID_ARGUMENT;
             if (misaligned(gen->gen_state, 8) || misaligned(sa.episode, 4)) return MGX_ERR_INVALID_ARGUMENT;

@@ -251,10 +251,11 @@ class HipBackend:
         return int(out.value)
 
     def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
-                truncated, auto_reset=None, one_hot: bool = False):
-        """T steps in one launch (mgx_step_ex with steps = T); `one_hot`: obs is u8[T,B,A,v,v,21]."""
+                truncated, auto_reset=None, one_hot: bool = False, generate=None):
+        """T steps in one launch (mgx_step_ex with steps = T); `one_hot`: obs is u8[T,B,A,v,v,21]; `generate` = (gen dict,
+        episode, was_reset[T,B]): episodes that end are regenerated on the device (then T launches of the step kernel)."""
         sa, keep = self.step_args(grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
-                                  auto_reset, one_hot)
+                                  auto_reset, one_hot, generate)
         sa.steps = T
         sa.actions = actions.data_ptr()
         with torch.cuda.device(grid.device):

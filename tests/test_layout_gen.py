@@ -164,6 +164,31 @@ def test_device_generation_equals_oracle_over_many_episodes(name, spec, gen, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("one_hot", [False, True])
+def test_rollout_with_device_generation_equals_steps(one_hot):
+    """mgx_step_ex(steps = T, generate): the rollout form of the step with episode starts generated on the device == T calls of
+    step(auto_reset=True) -- every output slice, `was_reset[T,B]`, the whole state and the generator states (the mode matrix:
+    rollout x generation, also with the one-hot output)."""
+    name, spec, gen, B = CASES[0]
+    dev = "cuda:0"
+    T = 2 * spec.max_steps + 5
+    a, b = _make(spec, gen, B, dev), _make(spec, gen, B, dev)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    acts = torch.randint(0, 7, (T, B, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+    out = b.rollout(acts, auto_reset=True, one_hot=one_hot)
+    for t in range(T):
+        o = a.step(acts[t], auto_reset=True, one_hot=one_hot)
+        for k, key in enumerate(("obs", "dir", "reward", "terminated", "truncated")):
+            assert torch.equal(out[key][t], o[k]), f"{name} step {t} {key}"
+        assert torch.equal(out["was_reset"][t], a.was_reset), f"{name} step {t} was_reset"
+    for f in ("grid", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    assert torch.equal(a._gen["gen_state"], b._gen["gen_state"])
+    assert int(b.episode.sum()) >= B
+    b.check_errors()
+
+
+@pytest.mark.gpu
 def test_generated_bup_episodes_have_the_reference_structure():
     dev = "cuda:0"
     spec = EnvSpec(11, 6, 2, 7, max_steps=1, joint_reward=True, env_kind="blockedunlockpickup")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-step time of a hipGraph of K fused steps, with phases skipped one at a time (profiling aid: results of skipped
-runs are garbage).  Unlike phase_probe.py this excludes the per-launch host overhead, so it shows the kernel's own
+runs are garbage).  This excludes the per-launch host overhead, so it shows the kernel's own
 critical path at small batches.  Usage (GPU box): python tools/graph_phase.py [batch ...]"""
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run W untimed + N profiled-looking fused steps (+ gen_obs) of the MGX_WORKLOAD configuration at a given batch; the target
-of the rocprofv3 passes (tools/pmc_probe.sh, tools/valu_by_phase.sh, tools/profile_round.sh).
+of the rocprofv3 passes (tools/profile_round.py, tools/valu_by_phase.sh).
     python tools/large_step.py [batch] [N] [warm]
 MGX_SKIP=<mask> (needs MGX_LIBMGX=multigrid_amd/lib/libmgx_dbg.so): skip phases -- results are then garbage."""
 import os

@@ -38,7 +38,7 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
         s_ = torch.cuda.Stream(dev); s_.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s_):
             with torch.cuda.graph(graph, stream=s_):
-                for t in range(20):
+                for t in range(int(os.environ.get("MGX_GRAPH_STEPS", "20"))):   # (2^18 wave records in all: fewer steps for big launches)
                     env.step(acts[t], auto_reset=bench.AUTO_RESET)
         torch.cuda.current_stream(dev).wait_stream(s_)
     for r in range(10):
