@@ -78,7 +78,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 6
+#define MGX_ABI_VERSION 7
 
 enum {
     MGX_OK = 0,
@@ -122,6 +122,9 @@ typedef struct MgxLaunchInfo {
     int32_t workgroups;
     int32_t lds_bytes;
     int32_t slots_per_group;     /* view slots a wavefront gathers / stages as one block: 16, or 4 / 8 in the latency regime */
+    int32_t fixed_shape;         /* ABI 7: > 0 = the plain step of this (spec, batch) runs a shape-specialised instantiation of the
+                                    latency family (W, H, A and the envs per wavefront are compile-time constants: the shapes
+                                    BASELINE.json names); 0 = the generic kernel.  Same results either way */
 } MgxLaunchInfo;
 
 int mgx_abi_version(void);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
@@ -30,7 +30,7 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
 
 class MgxLaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("envs_per_wavefront", "envs_per_workgroup", "threads_per_workgroup", "workgroups",
-                                          "lds_bytes", "slots_per_group")]
+                                          "lds_bytes", "slots_per_group", "fixed_shape")]
 
 
 class MgxAutoReset(C.Structure):

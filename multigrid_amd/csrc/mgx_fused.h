@@ -166,6 +166,9 @@ typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 #ifndef MGX_SLOTS_SMALL_VIEW
 #define MGX_SLOTS_SMALL_VIEW 64
 #endif
+#ifndef MGX_NO_FIXED_SHAPES
+#define MGX_NO_FIXED_SHAPES 0     // 1: build without the shape-specialised instantiations (kShapes below): A/B builds
+#endif
 constexpr int kSlotsSmallView = MGX_SLOTS_SMALL_VIEW;
 // cache policy bits of the obs stores (raw buffer store `aux`: 1 = sc0, 2 = nt, 16 = sc1 on gfx94x/gfx950)
 #ifndef MGX_OBS_AUX
@@ -287,6 +290,24 @@ inline int choose_group(const MgxSpec &sp, int64_t batch) {
     (void)sp; (void)batch;
     return 16;
 }
+
+// Shape-specialised instantiations of the latency family (template parameter SHAPE of mgx_fused_kernel; 0 = the shape is read
+// from the kernel arguments).  A lone wavefront issues one instruction per ~5 cycles whatever it is, so the scalar arithmetic a
+// runtime (W, H, A, envs per wavefront) costs -- LDS carve offsets, the row pitch, the lane -> (env, agent) split, loop bounds -- is
+// on its chain like everything else: ~1000 of its ~2000 static scalar instructions disappear when the shape is a constant, and the
+// agent loops unroll.  Measured with in-kernel spans (tools/span_probe.py, round 3): C2 wave 4.24 -> 3.78 us (step 6.6 -> 5.95),
+// BlockedUnlockPickup at 16384 envs 5.08 -> 4.45 us (step 9.6 -> 8.2); the throughput instantiation of C4 gains 1 % (its scalar work
+// runs beside four waves' VALU work) and has none.  The table holds the shapes BASELINE.json names, at the envs-per-wavefront
+// choose_Gw gives them in the latency regime; every other shape, and these at other launch geometries, run the generic kernels.
+struct FixedShape { int W, H, A, Gw; bool hooks; };
+constexpr FixedShape kShapes[] = {
+    {0, 0, 0, 0, false},
+    {16, 16, 4, 4, false},      // 1: MultiGrid-Empty-16x16 x 4 agents, up to 8192 envs (C2; C4's share of an 8-GPU node)
+    {16, 16, 4, 8, false},      // 2: the same at 16384 envs (C4's share of a 4-GPU node, one sub-shard of the pipelined C4)
+    {11, 6, 2, 8, true},        // 3: MultiGrid-BlockedUnlockPickup x 2 agents (C3)
+};
+constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
+constexpr int shape_slots(const FixedShape &f) { return (f.Gw * f.A + 15) / 16 * 16; }   // == slots_in_use() for <= 32 slots
 
 static __device__ const JumpTable kJump{};
 
@@ -476,7 +497,7 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // STREAM: the grid tensor is larger than the Infinity Cache can keep between steps: non-temporal tile loads.
 // DMA: the tile is loaded HBM -> LDS by LDS-DMA (small launches: P0).
 template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false, bool DMA = (MGX_LDS_DMA != 0),
-          int GRP = kGroup>
+          int GRP = kGroup, int SHAPE = 0>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
 #include "mgx_fused_body.inc"
 }
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 template <int V, bool OH, bool STREAM, bool DMA>
 __global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(6)))
 void mgx_obs_kernel(const KernelArgs a) {
-    constexpr int MODE = 0, GRP = kGroup;
+    constexpr int MODE = 0, GRP = kGroup, SHAPE = 0;
     constexpr bool HOOKS = false, AR = false, GEN = false;
 #include "mgx_fused_body.inc"
 }
@@ -504,6 +525,20 @@ void mgx_obs_kernel(const KernelArgs a) {
 // does not carry them.
 constexpr bool has_small_groups(int V, int MODE, bool OH, bool GEN) {
     return MGX_DEBUG_KNOBS != 0 && MODE == 1 && V <= 9 && !OH && !GEN;
+}
+
+// Which entry of kShapes, if any, the launch geometry the host derived for the plain step of the latency family matches exactly
+// (0 = none: the generic kernel).  Also what mgx_launch_info reports.
+inline int match_fixed_shape(const KernelArgs &ka, bool hooks) {
+    if (MGX_NO_FIXED_SHAPES || ka.sp.view_size != 7 || ka.grp != kGroup || (ka.flags & 3) != 2) return 0;
+    for (int k = 1; k < kNumShapes; ++k) {
+        const FixedShape &f = kShapes[k];
+        if (ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw && hooks == f.hooks
+            && ka.vpw == shape_slots(f)
+            && ka.wave_lds == make_carve(f.W, f.H, f.A, 7, f.Gw, shape_slots(f), false, f.hooks, false, kGroup).total())
+            return k;
+    }
+    return 0;
 }
 
 template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false, int GRP = kGroup>
@@ -525,13 +560,27 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
     const bool ar = MODE != 0 && ka.pool_grid != nullptr;
     constexpr bool S = MODE != 0;
-    if constexpr (MODE == 0 && V <= 7 && !GEN) {
-        kern = mgx_obs_kernel<V, OH, STREAM, DMA>;
-    } else if constexpr (GEN) {                                              // (generation replaces the pool pick-up)
-        kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
-    } else {
-        kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM, DMA, GRP> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM, DMA, GRP>)
-                     : (ar ? mgx_fused_kernel<V, MODE, false, S, OH, false, STREAM, DMA, GRP> : mgx_fused_kernel<V, MODE, false, false, OH, false, STREAM, DMA, GRP>);
+    // the shape-specialised instantiations (kShapes): the plain step of the latency family at 7x7 views, picked only when the
+    // launch geometry the host derived is exactly the one the instantiation was compiled for
+    int shape = 0;
+    if constexpr (DMA && MODE == 1 && !OH && !GEN && !STREAM && GRP == kGroup && V == 7) shape = match_fixed_shape(ka, hooks);
+    if constexpr (DMA && MODE == 1 && !OH && !GEN && !STREAM && GRP == kGroup && V == 7 && !MGX_NO_FIXED_SHAPES) {
+        switch (shape) {
+        case 1: kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, true, kGroup, 1> : mgx_fused_kernel<V, 1, false, false, false, false, false, true, kGroup, 1>; break;
+        case 2: kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, true, kGroup, 2> : mgx_fused_kernel<V, 1, false, false, false, false, false, true, kGroup, 2>; break;
+        case 3: kern = ar ? mgx_fused_kernel<V, 1, true, true, false, false, false, true, kGroup, 3> : mgx_fused_kernel<V, 1, true, false, false, false, false, true, kGroup, 3>; break;
+        default: break;
+        }
+    }
+    if (!kern) {
+        if constexpr (MODE == 0 && V <= 7 && !GEN) {
+            kern = mgx_obs_kernel<V, OH, STREAM, DMA>;
+        } else if constexpr (GEN) {                                          // (generation replaces the pool pick-up)
+            kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
+        } else {
+            kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM, DMA, GRP> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM, DMA, GRP>)
+                         : (ar ? mgx_fused_kernel<V, MODE, false, S, OH, false, STREAM, DMA, GRP> : mgx_fused_kernel<V, MODE, false, false, OH, false, STREAM, DMA, GRP>);
+        }
     }
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -250,6 +250,7 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     out->workgroups = (int32_t)nwg;
     out->lds_bytes = lds;
     out->slots_per_group = ka.grp;
+    out->fixed_shape = match_fixed_shape(ka, spec->env_kind != MGX_KIND_EMPTY);
     return MGX_OK;
 }
 

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     L = _lib.lib()
     for n in names:
         assert getattr(L, n) is not None
-    assert L.mgx_abi_version() == _lib.ABI_VERSION == 6
+    assert L.mgx_abi_version() == _lib.ABI_VERSION == 7
     assert _lib.error_string(0) == "ok" and "action" in _lib.error_string(-2)
 
 
@@ -44,6 +44,16 @@ def test_argument_validation_codes():
     assert L.mgx_launch_info(C.byref(ok), 4096, C.byref(info)) == _lib.OK
     assert info.threads_per_workgroup % 64 == 0 and info.workgroups > 0 and info.lds_bytes <= 160 * 1024
     assert info.envs_per_wavefront * ok.num_agents <= 64
+    # the shape-specialised instantiations (ABI 7): the shapes BASELINE.json names, at the launch geometry of the latency regime
+    assert info.fixed_shape == 1 and info.envs_per_wavefront == 4                    # Empty-16x16 x 4, 4096 envs (C2)
+    assert L.mgx_launch_info(C.byref(ok), 16384, C.byref(info)) == _lib.OK and info.fixed_shape == 2 and info.envs_per_wavefront == 8
+    assert L.mgx_launch_info(C.byref(ok), 65536, C.byref(info)) == _lib.OK and info.fixed_shape == 0   # throughput family
+    bup = EnvSpec(11, 6, 2, env_kind="blockedunlockpickup", joint_reward=True).to_c()
+    assert L.mgx_launch_info(C.byref(bup), 16384, C.byref(info)) == _lib.OK and info.fixed_shape == 3 and info.envs_per_wavefront == 8
+    other = EnvSpec(15, 16, 4).to_c()
+    assert L.mgx_launch_info(C.byref(other), 4096, C.byref(info)) == _lib.OK and info.fixed_shape == 0
+    v5 = EnvSpec(16, 16, 4, 5).to_c()
+    assert L.mgx_launch_info(C.byref(v5), 4096, C.byref(info)) == _lib.OK and info.fixed_shape == 0
     bad = EnvSpec(16, 16, 4).to_c()
     bad.view_size = 6                                                   # even view: agent.py:78
     assert L.mgx_launch_info(C.byref(bad), 16, C.byref(info)) == _lib.ERR_INVALID_ARGUMENT
