@@ -299,15 +299,17 @@ inline int choose_group(const MgxSpec &sp, int64_t batch) {
 // BlockedUnlockPickup at 16384 envs 5.08 -> 4.45 us (step 9.6 -> 8.2); the throughput instantiation of C4 gains 1 % (its scalar work
 // runs beside four waves' VALU work) and has none.  The table holds the shapes BASELINE.json names, at the envs-per-wavefront
 // choose_Gw gives them in the latency regime; every other shape, and these at other launch geometries, run the generic kernels.
-struct FixedShape { int W, H, A, Gw; bool hooks; };
+struct FixedShape { int W, H, A, Gw; bool hooks; int V; bool dma, stream; };     // (dma / stream: the instantiation family, launch_mode)
 constexpr FixedShape kShapes[] = {
-    {0, 0, 0, 0, false},
-    {16, 16, 4, 4, false},      // 1: MultiGrid-Empty-16x16 x 4 agents, up to 8192 envs (C2; C4's share of an 8-GPU node)
-    {16, 16, 4, 8, false},      // 2: the same at 16384 envs (C4's share of a 4-GPU node, one sub-shard of the pipelined C4)
-    {11, 6, 2, 8, true},        // 3: MultiGrid-BlockedUnlockPickup x 2 agents (C3)
+    {0, 0, 0, 0, false, 0, false, false},
+    {16, 16, 4, 4, false, 7, true, false},      // 1: MultiGrid-Empty-16x16 x 4 agents, up to 8192 envs (C2; C4's share of an 8-GPU node)
+    {16, 16, 4, 8, false, 7, true, false},      // 2: the same at 16384 envs (C4's share of a 4-GPU node, one sub-shard of the pipelined C4)
+    {11, 6, 2, 8, true, 7, true, false},        // 3: MultiGrid-BlockedUnlockPickup x 2 agents (C3)
+    {64, 64, 16, 1, false, 9, false, true},     // 4: the 64x64 grid x 16 agents, 9x9 views of C5 (one env per wavefront, streamed grids:
+                                                //    issue-bound at ~4 wavefronts per SIMD, so it gains less: 84.7 -> 81.5 us)
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
-constexpr int shape_slots(const FixedShape &f) { return (f.Gw * f.A + 15) / 16 * 16; }   // == slots_in_use() for <= 32 slots
+constexpr int shape_slots(const FixedShape &f) { return (f.Gw * f.A + 15) / 16 * 16; }   // == slots_in_use() (all entries: <= 32 slots)
 
 static __device__ const JumpTable kJump{};
 
@@ -530,12 +532,13 @@ constexpr bool has_small_groups(int V, int MODE, bool OH, bool GEN) {
 // Which entry of kShapes, if any, the launch geometry the host derived for the plain step of the latency family matches exactly
 // (0 = none: the generic kernel).  Also what mgx_launch_info reports.
 inline int match_fixed_shape(const KernelArgs &ka, bool hooks) {
-    if (MGX_NO_FIXED_SHAPES || ka.sp.view_size != 7 || ka.grp != kGroup || (ka.flags & 3) != 2) return 0;
+    if (MGX_NO_FIXED_SHAPES || ka.grp != kGroup) return 0;
     for (int k = 1; k < kNumShapes; ++k) {
         const FixedShape &f = kShapes[k];
-        if (ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw && hooks == f.hooks
+        if (ka.sp.view_size == f.V && ((ka.flags & 2) != 0) == f.dma && ((ka.flags & 1) != 0) == f.stream
+            && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw && hooks == f.hooks
             && ka.vpw == shape_slots(f)
-            && ka.wave_lds == make_carve(f.W, f.H, f.A, 7, f.Gw, shape_slots(f), false, f.hooks, false, kGroup).total())
+            && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), false, f.hooks, false, kGroup).total())
             return k;
     }
     return 0;
@@ -562,14 +565,18 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
     constexpr bool S = MODE != 0;
     // the shape-specialised instantiations (kShapes): the plain step of the latency family at 7x7 views, picked only when the
     // launch geometry the host derived is exactly the one the instantiation was compiled for
-    int shape = 0;
-    if constexpr (DMA && MODE == 1 && !OH && !GEN && !STREAM && GRP == kGroup && V == 7) shape = match_fixed_shape(ka, hooks);
-    if constexpr (DMA && MODE == 1 && !OH && !GEN && !STREAM && GRP == kGroup && V == 7 && !MGX_NO_FIXED_SHAPES) {
-        switch (shape) {
-        case 1: kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, true, kGroup, 1> : mgx_fused_kernel<V, 1, false, false, false, false, false, true, kGroup, 1>; break;
-        case 2: kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, true, kGroup, 2> : mgx_fused_kernel<V, 1, false, false, false, false, false, true, kGroup, 2>; break;
-        case 3: kern = ar ? mgx_fused_kernel<V, 1, true, true, false, false, false, true, kGroup, 3> : mgx_fused_kernel<V, 1, true, false, false, false, false, true, kGroup, 3>; break;
-        default: break;
+    if constexpr (MODE == 1 && !OH && !GEN && GRP == kGroup && !MGX_NO_FIXED_SHAPES) {
+        const int shape = match_fixed_shape(ka, hooks);          // (its V / dma / stream are this instantiation's: fill_args set the flags)
+        if constexpr (V == 7 && DMA && !STREAM) {
+            switch (shape) {
+            case 1: kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, true, kGroup, 1> : mgx_fused_kernel<V, 1, false, false, false, false, false, true, kGroup, 1>; break;
+            case 2: kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, true, kGroup, 2> : mgx_fused_kernel<V, 1, false, false, false, false, false, true, kGroup, 2>; break;
+            case 3: kern = ar ? mgx_fused_kernel<V, 1, true, true, false, false, false, true, kGroup, 3> : mgx_fused_kernel<V, 1, true, false, false, false, false, true, kGroup, 3>; break;
+            default: break;
+            }
+        }
+        if constexpr (V == 9 && !DMA && STREAM) {
+            if (shape == 4) kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, true, false, kGroup, 4> : mgx_fused_kernel<V, 1, false, false, false, false, true, false, kGroup, 4>;
         }
     }
     if (!kern) {

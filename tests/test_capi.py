@@ -52,6 +52,9 @@ def test_argument_validation_codes():
     assert L.mgx_launch_info(C.byref(bup), 16384, C.byref(info)) == _lib.OK and info.fixed_shape == 3 and info.envs_per_wavefront == 8
     other = EnvSpec(15, 16, 4).to_c()
     assert L.mgx_launch_info(C.byref(other), 4096, C.byref(info)) == _lib.OK and info.fixed_shape == 0
+    c5 = EnvSpec(64, 64, 16, 9, max_steps=16384).to_c()
+    assert L.mgx_launch_info(C.byref(c5), 32768, C.byref(info)) == _lib.OK and info.fixed_shape == 4 and info.envs_per_wavefront == 1
+    assert L.mgx_launch_info(C.byref(c5), 4096, C.byref(info)) == _lib.OK and info.fixed_shape == 0     # (fits the Infinity Cache: not streamed)
     v5 = EnvSpec(16, 16, 4, 5).to_c()
     assert L.mgx_launch_info(C.byref(v5), 4096, C.byref(info)) == _lib.OK and info.fixed_shape == 0
     bad = EnvSpec(16, 16, 4).to_c()
