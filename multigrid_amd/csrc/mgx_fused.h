@@ -94,6 +94,9 @@ struct KernelArgs {
 #ifndef MGX_P4_B16
 #define MGX_P4_B16 1
 #endif
+#ifndef MGX_P4_PERM
+#define MGX_P4_PERM 1     // P4: one v_perm_b32 per slot makes the store-ready bytes (0: the widening chain + per-store shifts of round 2)
+#endif
 #ifndef MGX_WRITELANE_NOP
 #define MGX_WRITELANE_NOP 0
 #endif
