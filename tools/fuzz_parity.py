@@ -34,15 +34,24 @@ while time.time() < t_end:
     if r.random() < 0.06:                       # launches of more than 2048 wavefronts: the throughput instantiations
         W, H = int(r.integers(3, 13)), int(r.integers(3, 13))
         B = int(r.integers(30000, 150000))
-    if W * H * A * B > 4e7:
+    fixed = None
+    if r.random() < 0.18:                       # the shape-specialised instantiations (mgx_fused.h: kShapes), at batches that pick them
+        fixed = int(r.integers(0, 2))           # (the C5 shape: tests/test_full_size.py, at its full 32768 envs)
+        V, W, H, A, B = [(7, 16, 16, 4, int(r.choice([5, 64, 1000, 4096, 8192]))), (7, 16, 16, 4, int(r.choice([8200, 12000, 16384])))][fixed]
+        spec = EnvSpec(W, H, A, V, max_steps=int(r.integers(3, 60)), see_through_walls=spec.see_through_walls,
+                       allow_agent_overlap=spec.allow_agent_overlap, joint_reward=spec.joint_reward,
+                       success_termination_mode=spec.success_termination_mode, failure_termination_mode=spec.failure_termination_mode)
+    if W * H * A * B > 4e7 and fixed is None:
         B = max(1, int(4e7 / (W * H * A)))
     T = int(r.integers(3, 14))
     seed = int(r.integers(0, 1 << 30))
     st = util.random_state(spec, B, seed=seed, density=float(r.choice([0.0, 0.1, 0.3, 0.5])),
                            terminated_p=float(r.choice([0.0, 0.05, 0.3])))
-    hook = r.random() < 0.15
+    hook = r.random() < 0.15 and fixed is None
     if hook:                                    # a hook env kind on generated layouts: BlockedUnlockPickup, 2..4 agents
         A = int(r.integers(2, 5)); B = min(B, 300)
+        if r.random() < 0.5:                    # (... half of them the shape with its own instantiation: 2 agents, 7x7 views)
+            A, V = 2, 7
         spec = EnvSpec(11, 6, A, V if V <= 9 else 7, max_steps=int(r.integers(5, 80)), joint_reward=True,
                        env_kind="blockedunlockpickup", see_through_walls=spec.see_through_walls)
         lr = np.random.default_rng(seed)
@@ -70,7 +79,8 @@ while time.time() < t_end:
         env.set_layout_pool(pool["grid"], pool["agents"]); roll.set_layout_pool(pool["grid"], pool["agents"])
         episode = np.zeros(B, dtype=np.int64)
     rr = roll.rollout(torch.from_numpy(acts).to(dev), auto_reset=ar)
-    ctx = f"case {n_case}: {spec} B={B} T={T} seed={seed} auto_reset={ar}"
+    ctx = f"case {n_case}: {spec} B={B} T={T} seed={seed} auto_reset={ar} fixed_shape={env.backend.launch_info(B).get('fixed_shape')}"
+    n_fixed = (n_fixed if n_case else 0) + (1 if env.backend.launch_info(B).get("fixed_shape") else 0)
     for t in range(T):
         if ar:
             done = (ref["agents"][:, :, 4].min(axis=1) > 0) | (ref["step_count"] >= spec.max_steps)
@@ -102,6 +112,7 @@ while time.time() < t_end:
     env.check_errors(); roll.check_errors()
     n_case += 1; n_steps += T * B
     del env, roll
+print(f"{n_case} cases, {n_steps} env-steps, {n_fixed} cases on a shape-specialised instantiation: clean")
 from multigrid_amd import _lib  # noqa: E402
 if hasattr(_lib.lib(), "mgx_debug_bounds_violations"):            # the checked build (MGX_LIBMGX=.../libmgx_chk.so)
     import ctypes
