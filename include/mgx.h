@@ -248,6 +248,32 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
 enum { MGX_GEN_EMPTY_FIXED = 0, MGX_GEN_EMPTY_RANDOM = 1, MGX_GEN_BLOCKEDUNLOCKPICKUP = 2, MGX_GEN_REDBLUEDOORS = 3,
        MGX_GEN_LOCKEDHALLWAY = 4, MGX_GEN_PLAYGROUND = 5 };
 
+/* Staged generation (ABI 7, optional; used by mgx_step_generate / mgx_step_ex only).  A launch lasts as long as its slowest
+ * wavefront, and the serial placement of one episode (~6500 cycles on one lane) in the tail of the step made the wavefront that
+ * holds a finished env exactly that -- every step, at thousands of envs.  Most episodes of a random-action rollout end by
+ * TRUNCATION, which is known in advance: two steps before an env's step_count reaches max_steps the step takes a snapshot of the
+ * env's PCG64 state (the reference's handle_actions draws exactly A numbers per step, multigrid/base.py:396-399, so the state at
+ * reset time is the snapshot advanced by A draws per remaining step), and in the NEXT launch a few extra wavefronts -- beside the
+ * step's own, not behind them -- generate that env's next episode from it into the staging slot below.  When the episode then
+ * ends by truncation its slot is adopted (a copy); an env that ends earlier (success / failure: its np_random is somewhere else)
+ * finds no slot for its episode and is generated in the tail as before.  Same results bit for bit either way: the slot's content is
+ * the same function of (gen_state, np_random at reset time) that the tail computes.  The slots are a cache, not state: any content
+ * with tag -1 is valid (all of it may be dropped at any time).  All pointers NULL = no staging.
+ *   grid    MgxCell[B,H,W]   agents u8[B,A,8]   aux u8[B,16] (may be NULL for MGX_KIND_EMPTY)
+ *   words   u64[B,12]   [0..5] gen_state after the staged generation, [6..9] rng (env.np_random) after it,
+ *                       [10..11] the snapshot: PCG64 state (lo, hi)
+ *   tag     i32[B,4]    [0] the episode whose successor the slot holds (-1: none), [1] snapshot: episode, [2] snapshot: step_count,
+ *                       [3] snapshot request: phase + 1 of the launch that took it, 0 = none / served
+ *   phase   the caller adds 1 for every step it issues (any wrap-around is fine; a constant phase only disables the staging) */
+typedef struct MgxGenStage {
+    MgxCell *grid;
+    uint8_t *agents;
+    uint8_t *aux;
+    uint64_t *words;
+    int32_t *tag;
+    int32_t phase;
+} MgxGenStage;
+
 typedef struct MgxLayoutGen {
     int32_t kind;
     int32_t room_size;                    /* MGX_GEN_BLOCKEDUNLOCKPICKUP, MGX_GEN_LOCKEDHALLWAY, MGX_GEN_PLAYGROUND */
@@ -256,6 +282,7 @@ typedef struct MgxLayoutGen {
     int32_t max_keys_per_room;            /* MGX_GEN_LOCKEDHALLWAY (locked_hallway.py:108) */
     const MgxCell *blank;
     uint64_t *gen_state;
+    MgxGenStage stage;                    /* ABI 7: staged generation of truncation resets (all NULL: off) */
 } MgxLayoutGen;
 
 int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,

@@ -39,11 +39,17 @@ class MgxAutoReset(C.Structure):
                 ("pool_agents", C.c_void_p), ("pool_aux", C.c_void_p), ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
 
 
+class MgxGenStage(C.Structure):
+    """include/mgx.h: struct MgxGenStage (staged generation of truncation resets)."""
+    _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("aux", C.c_void_p), ("words", C.c_void_p), ("tag", C.c_void_p),
+                ("phase", C.c_int32)]
+
+
 class MgxLayoutGen(C.Structure):
     """include/mgx.h: struct MgxLayoutGen."""
     _fields_ = [("kind", C.c_int32), ("room_size", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
                 ("start_dir", C.c_int32), ("max_hallway_keys", C.c_int32), ("max_keys_per_room", C.c_int32),
-                ("blank", C.c_void_p), ("gen_state", C.c_void_p)]
+                ("blank", C.c_void_p), ("gen_state", C.c_void_p), ("stage", MgxGenStage)]
 
 
 class MgxStepArgs(C.Structure):

@@ -336,6 +336,10 @@ class BatchedMultiGridEnv:
             c._gen = None
             if getattr(self, "_gen", None) is not None:
                 c._gen = dict(self._gen, gen_state=self._gen["gen_state"][lo:hi])
+                if self._gen.get("stage") is not None:          # (its own slice of the staging slots, its own step count)
+                    st = self._gen["stage"]
+                    c._gen["stage"] = {k: (v[lo:hi] if torch.is_tensor(v) else v) for k, v in st.items()}
+                    c._gen["stage"]["phase"] = [st["phase"][0]]
             if getattr(self, "episode", None) is not None:
                 c.episode, c.was_reset = self.episode[lo:hi], self.was_reset[lo:hi]
             c._range = (lo, hi)
@@ -480,7 +484,7 @@ class BatchedMultiGridEnv:
         self._layout_version += 1        #  ... and so do sub-shards and captured graphs made before: they now refuse to run)
 
     def set_layout_generator(self, kind: str, layout_seed: int = 0, *, room_size: int = 0, start=(1, 1, 0),
-                             max_hallway_keys: int = 1, max_keys_per_room: int = 2):
+                             max_hallway_keys: int = 1, max_keys_per_room: int = 2, staged: bool = True):
         """Episode starts generated ON THE DEVICE (mgx_reset_generate) instead of picked from a host-made pool: every
         finished env runs the reference's own `_gen_grid` (rejection-sampling placement with numpy-compatible draws) in a
         kernel, one lane per env.
@@ -493,6 +497,9 @@ class BatchedMultiGridEnv:
         `reset_done()` then regenerates every finished env; `step(auto_reset=True)` regenerates the envs whose episode ends
         with that step right after it -- in the tail of the step's own launch (mgx_step_generate), so the returned
         observation is the terminal one and the state tensors already hold the next episode's start.
+        staged       (default) truncation resets are generated two steps AHEAD by extra wavefronts beside the step's own and
+                     adopted when the episode ends (include/mgx.h: MgxGenStage) -- same results bit for bit, without the serial
+                     placement on the critical path of every step; False: always generate in the tail of the step
         """
         sp = self.spec
         if kind == "blockedunlockpickup":
@@ -525,6 +532,14 @@ class BatchedMultiGridEnv:
                      "max_hallway_keys": int(max_hallway_keys), "max_keys_per_room": int(max_keys_per_room),
                      "blank": torch.from_numpy(layouts.pack_cells(blank).view(np.int16)).to(self.device).contiguous(),
                      "gen_state": torch.from_numpy(rnglib.layout_gen_state(layout_seed, idx).view(np.int64)).to(self.device)}
+        if staged and sp.num_agents > 1:         # the staging slots: a cache, not state (tag -1 = empty)
+            B, dev = self.batch, self.device
+            tag = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+            tag[:, 0] = -1
+            self._gen["stage"] = {"grid": torch.zeros((B, sp.height, sp.width), dtype=torch.int16, device=dev),
+                                  "agents": torch.zeros((B, sp.num_agents, 8), dtype=torch.uint8, device=dev),
+                                  "aux": torch.zeros((B, 16), dtype=torch.uint8, device=dev) if sp.env_kind != "empty" else None,
+                                  "words": torch.zeros((B, 12), dtype=torch.int64, device=dev), "tag": tag, "phase": [0]}
         self._pool = None
         self.episode = torch.zeros((self.batch,), dtype=torch.int32, device=self.device)
         self.was_reset = torch.zeros((self.batch,), dtype=torch.uint8, device=self.device)

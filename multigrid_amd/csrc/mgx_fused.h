@@ -78,6 +78,8 @@ struct KernelArgs {
     int32_t *episode;
     uint8_t *was_reset;
     MgxLayoutGen gen;   // mgx_step_generate: finished envs are regenerated in the tail of the launch (template flag GEN)
+    int64_t gen_first_wg;   // GEN with staging (include/mgx.h: MgxGenStage): workgroups from this index on are GENERATOR wavefronts, one
+                            // lane per env, that serve the snapshot requests of earlier launches; INT64_MAX = none
     int32_t *bounds;    // -DMGX_BOUNDS_CHECK=1 builds: [0] += LDS accesses outside the wavefront's slice, [1] = last site id
     int32_t span_base;  // -DMGX_TIMESTAMPS=1 builds: first record of this launch in g_span (tools/span_probe.py, tools/chain_overlap.py)
 };
@@ -220,35 +222,37 @@ constexpr int kSlotsLatency = 32;        // DMA instantiations
 // Carve of ONE wavefront's LDS slice (byte offsets, all multiples of 16).  Everything is a closed form of
 // (vpw, nw, Gw, A, tile bytes, round bytes) so the kernel recomputes an offset where it needs it instead of carrying
 // fifteen of them in SGPRs from the kernel arguments.  Per-slot arrays first (vpw = slots in use, a multiple of 16).
+// (the members are always_inline: left to the inliner's budget the big GEN kernels called tile() / out() out of line, which put the
+// whole struct in scratch memory and every wavefront of the launch through its set-up)
 struct LdsCarve {
     int vpw, nw, Gw, A, tile_bytes, round_bytes;   // round_bytes: P4/P5 staging of one round (obs bytes, or one-hot cell masks)
     bool roll;      // mgx_rollout: tile and PCG64 state live across steps (no aliasing of the tile, rng kept in LDS)
     bool has_aux;   // env kinds with hook state
-    __host__ __device__ int rows() const { return 0; }                               // u64  [vpw]
+    __host__ __device__ __attribute__((always_inline)) int rows() const { return 0; }                               // u64  [vpw]
     // -- per-step temporaries, all dead once P2 has gathered the cells --
     // (the view records, written in P1d, lie over the draws and the rewards, both dead by then)
-    __host__ __device__ int rec() const { return 8 * vpw; }                          // ViewRec [vpw]  (P1d -> P2)
-    __host__ __device__ int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
-    __host__ __device__ int rew() const { return 16 * vpw; }                         // f64  [vpw]     (P0 -> hooks), same space
-    __host__ __device__ int woff() const { return 24 * vpw; }                        // i32  [vpw]     (P1s)
-    __host__ __device__ int temps_end() const { return woff() + 4 * vpw; }
+    __host__ __device__ __attribute__((always_inline)) int rec() const { return 8 * vpw; }                          // ViewRec [vpw]  (P1d -> P2)
+    __host__ __device__ __attribute__((always_inline)) int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
+    __host__ __device__ __attribute__((always_inline)) int rew() const { return 16 * vpw; }                         // f64  [vpw]     (P0 -> hooks), same space
+    __host__ __device__ __attribute__((always_inline)) int woff() const { return 24 * vpw; }                        // i32  [vpw]     (P1s)
+    __host__ __device__ __attribute__((always_inline)) int temps_end() const { return woff() + 4 * vpw; }
     // -- state that lives across phases / steps --
-    __host__ __device__ int act() const { return temps_end(); }                      // i8   [vpw]
-    __host__ __device__ int ord() const { return act() + vpw; }                      // u8   [vpw]
-    __host__ __device__ int rng() const { return ord() + vpw; }                      // u64  [Gw][4]   (rollout only)
-    __host__ __device__ int scnt() const { return rng() + (roll ? 32 * Gw : 0); }    // i32  [Gw]
-    __host__ __device__ int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
-    __host__ __device__ int own_jump() const { return aux() + (has_aux ? 16 * Gw : 0); }
-    __host__ __device__ int jump() const { return own_jump(); }                      // u64  [A][4]: k = 1..A   (rollout only: the
-    __host__ __device__ int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one-step kernels keep them in registers)
+    __host__ __device__ __attribute__((always_inline)) int act() const { return temps_end(); }                      // i8   [vpw]
+    __host__ __device__ __attribute__((always_inline)) int ord() const { return act() + vpw; }                      // u8   [vpw]
+    __host__ __device__ __attribute__((always_inline)) int rng() const { return ord() + vpw; }                      // u64  [Gw][4]   (rollout only)
+    __host__ __device__ __attribute__((always_inline)) int scnt() const { return rng() + (roll ? 32 * Gw : 0); }    // i32  [Gw]
+    __host__ __device__ __attribute__((always_inline)) int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
+    __host__ __device__ __attribute__((always_inline)) int own_jump() const { return aux() + (has_aux ? 16 * Gw : 0); }
+    __host__ __device__ __attribute__((always_inline)) int jump() const { return own_jump(); }                      // u64  [A][4]: k = 1..A   (rollout only: the
+    __host__ __device__ __attribute__((always_inline)) int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one-step kernels keep them in registers)
                                                                                      // wall: one WALL cell + the dword after it
     // P4/P5 staging of one round's obs bytes (skew + pad).  One-step kernels put it over the tile, which is dead once
     // P2 has gathered the cells; the rollout keeps the tile and uses the (equally dead) temporaries' space + its own.
-    __host__ __device__ int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
-    __host__ __device__ int own_out() const { return wall() + 16; }
-    __host__ __device__ int tile() const { return roll ? own_out() + out_bytes() : own_out(); }   // grid bytes, skew + over-read
-    __host__ __device__ int out() const { return roll ? own_out() : tile(); }
-    __host__ __device__ int total() const {
+    __host__ __device__ __attribute__((always_inline)) int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
+    __host__ __device__ __attribute__((always_inline)) int own_out() const { return wall() + 16; }
+    __host__ __device__ __attribute__((always_inline)) int tile() const { return roll ? own_out() + out_bytes() : own_out(); }   // grid bytes, skew + over-read
+    __host__ __device__ __attribute__((always_inline)) int out() const { return roll ? own_out() : tile(); }
+    __host__ __device__ __attribute__((always_inline)) int total() const {
         const int t = tile_bytes + 32 > out_bytes() || roll ? tile_bytes + 32 : out_bytes();
         return (tile() + t + 15) & ~15;
     }
@@ -256,7 +260,7 @@ struct LdsCarve {
 
 // one_hot: the round's staging holds one 32-bit one-hot mask per cell (+ a pad dword either side) instead of 3 obs bytes
 // `round`: slots staged per P4/P5 round (kRound, or the group size of a small-group latency instantiation)
-__host__ __device__ inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
+__host__ __device__ __attribute__((always_inline)) inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
                                                bool one_hot = false, int round = kRound) {
     return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * kCellBytes, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
                     roll, has_aux};
@@ -571,6 +575,10 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
             }
         }
     }
+    // GEN (round 3): the plain generated step at 7x7 views also has its latency instantiation (LDS-DMA tile, one cell per register)
+    if constexpr (GEN && !DMA && !STREAM && MODE == 1 && !OH && V == 7 && GRP == kGroup) {
+        if (ka.flags & 2) return launch_mode<V, MODE, OH, true, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    }
     if (ka.grp != GRP) return MGX_ERR_INVALID_ARGUMENT;       // (the host-side carve was made for another group size)
     void (*kern)(const KernelArgs) = nullptr;
     const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;        // (gen_obs never runs a hook)
@@ -596,6 +604,11 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
         if constexpr (MODE == 0 && V <= 7 && !GEN) {
             kern = mgx_obs_kernel<V, OH, STREAM, DMA>;
         } else if constexpr (GEN) {                                          // (generation replaces the pool pick-up)
+            if constexpr (DMA) {      // ... and, for BlockedUnlockPickup x 2 (C3 with its episodes generated on the device), its shape
+                const int shape = MGX_NO_FIXED_SHAPES ? 0 : match_fixed_shape(ka, hooks);
+                kern = shape == 3 ? mgx_fused_kernel<V, 1, true, false, false, true, false, true, kGroup, 3>
+                                  : (hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true, false, true> : mgx_fused_kernel<V, MODE, false, false, OH, true, false, true>);
+            } else
             kern = hooks ? mgx_fused_kernel<V, MODE, S, false, OH, true> : mgx_fused_kernel<V, MODE, false, false, OH, true>;
         } else {
             kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, OH, false, STREAM, DMA, GRP> : mgx_fused_kernel<V, MODE, S, false, OH, false, STREAM, DMA, GRP>)

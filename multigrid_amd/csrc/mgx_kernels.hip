@@ -333,9 +333,12 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
             // a rollout in one launch restarts its finished envs from the layout pool: auto_reset.)  Same results as T calls.
             if (occupancy) { MgxStepArgs one = sa; one.steps = 1; return step_common(spec, batch, one, stream, occupancy); }
             const int64_t BA = batch * spec->num_agents, V2 = (int64_t)spec->view_size * spec->view_size * (one_hot ? 21 : 3);
+            MgxLayoutGen gen_t = *gen;
             for (int32_t t = 0; t < sa.steps; ++t) {
                 MgxStepArgs one = sa;
                 one.steps = 1;
+                gen_t.stage.phase = gen->stage.phase + t;                       // (the staging protocol counts the steps)
+                one.generate = &gen_t;
                 one.actions = sa.actions + t * BA;
                 one.hook_order = sa.hook_order ? sa.hook_order + t * BA : nullptr;
                 one.obs = sa.obs + t * BA * V2;
@@ -357,6 +360,23 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
         rc = mgx_gen::check_layout_gen(spec, gen);
         if (rc) return rc;
         ka.gen = *gen; ka.episode = sa.episode; ka.was_reset = sa.was_reset;
+        ka.gen_first_wg = INT64_MAX;
+        // staged generation (include/mgx.h: MgxGenStage): generator wavefronts behind the step's own workgroups, one lane per env
+        MgxGenStage &st = ka.gen.stage;
+        const bool staged = st.grid && st.agents && st.words && st.tag && (st.aux || spec->env_kind == MGX_KIND_EMPTY)
+                            && spec->num_agents > 1 && ka.wave_lds >= 128 * spec->num_agents;
+        if (staged) {
+            if (misaligned(st.grid, 4) || misaligned(st.agents, 8) || misaligned(st.aux, 16) || misaligned(st.words, 8)
+                || misaligned(st.tag, 16))
+                return MGX_ERR_INVALID_ARGUMENT;
+            const int wpb = threads / 64;
+            const int64_t gen_waves = (batch + 63) / 64;
+            ka.gen_first_wg = nwg;
+            nwg += (gen_waves + wpb - 1) / wpb;
+            if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
+        } else {
+            st = MgxGenStage{};
+        }
         mode |= 8;
     }
     return launch(mode, ka, threads, lds, nwg, static_cast<hipStream_t>(stream), occupancy);
@@ -526,6 +546,12 @@ int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args,
         if (args->generate) {
             gen = *args->generate;
             gen.gen_state = gen.gen_state ? gen.gen_state + lo * 6 : nullptr;
+            MgxGenStage &st = gen.stage;
+            st.grid = st.grid ? st.grid + lo * HW : nullptr;
+            st.agents = st.agents ? st.agents + lo * A * MGX_AGENT_STRIDE : nullptr;
+            st.aux = st.aux ? st.aux + lo * MGX_AUX_BYTES : nullptr;
+            st.words = st.words ? st.words + lo * 12 : nullptr;
+            st.tag = st.tag ? st.tag + lo * 4 : nullptr;
             sa.generate = &gen;
         }
         const int rc = step_common(spec, n, sa, st);

@@ -165,9 +165,14 @@ class HipBackend:
     @staticmethod
     def _layout_gen_struct(gen):
         sx, sy, sd = gen.get("start", (0, 0, 0))
-        return _lib.MgxLayoutGen(_lib.GEN_KINDS[gen["kind"]], int(gen.get("room_size", 0)), int(sx), int(sy), int(sd),
-                                 int(gen.get("max_hallway_keys", 1)), int(gen.get("max_keys_per_room", 2)),
-                                 gen["blank"].data_ptr(), gen["gen_state"].data_ptr())
+        g = _lib.MgxLayoutGen(_lib.GEN_KINDS[gen["kind"]], int(gen.get("room_size", 0)), int(sx), int(sy), int(sd),
+                              int(gen.get("max_hallway_keys", 1)), int(gen.get("max_keys_per_room", 2)),
+                              gen["blank"].data_ptr(), gen["gen_state"].data_ptr())
+        st = gen.get("stage")
+        if st is not None:                      # staged generation of truncation resets (include/mgx.h: MgxGenStage)
+            g.stage = _lib.MgxGenStage(st["grid"].data_ptr(), st["agents"].data_ptr(), _ptr(st.get("aux")), st["words"].data_ptr(),
+                                       st["tag"].data_ptr(), int(st["phase"][0]))
+        return g
 
     def step_args(self, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
                   auto_reset=None, one_hot: bool = False, generate=None):
@@ -203,9 +208,15 @@ class HipBackend:
         dev, index = grid.device, grid.device.index
         device_ctx = torch.cuda.device
 
+        gen_c = keep[1]
+        phase = generate[0]["stage"]["phase"] if generate is not None and generate[0].get("stage") is not None else None
+
         def step(actions, hook_order=None):
             sa.actions = actions.data_ptr()
             sa.hook_order = hook_order.data_ptr() if hook_order is not None else None
+            if phase is not None:               # (the staging protocol counts the steps: one phase per step, whoever issues it)
+                gen_c.stage.phase = phase[0]
+                phase[0] = (phase[0] + 1) & 0x3fffffff
             if _cur_device() == index:
                 rc = fn(spec_ref, B, args_ref, _stream(dev))
             else:
@@ -227,9 +238,15 @@ class HipBackend:
         handles = (C.c_void_p * parts)(*[s.cuda_stream for s in streams])
         dev = grid.device
 
+        gen_c = keep[1]
+        phase = generate[0]["stage"]["phase"] if generate is not None and generate[0].get("stage") is not None else None
+
         def step(actions, fork_event, hook_order=None):
             sa.actions = actions.data_ptr()
             sa.hook_order = hook_order.data_ptr() if hook_order is not None else None
+            if phase is not None:
+                gen_c.stage.phase = phase[0]
+                phase[0] = (phase[0] + 1) & 0x3fffffff
             with torch.cuda.device(dev):
                 rc = fn(spec_ref, B, args_ref, parts, handles, fork_event)
             if rc:
@@ -261,6 +278,9 @@ class HipBackend:
         with torch.cuda.device(grid.device):
             rc = _lib.lib().mgx_step_ex(C.byref(self.sc), B, C.byref(sa), _stream(grid.device))
         _lib.check(rc, "mgx_rollout")
+        if generate is not None and generate[0].get("stage") is not None:      # (T launches: one phase each, mgx_kernels.hip)
+            ph = generate[0]["stage"]["phase"]
+            ph[0] = (ph[0] + T) & 0x3fffffff
 
     def one_hot(self, cells, out):
         _one_hot_into(cells, out)
