@@ -158,6 +158,17 @@ __device__ __forceinline__ T kernarg_at(size_t offset) {
 #define MGX_LATE(field) (a.field)
 #endif
 
+// A launch lasts as long as its slowest wavefront, and the slowest is the one that took a rare path (restart, events, sequential
+// fallback): from there on it asks for issue priority over the wavefronts it shares its SIMD with, which finish early anyway.
+#ifndef MGX_RARE_PRIO
+#define MGX_RARE_PRIO 1
+#endif
+#if MGX_RARE_PRIO
+#define MGX_RARE_PATH_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define MGX_RARE_PATH_PRIO() ((void)0)
+#endif
+
 // per-view record written by P1d and read (broadcast) by the wavefront in P2
 // origin: LDS address of the agent's own cell; steps / lo / hi: mgx_rules.h ViewClamp (packed i16 pairs, low half = forward)
 struct alignas(16) ViewRec { int32_t origin; uint32_t steps, lo, hi; };           // 16 bytes
