@@ -83,3 +83,35 @@ def test_launch_geometry_for_baseline_configs():
         li = _lib.launch_info(spec, batch)
         assert li["envs_per_wavefront"] >= 1
         assert li["workgroups"] * li["envs_per_workgroup"] >= batch
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """Every struct the Python binding declares (multigrid_amd/_lib.py) has the size and the field offsets the C compiler gives
+    include/mgx.h: an ABI drift between the two would otherwise only show as wrong results on the GPU."""
+    import shutil
+    import subprocess
+    import sys
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    structs = {"MgxSpec": _lib.MgxSpecC, "MgxLaunchInfo": _lib.MgxLaunchInfo, "MgxAutoReset": _lib.MgxAutoReset,
+               "MgxGenStage": _lib.MgxGenStage, "MgxLayoutGen": _lib.MgxLayoutGen, "MgxStepArgs": _lib.MgxStepArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mgx.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu", sizeof({name}));')
+        for f, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({name}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([cc, "-std=c11", f"-I{os.path.join(root, 'include')}", str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    assert len(out) == len(structs)
+    for line, (name, cls) in zip(out, structs.items()):
+        got = line.split()
+        assert got[0] == name
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(x) for x in got[1:]] == want, f"{name}: header {got[1:]} vs ctypes {want}"
