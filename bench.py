@@ -6,7 +6,8 @@
 One "step" = one `MultiGridEnv.step` over the whole per-GPU batch = one launch of the fused kernel (auto-reset fused in).
 Headline workload = BASELINE.json's north-star configuration C4: MultiGrid-Empty-16x16-v0, agents=4, view_size=7,
 batch=65536 envs -- all of it on one GPU at N=1 (it is ~100 MB).  For N>1 (launched by `python -m torch.distributed.run
---nproc-per-node N ...`, one rank per GPU) the SAME global batch is sharded over the ranks (strong scaling: 8192 envs per
+--nproc-per-node N ...`, one rank per GPU -- or plainly as `python bench.py --gpus N`, which then launches itself that way)
+the SAME global batch is sharded over the ranks (strong scaling: 8192 envs per
 GPU at N=8); the data path has NO collective -- envs never interact -- and torch.distributed
 (RCCL) is used only for the barrier and the max-over-ranks time.
 
@@ -421,6 +422,29 @@ def cpu_baseline(wl, threads, budget_s, sample_envs):
                       f"no auto-reset (as the reference)"}
 
 
+def self_launch(n_gpus: int) -> int:
+    """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`
+    (what the driver's multi-GPU form is) and hand its output through; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X (no HIP device visible); there is no CPU path to benchmark", file=sys.stderr)
+        return 1
+    have = torch.cuda.device_count()
+    if have < n_gpus and os.environ.get("MGX_BENCH_ONE_GPU") != "1":
+        print(f"--gpus {n_gpus}: only {have} HIP device(s) visible on this node (MGX_BENCH_ONE_GPU=1 runs every rank on "
+              f"device 0 to validate the plumbing; its numbers mean nothing)", file=sys.stderr)
+        return 1
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # (dmabuf IPC: what RCCL needs on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -442,13 +466,14 @@ def main():
     global AUTO_RESET
     AUTO_RESET = not args.no_auto_reset
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1) -- the
+        # same command line the driver's `python -m torch.distributed.run ... bench.py --gpus N` form runs; rank 0 prints the line
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} "
-                     f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to benchmark")
@@ -491,12 +516,14 @@ def main():
                       agree=lambda n: int(all_max(float(n))), sub_shards=P)
     env.check_errors()
     wall_max = all_max(m["wall_s"])
+    wall_min = -all_max(-m["wall_s"])
     S = m["timed_steps"]
     valid = _lib.is_product_lib()
     out = {
         "metric": "agent-steps/sec", "value": round(G * A * S / wall_max), "unit": "agent-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall_max * 1e3 / S, 6), "higher_is_better": True, "scaling": "strong",
+        "ms_per_step_ranks": {"min": round(wall_min * 1e3 / S, 6), "max": round(wall_max * 1e3 / S, 6)},
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "timed_steps": S, "timed_region_ms": round(wall_max * 1e3, 3),
         "config": {"workload": wl.title + ", uniform random actions 0..6", "name": name,

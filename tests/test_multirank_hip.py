@@ -68,3 +68,19 @@ def test_bench_under_eight_ranks_prints_the_8_gpu_line():
     assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 8192 and d["config"]["sub_shards"] == 1
     assert "roofline" in d and d["roofline"]["algorithmic_bytes"] == 8192 * 4 * 339 and "pipelined" not in d
     assert abs(d["value"] - 65536 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+
+
+def test_plain_bench_gpus_8_launches_itself():
+    """`python bench.py --gpus 8` WITHOUT a launcher (how the driver's 1-GPU BENCH command would read with N swapped in): bench.py
+    becomes the launcher (torch.distributed.run, 127.0.0.1) and rank 0 prints the same one line."""
+    env = dict(os.environ, MGX_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["batch_per_gpu"] == 8192 and d["scaling"] == "strong"
+    assert d["ms_per_step_ranks"]["min"] <= d["ms_per_step_ranks"]["max"] == d["ms_per_step"]
