@@ -78,7 +78,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 7
+#define MGX_ABI_VERSION 8
 
 enum {
     MGX_OK = 0,
@@ -374,6 +374,60 @@ int mgx_step_ex(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, voi
 int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t parts, void *const *streams,
                     void *fork_event);
 int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t *parts);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Persistent stepping (ABI 8): closed-loop stepping without a kernel boundary per step.  Replaces the loop a caller of the
+ * reference runs around multigrid/base.py:303-346 -- `obs = env.step(policy(obs))`, e.g. multigrid/rllib/__init__.py:59-63 -- for
+ * batches in the latency regime (a launch of the step is a lone wavefront's instruction chain per SIMD: BASELINE.json's
+ * Empty-16x16 x 4096 envs, the 8192-env share of an 8-GPU node, BlockedUnlockPickup x 16384), where the dependent-launch
+ * boundary (~1.5 us) and the reload of the env state (~0.6 us) are a third of a step.
+ *
+ * mgx_step_persistent enqueues ONE launch of the rollout kernel (mgx_rollout: every wavefront keeps its envs' grid tile, agent
+ * rows, PCG64 state and step counts in LDS) that stays resident for up to `max_steps` steps and, per step t = 1, 2, ...:
+ *   (1) waits until the actions of step t are there.  They are handed over as GRANULES, one aligned 8-byte word per 4 agents of
+ *       an env -- action_granules u64[B, ceil(A/4)], granule q of env b: bits [31:0] = the action bytes of agents 4q..4q+3
+ *       (i8, little-endian, -1 = absent, bytes of agents >= A ignored), bits [63:32] = the tag t.  The producer writes each
+ *       granule with ONE agent-scope 8-byte store (mgx_persistent_post does that from an ordinary i8[B,A] action tensor): the
+ *       data is the flag, a wavefront re-reads only its own granules, no fence on either side;
+ *   (2) applies the step exactly as mgx_step does (same results bit for bit, tests/test_persistent.py);
+ *   (3) writes obs / dir / reward / terminated / truncated (/ was_reset) of step t THROUGH to memory -- the same buffers every
+ *       step -- and then sets done[w] = t for its wavefront w.  The outputs of step t are complete once done[w] >= t for every
+ *       w < waves (mgx_persistent_waves); a kernel launched after that has been observed (mgx_persistent_wait) reads them.
+ * The producer may write the granules of step t+1 only after it has seen the outputs of step t complete (one action buffer,
+ * one set of output buffers: the hand-shake is the double buffer).  The env state tensors of `args` (grid, agents, rng,
+ * step_count, aux) are NOT current while the launch runs; they are written back when it ends: after `max_steps` steps, or after
+ * the step during which ctrl[0] became non-zero (stop request), or when a wavefront has waited `timeout_ms` for its granules
+ * (ctrl[1] counts those: the producer went away).  Every wait in these kernels is bounded by `timeout_ms`.
+ *   ctrl u32[8], zeroed by the caller except [3] = UINT32_MAX: [0] in: stop request; [1] out: wavefronts (or waiters) that timed
+ *        out; [2] out: wavefronts that have left; [3] out: min over them of the steps they completed
+ *   done u32[waves], zeroed by the caller
+ * Options of `args`: auto_reset (layout pool) yes; one_hot, generate, hook_order no (MGX_ERR_UNSUPPORTED); steps is ignored.
+ * Every wavefront of the launch must be resident at once: MGX_ERR_UNSUPPORTED when (spec, batch) needs more workgroups than the
+ * device holds (use mgx_step for such batches: they are throughput-bound, not boundary-bound).  The launch must run on a stream
+ * of its own: whatever produces the granules runs beside it. */
+#define MGX_PERSIST_CTRL_WORDS 8
+typedef struct MgxPersistent {
+    const uint64_t *action_granules;  /* u64[B, ceil(A/4)], written by the producer */
+    uint32_t *done;                   /* u32[waves] */
+    uint32_t *ctrl;                   /* u32[MGX_PERSIST_CTRL_WORDS] */
+    int32_t max_steps;                /* >= 1 */
+    int32_t timeout_ms;               /* 1 .. 30000 */
+} MgxPersistent;
+
+int mgx_persistent_waves(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t *waves);
+int mgx_step_persistent(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, const MgxPersistent *p, void *stream);
+/* actions i8[B,A] (as mgx_step takes them) -> the granules of step `step` (counted from 1); stream-ordered behind whatever
+ * produced `actions` on `stream`. */
+int mgx_persistent_post(const MgxSpec *spec, int64_t batch, const int8_t *actions, uint32_t step, uint64_t *action_granules,
+                        void *stream);
+/* Returns (in stream order) once done[w] >= step for every w < waves, or after timeout_ms (then ctrl[1] += 1). */
+int mgx_persistent_wait(const uint32_t *done, int32_t waves, uint32_t step, uint32_t *ctrl, int32_t timeout_ms, void *stream);
+/* A stand-in policy for benchmarks and tests: ONE resident workgroup (256 threads) that plays a recorded action sequence actions i8[T,B,A]
+ * through the closed-loop hand-shake -- for t = 1..T: wait for step t-1's outputs to be complete, post the granules of step t --
+ * i.e. the shortest producer there can be.  trace (u64[2T + 1], may be NULL): s_memrealtime ticks (100 MHz): [2(t-1)] = step t's
+ * predecessor seen complete, [2(t-1) + 1] = step t's granules posted, [2T] = step T seen complete. */
+int mgx_persistent_feed(const MgxSpec *spec, int64_t batch, const int8_t *actions, int32_t steps, const MgxPersistent *p,
+                        int32_t waves, uint64_t *trace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
@@ -25,7 +25,8 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
            "mgx_launch_info", "mgx_one_hot", "mgx_full_obs", "mgx_reset_done", "mgx_rollout", "mgx_step_autoreset",
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
            "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid",
-           "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards")
+           "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards",
+           "mgx_persistent_waves", "mgx_step_persistent", "mgx_persistent_post", "mgx_persistent_wait", "mgx_persistent_feed")
 
 
 class MgxLaunchInfo(C.Structure):
@@ -62,6 +63,14 @@ class MgxStepArgs(C.Structure):
                 ("auto_reset", C.POINTER(MgxAutoReset)), ("generate", C.POINTER(MgxLayoutGen)),
                 ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
 
+
+class MgxPersistent(C.Structure):
+    """include/mgx.h: struct MgxPersistent (persistent stepping)."""
+    _fields_ = [("action_granules", C.c_void_p), ("done", C.c_void_p), ("ctrl", C.c_void_p), ("max_steps", C.c_int32),
+                ("timeout_ms", C.c_int32)]
+
+
+PERSIST_CTRL_WORDS = 8
 
 GEN_KINDS = {"empty_fixed": 0, "empty_random": 1, "blockedunlockpickup": 2, "redbluedoors": 3, "lockedhallway": 4, "playground": 5}
 
@@ -125,6 +134,16 @@ def lib() -> C.CDLL:
     L.mgx_step_chains.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxStepArgs), C.c_int32, C.POINTER(vp), vp]
     L.mgx_sub_shards.restype = C.c_int
     L.mgx_sub_shards.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxStepArgs), C.POINTER(C.c_int32)]
+    L.mgx_persistent_waves.restype = C.c_int
+    L.mgx_persistent_waves.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxStepArgs), C.POINTER(C.c_int32)]
+    L.mgx_step_persistent.restype = C.c_int
+    L.mgx_step_persistent.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxStepArgs), C.POINTER(MgxPersistent), vp]
+    L.mgx_persistent_post.restype = C.c_int
+    L.mgx_persistent_post.argtypes = [C.POINTER(MgxSpecC), i64, vp, C.c_uint32, vp, vp]
+    L.mgx_persistent_wait.restype = C.c_int
+    L.mgx_persistent_wait.argtypes = [vp, C.c_int32, C.c_uint32, vp, C.c_int32, vp]
+    L.mgx_persistent_feed.restype = C.c_int
+    L.mgx_persistent_feed.argtypes = [C.POINTER(MgxSpecC), i64, vp, C.c_int32, C.POINTER(MgxPersistent), C.c_int32, vp, vp]
     if L.mgx_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {L.mgx_abi_version()} != {ABI_VERSION}; rebuild it")
     _lib = L

@@ -37,6 +37,127 @@ class StepGraph:
         self.graph.replay()
 
 
+class PersistentSession:
+    """Closed-loop stepping without a kernel boundary per step (include/mgx.h: mgx_step_persistent): ONE launch of the step kernel
+    stays resident on a stream of its own, keeps the env state in LDS, takes each step's actions as tagged granules and publishes
+    a per-wavefront flag behind the step's outputs.  For batches in the latency regime (C2, C4's 8-GPU share, C3), where the launch
+    boundary and the state reload are a third of a step.  Made by `BatchedMultiGridEnv.persistent()`; use as a context manager.
+
+        with env.persistent(max_steps=T) as ps:
+            obs, dirs, *_ = env.gen_obs(), ...
+            for t in range(T):
+                obs, dirs, reward, terminated, truncated = ps.step(policy(obs))      # == env.step(...) bit for bit
+
+    `ps.step(a)` = `ps.post(a)` (the actions, stream-ordered behind the policy that produced them) + `ps.wait()` (work enqueued on
+    the current stream afterwards sees the step's outputs in the env's output buffers).  The env's own `step()` / `rollout()` /
+    state tensors are unavailable until the session is closed (the state lives in the launch)."""
+
+    def __init__(self, env, max_steps: int, auto_reset: bool, timeout_ms: int):
+        be = env.backend
+        if not hasattr(be, "persistent_launch"):
+            raise RuntimeError("persistent stepping needs the HIP backend")
+        if auto_reset and getattr(env, "_gen", None) is not None:
+            raise RuntimeError("persistent stepping restarts finished envs from a layout pool (set_layout_pool), not from the "
+                               "device generator")
+        self.env, self.max_steps, self.timeout_ms = env, int(max_steps), int(timeout_ms)
+        self.auto_reset = bool(auto_reset)
+        B, A, dev = env.batch, env.spec.num_agents, env.device
+        self.waves = be.persistent_waves(B, self.auto_reset)
+        self.granules = torch.zeros((B, (A + 3) // 4), dtype=torch.int64, device=dev)
+        self.done = torch.zeros((self.waves,), dtype=torch.int32, device=dev)
+        self.ctrl = torch.tensor([0, 0, 0, -1] + [0] * 4, dtype=torch.int32, device=dev)
+        # a stream of its own, HIGH priority: the launch runs BESIDE whatever produces its actions (HIP multiplexes the streams of
+        # one priority over a few hardware queues; the priorities have queues of their own, so no producer stream ever shares
+        # one with the launch), and its few wavefronts are served first wherever they share a SIMD with the producer's
+        self.stream = torch.cuda.Stream(dev, priority=-1)
+        self.t = 0                       # steps posted
+        self.waited = 0                  # steps waited for
+        self.open = False
+        ar = env._auto_reset_args(self.auto_reset, getattr(env, "was_reset", None))
+        self._sa, self._keep = be.step_args(env.cells, env.agents, env.rng, env.step_count,
+                                            env.aux if env.spec.env_kind != "empty" else None, env.err, env.obs, env.dir,
+                                            env.reward, env.terminated, env.truncated, auto_reset=ar)
+        self._pers = be.persistent_struct(self.granules, self.done, self.ctrl, self.max_steps, self.timeout_ms)
+
+    def __enter__(self):
+        env = self.env
+        env._need_state()
+        env.join()
+        if env._session is not None:
+            raise RuntimeError("this env already has a persistent session open")
+        cur = torch.cuda.current_stream(env.device)
+        self.stream.wait_stream(cur)                       # (the state and the zeroed hand-shake words are in place)
+        env.backend.persistent_launch(env.batch, self._sa, self._pers, self.stream.cuda_stream)
+        env._session = self
+        self.open = True
+        return self
+
+    def post(self, actions: torch.Tensor):
+        """Hand over the actions of the next step (i8[B,A] on the env's device), stream-ordered on the current stream."""
+        env = self.env
+        if not self.open or self.t >= self.max_steps:
+            raise RuntimeError("the persistent session is closed or has used up its max_steps")
+        if actions.dtype is not torch.int8 or actions.shape != env._act_shape or actions.device != env.cells.device \
+                or not actions.is_contiguous():
+            raise ValueError(f"actions must be a contiguous int8 tensor of shape {tuple(env._act_shape)} on {env.cells.device}")
+        self.t += 1
+        env.backend.persistent_post(env.batch, actions, self.t, self.granules)
+
+    def wait(self):
+        """Work enqueued on the current stream after this call sees the outputs of the last posted step."""
+        self.env.backend.persistent_wait(self.done, self.waves, self.t, self.ctrl, self.timeout_ms)
+        self.waited = self.t
+        env = self.env
+        return env.obs, env.dir, env.reward, env.terminated, env.truncated
+
+    def step(self, actions: torch.Tensor):
+        self.post(actions)
+        return self.wait()
+
+    def feed(self, actions: torch.Tensor, trace: bool = False):
+        """A recorded action sequence i8[T,B,A] played through the closed-loop hand-shake by ONE resident workgroup
+        (mgx_persistent_feed: the shortest producer there can be; benchmarks and tests).  Returns the trace tensor
+        (i64[2T + 1], s_memrealtime ticks of 10 ns) or None.  The session's remaining steps must cover T."""
+        env = self.env
+        T = int(actions.shape[0])
+        if self.t != 0 or T != self.max_steps:
+            raise RuntimeError("feed() plays a whole session: max_steps == len(actions), nothing posted before")
+        if actions.dtype is not torch.int8 or tuple(actions.shape[1:]) != tuple(env._act_shape) or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous int8 tensor [T,B,A]")
+        tr = torch.zeros((2 * T + 1,), dtype=torch.int64, device=env.device) if trace else None
+        env.backend.persistent_feed(env.batch, actions, T, self._pers, self.waves, tr, torch.cuda.current_stream(env.device).cuda_stream)
+        self.t = self.waited = T
+        return tr
+
+    def close(self):
+        """End the launch (a stop request unless it has run all of its steps), join its stream: the env's state tensors hold
+        the state after the last completed step.  Raises if a wait inside the launch timed out."""
+        if not self.open:
+            return
+        env = self.env
+        cur = torch.cuda.current_stream(env.device)
+        if self.t < self.max_steps:
+            if self.waited < self.t:
+                self.wait()
+            self.ctrl[0:1].fill_(1)                         # stop request, stream-ordered behind the last wait
+        cur.wait_stream(self.stream)
+        self.open = False
+        env._session = None
+        c = [int(v) & 0xFFFFFFFF for v in self.ctrl.cpu()]
+        self.timeouts, self.waves_left, self.steps_completed = c[1], c[2], c[3]
+        if c[1]:
+            raise RuntimeError(f"persistent stepping: {c[1]} wait(s) timed out after {self.timeout_ms} ms "
+                               f"(steps completed by every wavefront: {c[3]})")
+
+    def __exit__(self, *exc):
+        try:
+            self.close()
+        except RuntimeError:
+            if exc[0] is None:
+                raise
+        return False
+
+
 class BatchedMultiGridEnv:
     def __init__(self, spec: EnvSpec, batch: int, device="cuda", *, first_env: int = 0, backend=None):
         """
@@ -75,6 +196,7 @@ class BatchedMultiGridEnv:
         self._parent = None              # captured graphs made before hold pointers into the old ones and refuse to run
         self._chain_streams = []         # side streams of the eager sub-shard form (step(..., sub_shards=P))
         self._chains_pending = False
+        self._session = None             # an open PersistentSession: the state lives in its launch
 
     @property
     def grid(self) -> torch.Tensor:
@@ -195,7 +317,7 @@ class BatchedMultiGridEnv:
         An unknown action value does not raise here (no device sync on the hot path); it is recorded in
         `err` and surfaced as ValueError by `check_errors()` (multigrid/base.py:473-474).
         """
-        if not self._loaded:
+        if not self._loaded or self._session is not None:
             self._need_state()
         if self._parent is not None:
             self._check_fresh()
@@ -330,7 +452,7 @@ class BatchedMultiGridEnv:
             c.err = self.err                                                  # (shared: the kernels update it atomically)
             c._loaded, c._act_shape, c._bound = True, torch.Size((hi - lo, self.spec.num_agents)), {}
             c._parent, c._made_version, c._layout_version = self, self._layout_version, 0
-            c._chain_streams, c._chains_pending = [], False
+            c._chain_streams, c._chains_pending, c._session = [], False, None
             c._one_hot = self._one_hot[lo:hi] if getattr(self, "_one_hot", None) is not None else None
             c._pool = getattr(self, "_pool", None)
             c._gen = None
@@ -580,6 +702,14 @@ class BatchedMultiGridEnv:
     def _need_state(self):
         if not self._loaded:
             raise RuntimeError("no state loaded: call load_state() / reset() first")
+        if self._session is not None:
+            raise RuntimeError("a persistent session is open: the env state lives in its launch until it is closed")
+
+    def persistent(self, max_steps: int, auto_reset: bool = False, timeout_ms: int = 2000) -> "PersistentSession":
+        """A `PersistentSession` over this env: closed-loop stepping with ONE resident launch instead of one launch per step
+        (include/mgx.h: mgx_step_persistent).  Same results as `step()` bit for bit.  `max_steps` bounds the launch; every wait
+        inside it gives up after `timeout_ms`."""
+        return PersistentSession(self, max_steps, auto_reset, timeout_ms)
 
     # ------------------------------------------------------------------------------------------ checkpoint
     def state_dict(self) -> dict:

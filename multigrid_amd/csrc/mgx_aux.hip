@@ -21,6 +21,7 @@ using namespace mgx;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int bytes) {
@@ -289,6 +290,131 @@ __global__ __launch_bounds__(256) void reset_done_kernel(int HWB, int A, int max
             reinterpret_cast<uint4 *>(aux)[e0 + l_env[j]] = reinterpret_cast<const uint4 *>(pool_aux)[l_lay[j]];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent stepping, the producer's side (include/mgx.h: MgxPersistent; the consumer is MODE 3 of the fused kernel).
+// A granule = {tag << 32 | 4 action bytes}, written by ONE relaxed agent-scope 8-byte store (write-through): the data is the
+// flag (guide: publish/consume recipe R2).  Every poll is a relaxed agent-scope load; every spin is bounded.
+// ---------------------------------------------------------------------------------------------------------------
+// the 4 action bytes of granule q of an env (agents 4q .. 4q+3; agents beyond A: "absent")
+__device__ __forceinline__ uint32_t granule_bytes(const int8_t *act_env, int A, int q) {
+    if ((A & 3) == 0) return *reinterpret_cast<const uint32_t *>(act_env + 4 * q);       // (the tensor is 4-byte aligned: host check)
+    uint32_t bytes = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ai = 4 * q + j;
+        bytes |= (ai < A ? (uint32_t)(uint8_t)act_env[ai] : 0xffu) << (8 * j);
+    }
+    return bytes;
+}
+__device__ __forceinline__ uint64_t make_granule(const int8_t *act_env, int A, int q, uint32_t tag) {
+    return ((uint64_t)tag << 32) | granule_bytes(act_env, A, q);
+}
+
+__global__ __launch_bounds__(256) void persistent_post_kernel(const int8_t *__restrict__ actions, int64_t n_granules, int A, int gpe,
+                                                              uint32_t inv_gpe, uint32_t tag, uint64_t *granules) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_granules) return;
+    const int64_t b = gpe == 1 ? g : (int64_t)(((uint64_t)g * inv_gpe) >> 32);     // g / gpe (n_granules < 2^31: checked by the host)
+    const int q = (int)(g - b * gpe);
+    __hip_atomic_store(granules + g, make_granule(actions + b * A, A, q, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// all of done[0 .. waves) >= step?  One workgroup; returns false on timeout (uniform over the workgroup).  Every wavefront polls
+// its own share of the flags on its own (relaxed agent loads, one ballot per pass: no workgroup barrier inside the loop -- it
+// would add its ~0.2 us to every pass, i.e. to the latency of the hand-off); ONE barrier when all have seen theirs.
+__device__ __forceinline__ bool wait_all_done(const uint32_t *done, int waves, uint32_t step, uint32_t timeout_ticks) {
+    __shared__ uint32_t s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t spin = 1;; ++spin) {
+        bool ok = true;
+        for (int w = threadIdx.x; w < waves; w += blockDim.x)
+            ok &= __hip_atomic_load(done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= step;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        if ((spin & 31u) == 0) {
+            const bool late = __builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)timeout_ticks;
+            if (late || __hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    const bool good = __hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+    __syncthreads();                                  // (s_fail is reset by the next call)
+    return good;
+}
+
+__global__ __launch_bounds__(256) void persistent_wait_kernel(const uint32_t *done, int waves, uint32_t step, uint32_t *ctrl,
+                                                              uint32_t timeout_ticks) {
+    if (!wait_all_done(done, waves, step, timeout_ticks) && threadIdx.x == 0) atomicAdd(ctrl + 1, 1u);
+}
+
+// The recorded sequence's next step is known while the current one runs: its action bytes are fetched into registers behind the
+// post (FAST = A is a multiple of 4: granule g's four bytes are the g-th dword of the step's action tensor; kFeedPre granules per
+// thread, i.e. batches up to 8192 granules; whatever does not fit -- and every other A -- is fetched at post time).
+// ONE workgroup of 256 threads = one wavefront per SIMD of one CU: it must fit BESIDE the persistent launch's wavefronts wherever
+// they are (a 1024-thread workgroup needs four wavefronts per SIMD at once: next to two 140-VGPR wavefronts per SIMD there is
+// no CU on the chip that can take it -- measured: the hand-shake then runs into its timeout).
+constexpr int kFeedPre = 32, kFeedThreads = 256;
+// GB: action bytes a granule takes from the tensor when they are contiguous and aligned -- 4 (A a multiple of 4), 2 (A = 2),
+// 1 (A = 1): granule g's bytes are then the g-th GB-byte word of the step's action tensor; 0 = any other A
+template <int GB>
+__global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int8_t *__restrict__ actions, int T, int64_t batch, int A, int gpe,
+                                                                       uint32_t inv_gpe, uint64_t *granules, const uint32_t *done, int waves,
+                                                                       uint32_t *ctrl, uint32_t timeout_ticks, uint64_t *trace) {
+    const int64_t ng = batch * gpe, BA = batch * A;
+    constexpr bool FAST = GB != 0;
+    const int npre = FAST ? (int)(ng < (int64_t)kFeedThreads * kFeedPre ? ng : (int64_t)kFeedThreads * kFeedPre) : 0;   // granules via registers
+    const __amdgpu_buffer_rsrc_t grs = make_rsrc(granules, npre * 8);
+    uint32_t pre[kFeedPre];
+    auto fetch = [&](int t) {
+        if constexpr (FAST) {
+            const __amdgpu_buffer_rsrc_t ars = make_rsrc(actions + (int64_t)t * BA, npre * GB);
+#pragma unroll
+            for (int k = 0; k < kFeedPre; ++k) {            // (agents beyond A: "absent" = 0xff)
+                if constexpr (GB == 4) pre[k] = __builtin_amdgcn_raw_buffer_load_b32(ars, threadIdx.x * 4, kFeedThreads * 4 * k, 0);
+                else if constexpr (GB == 2) pre[k] = 0xffff0000u | (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(ars, threadIdx.x * 2, kFeedThreads * 2 * k, 0);
+                else pre[k] = 0xffffff00u | (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(ars, threadIdx.x, kFeedThreads * k, 0);
+            }
+        }
+    };
+    fetch(0);
+    for (int t = 0; t < T; ++t) {
+        // the outputs of step t (counted from 1) complete?  (nothing to wait for before the first post)
+        if (t > 0 && !wait_all_done(done, waves, (uint32_t)t, timeout_ticks)) {
+            if (threadIdx.x == 0) { atomicAdd(ctrl + 1, 1u); __hip_atomic_store(ctrl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            return;
+        }
+        if (trace && threadIdx.x == 0) trace[2 * t] = __builtin_amdgcn_s_memrealtime();
+        const uint32_t tag = (uint32_t)t + 1u;
+        if constexpr (FAST) {
+            // one aligned 8-byte write-through store per granule (sc1, aux 16); lanes past the buffer's end are dropped
+#pragma unroll
+            for (int k = 0; k < kFeedPre; ++k) {
+                const u32x2 v = {pre[k], tag};
+                __builtin_amdgcn_raw_buffer_store_b64(v, grs, threadIdx.x * 8, kFeedThreads * 8 * k, 16);
+            }
+        }
+        const int8_t *act_t = actions + (int64_t)t * BA;
+        for (int64_t g = threadIdx.x + npre; g < ng; g += kFeedThreads) {
+            const int64_t b = gpe == 1 ? g : (int64_t)(((uint64_t)g * inv_gpe) >> 32);
+            __hip_atomic_store(granules + g, make_granule(act_t + b * A, A, (int)(g - b * gpe), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (trace) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) trace[2 * t + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+        if (t + 1 < T) fetch(t + 1);
+    }
+    // (the last step's outputs: so that "the feed kernel has ended" means "the rollout is complete")
+    if (!wait_all_done(done, waves, (uint32_t)T, timeout_ticks) && threadIdx.x == 0) atomicAdd(ctrl + 1, 1u);
+    if (trace && threadIdx.x == 0) trace[2 * T] = __builtin_amdgcn_s_memrealtime();
+}
+
 int finish_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mgx_internal_set_hip_error((int)e); return MGX_ERR_LAUNCH; }
@@ -300,6 +426,51 @@ inline bool misaligned(const void *p, uintptr_t a) { return (reinterpret_cast<ui
 }  // namespace
 
 extern "C" {
+
+static int granule_geometry(const MgxSpec *spec, int64_t batch, int &gpe, uint32_t &inv_gpe, int64_t &ng) {
+    if (!spec || batch < 1 || spec->num_agents < 1 || spec->num_agents > MGX_MAX_AGENTS) return MGX_ERR_INVALID_ARGUMENT;
+    gpe = (spec->num_agents + 3) / 4;
+    ng = batch * gpe;
+    if (ng >= ((int64_t)1 << 31)) return MGX_ERR_UNSUPPORTED;
+    inv_gpe = (uint32_t)((((uint64_t)1 << 32) + gpe - 1) / gpe);           // ceil(2^32 / gpe): g / gpe exact for g < 2^31, gpe <= 8
+    return MGX_OK;
+}
+
+int mgx_persistent_post(const MgxSpec *spec, int64_t batch, const int8_t *actions, uint32_t step, uint64_t *action_granules,
+                        void *stream) {
+    int gpe = 0; uint32_t inv = 0; int64_t ng = 0;
+    const int rc = granule_geometry(spec, batch, gpe, inv, ng);
+    if (rc) return rc;
+    if (!actions || !action_granules || step == 0 || misaligned(action_granules, 8)) return MGX_ERR_INVALID_ARGUMENT;
+    if ((spec->num_agents & 3) == 0 && misaligned(actions, 4)) return MGX_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(persistent_post_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       actions, ng, spec->num_agents, gpe, inv, step, action_granules);
+    return finish_launch();
+}
+
+int mgx_persistent_wait(const uint32_t *done, int32_t waves, uint32_t step, uint32_t *ctrl, int32_t timeout_ms, void *stream) {
+    if (!done || !ctrl || waves < 1 || timeout_ms < 1 || timeout_ms > 30000) return MGX_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(persistent_wait_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), done, (int)waves, step, ctrl,
+                       (uint32_t)timeout_ms * 100000u);
+    return finish_launch();
+}
+
+int mgx_persistent_feed(const MgxSpec *spec, int64_t batch, const int8_t *actions, int32_t steps, const MgxPersistent *p,
+                        int32_t waves, uint64_t *trace, void *stream) {
+    int gpe = 0; uint32_t inv = 0; int64_t ng = 0;
+    const int rc = granule_geometry(spec, batch, gpe, inv, ng);
+    if (rc) return rc;
+    if (!actions || !p || !p->action_granules || !p->done || !p->ctrl || steps < 1 || waves < 1 || p->timeout_ms < 1
+        || p->timeout_ms > 30000 || misaligned(trace, 8) || ((spec->num_agents & 3) == 0 && misaligned(actions, 4)))
+        return MGX_ERR_INVALID_ARGUMENT;
+    const int A_ = spec->num_agents;
+    auto kern = (A_ & 3) == 0 ? persistent_feed_kernel<4> : A_ == 2 ? persistent_feed_kernel<2> : A_ == 1 ? persistent_feed_kernel<1>
+                                                                                                   : persistent_feed_kernel<0>;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kFeedThreads), 0, static_cast<hipStream_t>(stream), actions, (int)steps, batch,
+                       spec->num_agents, gpe, inv, const_cast<uint64_t *>(p->action_granules), p->done, (int)waves, p->ctrl,
+                       (uint32_t)p->timeout_ms * 100000u, trace);
+    return finish_launch();
+}
 
 int mgx_one_hot(const uint8_t *cells, int64_t n_cells, const int32_t *dim_sizes, uint8_t *out, void *stream) {
     if (n_cells < 0 || !dim_sizes) return MGX_ERR_INVALID_ARGUMENT;

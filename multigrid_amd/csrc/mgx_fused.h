@@ -80,6 +80,12 @@ struct KernelArgs {
     MgxLayoutGen gen;   // mgx_step_generate: finished envs are regenerated in the tail of the launch (template flag GEN)
     int64_t gen_first_wg;   // GEN with staging (include/mgx.h: MgxGenStage): workgroups from this index on are GENERATOR wavefronts, one
                             // lane per env, that serve the snapshot requests of earlier launches; INT64_MAX = none
+    // persistent stepping (MODE 3, include/mgx.h: MgxPersistent): the launch stays resident for up to T steps, takes each step's
+    // actions as tagged 8-byte granules and publishes a per-wavefront flag once the step's outputs are in memory
+    const uint64_t *granules;   // u64[B, ceil(A/4)]
+    uint32_t *done;             // u32[wavefronts]
+    uint32_t *pctrl;            // u32[MGX_PERSIST_CTRL_WORDS]
+    uint32_t timeout_ticks;     // s_memrealtime ticks (100 MHz) a wavefront waits for its granules before it gives up
     int32_t *bounds;    // -DMGX_BOUNDS_CHECK=1 builds: [0] += LDS accesses outside the wavefront's slice, [1] = last site id
     int32_t span_base;  // -DMGX_TIMESTAMPS=1 builds: first record of this launch in g_span (tools/span_probe.py, tools/chain_overlap.py)
 };
@@ -559,14 +565,17 @@ constexpr bool has_small_groups(int V, int MODE, bool OH, bool GEN) {
 
 // Which entry of kShapes, if any, the launch geometry the host derived for the plain step of the latency family matches exactly
 // (0 = none: the generic kernel).  Also what mgx_launch_info reports.
-inline int match_fixed_shape(const KernelArgs &ka, bool hooks) {
+// `persist`: the persistent step kernel (MODE 3: the rollout's carve, no DMA / STREAM families) has instantiations for the latency
+// shapes too -- it exists for exactly those launches
+inline int match_fixed_shape(const KernelArgs &ka, bool hooks, bool persist = false) {
     if (MGX_NO_FIXED_SHAPES || ka.grp != kGroup) return 0;
     for (int k = 1; k < kNumShapes; ++k) {
         const FixedShape &f = kShapes[k];
-        if (ka.sp.view_size == f.V && ((ka.flags & 2) != 0) == f.dma && ((ka.flags & 1) != 0) == f.stream
+        if (persist ? !f.dma : (((ka.flags & 2) != 0) != f.dma || ((ka.flags & 1) != 0) != f.stream)) continue;
+        if (ka.sp.view_size == f.V
             && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw && hooks == f.hooks
             && ka.vpw == shape_slots(f)
-            && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), false, f.hooks, false, kGroup).total())
+            && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), persist, f.hooks, false, kGroup).total())
             return k;
     }
     return 0;
@@ -574,7 +583,7 @@ inline int match_fixed_shape(const KernelArgs &ka, bool hooks) {
 
 template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false, int GRP = kGroup>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
-    if constexpr (!STREAM && !DMA && MODE != 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
+    if constexpr (!STREAM && !DMA && MODE < 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
         if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
         if constexpr (!OH) {
             if (ka.flags & 2) {
@@ -609,6 +618,15 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
         }
         if constexpr (V == 9 && !DMA && STREAM) {
             if (shape == 4) kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, true, false, kGroup, 4> : mgx_fused_kernel<V, 1, false, false, false, false, true, false, kGroup, 4>;
+        }
+    }
+    if constexpr (MODE == 3 && !OH && !GEN && V == 7 && !MGX_NO_FIXED_SHAPES) {
+        // the persistent step kernel at the latency shapes (C2 / C4's 8-GPU and 4-GPU shares, C3)
+        switch (match_fixed_shape(ka, hooks, true)) {
+        case 1: kern = ar ? mgx_fused_kernel<V, 3, false, true, false, false, false, false, kGroup, 1> : mgx_fused_kernel<V, 3, false, false, false, false, false, false, kGroup, 1>; break;
+        case 2: kern = ar ? mgx_fused_kernel<V, 3, false, true, false, false, false, false, kGroup, 2> : mgx_fused_kernel<V, 3, false, false, false, false, false, false, kGroup, 2>; break;
+        case 3: kern = ar ? mgx_fused_kernel<V, 3, true, true, false, false, false, false, kGroup, 3> : mgx_fused_kernel<V, 3, true, false, false, false, false, false, kGroup, 3>; break;
+        default: break;
         }
     }
     if (!kern) {
@@ -650,6 +668,7 @@ inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_byte
     case 0: return launch_mode<V, 0, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+    case 3: return launch_mode<V, 3, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);     // persistent stepping
     case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 6: return launch_mode<V, 2, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);

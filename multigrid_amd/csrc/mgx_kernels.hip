@@ -560,6 +560,86 @@ int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args,
     return MGX_OK;
 }
 
+// ---- persistent stepping (include/mgx.h: MgxPersistent) --------------------------------------------------------------
+// Geometry + residency of the persistent launch: the rollout kernel's carve, every wavefront resident at once.
+static int persistent_geometry(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, KernelArgs &ka, int &threads, int &lds,
+                               int64_t &nwg) {
+    int rc = check_spec(spec, batch, true, false);
+    if (rc) return rc;
+    if (batch < 1) return MGX_ERR_INVALID_ARGUMENT;
+    if (args && (args->one_hot || args->generate || args->hook_order)) return MGX_ERR_UNSUPPORTED;
+    const MgxAutoReset *ar = args ? args->auto_reset : nullptr;
+    if (ar) ka.pool_grid = reinterpret_cast<const uint8_t *>(ar->pool_grid ? ar->pool_grid : reinterpret_cast<const MgxCell *>(spec));
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, true, false, false, false);
+    if (rc) return rc;
+    ka.T = 1;
+    int occ = 0;
+    rc = launch(3, ka, threads, lds, nwg, nullptr, &occ);              // workgroups of THIS instantiation one CU holds
+    if (rc) return rc;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGX_ERR_LAUNCH;
+    // (the occupancy API is optimistic for kernels with many SGPRs -- guide: "Residency and cooperative launch" -- and a
+    // workgroup that is admitted but not resident would hang the hand-shake until its timeout: at most 4 per CU are counted)
+    const int64_t resident = (int64_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1) * std::min(occ, 4);
+    if (nwg > resident) return MGX_ERR_UNSUPPORTED;
+    return MGX_OK;
+}
+
+int mgx_persistent_waves(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t *waves) {
+    if (!waves) return MGX_ERR_INVALID_ARGUMENT;
+    KernelArgs ka{};
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    const int rc = persistent_geometry(spec, batch, args, ka, threads, lds, nwg);
+    if (rc) return rc;
+    *waves = (int32_t)((batch + ka.Gw - 1) / ka.Gw);        // (the wavefronts that own envs: the ones that publish a flag)
+    return MGX_OK;
+}
+
+int mgx_step_persistent(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, const MgxPersistent *p, void *stream) {
+    if (!args || !p) return MGX_ERR_INVALID_ARGUMENT;
+    const MgxStepArgs &sa = *args;
+    KernelArgs ka{};
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    int rc = persistent_geometry(spec, batch, args, ka, threads, lds, nwg);
+    if (rc) return rc;
+    if (!sa.grid || !sa.agents || !sa.step_count || !sa.obs || !sa.reward || !sa.terminated || !sa.truncated)
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->num_agents > 1 && !sa.rng) return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->env_kind != MGX_KIND_EMPTY && !sa.aux) return MGX_ERR_INVALID_ARGUMENT;
+    if (misaligned(sa.grid, 16) || misaligned(sa.agents, 8) || misaligned(sa.obs, 16) || misaligned(sa.rng, 8)
+        || misaligned(sa.reward, 8) || misaligned(sa.step_count, 4) || misaligned(sa.err, 4) || misaligned(sa.aux, 16))
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (!p->action_granules || !p->done || !p->ctrl || p->max_steps < 1 || p->timeout_ms < 1 || p->timeout_ms > 30000
+        || misaligned(p->action_granules, 8) || misaligned(p->done, 4) || misaligned(p->ctrl, 4))
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (const MgxAutoReset *ar = sa.auto_reset) {
+        if (ar->pool_size < 1 || ar->first_env < 0 || !ar->pool_grid || !ar->pool_agents || !ar->episode) return MGX_ERR_INVALID_ARGUMENT;
+        if (spec->env_kind != MGX_KIND_EMPTY && !ar->pool_aux) return MGX_ERR_INVALID_ARGUMENT;
+        if (misaligned(ar->pool_agents, 8) || misaligned(ar->pool_aux, 16) || misaligned(ar->episode, 4)) return MGX_ERR_INVALID_ARGUMENT;
+        ka.pool_size = ar->pool_size; ka.first_env = ar->first_env;
+        ka.pool_magic = ar->pool_size > 1 ? ~0ull / (uint64_t)ar->pool_size + 1ull : 0ull;
+        ka.pool_grid = reinterpret_cast<const uint8_t *>(ar->pool_grid);
+        ka.pool_agents = ar->pool_agents; ka.pool_aux = ar->pool_aux; ka.episode = ar->episode; ka.was_reset = ar->was_reset;
+    }
+    ka.grid = reinterpret_cast<uint8_t *>(sa.grid); ka.agents = sa.agents; ka.rng = sa.rng; ka.step_count = sa.step_count;
+    ka.aux = sa.aux; ka.obs = sa.obs; ka.dir = sa.dir; ka.reward = sa.reward; ka.terminated = sa.terminated;
+    ka.truncated = sa.truncated; ka.err = sa.err;
+    ka.T = p->max_steps;
+    ka.granules = p->action_granules; ka.done = p->done; ka.pctrl = p->ctrl;
+    ka.timeout_ticks = (uint32_t)p->timeout_ms * 100000u;              // s_memrealtime: 100 MHz
+#if MGX_SPANS
+    {   // (spans build: one record per (step, wavefront) of this launch instead of one per wavefront)
+        const long long nrec = (long long)nwg * (threads / 64) * std::min<long long>(p->max_steps, 4096);
+        const int base = g_span_next;
+        rc = launch(3, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+        g_span_next = (int)std::min<long long>((long long)kSpanCap, base + nrec);
+        return rc;
+    }
+#endif
+    return launch(3, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
+}
+
 void mgx_internal_set_hip_error(int e) { g_last_hip_error = e; }   // (not in include/mgx.h: mgx_layout_gen.hip / mgx_aux.hip report
                                                                     // their failed launches through mgx_last_hip_error() too)
 

@@ -282,6 +282,55 @@ class HipBackend:
             ph = generate[0]["stage"]["phase"]
             ph[0] = (ph[0] + T) & 0x3fffffff
 
+    # ------------------------------------------------------------------------------------------ persistent stepping
+    def persistent_waves(self, B, auto_reset: bool = False) -> int:
+        """mgx_persistent_waves: wavefronts of the persistent launch for B envs (raises MgxError(UNSUPPORTED) when they cannot
+        all be resident at once)."""
+        sa = _lib.MgxStepArgs()
+        sa.steps = 1
+        ar = _lib.MgxAutoReset()
+        if auto_reset:
+            sa.auto_reset = C.pointer(ar)
+        out = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mgx_persistent_waves(C.byref(self.sc), B, C.byref(sa), C.byref(out))
+        _lib.check(rc, "mgx_persistent_waves")
+        return int(out.value)
+
+    def persistent_struct(self, granules, done, ctrl, max_steps: int, timeout_ms: int):
+        return _lib.MgxPersistent(granules.data_ptr(), done.data_ptr(), ctrl.data_ptr(), int(max_steps), int(timeout_ms))
+
+    def persistent_launch(self, B, sa, pers, stream_handle: int):
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mgx_step_persistent(C.byref(self.sc), B, C.byref(sa), C.byref(pers), stream_handle)
+        _lib.check(rc, "mgx_step_persistent")
+
+    def persistent_post(self, B, actions, step: int, granules):
+        dev = granules.device
+        if _cur_device() == dev.index:
+            rc = _lib.lib().mgx_persistent_post(C.byref(self.sc), B, actions.data_ptr(), step, granules.data_ptr(), _stream(dev))
+        else:
+            with torch.cuda.device(dev):
+                rc = _lib.lib().mgx_persistent_post(C.byref(self.sc), B, actions.data_ptr(), step, granules.data_ptr(), _stream(dev))
+        if rc:
+            _lib.check(rc, "mgx_persistent_post")
+
+    def persistent_wait(self, done, waves: int, step: int, ctrl, timeout_ms: int):
+        dev = done.device
+        if _cur_device() == dev.index:
+            rc = _lib.lib().mgx_persistent_wait(done.data_ptr(), waves, step, ctrl.data_ptr(), timeout_ms, _stream(dev))
+        else:
+            with torch.cuda.device(dev):
+                rc = _lib.lib().mgx_persistent_wait(done.data_ptr(), waves, step, ctrl.data_ptr(), timeout_ms, _stream(dev))
+        if rc:
+            _lib.check(rc, "mgx_persistent_wait")
+
+    def persistent_feed(self, B, actions, steps: int, pers, waves: int, trace, stream_handle: int):
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mgx_persistent_feed(C.byref(self.sc), B, actions.data_ptr(), steps, C.byref(pers), waves,
+                                                trace.data_ptr() if trace is not None else None, stream_handle)
+        _lib.check(rc, "mgx_persistent_feed")
+
     def one_hot(self, cells, out):
         _one_hot_into(cells, out)
 

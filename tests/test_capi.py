@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     L = _lib.lib()
     for n in names:
         assert getattr(L, n) is not None
-    assert L.mgx_abi_version() == _lib.ABI_VERSION == 7
+    assert L.mgx_abi_version() == _lib.ABI_VERSION == 8
     assert _lib.error_string(0) == "ok" and "action" in _lib.error_string(-2)
 
 
@@ -95,7 +95,8 @@ def test_ctypes_structs_match_the_header(tmp_path):
     if cc is None:
         pytest.skip("no C compiler")
     structs = {"MgxSpec": _lib.MgxSpecC, "MgxLaunchInfo": _lib.MgxLaunchInfo, "MgxAutoReset": _lib.MgxAutoReset,
-               "MgxGenStage": _lib.MgxGenStage, "MgxLayoutGen": _lib.MgxLayoutGen, "MgxStepArgs": _lib.MgxStepArgs}
+               "MgxGenStage": _lib.MgxGenStage, "MgxLayoutGen": _lib.MgxLayoutGen, "MgxStepArgs": _lib.MgxStepArgs,
+               "MgxPersistent": _lib.MgxPersistent}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mgx.h"', 'int main(void) {']
     for name, cls in structs.items():
         lines.append(f'  printf("{name} %zu", sizeof({name}));')
