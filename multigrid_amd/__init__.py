@@ -20,3 +20,7 @@ __all__ += ["Agent", "MultiGridEnv", "CONFIGURATIONS", "BlockedUnlockPickupEnv",
 from .wrappers import FullyObsWrapper, ImgObsWrapper, OneHotObsWrapper, SingleAgentWrapper  # noqa: F401,E402
 
 __all__ += ["FullyObsWrapper", "ImgObsWrapper", "OneHotObsWrapper", "SingleAgentWrapper"]
+from .world import Ball, Box, Door, Floor, Goal, Grid, Key, Lava, Wall, WorldObj  # noqa: F401,E402
+from .mission import MissionSpace  # noqa: F401,E402
+
+__all__ += ["Ball", "Box", "Door", "Floor", "Goal", "Grid", "Key", "Lava", "Wall", "WorldObj", "MissionSpace"]

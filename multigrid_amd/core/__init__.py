@@ -1,0 +1,15 @@
+"""`multigrid.core` of the reference, by name (multigrid/core/__init__.py): the classes a user-defined env is written against.
+
+    from multigrid_amd.base import MultiGridEnv
+    from multigrid_amd.core import Grid, Goal, Door, Key, Color, Direction
+
+(`import multigrid_amd as multigrid` + the reference's import lines is the drop-in; the submodules `core.grid`, `core.world_object`,
+`core.constants`, `core.actions`, `core.agent`, `core.mission` exist under the reference's names too.)
+"""
+from ..constants import DIR_TO_VEC, Action, Color, Direction, State, Type  # noqa: F401
+from ..env import Agent, AgentStateRow as AgentState  # noqa: F401
+from ..mission import Mission, MissionSpace  # noqa: F401
+from ..world import Ball, Box, Door, Floor, Goal, Grid, Key, Lava, Wall, WorldObj  # noqa: F401
+
+__all__ = ["Action", "Agent", "AgentState", "Color", "Direction", "State", "Type", "DIR_TO_VEC", "Grid", "Mission", "MissionSpace",
+           "Ball", "Box", "Door", "Floor", "Goal", "Key", "Lava", "Wall", "WorldObj"]

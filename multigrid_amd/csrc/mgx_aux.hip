@@ -327,10 +327,17 @@ __device__ __forceinline__ bool wait_all_done(const uint32_t *done, int waves, u
     if (threadIdx.x == 0) s_fail = 0;
     __syncthreads();
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc(done, waves * 4);
+    const int stride = (int)blockDim.x;
     for (uint32_t spin = 1;; ++spin) {
         bool ok = true;
-        for (int w = threadIdx.x; w < waves; w += blockDim.x)
-            ok &= __hip_atomic_load(done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= step;
+        for (int w0 = 0; w0 < waves; w0 += 8 * stride) {                  // 8 independent loads per thread in flight (sc1: aux 16)
+            uint32_t f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = __builtin_amdgcn_raw_buffer_load_b32(drs, (int)threadIdx.x * 4, (w0 + k * stride) * 4, 16);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ok &= (w0 + k * stride + (int)threadIdx.x >= waves) | (f[k] >= step);
+        }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         if ((spin & 31u) == 0) {
             const bool late = __builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)timeout_ticks;
@@ -399,7 +406,26 @@ __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int
             }
         }
         const int8_t *act_t = actions + (int64_t)t * BA;
-        for (int64_t g = threadIdx.x + npre; g < ng; g += kFeedThreads) {
+        int64_t gdone = npre;
+        if constexpr (FAST) {                 // batches beyond one register chunk: fetched now, 32 loads in flight per thread
+            for (; gdone < ng; gdone += kFeedThreads * kFeedPre) {
+                const int n = (int)(ng - gdone < (int64_t)kFeedThreads * kFeedPre ? ng - gdone : (int64_t)kFeedThreads * kFeedPre);
+                const __amdgpu_buffer_rsrc_t ars = make_rsrc(act_t + gdone * GB, n * GB), grs2 = make_rsrc(granules + gdone, n * 8);
+                uint32_t w[kFeedPre];
+#pragma unroll
+                for (int k = 0; k < kFeedPre; ++k) {
+                    if constexpr (GB == 4) w[k] = __builtin_amdgcn_raw_buffer_load_b32(ars, threadIdx.x * 4, kFeedThreads * 4 * k, 0);
+                    else if constexpr (GB == 2) w[k] = 0xffff0000u | (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(ars, threadIdx.x * 2, kFeedThreads * 2 * k, 0);
+                    else w[k] = 0xffffff00u | (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(ars, threadIdx.x, kFeedThreads * k, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < kFeedPre; ++k) {
+                    const u32x2 v = {w[k], tag};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, grs2, threadIdx.x * 8, kFeedThreads * 8 * k, 16);
+                }
+            }
+        }
+        for (int64_t g = threadIdx.x + gdone; g < ng; g += kFeedThreads) {
             const int64_t b = gpe == 1 ? g : (int64_t)(((uint64_t)g * inv_gpe) >> 32);
             __hip_atomic_store(granules + g, make_granule(act_t + b * A, A, (int)(g - b * gpe), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -7,8 +7,13 @@ constructor keywords (base.py:85-103), `reset` (250-301), `step` (303-346), `gen
 `step` launches the fused HIP kernel and copies the results back, so this class is for drop-in use and
 parity checks, not for throughput (use `BatchedMultiGridEnv` for that).
 
+User-defined envs (round 4): a subclass that overrides the reference's extension point `_gen_grid(width, height)`
+(base.py:229-247) -- `self.grid = Grid(width, height)`, `self.grid.wall_rect(...)`, `self.put_obj(Goal(), x, y)`,
+`self.place_obj(...)`, `self.place_agent(agent)`, `agent.state.pos = ...` -- runs unchanged: `reset()` executes it on the host
+against `multigrid_amd.world.Grid` / `WorldObj` value classes, checks the result and uploads it (see `MultiGridEnv.reset`).
+
 Out of scope: `render()` and everything pygame, `place_obj`-style editing of a live
-grid, user-defined object types.
+grid (outside `_gen_grid`), user-defined object types.
 """
 from __future__ import annotations
 
@@ -18,12 +23,60 @@ from typing import Any
 import numpy as np
 import torch
 
-from . import layouts, rng as rnglib
+from . import layouts, rng as rnglib, world
 from .batched import BatchedMultiGridEnv
-from .constants import NO_ACTION, Action, Color, Direction, Type
+from .constants import EMPTY_CELL, NO_ACTION, Action, Color, Direction, Type
 from .mission import Mission, MissionSpace
 from .spaces import Box, Dict, Discrete
 from .spec import EnvSpec
+
+
+class AgentStateRow(np.ndarray):
+    """One agent's `(9,)` int row `[type, color, dir, x, y, terminated, carry_type, carry_color, carry_state]` with the attribute
+    names of the reference's `AgentState` (multigrid/core/agent.py:222-346).  While `_gen_grid` runs it is a live view of the
+    episode's initial agent rows (`agent.state.pos = (1, 1)` places the agent, empty.py:164-167); at any other time it is a
+    snapshot of the device-resident row."""
+
+    @property
+    def color(self) -> Color:
+        return Color(int(self[1]))
+
+    @color.setter
+    def color(self, value):
+        self[1] = world._index(Color, value, "color")
+
+    @property
+    def dir(self) -> int:
+        return int(self[2])
+
+    @dir.setter
+    def dir(self, value):
+        self[2] = int(value)
+
+    @property
+    def pos(self) -> tuple[int, int]:
+        return (int(self[3]), int(self[4]))
+
+    @pos.setter
+    def pos(self, value):
+        self[3:5] = (int(value[0]), int(value[1]))
+
+    @property
+    def terminated(self) -> bool:
+        return bool(self[5])
+
+    @terminated.setter
+    def terminated(self, value):
+        self[5] = int(bool(value))
+
+    @property
+    def carrying(self):
+        """The carried object (a `WorldObj`) or None (agent.py:326-346)."""
+        return world.WorldObj.from_array(np.asarray(self[6:9]))
+
+    @carrying.setter
+    def carrying(self, obj):
+        self[6:9] = EMPTY_CELL if obj is None else tuple(obj.encode())
 
 
 class Agent:
@@ -51,11 +104,15 @@ class Agent:
         self.action_space = Discrete(len(Action))                        # agent.py:97
 
     @property
-    def state(self) -> np.ndarray:
-        """(9,) int row: [type, color, dir, x, y, terminated, carry_type, carry_color, carry_state]."""
+    def state(self) -> AgentStateRow:
+        """(9,) int row: [type, color, dir, x, y, terminated, carry_type, carry_color, carry_state] (`AgentStateRow`: also
+        `.pos`, `.dir`, `.color`, `.terminated`, `.carrying` as in multigrid/core/agent.py:222-346)."""
         if self._env is None:                                    # not in an env yet: a fresh AgentState row (agent.py:234-254)
-            return layouts._fresh_agents(self.index + 1)[self.index]
-        return self._env.agent_states[self.index]
+            return layouts._fresh_agents(self.index + 1)[self.index].view(AgentStateRow)
+        gen = self._env._gen_agents
+        if gen is not None:                                      # inside _gen_grid: the episode's initial rows, live
+            return gen[self.index].view(AgentStateRow)
+        return self._env.agent_states[self.index].view(AgentStateRow)
 
     @property
     def color(self) -> Color:
@@ -76,7 +133,8 @@ class Agent:
 
     @property
     def carrying(self):
-        """The carried cell as a (type, color, state) tuple, or None (agent.py:326-346)."""
+        """The carried cell as a (type, color, state) tuple, or None (agent.py:326-346; `agent.state.carrying` gives the
+        `WorldObj`)."""
         c = tuple(int(v) for v in self.state[6:9])
         return None if c[0] == Type.empty else c
 
@@ -122,7 +180,9 @@ class GridView:
 
 
 class MultiGridEnv:
-    """Base class; subclasses supply `_gen_layout` (the reference's `_gen_grid`)."""
+    """Base class.  A subclass supplies the episode start either the reference's way -- `_gen_grid(width, height)`
+    (multigrid/base.py:229-247; see the module docstring) -- or as `_gen_layout` (ready-made product tensors: what the
+    built-in env classes do)."""
 
     metadata = {"render_modes": [], "render_fps": 20}
     env_kind = "empty"
@@ -151,6 +211,7 @@ class MultiGridEnv:
         entropy)."""
         if render_mode is not None:
             raise NotImplementedError("rendering is out of scope for multigrid_amd (SURVEY.md section 2)")
+        self._gen_agents: np.ndarray | None = None        # (A,9) initial agent rows while a user's _gen_grid runs
         given_agents = None
         if not isinstance(agents, int):                                       # base.py:170-177: an iterable of Agent objects
             try:
@@ -241,8 +302,116 @@ class MultiGridEnv:
         return layouts.unpack_agents(self._benv.agents[0].cpu().numpy())
 
     def _gen_layout(self, layout_rng: np.random.Generator, np_random: np.random.Generator):
-        """Return (grid u8[H,W,3], agents u8[A,8], aux u8[16] | None) for a new episode."""
+        """Return (grid u8[H,W,3], agents u8[A,8], aux u8[16] | None) for a new episode.  The default runs the subclass'
+        `_gen_grid` (the reference's extension point) on the host and converts what it built."""
+        if type(self)._gen_grid is MultiGridEnv._gen_grid:
+            raise NotImplementedError(f"{type(self).__name__} defines neither _gen_grid(width, height) nor _gen_layout()")
+        if self.env_kind != "empty":
+            raise NotImplementedError("a user-defined _gen_grid is supported for hook-free envs (env_kind 'empty'): the built-in "
+                                      "hook envs carry per-episode hook state that their own generators fill in")
+        live_grid = self.grid
+        self._gen_agents = layouts._fresh_agents(self.num_agents)             # base.py:275-277: AgentState(num_agents) + reset
+        try:
+            self._gen_grid(self.width, self.height)                           # base.py:280
+            host = self.grid
+            if not isinstance(host, world.Grid):
+                raise TypeError("_gen_grid must set self.grid = Grid(width, height) (multigrid/base.py:229-247)")
+            if (host.width, host.height) != (self.width, self.height):
+                raise ValueError(f"_gen_grid built a {host.width}x{host.height} grid for a {self.width}x{self.height} env")
+            ag9 = self._gen_agents
+            # base.py:283-284
+            assert np.all(ag9[:, 3:5] >= 0)
+            assert np.all(ag9[:, 2] >= 0)
+            grid = layouts.grid_to_product(host.state)
+            layouts.check_walled(grid)                                        # the kernels' precondition (include/mgx.h)
+            return grid, layouts.pack_agents(ag9), None
+        finally:
+            self._gen_agents = None
+            self.grid = live_grid                                             # `env.grid` shows the device-resident state again
+
+    # ------------------------------------------------------------------------------------ the reference's extension point
+    def _gen_grid(self, width: int, height: int):
+        """multigrid/base.py:229-247: generate the grid for a new episode -- set `self.grid` and populate it with `WorldObj`s,
+        set the position and direction of every agent.  Override it in a subclass exactly as with the reference."""
         raise NotImplementedError
+
+    def put_obj(self, obj, i: int, j: int):
+        """multigrid/base.py:659-665"""
+        self.grid.set(i, j, obj)
+        obj.init_pos = (i, j)
+        obj.cur_pos = (i, j)
+
+    def place_obj(self, obj, top=None, size=None, reject_fn=None, max_tries=float("inf")):
+        """multigrid/base.py:604-657: rejection sampling of an empty cell in the rectangle (top, size); the draws come from the
+        construction-time generator (`_rand_int`), as in the reference."""
+        if self._gen_agents is None:
+            raise RuntimeError("place_obj edits the episode being generated: it is available inside _gen_grid only")
+        top = (0, 0) if top is None else (max(top[0], 0), max(top[1], 0))
+        if size is None:
+            size = (self.grid.width, self.grid.height)
+        num_tries = 0
+        while True:
+            if num_tries > max_tries:
+                raise RecursionError("rejection sampling failed in place_obj")
+            num_tries += 1
+            pos = (self._rand_int(top[0], min(top[0] + size[0], self.grid.width)),
+                   self._rand_int(top[1], min(top[1] + size[1], self.grid.height)))
+            if self.grid.get(*pos) is not None:                               # not on top of another object
+                continue
+            if ((self._gen_agents[:, 3] == pos[0]) & (self._gen_agents[:, 4] == pos[1])).any():     # not where agents are
+                continue
+            if reject_fn and reject_fn(self, pos):
+                continue
+            break
+        self.grid.set(pos[0], pos[1], obj)
+        if obj is not None:
+            obj.init_pos = pos
+            obj.cur_pos = pos
+        return pos
+
+    def place_agent(self, agent, top=None, size=None, rand_dir=True, max_tries=float("inf")):
+        """multigrid/base.py:667-686"""
+        agent.state.pos = (-1, -1)
+        pos = self.place_obj(None, top, size, max_tries=max_tries)
+        agent.state.pos = pos
+        if rand_dir:
+            agent.state.dir = self._rand_int(0, 4)
+        return pos
+
+    # multigrid/utils/random.py:9-103 (RandomMixin over the construction-time generator)
+    def _rand_int(self, low: int, high: int) -> int:
+        return self._layout_rng.integers(low, high)
+
+    def _rand_float(self, low: float, high: float) -> float:
+        return self._layout_rng.uniform(low, high)
+
+    def _rand_bool(self) -> bool:
+        return self._layout_rng.integers(0, 2) == 0
+
+    def _rand_elem(self, iterable):
+        lst = list(iterable)
+        return lst[self._rand_int(0, len(lst))]
+
+    def _rand_subset(self, iterable, num_elems: int) -> list:
+        lst = list(iterable)
+        assert num_elems <= len(lst)
+        out = []
+        while len(out) < num_elems:
+            elem = self._rand_elem(lst)
+            lst.remove(elem)
+            out.append(elem)
+        return out
+
+    def _rand_perm(self, iterable) -> list:
+        lst = list(iterable)
+        self._layout_rng.shuffle(lst)
+        return lst
+
+    def _rand_color(self) -> Color:
+        return self._rand_elem(Color)
+
+    def _rand_pos(self, x_low: int, x_high: int, y_low: int, y_high: int) -> tuple[int, int]:
+        return (self._layout_rng.integers(x_low, x_high), self._layout_rng.integers(y_low, y_high))
 
     def reset(self, seed: int | None = None, **kwargs):
         """multigrid/base.py:250-301.  Returns (observations, infos)."""

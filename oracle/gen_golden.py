@@ -283,6 +283,7 @@ def main():
     record_wrappers()
     record_hook_envs()
     record_dict_order()
+    record_custom()          # (last: every make_env() before it keeps the construction seed it always had)
 
 
 def face(env, i, target_xy, carrying=None):
@@ -490,6 +491,49 @@ def record_layouts():
         np.savez_compressed(path, **rec)
         print(f"{fname:34s} resets={len(reset_seeds)} missions={sorted(set(missions))[:2]} "
               f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def record_custom():
+    """User-defined envs written against the reference's extension point, `_gen_grid` + `put_obj` / `place_obj` / `place_agent` /
+    `Grid.wall_rect / horz_wall / vert_wall` / the WorldObj classes (multigrid/base.py:229-247, 604-697; core/grid.py:78-195;
+    core/world_object.py:279-616).  The class bodies are this repo's own (tests/custom_envs.py) and run here over the REAL
+    reference; the same bodies run over multigrid_amd in tests/test_custom_envs.py.  Same layout as the reset fixtures above,
+    plus the five steps after every reset with their outputs."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import custom_envs
+    classes = custom_envs.define(custom_envs.multigrid_namespace())
+    for fname, (cname, kw) in custom_envs.CASES.items():
+        cls = classes[cname]
+        _MAKE_COUNT[0] += 1
+        cls._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
+        env = cls(**kw)
+        construct_seed = cls._default_seed
+        A = env.num_agents
+        reset_seeds = [3, -1, 44, -1, -1, 2024]
+        ar = np.random.default_rng(7)
+        rec = dict(construct_seed=np.array(construct_seed), reset_seeds=np.array(reset_seeds),
+                   spec_json=np.array(json.dumps(spec_of_noreset(env, "empty"))))
+        grids, agents, rngs, obs0s, acts_all, obs_s, rew_s, term_s = [], [], [], [], [], [], [], []
+        for k, sd in enumerate(reset_seeds):
+            obs, _ = env.reset(seed=None if sd < 0 else sd)
+            grids.append(env.grid.state.copy()); agents.append(np.asarray(env.agent_states).copy())
+            rngs.append(rng_words(env.np_random))
+            obs0s.append(np.stack([obs[i]["image"] for i in range(A)]))
+            acts = ar.choice([0, 1, 2, 2, 2, 3, 4, 5, 6], size=(5, A)).astype(np.int8)
+            acts_all.append(acts)
+            o_k, r_k, t_k = [], [], []
+            for t in range(5):
+                o, r, tm, tr, _ = env.step({i: int(acts[t, i]) for i in range(A)})
+                o_k.append(np.stack([o[i]["image"] for i in range(A)]))
+                r_k.append([float(r[i]) for i in range(A)]); t_k.append([bool(tm[i]) for i in range(A)])
+            obs_s.append(o_k); rew_s.append(r_k); term_s.append(t_k)
+        rec.update(grid0=narrow(np.asarray(grids)), agents0=narrow(np.asarray(agents)), rng0=np.asarray(rngs),
+                   obs0=narrow(np.asarray(obs0s)), actions=np.asarray(acts_all), obs_steps=narrow(np.asarray(obs_s)),
+                   reward_steps=np.asarray(rew_s, dtype=np.float64), terminated_steps=narrow(np.asarray(term_s)))
+        path = os.path.join(OUT, fname + ".npz")
+        np.savez_compressed(path, **rec)
+        ntypes = sorted(set(int(v) for v in np.asarray(grids)[..., 0].ravel()))
+        print(f"{fname:34s} resets={len(reset_seeds)} cell types seen={ntypes} {os.path.getsize(path) / 1024:.1f} KiB")
 
 
 def spec_of_noreset(env, kind):

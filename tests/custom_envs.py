@@ -1,0 +1,100 @@
+"""User-defined environments written against the reference's extension point, `MultiGridEnv._gen_grid(width, height)`
+(multigrid/base.py:229-247).  The SAME class bodies run on both implementations:
+
+    define(multigrid_namespace())        -> classes over ini/multigrid         (oracle/gen_golden.py, build container only)
+    define(multigrid_amd_namespace())    -> classes over multigrid_amd         (tests/, CPU oracle backend and GPU)
+
+and tests/golden/custom_*.npz holds what the reference produced (reset sequences: grid, agent states, np_random, first
+observations).  The env definitions are this repo's own; nothing here comes from the reference's sources -- they only USE its
+public API (`Grid.wall_rect / horz_wall / vert_wall / set / get`, `put_obj`, `place_obj`, `place_agent`, `_rand_*`, the `WorldObj`
+classes, `agent.state.pos / dir`).
+"""
+from types import SimpleNamespace
+
+
+def multigrid_amd_namespace():
+    import multigrid_amd as m
+    from multigrid_amd import core
+    return SimpleNamespace(MultiGridEnv=m.MultiGridEnv, Grid=core.Grid, Goal=core.Goal, Wall=core.Wall, Door=core.Door, Key=core.Key,
+                           Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction)
+
+
+def multigrid_namespace():
+    from multigrid.base import MultiGridEnv
+    from multigrid import core
+    return SimpleNamespace(MultiGridEnv=MultiGridEnv, Grid=core.Grid, Goal=core.Goal, Wall=core.Wall, Door=core.Door, Key=core.Key,
+                           Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction)
+
+
+def define(ns):
+    """The custom env classes over the implementation `ns` names."""
+
+    class TwoRoomsEnv(ns.MultiGridEnv):
+        """Two rooms split by a wall with a locked yellow door; the key lies somewhere in the left room, the goal in the right
+        one behind a strip of lava with a gap; a ball and an (empty) box are scattered with a rejection rule; agent 0 starts at a
+        fixed cell, the others are placed at random in the left room."""
+
+        def __init__(self, size=11, **kwargs):
+            super().__init__(mission_space="unlock the door and reach the goal", grid_size=size, max_steps=6 * size * size,
+                             **kwargs)
+
+        def _gen_grid(self, width, height):
+            self.grid = ns.Grid(width, height)
+            self.grid.wall_rect(0, 0, width, height)
+            mid = width // 2
+            self.grid.vert_wall(mid, 0)                                  # to the bottom edge
+            door_y = self._rand_int(1, height - 1)
+            self.door = ns.Door(ns.Color.yellow, is_locked=True)
+            self.put_obj(self.door, mid, door_y)
+            # a lava strip in the right room, two cells before the goal column, with a one-cell gap
+            gap = self._rand_int(1, height - 1)
+            self.grid.vert_wall(width - 3, 1, height - 2, obj_type=ns.Lava)
+            self.grid.set(width - 3, gap, None)
+            self.put_obj(ns.Goal(), width - 2, height - 2)
+            self.put_obj(ns.Floor(ns.Color.purple), mid + 1, 1)
+            # agent 0 at a fixed start, the others anywhere in the left room
+            for agent in self.agents:
+                if agent.index == 0:
+                    agent.state.pos = (1, 1)
+                    agent.state.dir = ns.Direction.down
+                else:
+                    self.place_agent(agent, top=(1, 1), size=(mid - 1, height - 2))
+            self.key_pos = self.place_obj(ns.Key(ns.Color.yellow), top=(1, 1), size=(mid - 1, height - 2))
+            # a ball of a random colour, never on an even column; a box not next to the door row
+            self.place_obj(ns.Ball(self._rand_color()), reject_fn=lambda env, pos: pos[0] % 2 == 0)
+            self.place_obj(ns.Box(ns.Color.green), top=(mid + 1, 1), size=(2, height - 2),
+                           reject_fn=lambda env, pos: abs(pos[1] - door_y) <= 1, max_tries=1000)
+
+    class ScatterEnv(ns.MultiGridEnv):
+        """A non-square arena with an inner horizontal wall segment, closed and open doors, and objects drawn with the whole
+        `_rand_*` family; every agent placed at random with a random direction."""
+
+        def __init__(self, width=13, height=9, **kwargs):
+            super().__init__(mission_space="wander", width=width, height=height, max_steps=200, **kwargs)
+
+        def _gen_grid(self, width, height):
+            self.grid = ns.Grid(width, height)
+            self.grid.wall_rect(0, 0, width, height)
+            y = height // 2
+            self.grid.horz_wall(2, y, width - 4)
+            xs = self._rand_subset(range(3, width - 3), 2)
+            self.put_obj(ns.Door(self._rand_color(), is_open=self._rand_bool()), xs[0], y)
+            self.put_obj(ns.Door(ns.Color.red), xs[1], y)
+            for color in self._rand_perm([ns.Color.blue, ns.Color.green, ns.Color.grey]):
+                self.place_obj(ns.Key(color), top=(1, 1), size=(width - 2, y - 1))
+            x, yy = self._rand_pos(1, width - 1, y + 1, height - 1)
+            if self.grid.get(x, yy) is None:
+                self.put_obj(ns.Lava(), x, yy)
+            self.place_obj(ns.Ball(self._rand_elem([ns.Color.purple, ns.Color.yellow])), top=(1, y + 1), size=(width - 2, height - y - 2))
+            self.put_obj(ns.Goal(), width - 2, 1)
+            for agent in self.agents:
+                self.place_agent(agent)
+
+    return {"TwoRoomsEnv": TwoRoomsEnv, "ScatterEnv": ScatterEnv}
+
+
+#: fixture name -> (class name, constructor kwargs)
+CASES = {
+    "custom_tworooms_a3": ("TwoRoomsEnv", dict(size=11, agents=3)),
+    "custom_scatter_a2_v5": ("ScatterEnv", dict(width=13, height=9, agents=2, agent_view_size=5, allow_agent_overlap=False)),
+}

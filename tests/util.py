@@ -15,7 +15,7 @@ from oracle import binding as ob
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _ALL = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 #: rollout fixtures (state + actions + per-step outputs) and reset/layout fixtures, both written by oracle/gen_golden.py
-GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith(("layout_", "wrappers_"))]
+GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith(("layout_", "wrappers_", "custom_"))]
 GOLDEN_IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
 LAYOUT_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("layout_")]
 LAYOUT_IDS = [os.path.basename(p)[:-4] for p in LAYOUT_GOLDEN]
@@ -23,6 +23,9 @@ LAYOUT_ENV_IDS = {"layout_bup_a2": "MultiGrid-BlockedUnlockPickup-v0", "layout_b
                   "layout_emptyrandom6_a3": "MultiGrid-Empty-Random-6x6-v0", "layout_empty8_a2": "MultiGrid-Empty-8x8-v0",
                   "layout_rbd8_a2": "MultiGrid-RedBlueDoors-8x8-v0", "layout_lh4_a2": "MultiGrid-LockedHallway-4Rooms-v0",
                   "layout_playground_a2": "MultiGrid-Playground-v0"}
+#: reset sequences of the user-defined envs of tests/custom_envs.py, recorded over the reference (oracle/gen_golden.py: record_custom)
+CUSTOM_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("custom_")]
+CUSTOM_IDS = [os.path.basename(p)[:-4] for p in CUSTOM_GOLDEN]
 WRAPPER_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("wrappers_")]
 WRAPPER_IDS = [os.path.basename(p)[:-4] for p in WRAPPER_GOLDEN]
 
