@@ -4,6 +4,7 @@ envs -- the loop an RL rollout worker runs.  The whole iteration (policy + mgx_s
 in one hipGraph, so a step costs the policy's kernels + ONE env launch and no Python.
 
     python examples/closed_loop.py [--workload c4] [--batch 65536] [--steps 200]
+    python examples/closed_loop.py --workload c2 --persistent      (ONE resident env launch: BatchedMultiGridEnv.persistent)
 
 Prints one JSON line: env steps/s with the policy in the loop, and the env's share of the iteration."""
 import argparse
@@ -91,6 +92,59 @@ def run(workload="c4", batch=None, steps=200, hidden=64, device="cuda:0", one_ho
             "mean_return": float(ret.sum().item() / max(1, int(env.episode.sum().item())) / A)}
 
 
+def run_persistent(workload="c2", batch=None, steps=200, hidden=64, device="cuda:0"):
+    """The same loop over a PersistentSession (include/mgx.h: mgx_step_persistent): the env kernel is launched ONCE and stays
+    resident with the env state in LDS; per iteration the policy's kernels run on the main stream, `ps.post(actions)` hands the
+    actions over as tagged granules (one small kernel behind the policy), `ps.wait()` returns once every wavefront has published
+    its flag behind the step's outputs.  Eager (the hand-shake's step numbers are kernel arguments), so beside it the same eager
+    loop with one env launch per step.  For batches in the latency regime (c2, c3, or --batch 8192 of c4)."""
+    dev = torch.device(device)
+    wl = workloads.make(workload, batch=batch, global_batch=max(batch or 0, workloads.GLOBAL_BATCH[workload]))
+    B, A, v = wl.batch, wl.spec.num_agents, wl.spec.view_size
+    feat = v * v * 3
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    w1 = torch.randn(feat, hidden, device=dev, dtype=torch.float16, generator=g) * 0.05
+    w2 = torch.randn(hidden, 7, device=dev, dtype=torch.float16, generator=g) * 0.5
+
+    def policy(obs, actions):
+        logits = torch.relu(obs.view(B * A, feat).to(torch.float16) @ w1) @ w2
+        gumbel = -torch.log(-torch.log(torch.rand_like(logits, dtype=torch.float32).clamp_(1e-6, 1 - 1e-6)))
+        actions.copy_((logits.float() + gumbel).argmax(dim=1).view(B, A).to(torch.int8))
+
+    out = {"workload": wl.title, "batch": B, "agents": A, "policy": f"MLP {feat}-{hidden}-7 fp16, Gumbel sampling, eager"}
+    for mode in ("launches", "persistent"):
+        env = wl.make_env(dev, auto_reset=True)
+        actions = torch.zeros((B, A), dtype=torch.int8, device=dev)
+        obs, _ = env.gen_obs()
+        ret = torch.zeros((B, A), dtype=torch.float64, device=dev)
+        for _ in range(5):                                   # (warm: allocator, code objects)
+            policy(obs, actions)
+        torch.cuda.synchronize(dev)
+        if mode == "launches":
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                policy(obs, actions)
+                _, _, rew, _, _ = env.step(actions, auto_reset=True)
+                ret.add_(rew)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        else:
+            with env.persistent(max_steps=steps, auto_reset=True) as ps:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    policy(obs, actions)
+                    _, _, rew, _, _ = ps.step(actions)
+                    ret.add_(rew)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            out["wavefronts_resident"] = ps.waves
+        env.check_errors()
+        out[mode] = {"ms_per_iteration": round(dt * 1e3 / steps, 5), "agent_steps_per_s": round(B * A * steps / dt),
+                     "episodes_finished": int(env.episode.sum().item())}
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c4")
@@ -98,5 +152,10 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--plain-obs", action="store_true", help="3-channel observations instead of one-hot")
     ap.add_argument("--sub-shards", type=int, default=1, help="double-buffered actor loop over this many blocks of the batch")
+    ap.add_argument("--persistent", action="store_true",
+                    help="one resident env launch (BatchedMultiGridEnv.persistent) instead of one launch per step; eager")
     a = ap.parse_args()
-    print(json.dumps(run(a.workload, a.batch, a.steps, one_hot=not a.plain_obs, sub_shards=a.sub_shards)))
+    if a.persistent:
+        print(json.dumps(run_persistent("c2" if a.workload == "c4" and a.batch is None else a.workload, a.batch, a.steps)))
+    else:
+        print(json.dumps(run(a.workload, a.batch, a.steps, one_hot=not a.plain_obs, sub_shards=a.sub_shards)))

@@ -165,6 +165,18 @@ int mgx_rollout(const MgxSpec *spec, int64_t batch, int32_t steps, MgxCell *grid
  * n_cells = B*H*W for a whole grid tensor (both layouts are [b][y][x]). */
 int mgx_pack_grid(const uint8_t *cells3, int64_t n_cells, MgxCell *packed, int32_t *bad, void *stream);
 int mgx_unpack_grid(const MgxCell *packed, int64_t n_cells, uint8_t *cells3, void *stream);
+/* (ABI 8) mgx_pack_grid for whole env grids cells3 u8[B,H,W,3]: bad is i32[2] (may be NULL; the caller zeroes it) --
+ *   bad[0] += cells with a value the packed format cannot hold, bad[1] += cells of an env's outer ring that are not the
+ *   reference's WALL = (wall, grey, 0) (multigrid/utils/obs.py:14; the PRECONDITION under "grid" above).
+ * mgx_check_grid: the same preconditions for state that is already on the device in the packed format, opt-in (one cheap
+ * kernel; nothing else in this library re-checks what it is handed):
+ *   bad i32[4], the caller initialises it to {0, 0, 0, INT32_MAX}:  bad[0] += cells that are not a valid packed cell (reserved
+ *   bits, type > 10, color > 5, state > 2, opaque bit inconsistent with (type, state): multigrid/utils/obs.py:46-63),
+ *   bad[1] += outer-ring cells that are not WALL, bad[2] += agent rows outside the walls / with direction > 3 / with a carried
+ *   cell the format cannot hold (agents may be NULL: not checked), bad[3] = min index of an env with a violation. */
+int mgx_pack_grid_env(const uint8_t *cells3, int64_t batch, int32_t height, int32_t width, MgxCell *packed, int32_t *bad,
+                      void *stream);
+int mgx_check_grid(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents, int32_t *bad, void *stream);
 
 /* Geometry mgx_gen_obs / mgx_step / mgx_rollout would use. */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
@@ -422,7 +434,8 @@ int mgx_persistent_post(const MgxSpec *spec, int64_t batch, const int8_t *action
                         void *stream);
 /* Returns (in stream order) once done[w] >= step for every w < waves, or after timeout_ms (then ctrl[1] += 1). */
 int mgx_persistent_wait(const uint32_t *done, int32_t waves, uint32_t step, uint32_t *ctrl, int32_t timeout_ms, void *stream);
-/* A stand-in policy for benchmarks and tests: ONE resident workgroup (256 threads) that plays a recorded action sequence actions i8[T,B,A]
+/* A stand-in policy for benchmarks and tests: a few resident workgroups (256 threads per 2048 granules) that play a recorded
+ * action sequence actions i8[T,B,A]
  * through the closed-loop hand-shake -- for t = 1..T: wait for step t-1's outputs to be complete, post the granules of step t --
  * i.e. the shortest producer there can be.  trace (u64[2T + 1], may be NULL): s_memrealtime ticks (100 MHz): [2(t-1)] = step t's
  * predecessor seen complete, [2(t-1) + 1] = step t's granules posted, [2T] = step T seen complete. */

@@ -26,6 +26,7 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
            "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid",
            "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards",
+           "mgx_pack_grid_env", "mgx_check_grid",
            "mgx_persistent_waves", "mgx_step_persistent", "mgx_persistent_post", "mgx_persistent_wait", "mgx_persistent_feed")
 
 
@@ -126,6 +127,10 @@ def lib() -> C.CDLL:
     L.mgx_pack_grid.argtypes = [vp, i64, vp, vp, vp]
     L.mgx_unpack_grid.restype = C.c_int
     L.mgx_unpack_grid.argtypes = [vp, i64, vp, vp]
+    L.mgx_pack_grid_env.restype = C.c_int
+    L.mgx_pack_grid_env.argtypes = [vp, i64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.mgx_check_grid.restype = C.c_int
+    L.mgx_check_grid.argtypes = [C.POINTER(MgxSpecC), i64, vp, vp, vp, vp]
     L.mgx_launch_info.restype = C.c_int
     L.mgx_launch_info.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLaunchInfo)]
     L.mgx_step_ex.restype = C.c_int

@@ -117,7 +117,8 @@ def _torch_build_cmd(out: str) -> list[str]:
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
     cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", TORCH_SRC, "-o", out]
     cmd += [f"-L{p}" for p in ce.library_paths()] + ["-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip",
-                                                      f"-L{os.path.dirname(LIB)}", "-lmgx", "-Wl,-rpath,$ORIGIN"]
+                                                      f"-L{os.path.dirname(LIB)}", "-lmgx", "-Wl,-rpath,$ORIGIN",
+                                                      f"-L{rocm}/lib", "-lamdhip64"]
     cmd += [f"-Wl,-rpath,{p}" for p in ce.library_paths()]      # (a C++ host that dlopen()s the library finds torch's own)
     return cmd
 

@@ -7,6 +7,7 @@
 //
 // All three are streaming kernels: 16-byte loads and stores, the byte shuffling in between goes through LDS.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <limits.h>
 #include <stdint.h>
 
@@ -188,18 +189,28 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
 // pack / unpack: (type, color, state) bytes <-> packed 16-bit cells (include/mgx.h).  One thread converts 8 cells: 24 bytes in
 // three dword pairs on one side, one 16-byte vector on the other.
 // ---------------------------------------------------------------------------------------------------------------
+// W, H > 0: the cells are whole env grids [b][y][x] and bad[1] counts the cells of every env's OUTER RING that are not the
+// reference's WALL = (wall, grey, 0) -- the precondition of every kernel that reads the grid (include/mgx.h)
 __global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restrict__ c3, int64_t n, uint16_t *__restrict__ out,
-                                                        int32_t *bad) {
+                                                        int32_t *bad, int W, int H) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i0 >= n) return;
-    int nbad = 0;
+    int nbad = 0, nring = 0;
     uint16_t v[8];
+    int x = 0, y = 0;
+    if (W > 0) { const int r = (int)(i0 % ((int64_t)W * H)); y = r / W; x = r - y * W; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t c = (i0 + k < n) ? load_obs_cell(c3 + (i0 + k) * 3) : 0u;
         nbad += ((c & 0xf0u) != 0) | (((c >> 8) & 0xf8u) != 0) | (((c >> 16) & 0xfcu) != 0);
         v[k] = (uint16_t)cell_pack(c);
+        if (W > 0) {
+            const bool ring = (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
+            nring += (i0 + k < n) & ring & (c != CELL_WALL);
+            if (++x == W) { x = 0; if (++y == H) y = 0; }
+        }
     }
+    if (nring && bad) atomicAdd(bad + 1, nring);
     if (i0 + 8 <= n && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         u32x4 w;
         w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
@@ -209,6 +220,46 @@ __global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restric
         for (int k = 0; k < 8 && i0 + k < n; ++k) out[i0 + k] = v[k];
     }
     if (nbad && bad) atomicAdd(bad, nbad);
+}
+
+// mgx_check_grid: the state preconditions of the kernels, counted (include/mgx.h).  One thread looks at 8 cells and at one
+// agent row.
+__global__ __launch_bounds__(256) void check_grid_kernel(const uint16_t *__restrict__ cells, int64_t n, int W, int H,
+                                                         const uint8_t *__restrict__ agents, int64_t n_rows, int A, int32_t *bad) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = tid * 8;
+    int nfmt = 0, nring = 0, nag = 0;
+    int64_t first = INT64_MAX;
+    if (i0 < n) {
+        const int64_t HW = (int64_t)W * H;
+        const int64_t b0 = i0 / HW;
+        int r = (int)(i0 - b0 * HW), y = r / W, x = r - y * W;
+        int64_t b = b0;
+        for (int k = 0; k < 8 && i0 + k < n; ++k) {
+            const uint32_t p = cells[i0 + k];
+            const uint32_t t = p & 0xfu, c = (p >> 8) & 0x7u, st = (p >> 12) & 0x3u;
+            // reserved bits clear, values the reference has, and the opaque bit what the (type, state) says (obs.py:46-63)
+            const bool fmt = ((p & 0x48f0u) != 0) | (t > (uint32_t)T_AGENT) | (c > 5u) | (st > 2u) | (cell_pack(cell_unpack(p)) != p);
+            const bool ring = (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
+            const bool rbad = ring & (p != CELL16_WALL);
+            nfmt += fmt; nring += rbad;
+            if ((fmt | rbad) && b < first) first = b;
+            if (++x == W) { x = 0; if (++y == H) { y = 0; ++b; } }
+        }
+    }
+    if (tid < n_rows) {
+        const uint8_t *row = agents + tid * MGX_AGENT_STRIDE;
+        const int ax = row[AG_X], ay = row[AG_Y];
+        // inside the walls (never on the ring: nothing can stand on a wall), a direction, 0/1 terminated, a packable carried cell
+        const bool abad = (ax < 1) | (ax > W - 2) | (ay < 1) | (ay > H - 2) | (row[AG_DIR] > 3) | (row[AG_TERM] > 1) | (row[AG_COLOR] > 5)
+                        | (row[AG_CARRY] > (uint8_t)T_AGENT) | (row[AG_CARRY + 1] > 5) | (row[AG_CARRY + 2] > 2);
+        nag += abad;
+        if (abad && tid / A < first) first = tid / A;
+    }
+    if (nfmt) atomicAdd(bad + 0, nfmt);
+    if (nring) atomicAdd(bad + 1, nring);
+    if (nag) atomicAdd(bad + 2, nag);
+    if (first != INT64_MAX) atomicMin(bad + 3, (int32_t)(first > INT32_MAX ? INT32_MAX : first));
 }
 
 __global__ __launch_bounds__(256) void unpack_grid_kernel(const uint16_t *__restrict__ in, int64_t n, uint8_t *__restrict__ c3) {
@@ -362,24 +413,33 @@ __global__ __launch_bounds__(256) void persistent_wait_kernel(const uint32_t *do
 // The recorded sequence's next step is known while the current one runs: its action bytes are fetched into registers behind the
 // post (FAST = A is a multiple of 4: granule g's four bytes are the g-th dword of the step's action tensor; kFeedPre granules per
 // thread, i.e. batches up to 8192 granules; whatever does not fit -- and every other A -- is fetched at post time).
-// ONE workgroup of 256 threads = one wavefront per SIMD of one CU: it must fit BESIDE the persistent launch's wavefronts wherever
+// Workgroups of 256 threads = one wavefront per SIMD of a CU: they must fit BESIDE the persistent launch's wavefronts wherever
 // they are (a 1024-thread workgroup needs four wavefronts per SIMD at once: next to two 140-VGPR wavefronts per SIMD there is
-// no CU on the chip that can take it -- measured: the hand-shake then runs into its timeout).
-constexpr int kFeedPre = 32, kFeedThreads = 256;
+// no CU on the chip that can take it -- measured: the hand-shake then runs into its timeout).  One workgroup per slice of 2048
+// granules (at most 32): 8-byte write-through stores leave ONE CU at ~15 GB/s (16384 granules from one workgroup: 9 us per
+// step), so the post is spread; every workgroup sees ALL flags before it posts its slice (the lock-step of a real policy).
+constexpr int kFeedPre = 8, kFeedThreads = 256, kFeedSlice = kFeedPre * kFeedThreads, kFeedMaxWgs = 32;
 // GB: action bytes a granule takes from the tensor when they are contiguous and aligned -- 4 (A a multiple of 4), 2 (A = 2),
 // 1 (A = 1): granule g's bytes are then the g-th GB-byte word of the step's action tensor; 0 = any other A
 template <int GB>
 __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int8_t *__restrict__ actions, int T, int64_t batch, int A, int gpe,
                                                                        uint32_t inv_gpe, uint64_t *granules, const uint32_t *done, int waves,
                                                                        uint32_t *ctrl, uint32_t timeout_ticks, uint64_t *trace) {
-    const int64_t ng = batch * gpe, BA = batch * A;
+    const int64_t ng_all = batch * gpe, BA = batch * A;
+    // this workgroup's slice of the granules: [g_lo, g_lo + ng)
+    const int64_t per_wg = ((ng_all + gridDim.x - 1) / gridDim.x + 1) & ~(int64_t)1;
+    const int64_t g_lo = (int64_t)blockIdx.x * per_wg;
+    const int64_t ng = g_lo >= ng_all ? 0 : (ng_all - g_lo < per_wg ? ng_all - g_lo : per_wg);
+    granules += g_lo;
+    const bool lead = blockIdx.x == 0;
+    if (!lead) trace = nullptr;
     constexpr bool FAST = GB != 0;
     const int npre = FAST ? (int)(ng < (int64_t)kFeedThreads * kFeedPre ? ng : (int64_t)kFeedThreads * kFeedPre) : 0;   // granules via registers
     const __amdgpu_buffer_rsrc_t grs = make_rsrc(granules, npre * 8);
     uint32_t pre[kFeedPre];
     auto fetch = [&](int t) {
         if constexpr (FAST) {
-            const __amdgpu_buffer_rsrc_t ars = make_rsrc(actions + (int64_t)t * BA, npre * GB);
+            const __amdgpu_buffer_rsrc_t ars = make_rsrc(actions + (int64_t)t * BA + g_lo * GB, npre * GB);
 #pragma unroll
             for (int k = 0; k < kFeedPre; ++k) {            // (agents beyond A: "absent" = 0xff)
                 if constexpr (GB == 4) pre[k] = __builtin_amdgcn_raw_buffer_load_b32(ars, threadIdx.x * 4, kFeedThreads * 4 * k, 0);
@@ -392,7 +452,7 @@ __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int
     for (int t = 0; t < T; ++t) {
         // the outputs of step t (counted from 1) complete?  (nothing to wait for before the first post)
         if (t > 0 && !wait_all_done(done, waves, (uint32_t)t, timeout_ticks)) {
-            if (threadIdx.x == 0) { atomicAdd(ctrl + 1, 1u); __hip_atomic_store(ctrl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (threadIdx.x == 0 && lead) { atomicAdd(ctrl + 1, 1u); __hip_atomic_store(ctrl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             return;
         }
         if (trace && threadIdx.x == 0) trace[2 * t] = __builtin_amdgcn_s_memrealtime();
@@ -405,7 +465,7 @@ __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int
                 __builtin_amdgcn_raw_buffer_store_b64(v, grs, threadIdx.x * 8, kFeedThreads * 8 * k, 16);
             }
         }
-        const int8_t *act_t = actions + (int64_t)t * BA;
+        const int8_t *act_t = actions + (int64_t)t * BA + (FAST ? g_lo * GB : 0);
         int64_t gdone = npre;
         if constexpr (FAST) {                 // batches beyond one register chunk: fetched now, 32 loads in flight per thread
             for (; gdone < ng; gdone += kFeedThreads * kFeedPre) {
@@ -425,9 +485,10 @@ __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int
                 }
             }
         }
-        for (int64_t g = threadIdx.x + gdone; g < ng; g += kFeedThreads) {
-            const int64_t b = gpe == 1 ? g : (int64_t)(((uint64_t)g * inv_gpe) >> 32);
-            __hip_atomic_store(granules + g, make_granule(act_t + b * A, A, (int)(g - b * gpe), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int64_t g = threadIdx.x + gdone; g < ng; g += kFeedThreads) {          // (any other A: by env and granule index)
+            const int64_t gg = g_lo + g;
+            const int64_t b = gpe == 1 ? gg : (int64_t)(((uint64_t)gg * inv_gpe) >> 32);
+            __hip_atomic_store(granules + g, make_granule(act_t + b * A, A, (int)(gg - b * gpe), tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (trace) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -437,6 +498,7 @@ __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int
         if (t + 1 < T) fetch(t + 1);
     }
     // (the last step's outputs: so that "the feed kernel has ended" means "the rollout is complete")
+    if (!lead) return;
     if (!wait_all_done(done, waves, (uint32_t)T, timeout_ticks) && threadIdx.x == 0) atomicAdd(ctrl + 1, 1u);
     if (trace && threadIdx.x == 0) trace[2 * T] = __builtin_amdgcn_s_memrealtime();
 }
@@ -492,7 +554,9 @@ int mgx_persistent_feed(const MgxSpec *spec, int64_t batch, const int8_t *action
     const int A_ = spec->num_agents;
     auto kern = (A_ & 3) == 0 ? persistent_feed_kernel<4> : A_ == 2 ? persistent_feed_kernel<2> : A_ == 1 ? persistent_feed_kernel<1>
                                                                                                    : persistent_feed_kernel<0>;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(kFeedThreads), 0, static_cast<hipStream_t>(stream), actions, (int)steps, batch,
+    int64_t nwg = (ng + kFeedSlice - 1) / kFeedSlice;
+    if (nwg > kFeedMaxWgs) nwg = kFeedMaxWgs;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kFeedThreads), 0, static_cast<hipStream_t>(stream), actions, (int)steps, batch,
                        spec->num_agents, gpe, inv, const_cast<uint64_t *>(p->action_granules), p->done, (int)waves, p->ctrl,
                        (uint32_t)p->timeout_ms * 100000u, trace);
     return finish_launch();
@@ -552,7 +616,35 @@ int mgx_pack_grid(const uint8_t *cells3, int64_t n_cells, MgxCell *packed, int32
     const int64_t blocks = (n_cells + 2047) / 2048;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3, n_cells,
-                       packed, bad);
+                       packed, bad, 0, 0);
+    return finish_launch();
+}
+
+int mgx_pack_grid_env(const uint8_t *cells3, int64_t batch, int32_t height, int32_t width, MgxCell *packed, int32_t *bad,
+                      void *stream) {
+    if (batch < 0 || height < 3 || width < 3 || height > 255 || width > 255) return MGX_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return MGX_OK;
+    const int64_t n_cells = batch * height * width;
+    if (!cells3 || !packed || misaligned(packed, 2) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
+    const int64_t blocks = (n_cells + 2047) / 2048;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3, n_cells,
+                       packed, bad, (int)width, (int)height);
+    return finish_launch();
+}
+
+int mgx_check_grid(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents, int32_t *bad, void *stream) {
+    if (!spec || batch < 0 || spec->width < 3 || spec->height < 3 || spec->width > 255 || spec->height > 255
+        || spec->num_agents < 1 || spec->num_agents > MGX_MAX_AGENTS)
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return MGX_OK;
+    if (!grid || !bad || misaligned(grid, 2) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
+    const int64_t n_cells = batch * spec->height * spec->width, n_rows = agents ? batch * spec->num_agents : 0;
+    const int64_t work = std::max((n_cells + 7) / 8, n_rows);
+    const int64_t blocks = (work + 255) / 256;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(check_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), grid, n_cells,
+                       (int)spec->width, (int)spec->height, agents, n_rows, (int)spec->num_agents, bad);
     return finish_launch();
 }
 

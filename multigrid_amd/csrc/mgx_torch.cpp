@@ -11,13 +11,22 @@
 //
 // `grid` / `pool_grid` are packed cells (int16 [B,H,W], MgxCell bit patterns).  The same ops accept the reference's form,
 // (type, color, state) bytes uint8 [B,H,W,3]: packed on the way in (mgx_pack_grid) and, for the mutating ops, unpacked back into
-// the caller's tensor on the way out (mgx_unpack_grid) -- two more streaming kernels, NO host synchronisation (values the packed
-// format cannot hold are stored truncated; torch.ops.mgx.pack_grid reports their count for callers who want to check).
+// the caller's tensor on the way out (mgx_unpack_grid) -- two more streaming kernels, NO host synchronisation.  What such a grid
+// may get wrong -- a value the packed format cannot hold, or an outer ring that is not the reference's WALL (the precondition of
+// include/mgx.h) -- is counted by the pack kernel and reported DEFERRED, the way the device reports its own faults: the counts
+// travel to pinned host memory behind the pack, and the next mgx op on that device (or torch.ops.mgx.check_errors(), which
+// waits) raises once they have arrived.  State that is already packed is checked on request: torch.ops.mgx.check_grid.
+//
+// Out-variants (`step_out`, `step_autoreset_out`, `step_one_hot_out`, `gen_obs_out`): the caller owns the output tensors -- no
+// allocation per call (five at::empty were most of the op's host time), same checks, same launch.
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/library.h>
 
+#include <map>
+#include <mutex>
 #include <optional>
 #include <tuple>
 #include <vector>
@@ -38,8 +47,15 @@ MgxSpec spec_from(at::IntArrayRef v) {
     return s;
 }
 
+// every tensor of a call lives on ONE device: the first one checked sets it (DeviceGuard below), the others must match -- a
+// mix of cuda:0 and cuda:1 tensors would otherwise end in an illegal memory access inside the kernel
+thread_local c10::Device t_device(c10::DeviceType::CPU);
+thread_local bool t_device_set = false;
+
 void want(const Tensor &t, const char *name, at::ScalarType dtype, at::IntArrayRef shape = {}, bool check_shape = false) {
     TORCH_CHECK(t.is_cuda(), "mgx: `", name, "` must live on a HIP device (got ", t.device(), "); there is no CPU path");
+    TORCH_CHECK(!t_device_set || t.device() == t_device, "mgx: `", name, "` is on ", t.device(), " but the call's grid is on ", t_device,
+                ": every tensor of a call must live on one device");
     TORCH_CHECK_TYPE(t.scalar_type() == dtype, "mgx: `", name, "` must be ", dtype, ", got ", t.scalar_type());
     TORCH_CHECK_VALUE(t.is_contiguous(), "mgx: `", name, "` must be contiguous");
     if (check_shape) TORCH_CHECK_VALUE(t.sizes() == shape, "mgx: `", name, "` must have shape ", shape, ", got ", t.sizes());
@@ -53,8 +69,57 @@ void *stream_of(const Tensor &t) { return (void *)c10::hip::getCurrentHIPStreamM
 
 struct DeviceGuard {
     c10::hip::HIPGuardMasqueradingAsCUDA g;
-    explicit DeviceGuard(const Tensor &t) : g(t.device()) {}
+    explicit DeviceGuard(const Tensor &t) : g(t.device()) { t_device = t.device(); t_device_set = true; }
+    ~DeviceGuard() { t_device_set = false; }
 };
+
+// ---- deferred report of what a byte grid got wrong (see the header comment) ------------------------------------------------
+struct GridFaults {
+    int32_t *dev = nullptr;        // i32[2] on the device: [0] unpackable values, [1] ring cells that are not WALL (accumulating)
+    int32_t *host = nullptr;       // pinned copy
+    hipEvent_t ev = nullptr;       // recorded behind the copy
+    bool pending = false;
+};
+std::mutex g_faults_mutex;
+std::map<int, GridFaults> g_faults;
+
+void raise_faults(GridFaults &f, void *stream) {
+    const int32_t unpackable = f.host[0], ring = f.host[1];
+    f.pending = false;
+    if (unpackable == 0 && ring == 0) return;
+    f.host[0] = f.host[1] = 0;
+    (void)hipMemsetAsync(f.dev, 0, 8, (hipStream_t)stream);
+    TORCH_CHECK(false, "mgx: an earlier call was handed a byte grid with ", ring, " outer-ring cell(s) that are not WALL = (wall, grey, 0) "
+                "and ", unpackable, " cell value(s) the packed format cannot hold (type > 15, color > 7 or state > 3); its results are "
+                "undefined.  The outer ring of every env's grid must be the reference's WALL (include/mgx.h; every _gen_grid of the "
+                "reference starts from Grid.wall_rect(0, 0, W, H))");
+}
+
+// before a call: has an earlier byte grid's report arrived?  (never blocks; `wait`: torch.ops.mgx.check_errors)
+void poll_faults(int device, void *stream, bool wait = false) {
+    std::lock_guard<std::mutex> lock(g_faults_mutex);
+    auto it = g_faults.find(device);
+    if (it == g_faults.end() || !it->second.pending) return;
+    GridFaults &f = it->second;
+    if (wait) {
+        TORCH_CHECK(hipEventSynchronize(f.ev) == hipSuccess, "mgx: hipEventSynchronize failed");
+    } else if (hipEventQuery(f.ev) != hipSuccess) {
+        return;
+    }
+    raise_faults(f, stream);
+}
+
+// the pack kernel's counters of this device, and -- behind the pack -- their trip to the host
+GridFaults &faults_of(int device) {
+    GridFaults &f = g_faults[device];
+    if (!f.dev) {
+        TORCH_CHECK(hipMalloc((void **)&f.dev, 8) == hipSuccess && hipMemset(f.dev, 0, 8) == hipSuccess
+                    && hipHostMalloc((void **)&f.host, 8, hipHostMallocDefault) == hipSuccess
+                    && hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) == hipSuccess, "mgx: could not set up the grid check");
+        f.host[0] = f.host[1] = 0;
+    }
+    return f;
+}
 
 template <class T> T *ptr(const Tensor &t) { return reinterpret_cast<T *>(t.data_ptr()); }
 template <class T> T *ptr(const OptTensor &t) { return t.has_value() ? reinterpret_cast<T *>(t->data_ptr()) : nullptr; }
@@ -89,7 +154,14 @@ Tensor as_cells(const Tensor &grid, const char *name, bool &bytes) {
     TORCH_CHECK_VALUE(grid.dim() == 4 && grid.size(-1) == 3, "mgx: a byte `", name, "` must be uint8 [B,H,W,3]");
     auto shape = grid.sizes().vec(); shape.pop_back();
     Tensor out = at::empty(shape, grid.options().dtype(at::kShort));
-    check(mgx_pack_grid(ptr<const uint8_t>(grid), out.numel(), ptr<MgxCell>(out), nullptr, stream_of(grid)), "mgx_pack_grid");
+    void *st = stream_of(grid);
+    std::lock_guard<std::mutex> lock(g_faults_mutex);
+    GridFaults &f = faults_of(grid.device().index());
+    check(mgx_pack_grid_env(ptr<const uint8_t>(grid), grid.size(0), (int32_t)grid.size(1), (int32_t)grid.size(2), ptr<MgxCell>(out), f.dev, st),
+          "mgx_pack_grid_env");
+    TORCH_CHECK(hipMemcpyAsync(f.host, f.dev, 8, hipMemcpyDeviceToHost, (hipStream_t)st) == hipSuccess
+                && hipEventRecord(f.ev, (hipStream_t)st) == hipSuccess, "mgx: could not queue the grid check's report");
+    f.pending = true;
     return out;
 }
 
@@ -105,15 +177,24 @@ int64_t check_state(const MgxSpec &sc, const Tensor &cells, const Tensor &agents
 }
 
 // ---- gen_obs ---------------------------------------------------------------------------------------------------------------
-std::tuple<Tensor, Tensor> gen_obs_any(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec, bool one_hot) {
+std::tuple<Tensor, Tensor> gen_obs_any(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec, bool one_hot,
+                                       const Tensor *out_obs = nullptr, const Tensor *out_dirs = nullptr) {
     const MgxSpec sc = spec_from(spec);
     DeviceGuard g(grid);
+    poll_faults(grid.device().index(), stream_of(grid));
     bool bytes;
     const Tensor cells = as_cells(grid, "grid", bytes);
     const int64_t B = check_state(sc, cells, agents);
     const int64_t A = sc.num_agents, v = sc.view_size;
-    Tensor obs = at::empty({B, A, v, v, one_hot ? 21 : 3}, agents.options());
-    Tensor dirs = at::empty({B, A}, agents.options());
+    Tensor obs, dirs;
+    if (out_obs) {
+        want(*out_obs, "obs", at::kByte, {B, A, v, v, one_hot ? 21 : 3}, true);
+        want(*out_dirs, "dir", at::kByte, {B, A}, true);
+        obs = *out_obs; dirs = *out_dirs;
+    } else {
+        obs = at::empty({B, A, v, v, one_hot ? 21 : 3}, agents.options());
+        dirs = at::empty({B, A}, agents.options());
+    }
     if (one_hot)
         check(mgx_gen_obs_one_hot(&sc, B, ptr<const MgxCell>(cells), ptr<const uint8_t>(agents), ptr<uint8_t>(obs), ptr<uint8_t>(dirs),
                                   stream_of(cells)), "mgx_gen_obs_one_hot");
@@ -124,6 +205,9 @@ std::tuple<Tensor, Tensor> gen_obs_any(const Tensor &grid, const Tensor &agents,
 }
 std::tuple<Tensor, Tensor> gen_obs(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec) { return gen_obs_any(grid, agents, spec, false); }
 std::tuple<Tensor, Tensor> gen_obs_one_hot(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec) { return gen_obs_any(grid, agents, spec, true); }
+void gen_obs_out(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec, Tensor obs, Tensor dirs) {
+    gen_obs_any(grid, agents, spec, obs.dim() == 5 && obs.size(4) == 21, &obs, &dirs);
+}
 
 // ---- step family: one implementation over MgxStepArgs / mgx_step_ex ----------------------------------------------------
 struct StepOut { Tensor obs, dirs, reward, terminated, truncated, was_reset; };
@@ -131,9 +215,10 @@ struct StepOut { Tensor obs, dirs, reward, terminated, truncated, was_reset; };
 StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, const Tensor &step_count, const Tensor &actions,
                  const OptTensor &aux, const Tensor &err, at::IntArrayRef spec, int64_t T /* 0 = one step */, bool one_hot,
                  const OptTensor &pool_grid, const OptTensor &pool_agents, const OptTensor &pool_aux, const OptTensor &episode,
-                 int64_t first_env, const OptTensor &hook_order, const char *what) {
+                 int64_t first_env, const OptTensor &hook_order, const char *what, const StepOut *pre = nullptr) {
     const MgxSpec sc = spec_from(spec);
     DeviceGuard g(grid);
+    poll_faults(grid.device().index(), stream_of(grid));
     bool bytes, pool_bytes = false;
     const Tensor cells = as_cells(grid, "grid", bytes);
     const int64_t B = check_state(sc, cells, agents);
@@ -152,11 +237,20 @@ StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, co
     std::vector<int64_t> lead = T > 0 ? std::vector<int64_t>{T, B} : std::vector<int64_t>{B};
     auto shape = [&](std::initializer_list<int64_t> tail) { auto s = lead; s.insert(s.end(), tail); return s; };
     StepOut o;
-    o.obs = at::empty(shape({A, v, v, one_hot ? 21 : 3}), agents.options());
-    o.dirs = at::empty(shape({A}), agents.options());
-    o.reward = at::empty(shape({A}), agents.options().dtype(at::kDouble));
-    o.terminated = at::empty(shape({A}), agents.options());
-    o.truncated = at::empty(lead, agents.options());
+    if (pre) {                                  // out-variant: the caller's tensors, checked like every other argument
+        o = *pre;
+        want(o.obs, "obs", at::kByte, shape({A, v, v, one_hot ? 21 : 3}), true);
+        want(o.dirs, "dir", at::kByte, shape({A}), true);
+        want(o.reward, "reward", at::kDouble, shape({A}), true);
+        want(o.terminated, "terminated", at::kByte, shape({A}), true);
+        want(o.truncated, "truncated", at::kByte, lead, true);
+    } else {
+        o.obs = at::empty(shape({A, v, v, one_hot ? 21 : 3}), agents.options());
+        o.dirs = at::empty(shape({A}), agents.options());
+        o.reward = at::empty(shape({A}), agents.options().dtype(at::kDouble));
+        o.terminated = at::empty(shape({A}), agents.options());
+        o.truncated = at::empty(lead, agents.options());
+    }
     MgxStepArgs sa{};
     sa.grid = ptr<MgxCell>(cells); sa.agents = ptr<uint8_t>(agents); sa.rng = ptr<uint64_t>(rng); sa.step_count = ptr<int32_t>(step_count);
     sa.aux = ptr<uint8_t>(aux); sa.actions = ptr<const int8_t>(actions); sa.hook_order = ptr<const uint8_t>(hook_order);
@@ -174,12 +268,13 @@ StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, co
         want(*pool_agents, "pool_agents", at::kByte, {K, A, 8}, true);
         if (pool_aux.has_value()) want(*pool_aux, "pool_aux", at::kByte, {K, 16}, true);
         want(*episode, "episode", at::kInt, {B}, true);
-        o.was_reset = at::empty(lead, agents.options());
+        if (pre) want(o.was_reset, "was_reset", at::kByte, lead, true);
+        else o.was_reset = at::empty(lead, agents.options());
         ar.first_env = first_env; ar.pool_size = (int32_t)K; ar.pool_grid = ptr<const MgxCell>(pool_cells);
         ar.pool_agents = ptr<const uint8_t>(*pool_agents); ar.pool_aux = ptr<const uint8_t>(pool_aux);
         ar.episode = ptr<int32_t>(*episode); ar.was_reset = ptr<uint8_t>(o.was_reset);
         sa.auto_reset = &ar;
-    } else {
+    } else if (!pre) {
         o.was_reset = at::zeros(lead, agents.options());
     }
     check(mgx_step_ex(&sc, B, &sa, stream_of(cells)), what);
@@ -234,6 +329,51 @@ Out6 step_one_hot(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, con
     return {o.obs, o.dirs, o.reward, o.terminated, o.truncated, o.was_reset};
 }
 
+// out-variants: nothing is allocated; the outputs are written into the caller's tensors
+void step_out(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+              at::IntArrayRef spec, Tensor obs, Tensor dirs, Tensor reward, Tensor terminated, Tensor truncated) {
+    const StepOut pre{obs, dirs, reward, terminated, truncated, Tensor()};
+    step_any(grid, agents, rng, step_count, actions, aux, err, spec, 0, false, {}, {}, {}, {}, 0, {}, "mgx_step", &pre);
+}
+
+void step_autoreset_out(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+                        const Tensor &pool_grid, const Tensor &pool_agents, const OptTensor &pool_aux, Tensor episode,
+                        int64_t first_env, at::IntArrayRef spec, Tensor obs, Tensor dirs, Tensor reward, Tensor terminated,
+                        Tensor truncated, Tensor was_reset) {
+    const StepOut pre{obs, dirs, reward, terminated, truncated, was_reset};
+    step_any(grid, agents, rng, step_count, actions, aux, err, spec, 0, false, pool_grid, pool_agents, pool_aux, episode, first_env, {},
+             "mgx_step_autoreset", &pre);
+}
+
+void step_one_hot_out(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, const Tensor &actions, OptTensor aux, Tensor err,
+                      const OptTensor &pool_grid, const OptTensor &pool_agents, const OptTensor &pool_aux, OptTensor episode,
+                      int64_t first_env, at::IntArrayRef spec, Tensor obs, Tensor dirs, Tensor reward, Tensor terminated,
+                      Tensor truncated, OptTensor was_reset) {
+    TORCH_CHECK_VALUE(!pool_grid.has_value() || was_reset.has_value(), "mgx: step_one_hot_out with a layout pool needs `was_reset`");
+    const StepOut pre{obs, dirs, reward, terminated, truncated, was_reset.has_value() ? *was_reset : Tensor()};
+    step_any(grid, agents, rng, step_count, actions, aux, err, spec, 0, true, pool_grid, pool_agents, pool_aux, episode, first_env, {},
+             "mgx_step_one_hot", &pre);
+}
+
+// ---- the kernels' preconditions, on request -----------------------------------------------------------------------------------
+// bad i32[4] on the device: [0] cells that are not a valid packed cell, [1] outer-ring cells that are not WALL, [2] agent rows
+// outside the walls / malformed, [3] first env with a violation (INT32_MAX: none).  No synchronisation: the caller reads it.
+Tensor check_grid(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec) {
+    const MgxSpec sc = spec_from(spec);
+    DeviceGuard g(grid);
+    const int64_t B = check_state(sc, grid, agents);
+    Tensor bad = at::zeros({4}, grid.options().dtype(at::kInt));
+    bad.select(0, 3).fill_(INT32_MAX);
+    check(mgx_check_grid(&sc, B, ptr<const MgxCell>(grid), ptr<const uint8_t>(agents), ptr<int32_t>(bad), stream_of(grid)), "mgx_check_grid");
+    return bad;
+}
+
+// waits for the report of the last byte grid handed to an op on `device` and raises if it had faults (see the header comment)
+void check_errors(int64_t device) {
+    c10::hip::HIPGuardMasqueradingAsCUDA g(c10::Device(c10::DeviceType::CUDA, (c10::DeviceIndex)device));
+    poll_faults((int)device, (void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA((c10::DeviceIndex)device).stream(), true);
+}
+
 // ---- either side of the path ---------------------------------------------------------------------------------------------
 Tensor one_hot(const Tensor &cells, at::IntArrayRef dim_sizes) {
     want(cells, "cells", at::kByte);
@@ -249,6 +389,7 @@ Tensor one_hot(const Tensor &cells, at::IntArrayRef dim_sizes) {
 Tensor full_obs(const Tensor &grid, const Tensor &agents, at::IntArrayRef spec) {
     const MgxSpec sc = spec_from(spec);
     DeviceGuard g(grid);
+    poll_faults(grid.device().index(), stream_of(grid));
     bool bytes;
     const Tensor cells = as_cells(grid, "grid", bytes);
     const int64_t B = check_state(sc, cells, agents);
@@ -278,6 +419,19 @@ TORCH_LIBRARY(mgx, m) {
     m.def("step_one_hot(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
           "Tensor(f!)? aux, Tensor(e!) err, Tensor? pool_grid, Tensor? pool_agents, Tensor? pool_aux, Tensor(g!)? episode, "
           "int first_env, int[] spec) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("gen_obs_out(Tensor grid, Tensor agents, int[] spec, Tensor(a!) obs, Tensor(b!) dir) -> ()");
+    m.def("step_out(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, Tensor(f!)? aux, "
+          "Tensor(e!) err, int[] spec, Tensor(g!) obs, Tensor(h!) dir, Tensor(i!) reward, Tensor(j!) terminated, Tensor(k!) truncated) -> ()");
+    m.def("step_autoreset_out(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor(f!)? aux, Tensor(e!) err, Tensor pool_grid, Tensor pool_agents, Tensor? pool_aux, Tensor(g!) episode, int first_env, "
+          "int[] spec, Tensor(h!) obs, Tensor(i!) dir, Tensor(j!) reward, Tensor(k!) terminated, Tensor(l!) truncated, "
+          "Tensor(m!) was_reset) -> ()");
+    m.def("step_one_hot_out(Tensor(a!) grid, Tensor(b!) agents, Tensor(c!) rng, Tensor(d!) step_count, Tensor actions, "
+          "Tensor(f!)? aux, Tensor(e!) err, Tensor? pool_grid, Tensor? pool_agents, Tensor? pool_aux, Tensor(g!)? episode, int first_env, "
+          "int[] spec, Tensor(h!) obs, Tensor(i!) dir, Tensor(j!) reward, Tensor(k!) terminated, Tensor(l!) truncated, "
+          "Tensor(m!)? was_reset) -> ()");
+    m.def("check_grid(Tensor grid, Tensor agents, int[] spec) -> Tensor");
+    m.def("check_errors(int device) -> ()", &check_errors);
     m.def("one_hot(Tensor cells, int[] dim_sizes) -> Tensor");
     m.def("full_obs(Tensor grid, Tensor agents, int[] spec) -> Tensor");
     m.def("pack_grid(Tensor cells3) -> (Tensor, Tensor)");
@@ -294,6 +448,11 @@ TORCH_LIBRARY_IMPL(mgx, CUDA, m) {
     m.impl("rollout_one_hot", &rollout_one_hot);
     m.impl("gen_obs_one_hot", &gen_obs_one_hot);
     m.impl("step_one_hot", &step_one_hot);
+    m.impl("gen_obs_out", &gen_obs_out);
+    m.impl("step_out", &step_out);
+    m.impl("step_autoreset_out", &step_autoreset_out);
+    m.impl("step_one_hot_out", &step_one_hot_out);
+    m.impl("check_grid", &check_grid);
     m.impl("one_hot", &one_hot);
     m.impl("full_obs", &full_obs);
     m.impl("pack_grid", &pack_grid);

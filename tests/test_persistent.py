@@ -113,11 +113,13 @@ def test_feed_plays_a_recorded_sequence_in_closed_loop():
 
 
 def test_persistent_runs_beside_its_producer_whatever_streams_exist():
-    """HIP maps streams onto a few hardware queues; the persistent launch and its producer must never share one (they would
-    serialise into a timeout).  Sessions opened after many other streams were created, producer on side streams too."""
+    """The persistent launch and its producer must never serialise (HIP maps streams onto a few hardware queues; the launch has a
+    high-priority stream of its own).  Sessions opened after many other streams were created; the actions are posted from a side
+    stream, the outputs awaited on the default stream."""
     spec = EnvSpec(width=16, height=16, num_agents=4, view_size=7, max_steps=1024)
     B, T = 2048, 6
     keep = []
+    main = torch.cuda.current_stream(dev())
     for n_streams in (1, 2, 3, 5, 8):
         keep += [torch.cuda.Stream(dev()) for _ in range(n_streams)]
         for s in keep[-2:]:
@@ -126,16 +128,16 @@ def test_persistent_runs_beside_its_producer_whatever_streams_exist():
         e_ref, e_per = _pair(spec, B, seed=n_streams)
         acts = torch.from_numpy(np.stack([util.random_actions(B, 4, seed=t) for t in range(T)])).to(dev())
         side = keep[-1]
-        side.wait_stream(torch.cuda.current_stream(dev()))
+        torch.cuda.synchronize()
         with e_per.persistent(max_steps=T, timeout_ms=500) as ps:
             for t in range(T):
                 want = [x.clone() for x in e_ref.step(acts[t])]
-                torch.cuda.current_stream(dev()).wait_stream(side)
-                with torch.cuda.stream(side if t % 2 else torch.cuda.current_stream(dev())):
-                    got = ps.step(acts[t])
-                    for w, g in zip(want, got):
-                        assert torch.equal(w, g), (n_streams, t)
-                side.wait_stream(torch.cuda.current_stream(dev()))
+                side.wait_stream(main)                      # (the producer's stream has seen the previous step's outputs)
+                with torch.cuda.stream(side):
+                    ps.post(acts[t])
+                got = ps.wait()
+                for w, g in zip(want, got):
+                    assert torch.equal(w, g), (n_streams, t)
         assert ps.timeouts == 0
 
 

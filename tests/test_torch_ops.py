@@ -149,7 +149,90 @@ def test_ops_accept_the_reference_byte_grids():
     bad = d["grid"].clone(); bad[0, 2, 2, 0] = 99                                                                  # no such type
     cells, n_bad = torch.ops.mgx.pack_grid(bad)
     assert int(n_bad[0]) == 1 and int(torch.ops.mgx.pack_grid(d["grid"])[1][0]) == 0
-    torch.ops.mgx.gen_obs(bad, d["agents"], ints)                                                                  # (no sync, no raise)
+    torch.ops.mgx.gen_obs(bad, d["agents"], ints)                                                                  # (no sync, no raise ...
+    with pytest.raises(RuntimeError, match="cannot hold"):                           # ... the report is deferred: the next op, or:)
+        torch.ops.mgx.check_errors(0)
+    torch.ops.mgx.check_errors(0)                                                    # (reported once)
+
+
+def test_out_variants_allocate_nothing_and_equal_the_allocating_ops():
+    """torch.ops.mgx.step_out / step_autoreset_out / step_one_hot_out / gen_obs_out: the outputs go into the caller's tensors
+    (multigrid/base.py:303-346 per call without five allocations); same bytes as the allocating forms."""
+    wl = workloads.make("c2", batch=1024, global_batch=1024)
+    spec = wl.spec
+    ints = ops.spec_to_ints(spec)
+    e1, e2 = wl.make_env(torch.device(DEV), auto_reset=True), wl.make_env(torch.device(DEV), auto_reset=True)
+    for e in (e1, e2):
+        e.step_count.fill_(spec.max_steps - 3)                       # (truncation resets inside the run)
+    B, A, v = 1024, spec.num_agents, spec.view_size
+    o = dict(obs=torch.zeros((B, A, v, v, 3), dtype=torch.uint8, device=DEV), dir=torch.zeros((B, A), dtype=torch.uint8, device=DEV),
+             rew=torch.zeros((B, A), dtype=torch.float64, device=DEV), term=torch.zeros((B, A), dtype=torch.uint8, device=DEV),
+             trunc=torch.zeros((B,), dtype=torch.uint8, device=DEV), was=torch.zeros((B,), dtype=torch.uint8, device=DEV))
+    oh = torch.zeros((B, A, v, v, 21), dtype=torch.uint8, device=DEV)
+    pg, pa, _ = e1._pool
+    for t in range(8):
+        act = torch.from_numpy(util.random_actions(B, A, seed=t)).to(DEV)
+        want = torch.ops.mgx.step_autoreset(e1.cells, e1.agents, e1.rng, e1.step_count, act, None, e1.err, pg, pa, None, e1.episode, 0, ints)
+        before = torch.cuda.memory_allocated()
+        ret = torch.ops.mgx.step_autoreset_out(e2.cells, e2.agents, e2.rng, e2.step_count, act, None, e2.err, pg, pa, None, e2.episode, 0,
+                                               ints, o["obs"], o["dir"], o["rew"], o["term"], o["trunc"], o["was"])
+        assert ret is None and torch.cuda.memory_allocated() == before
+        for w, g in zip(want, (o["obs"], o["dir"], o["rew"], o["term"], o["trunc"], o["was"])):
+            assert torch.equal(w, g), t
+    assert torch.equal(e1.cells, e2.cells) and int(e1.episode.sum()) >= B
+    act = torch.from_numpy(util.random_actions(B, A, seed=99)).to(DEV)
+    want = torch.ops.mgx.step(e1.cells, e1.agents, e1.rng, e1.step_count, act, None, e1.err, ints)
+    torch.ops.mgx.step_out(e2.cells, e2.agents, e2.rng, e2.step_count, act, None, e2.err, ints, o["obs"], o["dir"], o["rew"], o["term"], o["trunc"])
+    for w, g in zip(want, (o["obs"], o["dir"], o["rew"], o["term"], o["trunc"])):
+        assert torch.equal(w, g)
+    want = torch.ops.mgx.step_one_hot(e1.cells, e1.agents, e1.rng, e1.step_count, act, None, e1.err, None, None, None, None, 0, ints)
+    torch.ops.mgx.step_one_hot_out(e2.cells, e2.agents, e2.rng, e2.step_count, act, None, e2.err, None, None, None, None, 0, ints,
+                                   oh, o["dir"], o["rew"], o["term"], o["trunc"], None)
+    assert torch.equal(want[0], oh) and torch.equal(want[2], o["rew"])
+    w_obs, w_dir = torch.ops.mgx.gen_obs(e1.cells, e1.agents, ints)
+    torch.ops.mgx.gen_obs_out(e2.cells, e2.agents, ints, o["obs"], o["dir"])
+    assert torch.equal(w_obs, o["obs"]) and torch.equal(w_dir, o["dir"])
+    w_oh, _ = torch.ops.mgx.gen_obs_one_hot(e1.cells, e1.agents, ints)
+    torch.ops.mgx.gen_obs_out(e2.cells, e2.agents, ints, oh, o["dir"])
+    assert torch.equal(w_oh, oh)
+    with pytest.raises(ValueError, match="obs"):                     # wrong shape of an output
+        torch.ops.mgx.step_out(e2.cells, e2.agents, e2.rng, e2.step_count, act, None, e2.err, ints, oh, o["dir"], o["rew"], o["term"], o["trunc"])
+    with pytest.raises(TypeError, match="reward"):
+        torch.ops.mgx.step_out(e2.cells, e2.agents, e2.rng, e2.step_count, act, None, e2.err, ints, o["obs"], o["dir"], o["rew"].float(),
+                               o["term"], o["trunc"])
+
+
+def test_the_wall_ring_contract_is_enforced_at_the_op_boundary():
+    """include/mgx.h: the outer ring of every env's grid is the reference's WALL (what multigrid/utils/obs.py:199-202 shows for
+    cells outside the grid; every _gen_grid starts from Grid.wall_rect).  A byte grid that breaks it is reported -- deferred, without
+    a host synchronisation on the call itself; packed state is checked on request by torch.ops.mgx.check_grid."""
+    spec = EnvSpec(9, 7, 2, 5, max_steps=50)
+    B = 64
+    st = util.random_state(spec, B, seed=5)
+    ints = ops.spec_to_ints(spec)
+    agents = torch.from_numpy(st["agents"]).to(DEV)
+    good = torch.from_numpy(st["grid"]).to(DEV)
+    torch.ops.mgx.gen_obs(good, agents, ints)
+    torch.ops.mgx.check_errors(0)                                    # a valid grid: nothing to report
+    holed = good.clone(); holed[3, 0, 4] = torch.tensor([1, 0, 0], dtype=torch.uint8)       # a hole in env 3's top wall
+    holed[5, 6, 0] = torch.tensor([2, 1, 0], dtype=torch.uint8)                              # a GREEN wall in env 5's ring
+    torch.ops.mgx.gen_obs(holed, agents, ints)                       # (returns: the launch is asynchronous)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="2 outer-ring cell"):
+        torch.ops.mgx.gen_obs(good, agents, ints)                    # the next op on the device raises
+    torch.ops.mgx.gen_obs(good, agents, ints)                        # (once)
+    # packed state, on request
+    cells = util.dev_cells(st["grid"], DEV)
+    assert torch.ops.mgx.check_grid(cells, agents, ints).cpu().tolist() == [0, 0, 0, 2 ** 31 - 1]
+    bad = cells.clone()
+    bad[7, 0, 0] = 0x0001                                            # ring cell = empty
+    bad[9, 3, 3] = 0x0502                                            # a wall without its opaque bit
+    bad[11, 2, 2] = 0x00f1                                           # reserved bits
+    ag = agents.clone(); ag[20, 1, 2] = 0; ag[21, 0, 1] = 7          # an agent on the ring; a direction of 7
+    assert torch.ops.mgx.check_grid(bad, ag, ints).cpu().tolist() == [2, 1, 2, 7]
+    # a tensor of another kind of device is refused before anything is launched
+    with pytest.raises(RuntimeError):
+        torch.ops.mgx.check_grid(cells, agents.cpu(), ints)
 
 
 def test_ops_are_the_compiled_library_and_step_ordered_follows_the_dict_order():

@@ -51,5 +51,14 @@ timeit("torch.cuda.current_stream(dev).cuda_stream alone", lambda: torch.cuda.cu
 ints = ops.spec_to_ints(wl.spec)
 timeit("torch.ops.mgx.step (compiled op: allocates 5 outputs)",
        lambda: torch.ops.mgx.step(env.cells, env.agents, env.rng, env.step_count, a0, None, env.err, ints))
+step_out = torch.ops.mgx.step_out
+timeit("torch.ops.mgx.step_out (compiled op: the caller's outputs)",
+       lambda: step_out(env.cells, env.agents, env.rng, env.step_count, a0, None, env.err, ints, env.obs, env.dir, env.reward,
+                        env.terminated, env.truncated))
+pg, pa, _ = env._pool
+ar_out = torch.ops.mgx.step_autoreset_out
+timeit("torch.ops.mgx.step_autoreset_out (+ layout pool, was_reset)",
+       lambda: ar_out(env.cells, env.agents, env.rng, env.step_count, a0, None, env.err, pg, pa, None, env.episode, 0, ints, env.obs,
+                      env.dir, env.reward, env.terminated, env.truncated, env.was_reset))
 x = torch.zeros(16, device=dev)
 timeit("x.add_(1) (a torch elementwise launch, for scale)", lambda: x.add_(1))

@@ -131,7 +131,7 @@ def main():
         except _lib.MgxError as e:
             print("persistent: ", e)
             continue
-        print(f"persistent  ({p['waves']} wavefronts resident; feeder = 1 workgroup)   p1 p10 p50 p90 p99 max")
+        print(f"persistent  ({p['waves']} wavefronts resident; feeder = 1 workgroup per 2048 granules)   p1 p10 p50 p90 p99 max")
         for kname in ("step", "env", "producer"):
             print(f"   {kname:9s} {pct(p[kname])}    mean {p[kname].mean():7.2f}")
         if "spans" in p:
