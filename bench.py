@@ -398,6 +398,79 @@ def rollout_point(wl, device, steps):
     return res
 
 
+def persistent_point(name, base, batch, device, T=400):
+    """Closed-loop stepping with ONE resident launch (mgx_step_persistent) fed by the shortest producer there can be
+    (mgx_persistent_feed: wait for step t-1's flags, post step t's granules), from the producer's own s_memrealtime trace; beside it
+    the same steps as one launch per step with ONE copy kernel per step as the policy (hipGraph).  In-kernel spans per wavefront
+    (granules seen -> flag stored): profiles/r4_persistent.txt."""
+    wl = workloads.make(base, batch=batch, global_batch=max(batch, workloads.GLOBAL_BATCH[base]))
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
+    B, A = wl.batch, wl.spec.num_agents
+    acts = random_actions(T, B, A, device, 1234)
+    for t in range(50):
+        env.step(acts[t], auto_reset=AUTO_RESET)
+    for _ in range(2):
+        with env.persistent(max_steps=T, auto_reset=AUTO_RESET) as ps:
+            tr = ps.feed(acts, trace=True)
+    torch.cuda.synchronize(device)
+    tr = tr.cpu().numpy().astype(np.int64) / 100.0                 # us
+    seen, posted = tr[0::2], tr[1::2]
+    k = T // 5
+    step_us = float(np.diff(posted)[k:].mean())
+    # the launches' side of the A/B: [copy kernel -> step launch] x T in one graph
+    cur = torch.zeros((B, A), dtype=torch.int8, device=device)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(device)
+    s.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for t in range(T):
+                cur.copy_(acts[t])
+                env.step(cur, auto_reset=AUTO_RESET)
+    torch.cuda.current_stream(device).wait_stream(s)
+    g.replay()
+    ms = kernel_time_ms(g.replay, 5, device, warm=1)
+    out = {"workload": wl.title, "batch": B, "wavefronts_resident": ps.waves,
+           "us_per_step": round(step_us, 3), "value": round(B * A / (step_us * 1e-6)), "unit": "agent-steps/s",
+           "env_us": round(float((seen[1:] - posted)[k:].mean()), 3), "producer_us": round(float((posted - seen[:-1])[k:].mean()), 3),
+           "launches_with_a_policy_kernel_us_per_step": round(ms * 1e3 / T, 3),
+           "note": "closed loop: env_us = granules of step t posted -> all flags of step t seen by the producer (the env's chain + "
+                   "write-through drain + the producer's flag sweep), producer_us = flags seen -> next granules posted; against one launch "
+                   "per step with one copy kernel per step as policy (two launch boundaries per step); `value`'s open-loop graph number "
+                   "has no policy and no hand-off"}
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
+def byte_grid_overhead(wl, device):
+    """The step through torch.ops.mgx.step_out on the reference's grid form, u8[B,H,W,3] (packed on the way in, unpacked into the
+    caller's tensor on the way out: two more streaming kernels per call), against the same op on packed cells."""
+    from multigrid_amd import ops
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
+    ints = ops.spec_to_ints(wl.spec)
+    acts = random_actions(4, wl.batch, wl.spec.num_agents, device, 5)
+    grid_u8 = env.grid.contiguous()
+    i = [0]
+
+    def packed():
+        torch.ops.mgx.step_out(env.cells, env.agents, env.rng, env.step_count, acts[i[0] & 3], None, env.err, ints, env.obs, env.dir,
+                               env.reward, env.terminated, env.truncated); i[0] += 1
+
+    def as_bytes():
+        torch.ops.mgx.step_out(grid_u8, env.agents, env.rng, env.step_count, acts[i[0] & 3], None, env.err, ints, env.obs, env.dir,
+                               env.reward, env.terminated, env.truncated); i[0] += 1
+    t_p = kernel_time_ms(packed, 200, device, warm=50)
+    t_b = kernel_time_ms(as_bytes, 200, device, warm=50)
+    torch.ops.mgx.check_errors(device.index or 0)
+    del env
+    torch.cuda.empty_cache()
+    return {"workload": wl.name, "batch": wl.batch, "packed_cells_ms_per_step": round(t_p, 5), "byte_grid_ms_per_step": round(t_b, 5),
+            "overhead_ms": round(t_b - t_p, 5),
+            "note": "torch.ops.mgx.step_out eager, no auto-reset; byte grid u8[B,H,W,3] = mgx_pack_grid_env (with the wall-ring check) + "
+                    "the step + mgx_unpack_grid per call"}
+
+
 def cpu_baseline(wl, threads, budget_s, sample_envs):
     """Oracle (C port of the reference algorithm, OpenMP over envs) on this host, bounded sample of the workload."""
     from oracle import binding as ob
@@ -419,7 +492,9 @@ def cpu_baseline(wl, threads, budget_s, sample_envs):
     return {"value": round(n * n_env * A / el), "unit": "agent-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} steps of the first {n_env} envs of the timed workload ({wl.name}: {wl.title}) = "
                       f"{n * n_env * A} agent-steps in {el:.1f} s; oracle/mgx_oracle.c, OpenMP over envs, {threads} thread(s), "
-                      f"no auto-reset (as the reference)"}
+                      f"no auto-reset (as the reference).  A C port of the reference's algorithm, NOT a proxy for the reference's "
+                      f"speed: the reference itself (Python, interpreter mode, 1 core) measured ~5.4e3 agent-steps/s in the build "
+                      f"container (BASELINE.md), ~580x below this port on one core"}
 
 
 def self_launch(n_gpus: int) -> int:
@@ -557,6 +632,7 @@ def main():
         if rank == 0:
             out["pipelined"] = pp
     if rank == 0:
+        out["roofline"]["cache_resident"] = bool(B * A * spec.bytes_step() < 200e6)
         if B * A * spec.bytes_step() < 200e6:
             out["roofline"]["note"] = ("working set fits the 256 MiB Infinity Cache at this batch: see roofline_large for "
                                        "the HBM-resident regime")
@@ -570,6 +646,14 @@ def main():
             out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)
             out.update(large_batch_points(device, args.large_batch))
             out["device_generation"] = generation_point(device)
+            out["roofline"]["hbm_resident"] = {k: out["roofline_large"][k] for k in ("batch", "frac", "achieved", "ms_per_launch")}
+            out["persistent"] = {}
+            for pname, pbase, pbatch in (("c2", "c2", 4096), ("c4_share8", "c4", 8192), ("c3", "c3", 16384)):
+                try:
+                    out["persistent"][pname] = persistent_point(pname, pbase, pbatch, device)
+                except Exception as e:                     # (a hand-shake that timed out must not take the bench line down)
+                    out["persistent"][pname] = {"error": repr(e)[:200]}
+            out["byte_grid_overhead"] = byte_grid_overhead(workloads.make("c4"), device)
             try:                                            # policy in the loop (examples/closed_loop.py), one hipGraph per iteration
                 sys.path.insert(0, os.path.join(ROOT, "examples"))
                 import closed_loop

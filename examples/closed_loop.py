@@ -129,14 +129,15 @@ def run_persistent(workload="c2", batch=None, steps=200, hidden=64, device="cuda
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
         else:
+            main = torch.cuda.current_stream(dev)
             with env.persistent(max_steps=steps, auto_reset=True) as ps:
-                torch.cuda.synchronize(dev)
+                main.synchronize()          # (the STREAM: a device-wide synchronize would wait for the resident launch itself)
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     policy(obs, actions)
                     _, _, rew, _, _ = ps.step(actions)
                     ret.add_(rew)
-                torch.cuda.synchronize(dev)
+                main.synchronize()
                 dt = time.perf_counter() - t0
             out["wavefronts_resident"] = ps.waves
         env.check_errors()

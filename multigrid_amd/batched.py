@@ -50,7 +50,9 @@ class PersistentSession:
 
     `ps.step(a)` = `ps.post(a)` (the actions, stream-ordered behind the policy that produced them) + `ps.wait()` (work enqueued on
     the current stream afterwards sees the step's outputs in the env's output buffers).  The env's own `step()` / `rollout()` /
-    state tensors are unavailable until the session is closed (the state lives in the launch)."""
+    state tensors are unavailable until the session is closed (the state lives in the launch).  Inside a session synchronise
+    STREAMS (`torch.cuda.current_stream().synchronize()`, events), never the device: `torch.cuda.synchronize()` waits for the
+    resident launch itself, which waits for the next actions -- until its timeout ends the session."""
 
     def __init__(self, env, max_steps: int, auto_reset: bool, timeout_ms: int):
         be = env.backend
