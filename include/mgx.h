@@ -249,7 +249,7 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
  *         MGX_GEN_LOCKEDHALLWAY        multigrid/envs/locked_hallway.py:152-201 (room_size, max_hallway_keys, max_keys_per_room; the grid
  *                                      is 3 columns of rooms x num_rooms / 2 rows, num_rooms <= 16; numpy's Generator.shuffle for
  *                                      _rand_perm; writes the whole aux; `blank` = multigrid_amd.layouts.lockedhallway_blank)
- *         MGX_GEN_PLAYGROUND           multigrid/envs/playground.py:122-137 (room_size; rooms x rooms from the grid size, at most 64
+ *         MGX_GEN_PLAYGROUND           multigrid/envs/playground.py:122-137 (room_size; rooms x rooms from the grid size, at most 16
  *                                      rooms; connect_all's doors are placed with env.np_random, roomgrid.py:104-124; `blank` =
  *                                      multigrid_amd.layouts.roomgrid_blank; spec->env_kind = MGX_KIND_EMPTY: no hook)
  *         MGX_GEN_REDBLUEDOORS         multigrid/envs/redbluedoors.py:142-168 (grid 2*size x size: agents placed in the middle

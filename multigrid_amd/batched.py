@@ -197,7 +197,7 @@ class BatchedMultiGridEnv:
         self._layout_version = 0         # bumped whenever the layout pool / generator tensors are REPLACED: sub-shards and
         self._parent = None              # captured graphs made before hold pointers into the old ones and refuse to run
         self._chain_streams = []         # side streams of the eager sub-shard form (step(..., sub_shards=P))
-        self._chains_pending = False
+        self._chains_pending, self._chains_P = False, 1
         self._session = None             # an open PersistentSession: the state lives in its launch
 
     @property
@@ -222,6 +222,7 @@ class BatchedMultiGridEnv:
                 raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
             return t.to(dtype=dtype).contiguous()
 
+        self.join()
         g = prep(grid, sp.grid_shape(B), torch.uint8)
         a = prep(agents, sp.agents_shape(B), torch.uint8)
         if validate:
@@ -249,6 +250,7 @@ class BatchedMultiGridEnv:
         else:
             self.step_count.copy_(prep(step_count, (B,), torch.int32))
         self._reset_err()
+        self._state_written()
         self._loaded = True
 
     def seed(self, seed: int):
@@ -257,16 +259,28 @@ class BatchedMultiGridEnv:
         (multigrid/base.py:269).  Keyed on the pair so that consecutive experiment seeds share no stream (seed + index
         would give env b under seed s+1 the stream of env b+1 under seed s), and a pure function of the GLOBAL env index
         so that sharding does not change any env's stream."""
+        self.join()
         idx = self.first_env + np.arange(self.batch)
         self.rng.copy_(torch.from_numpy(rnglib.words_from_seed_and_index(seed, idx).view(np.int64)))
+        self._state_written()
 
     def seed_synthetic(self, seed: int):
         """Benchmark-grade seeding: valid PCG64 states from a hash of the global env index (fast for large B)."""
+        self.join()
         words = rnglib.synthetic_words(self.batch, seed, self.first_env)
         self.rng.copy_(torch.from_numpy(words.view(np.int64)))
+        self._state_written()
 
     def _reset_err(self):
         self.err.copy_(torch.tensor([0, INT32_MAX], dtype=torch.int32))
+
+    def _state_written(self):
+        """The env state (np_random, step counts, grids) was replaced from outside: what the staged generator prepared from the
+        old state is void (the slots are a cache: dropping them is always valid), and nothing of the old state is in flight."""
+        st = (getattr(self, "_gen", None) or {}).get("stage")
+        if st is not None:
+            st["tag"][:, 0] = -1
+            st["tag"][:, 3] = 0
 
     # ------------------------------------------------------------------------------------------ hot path
     def gen_obs(self, one_hot: bool = False):
@@ -344,7 +358,7 @@ class BatchedMultiGridEnv:
         if sub_shards != 1:
             P = self.sub_shards_hint(auto_reset or generate, one_hot) if sub_shards == "auto" else int(sub_shards)
             P = max(1, min(P, self.batch // self.SUB_SHARD_ALIGN))
-        if P == 1 and self._chains_pending:
+        if self._chains_pending and P != self._chains_P:       # (another cut of the batch over other streams: join the old chains)
             self.join()
         key = (bool(auto_reset), bool(one_hot), generate, P)
         fast = self._bound.get(key)
@@ -356,7 +370,13 @@ class BatchedMultiGridEnv:
                 ev = self._fork_event
                 ev.record(torch.cuda.current_stream(self.device))
                 fast(actions, ev.cuda_event, hook_order)
-                self._chains_pending = True
+                # the chains read `actions` / `hook_order` on their own streams and are not joined: the caching allocator must
+                # not hand a temporary's block to the next allocation of the current stream while they still read it
+                for st in self._chain_streams[:P]:
+                    actions.record_stream(st)
+                    if hook_order is not None:
+                        hook_order.record_stream(st)
+                self._chains_pending, self._chains_P = True, P
                 return out
             if isinstance(auto_reset, bool) and isinstance(one_hot, bool):
                 self._bound[(auto_reset or generate, one_hot)] = (fast, out)       # (the hot path's entry: cleared with _bound)
@@ -454,7 +474,7 @@ class BatchedMultiGridEnv:
             c.err = self.err                                                  # (shared: the kernels update it atomically)
             c._loaded, c._act_shape, c._bound = True, torch.Size((hi - lo, self.spec.num_agents)), {}
             c._parent, c._made_version, c._layout_version = self, self._layout_version, 0
-            c._chain_streams, c._chains_pending, c._session = [], False, None
+            c._chain_streams, c._chains_pending, c._chains_P, c._session = [], False, 1, None
             c._one_hot = self._one_hot[lo:hi] if getattr(self, "_one_hot", None) is not None else None
             c._pool = getattr(self, "_pool", None)
             c._gen = None

@@ -669,9 +669,9 @@ inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_byte
     case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 3:                                                                                                // persistent stepping
-        // (the checked build leaves out the persistent kernels of the three largest views: hipcc 7.2 crashes on them with the
-        // bounds checks compiled in; the product library has them all)
-        if constexpr (MGX_BOUNDS_CHECK != 0 && V >= 11) return MGX_ERR_UNSUPPORTED;
+        // (the checked build and the tools' build leave out the persistent kernels of the three largest views: hipcc 7.2 crashes
+        // on them with the bounds checks / the debug knobs compiled in; the product library has them all)
+        if constexpr ((MGX_BOUNDS_CHECK != 0 || MGX_DEBUG_KNOBS != 0) && V >= 11) return MGX_ERR_UNSUPPORTED;
         else return launch_mode<V, 3, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);

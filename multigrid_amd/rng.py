@@ -141,7 +141,12 @@ def _u32_words(value: int) -> list:
 
 def words_from_seeds(seeds) -> np.ndarray:
     """Per-env states for per-env integer seeds (< 2^32 each): env b gets Generator(PCG64(SeedSequence(seeds[b])))."""
-    seeds = np.asarray(seeds, dtype=np.uint64)
+    seeds = np.asarray(seeds)
+    if seeds.dtype.kind not in "iu":
+        raise TypeError("seeds must be integers")
+    if seeds.size and seeds.dtype.kind == "i" and int(seeds.min()) < 0:   # (a cast to uint64 would wrap them into other streams)
+        raise ValueError("seeds must be non-negative")
+    seeds = seeds.astype(np.uint64)
     if seeds.size and int(seeds.max()) >> 32:
         return np.stack([words_from_seed(int(s)) for s in seeds])
     return _pcg64_words_from_entropy([seeds.astype(np.uint32)])

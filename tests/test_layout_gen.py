@@ -189,6 +189,46 @@ def test_rollout_with_device_generation_equals_steps(one_hot):
 
 
 @pytest.mark.gpu
+def test_staged_slots_are_a_cache_not_state():
+    """The staging slots of the truncation resets (include/mgx.h: MgxGenStage) must never change results: staged == unstaged bit for
+    bit when (a) the caller replaces np_random / the step counts mid-episode AFTER the snapshot was taken (seed_synthetic, a
+    partial load of step counts), and (b) a truncated env is stepped once more WITHOUT auto-reset and only then with it (the slot
+    was made for np_random as it was at the truncation step)."""
+    name, spec, gen, B = CASES[0]
+    dev = "cuda:0"
+    M = spec.max_steps
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    acts = torch.randint(0, 7, (3 * M, B, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+
+    def run(staged, scenario):
+        env = _make(spec, gen, B, dev)
+        env.set_layout_generator(layout_seed=11, staged=staged, **gen)
+        outs = []
+        for t in range(2 * M + 4):
+            if scenario == "reseed" and t == M - 1:              # the snapshot (step M - 2) is taken, its slot generated: now
+                env.seed_synthetic(77)                           # np_random is replaced
+            if scenario == "step_past" and t == M - 1:
+                o = env.step(acts[t], auto_reset=False)          # the truncating step, without auto-reset ...
+                outs.append([x.clone() for x in o])
+                continue                                         # ... the envs are regenerated one step LATER
+            o = env.step(acts[t], auto_reset=True)
+            outs.append([x.clone() for x in o] + [env.was_reset.clone()])
+        env.check_errors()
+        return outs, {f: getattr(env, f).clone() for f in ("cells", "agents", "rng", "step_count", "aux", "episode")}, \
+            env._gen["gen_state"].clone()
+
+    for scenario in ("reseed", "step_past"):
+        (o1, s1, g1), (o2, s2, g2) = run(True, scenario), run(False, scenario)
+        for t, (a, b) in enumerate(zip(o1, o2)):
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), f"{scenario}: step {t} output {k}"
+        for f in s1:
+            assert torch.equal(s1[f], s2[f]), f"{scenario}: {f}"
+        assert torch.equal(g1, g2), scenario
+        assert int(s1["episode"].sum()) >= B
+
+
+@pytest.mark.gpu
 def test_generated_bup_episodes_have_the_reference_structure():
     dev = "cuda:0"
     spec = EnvSpec(11, 6, 2, 7, max_steps=1, joint_reward=True, env_kind="blockedunlockpickup")
