@@ -366,7 +366,7 @@ MGX_HD int handle_actions(const StepCfg &cf, uint8_t *tile, uint64_t *rows, cons
     const int A = cf.A;
     int rc = 0;
     for (int k = k0; k < A; ++k) {                   // k0 = 1: the first visited agent's turn has been committed by the caller
-        const int i = (A == 1) ? 0 : ord[k];
+        const int i = (A == 1) ? 0 : (ord[k] & 0x1f);        // (the kernel marks entries in bits 6, 7)
         // (after an unknown action the reference has raised: the later agents do nothing)
         if (agent_turn(cf, tile, rows, i, act[i], rc == 0, rew, step_count, dirty, aux, env_kind)) rc = MGX_ERR_UNKNOWN_ACTION;
     }
@@ -416,6 +416,26 @@ MGX_HD bool spec_cell_conflict(const int32_t *woff /* [A]: cell written by agent
 // m_*: bit j = agent j of this env
 MGX_HD bool spec_needs_fallback(uint64_t m_bad, uint64_t m_conflict, uint64_t m_presence, uint64_t m_moved) {
     return (m_bad != 0) | (m_conflict != 0) | ((m_presence != 0) & (m_moved != 0));
+}
+
+// The sequential fallback, shortened (round 4).  In the reference's loop the agent visited at rank r sees the effects of the agents
+// ranked before it.  Its order-free evaluation (against the PRE-step state) is therefore still exact when none of THOSE changed
+// an input of it: its front cell (when its action reads it), or -- when its outcome used the other agents' positions -- anybody's
+// position.  `prefix_blocked` says whether agent `i` (rank `my_rank`) is NOT such an agent; events and unknown actions always
+// block (the sequential loop owns their bookkeeping).  The env's cutoff = the lowest blocked rank: the agents ranked below it are
+// committed in parallel with the order-free results, the loop starts at the cutoff (one lane walking through 16 agents costs
+// ~0.85 us each, and a launch lasts as long as its slowest wavefront: C5).
+//   ord: the env's visiting order (ord[k] & 0x1f = agent visited k-th)   woff: [A] cell offset each agent writes or -1 (readable
+//   garbage when !woff_valid: no agent of the wavefront writes at all)   m_moved: bit j = agent j of THIS env moves
+MGX_HD bool prefix_blocked(const AgentEval &ev, int my_rank, const uint8_t *ord, const int32_t *woff, bool woff_valid,
+                            uint64_t m_moved, int A) {
+    bool block = ev.bad | ev.success | ev.failure;
+    (void)A;
+    for (int k = 0; k < my_rank; ++k) {
+        const int j = ord[k] & 0x1f;                         // (bits 6, 7: the kernel's marks; agents are < MGX_MAX_AGENTS = 32)
+        block |= (ev.reads_cell & woff_valid & (woff[j] == ev.off)) | (ev.used_presence & (bool)((m_moved >> j) & 1ull));
+    }
+    return block;
 }
 
 // The env subclasses' step() post-hooks, run after the base step on the CLEAN tile (no agent overlay) with the

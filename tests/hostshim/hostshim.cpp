@@ -77,8 +77,25 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
             if ((acts[ai] & event_ends_self(cf, ev[ai])) | (m_ends_all != 0))
                 reinterpret_cast<uint8_t *>(rows)[ai * MGX_AGENT_STRIDE + AG_TERM] = 1;
         }
-    } else {
+    } else if (force_serial || A == 1) {
         rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty, aux, sp->env_kind);
+    } else {
+        // the kernel's shortened fallback: the agents ranked below the first blocked one commit with the order-free results, the
+        // reference's loop starts at that cutoff (mgx_rules.h: prefix_blocked)
+        bool any_writes = false;
+        for (int ai = 0; ai < A; ++ai) any_writes |= ev[ai].writes;
+        int cut = A;
+        for (int ai = 0; ai < A; ++ai) {
+            const int rank = draw_rank(rnd.data(), A, ai);
+            if (prefix_blocked(ev[ai], rank, ord.data(), woff.data(), any_writes, m_moved, A) && rank < cut) cut = rank;
+        }
+        for (int k = 0; k < cut; ++k) {
+            const int ai = ord[k];
+            if (ev[ai].go) rows[ai] = ev[ai].nrow;
+            if (ev[ai].unstale) aux[4] = 0;
+            if (ev[ai].writes) { store_cell(tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
+        }
+        rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty, aux, sp->env_kind, cut);
     }
     *n_dirty = fallback ? -nd - 1 : nd;          // negative = the sequential loop ran
     // the kernel's per-agent overlay (one lane per agent): offsets from the PRE-hook rows, cells written after the hook
