@@ -72,7 +72,10 @@
 #ifndef MGX_H
 #define MGX_H
 
+#if !defined(__HIPCC_RTC__)      /* (hipRTC has the fixed-width integer types built in and no system headers) */
+#include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -386,6 +389,27 @@ int mgx_step_ex(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, voi
 int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t parts, void *const *streams,
                     void *fork_event);
 int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t *parts);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Shape specialisation for ANY shape, at run time (ABI 8).  The library carries shape-specialised instantiations of the step
+ * kernel for the shapes BASELINE.json names (MgxLaunchInfo.fixed_shape > 0); a launch in the latency regime is a lone wavefront's
+ * instruction chain, where a compile-time (W, H, A, envs per wavefront) is worth 10-14 %.  Every other shape -- the reference
+ * registers 17 env ids (multigrid/envs/__init__.py:38-52) and users define their own -- gets the same treatment by compiling
+ * csrc/mgx_fused.h for its geometry at run time (hipRTC; multigrid_amd/jit.py does it and caches the code object) and registering
+ * the result: mgx_shape_key says what to compile for (spec, batch), mgx_shape_register loads the code object -- which must define
+ * `mgx_jit_step`, `mgx_jit_step_ar` (extern "C" kernels taking the library's kernel-argument struct) and the i32 global
+ * `mgx_jit_kernel_args_bytes` -- for the CURRENT device; later launches of the plain step with exactly that geometry run it
+ * (mgx_step / mgx_step_autoreset / mgx_step_ex without one_hot / generate / steps > 1).  Same results bit for bit: it is the same
+ * source.  Registrations live until the process ends. */
+#define MGX_SHAPE_RUNTIME_COMPILED 100     /* MgxLaunchInfo.fixed_shape of a registered runtime-compiled shape */
+typedef struct MgxShapeKey {
+    int32_t width, height, num_agents, envs_per_wavefront, hooks, view_size, dma, stream;   /* the MGX_JIT_SHAPE initialiser, in order */
+    int32_t kernel_args_bytes;   /* sizeof the kernel-argument struct of THIS library (checked against the code object's) */
+    int32_t built_in;            /* out: > 0 = the library has its own instantiation for this geometry (nothing to compile) */
+    int32_t registered;          /* out: a runtime-compiled one is registered for it on the current device */
+} MgxShapeKey;
+int mgx_shape_key(const MgxSpec *spec, int64_t batch, MgxShapeKey *key);
+int mgx_shape_register(const MgxShapeKey *key, const void *code_object, size_t bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Persistent stepping (ABI 8): closed-loop stepping without a kernel boundary per step.  Replaces the loop a caller of the

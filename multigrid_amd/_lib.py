@@ -26,7 +26,7 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
            "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid",
            "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards",
-           "mgx_pack_grid_env", "mgx_check_grid",
+           "mgx_pack_grid_env", "mgx_check_grid", "mgx_shape_key", "mgx_shape_register",
            "mgx_persistent_waves", "mgx_step_persistent", "mgx_persistent_post", "mgx_persistent_wait", "mgx_persistent_feed")
 
 

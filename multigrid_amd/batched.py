@@ -12,6 +12,8 @@ Outputs of `step` (pre-allocated, overwritten by every call -- clone what you ke
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -161,7 +163,7 @@ class PersistentSession:
 
 
 class BatchedMultiGridEnv:
-    def __init__(self, spec: EnvSpec, batch: int, device="cuda", *, first_env: int = 0, backend=None):
+    def __init__(self, spec: EnvSpec, batch: int, device="cuda", *, first_env: int = 0, backend=None, specialise=None):
         """
         spec       environment class configuration
         batch      number of envs held by THIS process (its shard of the global batch)
@@ -170,6 +172,9 @@ class BatchedMultiGridEnv:
                    results do not depend on how the batch is sharded over GPUs
         backend    launcher override used by the test-suite to exercise this host logic without a GPU;
                    product code leaves it None (= ops.HipBackend).
+        specialise True: compile a shape-specialised step kernel for this (spec, batch) at run time if the library has none built
+                   in (multigrid_amd/jit.py: hipRTC, ~1-2 s once, cached on disk; 10-14 % of a step in the latency regime, same
+                   results).  None (default): what the environment variable MGX_JIT says (unset / 0 = no).
         """
         self.spec = spec
         self.batch = int(batch)
@@ -199,6 +204,18 @@ class BatchedMultiGridEnv:
         self._chain_streams = []         # side streams of the eager sub-shard form (step(..., sub_shards=P))
         self._chains_pending, self._chains_P = False, 1
         self._session = None             # an open PersistentSession: the state lives in its launch
+        self.shape_kernel = None
+        if specialise is None:
+            specialise = os.environ.get("MGX_JIT", "0") not in ("", "0")
+        if specialise and self.device.type == "cuda" and getattr(self.backend, "name", "") == "hip":
+            self.specialise()
+
+    def specialise(self) -> str:
+        """Run this env's step on a kernel compiled for exactly its shape (multigrid_amd.jit.ensure_shape).  Returns what happened:
+        "built-in" / "registered" / "compiled" / "not-latency" / "unavailable" (also kept in `.shape_kernel`)."""
+        from . import jit
+        self.shape_kernel = jit.ensure_shape(self.spec, self.batch, self.device)
+        return self.shape_kernel
 
     @property
     def grid(self) -> torch.Tensor:

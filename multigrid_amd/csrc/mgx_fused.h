@@ -29,9 +29,26 @@
 // cell lanes as LDS broadcasts or SGPR masks, and as few VALU instructions per slot as possible.  Workgroups touch
 // disjoint memory, so the blockIdx -> XCD mapping needs no swizzle.
 #pragma once
+// (hipRTC -- the runtime compilation of shape-specialised kernels, multigrid_amd/jit.py -- has the HIP runtime built in and no
+// system headers)
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#else
+namespace __hip_internal {}
+using namespace __hip_internal;          // (where hipRTC keeps the <stdint.h> names)
+typedef unsigned long uintptr_t;
+#ifndef offsetof
+#define offsetof(t, m) __builtin_offsetof(t, m)
+#endif
+#ifndef INT_MAX
+#define INT_MAX 2147483647
+#endif
+#ifndef INT64_MAX
+#define INT64_MAX 9223372036854775807LL
+#endif
+#endif
 
 #include "mgx_rules.h"
 #include "mgx_layout_gen.h"
@@ -341,6 +358,10 @@ constexpr FixedShape kShapes[] = {
     {11, 6, 2, 8, true, 7, true, false},        // 3: MultiGrid-BlockedUnlockPickup x 2 agents (C3)
     {64, 64, 16, 1, false, 9, false, true},     // 4: the 64x64 grid x 16 agents, 9x9 views of C5 (one env per wavefront, streamed grids:
                                                 //    issue-bound at ~4 wavefronts per SIMD, so it gains less: 84.7 -> 81.5 us)
+#ifdef MGX_JIT_SHAPE
+    {MGX_JIT_SHAPE},                            // 5: ANY other shape, compiled at run time (hipRTC) from these same headers with its
+                                                //    launch geometry as MGX_JIT_SHAPE (multigrid_amd/jit.py, mgx_shape_register)
+#endif
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 constexpr int shape_slots(const FixedShape &f) { return (f.Gw * f.A + 15) / 16 * 16; }   // == slots_in_use() (all entries: <= 32 slots)
@@ -581,6 +602,11 @@ inline int match_fixed_shape(const KernelArgs &ka, bool hooks, bool persist = fa
     return 0;
 }
 
+#if !defined(__HIPCC_RTC__)      // host side: the launchers (a runtime-compiled translation unit holds kernels only)
+// Shape-specialised kernels compiled at run time and handed to mgx_shape_register (mgx_kernels.hip): looked up by the launch geometry
+// the host derived, exactly like the built-in kShapes entries.  fn[ar]: the plain step without / with the fused auto-reset.
+struct JitShape { FixedShape f; int vpw, wave_lds; hipFunction_t fn[2]; };
+const JitShape *jit_shape_lookup(const KernelArgs &ka, bool hooks);
 template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false, int GRP = kGroup>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
     if constexpr (!STREAM && !DMA && MODE < 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
@@ -627,6 +653,19 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
         case 2: kern = ar ? mgx_fused_kernel<V, 3, false, true, false, false, false, false, kGroup, 2> : mgx_fused_kernel<V, 3, false, false, false, false, false, false, kGroup, 2>; break;
         case 3: kern = ar ? mgx_fused_kernel<V, 3, true, true, false, false, false, false, kGroup, 3> : mgx_fused_kernel<V, 3, true, false, false, false, false, false, kGroup, 3>; break;
         default: break;
+        }
+    }
+    if constexpr (MODE == 1 && !OH && !GEN && GRP == kGroup && !MGX_NO_FIXED_SHAPES) {
+        if (!kern && !occupancy) {
+            if (const JitShape *js = jit_shape_lookup(ka, hooks)) {          // a runtime-compiled instantiation of this very geometry
+                size_t arg_size = sizeof(KernelArgs);
+                void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<KernelArgs *>(&ka), HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size,
+                                  HIP_LAUNCH_PARAM_END};
+                hipError_t e = hipModuleLaunchKernel(js->fn[ar ? 1 : 0], (unsigned)nwg, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds_bytes,
+                                                     stream, nullptr, config);
+                if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+                return MGX_OK;
+            }
         }
     }
     if (!kern) {
@@ -689,5 +728,7 @@ inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_byte
                     int *occupancy);
 MGX_FOR_EACH_VIEW(MGX_DECLARE_LAUNCHER)
 #undef MGX_DECLARE_LAUNCHER
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace mgx_fused

@@ -1,6 +1,7 @@
 // mgx_kernels.hip -- the C ABI of libmgx.so (include/mgx.h): argument checks, launch geometry, dispatch to the fused
 // kernel's per-view-size translation units (mgx_fused.h / mgx_fused_inst.hip).
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "mgx_fused.h"
@@ -163,7 +164,30 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
 
 inline bool misaligned(const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
 
+// runtime-compiled shape instantiations (mgx_shape_register); never removed: a launch may hold a pointer into the vector's elements,
+// so they live in a list of stable nodes
+struct JitNode { mgx_fused::JitShape s; int device; JitNode *next; };
+std::mutex g_jit_mutex;
+JitNode *g_jit_head = nullptr;
+
 }  // namespace
+
+namespace mgx_fused {
+const JitShape *jit_shape_lookup(const KernelArgs &ka, bool hooks) {
+    if (!g_jit_head) return nullptr;                                   // (the common case: one load, no lock)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    for (const JitNode *n = g_jit_head; n; n = n->next) {
+        const FixedShape &f = n->s.f;
+        if (n->device == dev && ka.sp.view_size == f.V && ((ka.flags & 2) != 0) == f.dma && ((ka.flags & 1) != 0) == f.stream
+            && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw && hooks == f.hooks
+            && ka.vpw == n->s.vpw && ka.wave_lds == n->s.wave_lds && ka.grp == kGroup)
+            return &n->s;
+    }
+    return nullptr;
+}
+}  // namespace mgx_fused
 
 extern "C" {
 
@@ -251,6 +275,55 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     out->lds_bytes = lds;
     out->slots_per_group = ka.grp;
     out->fixed_shape = match_fixed_shape(ka, spec->env_kind != MGX_KIND_EMPTY);
+    if (!out->fixed_shape && jit_shape_lookup(ka, spec->env_kind != MGX_KIND_EMPTY)) out->fixed_shape = MGX_SHAPE_RUNTIME_COMPILED;
+    return MGX_OK;
+}
+
+// ---- runtime-compiled shape specialisation (include/mgx.h: MgxShapeKey) -------------------------------------------------
+int mgx_shape_key(const MgxSpec *spec, int64_t batch, MgxShapeKey *key) {
+    int rc = check_spec(spec, batch);
+    if (rc) return rc;
+    if (!key || batch < 1) return MGX_ERR_INVALID_ARGUMENT;
+    KernelArgs ka{};
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, false, false, true);
+    if (rc) return rc;
+    const bool hooks = spec->env_kind != MGX_KIND_EMPTY;
+    key->width = spec->width; key->height = spec->height; key->num_agents = spec->num_agents; key->envs_per_wavefront = ka.Gw;
+    key->hooks = hooks ? 1 : 0; key->view_size = spec->view_size; key->dma = (ka.flags & 2) ? 1 : 0; key->stream = (ka.flags & 1) ? 1 : 0;
+    key->kernel_args_bytes = (int32_t)sizeof(KernelArgs);
+    key->built_in = match_fixed_shape(ka, hooks);
+    key->registered = jit_shape_lookup(ka, hooks) ? 1 : 0;
+    return MGX_OK;
+}
+
+int mgx_shape_register(const MgxShapeKey *key, const void *code_object, size_t bytes) {
+    if (!key || !code_object || bytes == 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (key->kernel_args_bytes != (int32_t)sizeof(KernelArgs)) return MGX_ERR_INVALID_ARGUMENT;   // built for another library
+    if (key->view_size < 3 || key->view_size > MGX_MAX_VIEW || !(key->view_size & 1) || key->num_agents < 1
+        || key->num_agents > MGX_MAX_AGENTS || key->envs_per_wavefront < 1)
+        return MGX_ERR_INVALID_ARGUMENT;
+    JitShape js{};
+    js.f = FixedShape{key->width, key->height, key->num_agents, key->envs_per_wavefront, key->hooks != 0, key->view_size, key->dma != 0,
+                      key->stream != 0};
+    js.vpw = shape_slots(js.f);
+    js.wave_lds = make_carve(js.f.W, js.f.H, js.f.A, js.f.V, js.f.Gw, js.vpw, false, js.f.hooks, false, kGroup).total();
+    int dev = 0;
+    hipModule_t mod = nullptr;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipModuleLoadData(&mod, code_object);
+    if (e == hipSuccess) e = hipModuleGetFunction(&js.fn[0], mod, "mgx_jit_step");
+    if (e == hipSuccess) e = hipModuleGetFunction(&js.fn[1], mod, "mgx_jit_step_ar");
+    int32_t *d_size = nullptr; size_t gbytes = 0; int32_t built_for = 0;
+    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&d_size), &gbytes, mod, "mgx_jit_kernel_args_bytes");
+    if (e == hipSuccess) e = hipMemcpy(&built_for, d_size, sizeof built_for, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return MGX_ERR_LAUNCH; }
+    if (built_for != (int32_t)sizeof(KernelArgs)) return MGX_ERR_INVALID_ARGUMENT;              // compiled from other headers
+    if (js.wave_lds * 4 > 64 * 1024)
+        for (int k = 0; k < 2; ++k)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(js.fn[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    g_jit_head = new JitNode{js, dev, g_jit_head};
     return MGX_OK;
 }
 

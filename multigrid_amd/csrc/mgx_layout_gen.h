@@ -2,8 +2,10 @@
 // the fused step kernel (mgx_step_generate: the finished envs of a step are regenerated in the tail of the same launch).
 // What is restated (numpy's Generator.integers, place_obj, the two _gen_grid) and how it is pinned: mgx_layout_gen.hip.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "mgx_rules.h"
 

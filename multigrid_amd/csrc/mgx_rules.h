@@ -6,7 +6,9 @@
 //
 // Semantics follow ini/multigrid (paths relative to the reference root); see SURVEY.md App. A.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#endif
 
 #include "../../include/mgx.h"
 
