@@ -208,7 +208,7 @@ def sub_shard_launch_ms(env, P, device):
     return kernel_time_ms(step, 200, device, warm=50)
 
 
-def config_point(name, device, K, warmup, device_generated=False):
+def config_point(name, device, K, warmup, device_generated=False, steady=False):
     """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline (lock-step: one launch per
     step); `pipelined` beside it when the product's policy suggests sub-shards for it.
     device_generated: episode starts are generated ON THE DEVICE (the reference's _gen_grid with numpy-exact draws, in the
@@ -216,7 +216,12 @@ def config_point(name, device, K, warmup, device_generated=False):
     wl = workloads.make(name)
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     if device_generated:
+        # (truncation resets staged by generator launches between the steps, 64 steps ahead: set_layout_generator's default)
+        # steady: the episodes are OUT OF PHASE (uniform over the episode length: what any long rollout settles into -- every step
+        # then sees its share of truncations, ~B / max_steps, instead of one burst every max_steps steps)
         env.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6)
+        if steady:
+            env.step_count.copy_(torch.arange(wl.batch, device=device, dtype=torch.int32) % wl.spec.max_steps)
     m = measure_steps(env, K, warmup, "graph", lambda: None, seed=4321, min_region_ms=30.0)
     env.check_errors()
     B, A = wl.batch, wl.spec.num_agents
@@ -225,8 +230,10 @@ def config_point(name, device, K, warmup, device_generated=False):
            "view_size": wl.spec.view_size, "ms_per_step": round(m["wall_s"] * 1e3 / m["timed_steps"], 6),
            "value": round(B * A * m["timed_steps"] / m["wall_s"]), "unit": "agent-steps/s",
            "timed_steps": m["timed_steps"],
-           "layout_pool": "generated on the device in the step's own launch (mgx_step_generate)" if device_generated
-                          else int(wl.pool[0].shape[0]),
+           "layout_pool": ("generated on the device in the step's own launch (mgx_step_generate)"
+                           + "; truncation resets staged 64 steps ahead by generator launches between the steps"
+                           + ("; episodes out of phase" if steady else ""))
+                          if device_generated else int(wl.pool[0].shape[0]),
            "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,
            "launch": env.backend.launch_info(B),
            "roofline": step_roofline(name, wl.spec, B, ms)}
@@ -641,6 +648,7 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = {c: config_point(c, device, 256, 50) for c in ("c2", "c3", "c5") if c != name}
             out["configs"]["c3_device_generated"] = config_point("c3", device, 256, 50, device_generated=True)
+            out["configs"]["c3_device_generated_steady"] = config_point("c3", device, 256, 50, device_generated=True, steady=True)
             out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}
             out["eager"]["c4_chains"] = eager_point(workloads.make("c4"), device, sub_shards="auto")
             out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)

@@ -287,6 +287,11 @@ typedef struct MgxGenStage {
     uint64_t *words;
     int32_t *tag;
     int32_t phase;
+    int32_t lead;                 /* ABI 8: the snapshot is taken `lead` steps before the truncation (0 = 2, the least the in-launch
+                                     generators need; more when the generator runs beside the steps: see `external`) */
+    int32_t external;             /* ABI 8: 1 = the step's launch carries NO generator wavefronts: the caller runs them as their own
+                                     launches on a stream beside the steps' (mgx_stage_generate), a few steps ahead of the truncation --
+                                     off the step's critical path altogether */
 } MgxGenStage;
 
 typedef struct MgxLayoutGen {
@@ -302,6 +307,15 @@ typedef struct MgxLayoutGen {
 
 int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,
                        uint64_t *rng, int32_t *step_count, uint8_t *aux, int32_t *episode, uint8_t *was_reset, void *stream);
+
+/* (ABI 8) The staging slots' generator as a launch of its own: serves every pending snapshot request of `gen->stage` (one lane
+ * per env; envs without a request cost one load).  Enqueue it on a stream BESIDE the one the steps run on, ordered behind the step
+ * that took the snapshots (an event): with gen->stage.external = 1 and a lead of a few steps the next episodes of the envs about to
+ * truncate are ready when their truncating step adopts them, and no step ever waits for a generator.  A slot that is not ready in
+ * time is simply not adopted (that env is generated in the tail of its step, as without staging): same results either way.
+ * rng = the env.np_random words of mgx_step (read: the stream increments), episode as in mgx_step_generate. */
+int mgx_stage_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, const uint64_t *rng, const int32_t *episode,
+                       void *stream);
 
 /* mgx_step followed by mgx_reset_generate, in ONE launch: the envs whose episode ends with this step (all agents terminated
  * or step_count >= max_steps after it) are regenerated in the tail of the step's own kernel; the outputs are the step's
@@ -337,7 +351,8 @@ int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar,
  *   generate     the envs whose episode ends WITH the step are regenerated on the device right after it
  *                (mgx_step_generate; needs `episode`, optional `was_reset`; not together with `auto_reset`), or NULL.  With
  *                steps = T the call enqueues T launches of the step kernel over the [t] slices (generation writes the state in
- *                device memory, which the one-launch rollout keeps in LDS between its steps): same results as T calls
+ *                device memory, which the one-launch rollout keeps in LDS between its steps): same results as T calls; every
+ *                slice of `obs` must then be 16-byte aligned (B * A * v * v * 3 a multiple of 16, else MGX_ERR_INVALID_ARGUMENT)
  *   hook_order   u8[B, A] or NULL: the order in which the env subclass' step hook visits the agents -- the reference's hooks
  *                iterate `actions.items()`, i.e. the insertion order of the caller's dict (multigrid/envs/redbluedoors.py:176,
  *                locked_hallway.py:210); row b lists agent indices in that order (a permutation of 0..A-1; agents absent from

@@ -26,7 +26,7 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
            "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid",
            "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards",
-           "mgx_pack_grid_env", "mgx_check_grid", "mgx_shape_key", "mgx_shape_register",
+           "mgx_pack_grid_env", "mgx_check_grid", "mgx_shape_key", "mgx_shape_register", "mgx_stage_generate",
            "mgx_persistent_waves", "mgx_step_persistent", "mgx_persistent_post", "mgx_persistent_wait", "mgx_persistent_feed")
 
 
@@ -44,7 +44,7 @@ class MgxAutoReset(C.Structure):
 class MgxGenStage(C.Structure):
     """include/mgx.h: struct MgxGenStage (staged generation of truncation resets)."""
     _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("aux", C.c_void_p), ("words", C.c_void_p), ("tag", C.c_void_p),
-                ("phase", C.c_int32)]
+                ("phase", C.c_int32), ("lead", C.c_int32), ("external", C.c_int32)]
 
 
 class MgxLayoutGen(C.Structure):
@@ -121,6 +121,8 @@ def lib() -> C.CDLL:
     L.mgx_reset_done.argtypes = [C.POINTER(MgxSpecC), i64, i64, C.c_int32] + [vp] * 10
     L.mgx_reset_generate.restype = C.c_int
     L.mgx_reset_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen)] + [vp] * 8
+    L.mgx_stage_generate.restype = C.c_int
+    L.mgx_stage_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen), vp, vp, vp]
     L.mgx_step_generate.restype = C.c_int
     L.mgx_step_generate.argtypes = [C.POINTER(MgxSpecC), i64, C.POINTER(MgxLayoutGen)] + [vp] * 15
     L.mgx_pack_grid.restype = C.c_int

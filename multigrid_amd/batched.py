@@ -500,6 +500,8 @@ class BatchedMultiGridEnv:
                 if self._gen.get("stage") is not None:          # (its own slice of the staging slots, its own step count)
                     st = self._gen["stage"]
                     c._gen["stage"] = {k: (v[lo:hi] if torch.is_tensor(v) else v) for k, v in st.items()}
+                    if st.get("external") and st.get("stream") is not None:
+                        c._gen["stage"]["stream"] = torch.cuda.Stream(self.device)
                     c._gen["stage"]["phase"] = [st["phase"][0]]
             if getattr(self, "episode", None) is not None:
                 c.episode, c.was_reset = self.episode[lo:hi], self.was_reset[lo:hi]
@@ -546,6 +548,10 @@ class BatchedMultiGridEnv:
                             ho = None if hook_order is None else (hook_order[t] if sh is self else hook_order[t, lo:hi])
                             sh.step(actions[t] if sh is self else actions[t, lo:hi], auto_reset=auto_reset, one_hot=one_hot,
                                     hook_order=ho)
+                for i, sh in enumerate(shards):                              # (generator streams of side-staged envs: join)
+                    gs = ((getattr(sh, "_gen", None) or {}).get("stage") or {}).get("stream")
+                    if gs is not None:
+                        (side if i == 0 else others[i - 1]).wait_stream(gs)
                 for s in others:                                             # join
                     side.wait_stream(s)
         stream.wait_stream(side)
@@ -645,7 +651,7 @@ class BatchedMultiGridEnv:
         self._layout_version += 1        #  ... and so do sub-shards and captured graphs made before: they now refuse to run)
 
     def set_layout_generator(self, kind: str, layout_seed: int = 0, *, room_size: int = 0, start=(1, 1, 0),
-                             max_hallway_keys: int = 1, max_keys_per_room: int = 2, staged: bool = True):
+                             max_hallway_keys: int = 1, max_keys_per_room: int = 2, staged=True, lead: int | None = None):
         """Episode starts generated ON THE DEVICE (mgx_reset_generate) instead of picked from a host-made pool: every
         finished env runs the reference's own `_gen_grid` (rejection-sampling placement with numpy-compatible draws) in a
         kernel, one lane per env.
@@ -658,9 +664,19 @@ class BatchedMultiGridEnv:
         `reset_done()` then regenerates every finished env; `step(auto_reset=True)` regenerates the envs whose episode ends
         with that step right after it -- in the tail of the step's own launch (mgx_step_generate), so the returned
         observation is the terminal one and the state tensors already hold the next episode's start.
-        staged       (default) truncation resets are generated two steps AHEAD by extra wavefronts beside the step's own and
-                     adopted when the episode ends (include/mgx.h: MgxGenStage) -- same results bit for bit, without the serial
-                     placement on the critical path of every step; False: always generate in the tail of the step
+        staged       how the truncation resets -- known in advance -- are kept off the step's critical path (include/mgx.h: MgxGenStage;
+                     same results bit for bit in every mode, the slots are a cache):
+                       True / "between" (default)  `lead` steps before an env truncates its step takes a snapshot of np_random; every
+                                    lead/2 steps ONE generator launch (mgx_stage_generate) between two steps serves the pending
+                                    snapshots into per-env slots; the truncating step adopts its slot (a copy).  Measured at C3 with the
+                                    episodes out of phase: 12.0 us per step, against 15.6 in-launch and 16.5 unstaged (pool: 7.3)
+                       "side"       the same generator launches on a stream of their own beside the steps (a parallel branch of a
+                                    captured graph): measured slower than "between" (14.2 us): the fork / join of the branches costs
+                                    more than the generator's few microseconds every lead/2 steps
+                       "in_launch"  round 3's form: generator wavefronts appended to every step's launch, two steps ahead
+                       False        no staging: every finished env is generated in the tail of its step
+                     (`step()` and `capture_steps()` issue the generator launches; `rollout()` does it inside mgx_step_ex)
+        lead         steps between the snapshot and the truncation (default: max_steps / 4, at most 64; 2 for "in_launch")
         """
         sp = self.spec
         if kind == "blockedunlockpickup":
@@ -693,11 +709,20 @@ class BatchedMultiGridEnv:
                      "max_hallway_keys": int(max_hallway_keys), "max_keys_per_room": int(max_keys_per_room),
                      "blank": torch.from_numpy(layouts.pack_cells(blank).view(np.int16)).to(self.device).contiguous(),
                      "gen_state": torch.from_numpy(rnglib.layout_gen_state(layout_seed, idx).view(np.int64)).to(self.device)}
+        if staged is True:
+            staged = "between"
+        if staged not in (False, "between", "side", "in_launch"):
+            raise ValueError(f"staged must be True / 'between' / 'side' / 'in_launch' / False, got {staged!r}")
         if staged and sp.num_agents > 1:         # the staging slots: a cache, not state (tag -1 = empty)
             B, dev = self.batch, self.device
             tag = torch.zeros((B, 4), dtype=torch.int32, device=dev)
             tag[:, 0] = -1
-            self._gen["stage"] = {"grid": torch.zeros((B, sp.height, sp.width), dtype=torch.int16, device=dev),
+            side = staged in ("side", "between")
+            lead = int(lead) if lead is not None else (max(2, min(64, sp.max_steps // 4)) if side else 2)
+            if not 2 <= lead < sp.max_steps or (side and lead < 4):
+                side, lead, staged = False, 2, "in_launch"      # (episodes too short to look that far ahead: the in-launch form)
+            self._gen["stage"] = {"lead": lead, "external": side, "stream": torch.cuda.Stream(dev) if side and staged == "side" and dev.type == "cuda" else None,
+                                  "grid": torch.zeros((B, sp.height, sp.width), dtype=torch.int16, device=dev),
                                   "agents": torch.zeros((B, sp.num_agents, 8), dtype=torch.uint8, device=dev),
                                   "aux": torch.zeros((B, 16), dtype=torch.uint8, device=dev) if sp.env_kind != "empty" else None,
                                   "words": torch.zeros((B, 12), dtype=torch.int64, device=dev), "tag": tag, "phase": [0]}

@@ -422,6 +422,15 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
                 one.was_reset = sa.was_reset ? sa.was_reset + t * batch : nullptr;
                 rc = step_common(spec, batch, one, stream, nullptr);
                 if (rc) return rc;
+                // staging with the generator between the steps (MgxGenStage.external): every lead / 2 steps, as the callers of the
+                // one-step form do it
+                if (gen->stage.external && gen->stage.tag) {
+                    const int every = gen->stage.lead >= 4 ? gen->stage.lead / 2 : 1;
+                    if ((gen_t.stage.phase + 1) % every == 0) {
+                        rc = mgx_stage_generate(spec, batch, &gen_t, sa.rng, sa.episode, stream);
+                        if (rc) return rc;
+                    }
+                }
             }
             return MGX_OK;
         }
@@ -442,11 +451,15 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
             if (misaligned(st.grid, 4) || misaligned(st.agents, 8) || misaligned(st.aux, 16) || misaligned(st.words, 8)
                 || misaligned(st.tag, 16))
                 return MGX_ERR_INVALID_ARGUMENT;
-            const int wpb = threads / 64;
-            const int64_t gen_waves = (batch + 63) / 64;
-            ka.gen_first_wg = nwg;
-            nwg += (gen_waves + wpb - 1) / wpb;
-            if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
+            if (st.lead < 0 || st.lead >= spec->max_steps) return MGX_ERR_INVALID_ARGUMENT;
+            if (st.lead < 2) st.lead = 2;
+            if (!st.external) {                                  // generator wavefronts behind the step's own workgroups
+                const int wpb = threads / 64;
+                const int64_t gen_waves = (batch + 63) / 64;
+                ka.gen_first_wg = nwg;
+                nwg += (gen_waves + wpb - 1) / wpb;
+                if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
+            }
         } else {
             st = MgxGenStage{};
         }
@@ -518,6 +531,40 @@ int mgx_step_one_hot(const MgxSpec *spec, int64_t batch, const MgxAutoReset *ar,
     MgxStepArgs sa = step_args(grid, agents, rng, step_count, actions, aux, obs_one_hot, dir, reward, terminated, truncated, err);
     sa.auto_reset = ar; sa.one_hot = 1;
     return step_common(spec, batch, sa, stream);
+}
+
+int mgx_stage_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, const uint64_t *rng, const int32_t *episode,
+                       void *stream) {
+    int rc = check_spec(spec, batch);
+    if (rc) return rc;
+    if (batch == 0) return MGX_OK;
+    if (!gen || !rng || !episode || !gen->blank || !gen->gen_state) return MGX_ERR_INVALID_ARGUMENT;
+    const MgxGenStage &gs = gen->stage;
+    if (!gs.grid || !gs.agents || !gs.words || !gs.tag || (!gs.aux && spec->env_kind != MGX_KIND_EMPTY) || spec->num_agents < 2)
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (misaligned(gs.grid, 4) || misaligned(gs.agents, 8) || misaligned(gs.aux, 16) || misaligned(gs.words, 8) || misaligned(gs.tag, 16)
+        || misaligned(gen->gen_state, 8) || misaligned(rng, 8) || misaligned(episode, 4))
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->width > 254 || spec->height > 254) return MGX_ERR_UNSUPPORTED;
+    rc = mgx_gen::check_layout_gen(spec, gen);
+    if (rc) return rc;
+    KernelArgs ka{};
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, false, false, false, false);     // (the generated step's carve: its LDS slice)
+    if (rc) return rc;
+    if (ka.wave_lds < 128 * spec->num_agents) return MGX_ERR_UNSUPPORTED;
+    ka.rng = const_cast<uint64_t *>(rng);
+    ka.episode = const_cast<int32_t *>(episode);
+    ka.gen = *gen;
+    ka.gen.stage.phase = -2;                             // (no request carries phase + 1 = -1: every pending one is served)
+    ka.gen.stage.lead = ka.gen.stage.lead < 2 ? 2 : ka.gen.stage.lead;
+    ka.gen_first_wg = 0;                                 // every workgroup of this launch is a generator workgroup
+    ka.T = 1;
+    const int wpb = threads / 64;
+    const int64_t gen_waves = (batch + 63) / 64;
+    nwg = (gen_waves + wpb - 1) / wpb;
+    if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    return launch(1 | 8, ka, threads, lds, nwg, static_cast<hipStream_t>(stream));
 }
 
 int mgx_step_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, MgxCell *grid, uint8_t *agents,

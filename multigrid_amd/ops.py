@@ -171,7 +171,7 @@ class HipBackend:
         st = gen.get("stage")
         if st is not None:                      # staged generation of truncation resets (include/mgx.h: MgxGenStage)
             g.stage = _lib.MgxGenStage(st["grid"].data_ptr(), st["agents"].data_ptr(), _ptr(st.get("aux")), st["words"].data_ptr(),
-                                       st["tag"].data_ptr(), int(st["phase"][0]))
+                                       st["tag"].data_ptr(), int(st["phase"][0]), int(st.get("lead", 2)), int(bool(st.get("external"))))
         return g
 
     def step_args(self, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
@@ -209,7 +209,15 @@ class HipBackend:
         device_ctx = torch.cuda.device
 
         gen_c = keep[1]
-        phase = generate[0]["stage"]["phase"] if generate is not None and generate[0].get("stage") is not None else None
+        stage = generate[0].get("stage") if generate is not None else None
+        phase = stage["phase"] if stage is not None else None
+        # staging with the generator BESIDE the steps (MgxGenStage.external): every `every` steps the pending snapshot requests are
+        # served by a launch of their own on the env's generator stream, ordered behind the step that took them
+        side = stage is not None and bool(stage.get("external"))
+        if side:
+            gen_stream, every = stage["stream"], max(1, int(stage.get("lead", 2)) // 2)
+            stage_fn, gen_ref = _lib.lib().mgx_stage_generate, C.byref(gen_c)
+            rng_ptr, episode_ptr = rng.data_ptr(), generate[1].data_ptr()
 
         def step(actions, hook_order=None):
             sa.actions = actions.data_ptr()
@@ -224,6 +232,16 @@ class HipBackend:
                     rc = fn(spec_ref, B, args_ref, _stream(dev))
             if rc:
                 _lib.check(rc, "mgx_step_ex")
+            if side and phase[0] % every == 0:
+                if gen_stream is not None:          # beside the steps: its own stream, ordered behind this step
+                    gen_stream.wait_stream(torch.cuda.current_stream(dev))
+                    handle = gen_stream.cuda_stream
+                else:                               # between the steps, every `every`-th one: the steps' own stream
+                    handle = _stream(dev)
+                with device_ctx(dev):
+                    rc = stage_fn(spec_ref, B, gen_ref, rng_ptr, episode_ptr, handle)
+                if rc:
+                    _lib.check(rc, "mgx_stage_generate")
         step._keep = (sa, keep)
         return step
 
@@ -278,7 +296,8 @@ class HipBackend:
         with torch.cuda.device(grid.device):
             rc = _lib.lib().mgx_step_ex(C.byref(self.sc), B, C.byref(sa), _stream(grid.device))
         _lib.check(rc, "mgx_rollout")
-        if generate is not None and generate[0].get("stage") is not None:      # (T launches: one phase each, mgx_kernels.hip)
+        if generate is not None and generate[0].get("stage") is not None:      # (T launches: one phase each, and the generator
+                                                                                # launches between them: mgx_kernels.hip)
             ph = generate[0]["stage"]["phase"]
             ph[0] = (ph[0] + T) & 0x3fffffff
 

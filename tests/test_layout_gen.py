@@ -189,6 +189,67 @@ def test_rollout_with_device_generation_equals_steps(one_hot):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["between", "side"])
+@pytest.mark.parametrize("case", [0, 2, 5], ids=lambda k: CASES[k][0])
+def test_generator_launches_of_their_own_equal_unstaged(case, mode):
+    """MgxGenStage.external (set_layout_generator(staged="between" -- the default -- / "side")): the staging slots are filled by
+    launches of their own (mgx_stage_generate), `lead` steps ahead of each truncation, between the steps or on a stream beside
+    them.  Bit-identical to generating every episode in the tail of its step -- eagerly, as a captured hipGraph and as a rollout --
+    and the slots ARE used (adoptions happen)."""
+    name, spec, gen, B = CASES[case]
+    if spec.max_steps < 6:
+        spec = EnvSpec(**{**spec.as_dict(), "max_steps": 9})
+    dev = "cuda:0"
+    T = 5 * spec.max_steps + 2
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    acts = torch.randint(0, 7, (T, B, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+
+    def make(staged, lead=None):
+        env = _make(spec, gen, B, dev)
+        env.set_layout_generator(layout_seed=11, staged=staged, lead=lead, **gen)
+        env.step_count.copy_(torch.arange(B, device=dev, dtype=torch.int32) % spec.max_steps)      # episodes out of phase
+        return env
+
+    ref, side = make(False), make(mode, lead=4)
+    assert side._gen["stage"]["external"] and side._gen["stage"]["lead"] == 4
+    assert (side._gen["stage"]["stream"] is not None) == (mode == "side")
+    for t in range(T):
+        want = [x.clone() for x in ref.step(acts[t], auto_reset=True)] + [ref.was_reset.clone()]
+        got = list(side.step(acts[t], auto_reset=True)) + [side.was_reset]
+        for k, (w, gg) in enumerate(zip(want, got)):
+            assert torch.equal(w, gg), f"{name} step {t} output {k}"
+    torch.cuda.synchronize()
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(ref, f), getattr(side, f)), f
+    assert torch.equal(ref._gen["gen_state"], side._gen["gen_state"])
+    served = int((side._gen["stage"]["tag"][:, 0] >= 0).sum())
+    assert served > B // 2, served                                   # the generator launches did fill the slots
+    # ... and as a graph: the generator launches are parallel branches of the captured block
+    ref2, side2 = make(False), make(mode, lead=4)
+    K = 2 * spec.max_steps
+    graph = side2.capture_steps(acts[:K], auto_reset=True)
+    for rep in range(2):
+        graph.replay()
+        for t in range(K):
+            ref2.step(acts[t], auto_reset=True)
+    torch.cuda.synchronize()
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode", "obs", "reward"):
+        assert torch.equal(getattr(ref2, f), getattr(side2, f)), f"graph: {f}"
+    side.check_errors(); side2.check_errors()
+    # the rollout form issues the generator launches inside mgx_step_ex (T launches over the [t] slices: they must be 16-byte
+    # aligned, include/mgx.h)
+    if mode == "between" and (B * spec.num_agents * spec.view_size ** 2 * 3) % 16 == 0:
+        ref3, roll = make(False), make(mode, lead=4)
+        out = roll.rollout(acts[:K], auto_reset=True)
+        for t in range(K):
+            o = ref3.step(acts[t], auto_reset=True)
+            assert torch.equal(out["obs"][t], o[0]) and torch.equal(out["was_reset"][t], ref3.was_reset), f"rollout step {t}"
+        for f in ("cells", "agents", "rng", "step_count", "aux", "episode"):
+            assert torch.equal(getattr(ref3, f), getattr(roll, f)), f"rollout: {f}"
+        assert int((roll._gen["stage"]["tag"][:, 0] >= 0).sum()) > B // 2
+
+
+@pytest.mark.gpu
 def test_staged_slots_are_a_cache_not_state():
     """The staging slots of the truncation resets (include/mgx.h: MgxGenStage) must never change results: staged == unstaged bit for
     bit when (a) the caller replaces np_random / the step counts mid-episode AFTER the snapshot was taken (seed_synthetic, a
