@@ -199,9 +199,23 @@ __global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restric
     uint16_t v[8];
     int x = 0, y = 0;
     if (W > 0) { const int r = (int)(i0 % ((int64_t)W * H)); y = r / W; x = r - y * W; }
+    // 8 cells = 24 bytes: three 8-byte loads when the chunk is whole and aligned (byte loads otherwise)
+    uint32_t w6[6];
+    const bool whole = i0 + 8 <= n && (reinterpret_cast<uintptr_t>(c3) & 7) == 0;
+    if (whole) {
+        const u32x2 *src = reinterpret_cast<const u32x2 *>(c3 + i0 * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const u32x2 t = src[k]; w6[2 * k] = t.x; w6[2 * k + 1] = t.y; }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const uint32_t c = (i0 + k < n) ? load_obs_cell(c3 + (i0 + k) * 3) : 0u;
+        uint32_t c;
+        if (whole) {                                                     // bytes [3k, 3k + 3) of the 24
+            const int d = (3 * k) >> 2, sh = 8 * ((3 * k) & 3);
+            c = (sh <= 8 ? w6[d] >> sh : (w6[d] >> sh) | (w6[d + 1] << (32 - sh))) & 0xffffffu;
+        } else {
+            c = (i0 + k < n) ? load_obs_cell(c3 + (i0 + k) * 3) : 0u;
+        }
         nbad += ((c & 0xf0u) != 0) | (((c >> 8) & 0xf8u) != 0) | (((c >> 16) & 0xfcu) != 0);
         v[k] = (uint16_t)cell_pack(c);
         if (W > 0) {
@@ -265,6 +279,21 @@ __global__ __launch_bounds__(256) void check_grid_kernel(const uint16_t *__restr
 __global__ __launch_bounds__(256) void unpack_grid_kernel(const uint16_t *__restrict__ in, int64_t n, uint8_t *__restrict__ c3) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i0 >= n) return;
+    if (i0 + 8 <= n && ((reinterpret_cast<uintptr_t>(in) & 15) | (reinterpret_cast<uintptr_t>(c3) & 7)) == 0) {
+        // one 16-byte load, 24 bytes out as three 8-byte stores
+        const u32x4 p = *reinterpret_cast<const u32x4 *>(in + i0);
+        const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = cell_unpack((pw[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        uint32_t o[6];
+        o[0] = c[0] | (c[1] << 24);               o[1] = (c[1] >> 8) | (c[2] << 16);   o[2] = (c[2] >> 16) | (c[3] << 8);
+        o[3] = c[4] | (c[5] << 24);               o[4] = (c[5] >> 8) | (c[6] << 16);   o[5] = (c[6] >> 16) | (c[7] << 8);
+        u32x2 *dst = reinterpret_cast<u32x2 *>(c3 + i0 * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dst[k] = u32x2{o[2 * k], o[2 * k + 1]};
+        return;
+    }
     for (int k = 0; k < 8 && i0 + k < n; ++k) store_obs_cell(c3 + (i0 + k) * 3, cell_unpack(in[i0 + k]));
 }
 
