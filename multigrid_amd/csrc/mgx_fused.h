@@ -663,7 +663,7 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
                                   HIP_LAUNCH_PARAM_END};
                 hipError_t e = hipModuleLaunchKernel(js->fn[ar ? 1 : 0], (unsigned)nwg, 1, 1, (unsigned)threads, 1, 1, (unsigned)lds_bytes,
                                                      stream, nullptr, config);
-                if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+                if (e != hipSuccess) { *hip_err = (int)e; (void)hipGetLastError(); return MGX_ERR_LAUNCH; }
                 return MGX_OK;
             }
         }
@@ -686,12 +686,12 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+        if (e != hipSuccess) { *hip_err = (int)e; (void)hipGetLastError(); return MGX_ERR_LAUNCH; }   // (off HIP's sticky state too)
     }
     if (occupancy) {        // query only (mgx_sub_shards): workgroups of this instantiation that one CU holds at a time
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, reinterpret_cast<const void *>(kern), threads,
                                                                     (size_t)lds_bytes);
-        if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+        if (e != hipSuccess) { *hip_err = (int)e; (void)hipGetLastError(); return MGX_ERR_LAUNCH; }
         return MGX_OK;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, stream, ka);

@@ -55,6 +55,17 @@ using namespace mgx_fused;
 int launch(int mode, const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *occupancy = nullptr);
 
 int g_last_hip_error = 0;
+
+// A HIP call of ours failed: remember its code for mgx_last_hip_error() AND take it off HIP's own per-thread "last error".  HIP keeps
+// a failed call's code sticky until somebody reads it with hipGetLastError(); PyTorch reads it after every launch of its own
+// (C10_HIP_KERNEL_LAUNCH_CHECK) -- so an entry point that reports a failure through its return code but leaves the sticky state set
+// makes the caller's NEXT torch op raise "device kernel image is invalid" (found by the test-suite: a refused mgx_shape_register,
+// then torch.zeros).  Every failure path of this library that is not a kernel launch (those read the state themselves) goes here.
+int hip_failed(hipError_t e) {
+    g_last_hip_error = (int)e;
+    (void)hipGetLastError();
+    return MGX_ERR_LAUNCH;
+}
 #if MGX_DEBUG_KNOBS
 int g_debug_skip = 0;
 int g_debug_G = 0;
@@ -79,8 +90,9 @@ int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_
     KernelArgs ka = ka_in;
 #if MGX_BOUNDS_CHECK
     if (!g_bounds) {
-        if (hipMalloc(reinterpret_cast<void **>(&g_bounds), 8) != hipSuccess) return MGX_ERR_LAUNCH;
-        if (hipMemset(g_bounds, 0, 8) != hipSuccess) return MGX_ERR_LAUNCH;
+        hipError_t eb = hipMalloc(reinterpret_cast<void **>(&g_bounds), 8);
+        if (eb == hipSuccess) eb = hipMemset(g_bounds, 0, 8);
+        if (eb != hipSuccess) return hip_failed(eb);
     }
     ka.bounds = g_bounds;
 #endif
@@ -317,8 +329,11 @@ int mgx_shape_register(const MgxShapeKey *key, const void *code_object, size_t b
     int32_t *d_size = nullptr; size_t gbytes = 0; int32_t built_for = 0;
     if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&d_size), &gbytes, mod, "mgx_jit_kernel_args_bytes");
     if (e == hipSuccess) e = hipMemcpy(&built_for, d_size, sizeof built_for, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return MGX_ERR_LAUNCH; }
-    if (built_for != (int32_t)sizeof(KernelArgs)) return MGX_ERR_INVALID_ARGUMENT;              // compiled from other headers
+    if (e != hipSuccess) {
+        if (mod) (void)hipModuleUnload(mod);
+        return hip_failed(e);
+    }
+    if (built_for != (int32_t)sizeof(KernelArgs)) { (void)hipModuleUnload(mod); return MGX_ERR_INVALID_ARGUMENT; }   // compiled from other headers
     if (js.wave_lds * 4 > 64 * 1024)
         for (int k = 0; k < 2; ++k)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(js.fn[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -600,7 +615,11 @@ int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, 
     if (batch == 0) return MGX_OK;
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGX_ERR_LAUNCH;
+    {
+        hipError_t ed = hipGetDevice(&dev);
+        if (ed == hipSuccess) ed = hipGetDeviceProperties(&prop, dev);
+        if (ed != hipSuccess) return hip_failed(ed);
+    }
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
     const int simds = 4 * cus;                                         // CDNA: four SIMDs per CU
     KernelArgs ka{};
@@ -635,9 +654,9 @@ int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args,
         const int64_t lo = cuts[k], n = cuts[k + 1] - lo;
         if (n <= 0) continue;
         hipStream_t st = static_cast<hipStream_t>(streams[k]);
-        if (fork_event && hipStreamWaitEvent(st, static_cast<hipEvent_t>(fork_event), 0) != hipSuccess) {
-            g_last_hip_error = (int)hipGetLastError();
-            return MGX_ERR_LAUNCH;
+        if (fork_event) {
+            const hipError_t ew = hipStreamWaitEvent(st, static_cast<hipEvent_t>(fork_event), 0);
+            if (ew != hipSuccess) return hip_failed(ew);
         }
         MgxStepArgs sa = *args;
         MgxAutoReset ar;
@@ -698,7 +717,11 @@ static int persistent_geometry(const MgxSpec *spec, int64_t batch, const MgxStep
     if (rc) return rc;
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGX_ERR_LAUNCH;
+    {
+        hipError_t ed = hipGetDevice(&dev);
+        if (ed == hipSuccess) ed = hipGetDeviceProperties(&prop, dev);
+        if (ed != hipSuccess) return hip_failed(ed);
+    }
     // (the occupancy API is optimistic for kernels with many SGPRs -- guide: "Residency and cooperative launch" -- and a
     // workgroup that is admitted but not resident would hang the hand-shake until its timeout: at most 4 per CU are counted)
     const int64_t resident = (int64_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1) * std::min(occ, 4);

@@ -65,6 +65,14 @@ void check(int rc, const char *what) {
     TORCH_CHECK(rc == MGX_OK, what, ": ", mgx_error_string(rc), " (code ", rc, ", hip error ", mgx_last_hip_error(), ")");
 }
 
+// (a failed HIP call stays HIP's sticky "last error" until somebody reads it, and torch reads it after its own launches: take it off
+// before raising, or the caller's next torch op reports OUR failure a second time, as its own)
+bool hip_ok(hipError_t e) {
+    if (e == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 void *stream_of(const Tensor &t) { return (void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 struct DeviceGuard {
@@ -102,8 +110,8 @@ void poll_faults(int device, void *stream, bool wait = false) {
     if (it == g_faults.end() || !it->second.pending) return;
     GridFaults &f = it->second;
     if (wait) {
-        TORCH_CHECK(hipEventSynchronize(f.ev) == hipSuccess, "mgx: hipEventSynchronize failed");
-    } else if (hipEventQuery(f.ev) != hipSuccess) {
+        TORCH_CHECK(hip_ok(hipEventSynchronize(f.ev)), "mgx: hipEventSynchronize failed");
+    } else if (!hip_ok(hipEventQuery(f.ev))) {          // (hipErrorNotReady is not an error: and must not stay behind as one)
         return;
     }
     raise_faults(f, stream);
@@ -113,9 +121,9 @@ void poll_faults(int device, void *stream, bool wait = false) {
 GridFaults &faults_of(int device) {
     GridFaults &f = g_faults[device];
     if (!f.dev) {
-        TORCH_CHECK(hipMalloc((void **)&f.dev, 8) == hipSuccess && hipMemset(f.dev, 0, 8) == hipSuccess
-                    && hipHostMalloc((void **)&f.host, 8, hipHostMallocDefault) == hipSuccess
-                    && hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) == hipSuccess, "mgx: could not set up the grid check");
+        TORCH_CHECK(hip_ok(hipMalloc((void **)&f.dev, 8)) && hip_ok(hipMemset(f.dev, 0, 8))
+                    && hip_ok(hipHostMalloc((void **)&f.host, 8, hipHostMallocDefault))
+                    && hip_ok(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming)), "mgx: could not set up the grid check");
         f.host[0] = f.host[1] = 0;
     }
     return f;
@@ -159,8 +167,8 @@ Tensor as_cells(const Tensor &grid, const char *name, bool &bytes) {
     GridFaults &f = faults_of(grid.device().index());
     check(mgx_pack_grid_env(ptr<const uint8_t>(grid), grid.size(0), (int32_t)grid.size(1), (int32_t)grid.size(2), ptr<MgxCell>(out), f.dev, st),
           "mgx_pack_grid_env");
-    TORCH_CHECK(hipMemcpyAsync(f.host, f.dev, 8, hipMemcpyDeviceToHost, (hipStream_t)st) == hipSuccess
-                && hipEventRecord(f.ev, (hipStream_t)st) == hipSuccess, "mgx: could not queue the grid check's report");
+    TORCH_CHECK(hip_ok(hipMemcpyAsync(f.host, f.dev, 8, hipMemcpyDeviceToHost, (hipStream_t)st))
+                && hip_ok(hipEventRecord(f.ev, (hipStream_t)st)), "mgx: could not queue the grid check's report");
     f.pending = true;
     return out;
 }

@@ -92,3 +92,16 @@ def test_a_code_object_built_for_another_library_is_refused():
     assert jit._bind().mgx_shape_register(C.byref(bad), buf, len(code)) == _lib.ERR_INVALID_ARGUMENT
     junk = C.create_string_buffer(b"not an ELF" * 10, 100)
     assert jit._bind().mgx_shape_register(C.byref(key), junk, 100) == _lib.ERR_LAUNCH
+    assert _lib.lib().mgx_last_hip_error() != 0                     # hipErrorInvalidImage, reported through the library ...
+    # ... and NOT left behind as HIP's sticky per-thread error: torch reads that after its own launches, and the caller's next op
+    # would raise "device kernel image is invalid" for a failure that was ours and had already been reported (round 4: the full
+    # GPU suite found it -- this test, then a torch.zeros in another test)
+    x = torch.zeros(1 << 16, dtype=torch.int16, device="cuda:0")
+    x.add_(3)
+    torch.cuda.synchronize()
+    assert int(x.sum()) == 3 << 16
+    env = BatchedMultiGridEnv(spec, 512, torch.device("cuda", 0))    # (what failed in the suite: an env made after the refusal)
+    st = util.random_state(spec, 512, seed=2)
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    env.step(torch.from_numpy(util.random_actions(512, 2, seed=0)).to("cuda:0"))
+    env.check_errors()
