@@ -7,9 +7,12 @@ One "step" = one `MultiGridEnv.step` over the whole per-GPU batch = one launch o
 Headline workload = BASELINE.json's north-star configuration C4: MultiGrid-Empty-16x16-v0, agents=4, view_size=7,
 batch=65536 envs -- all of it on one GPU at N=1 (it is ~100 MB).  For N>1 (launched by `python -m torch.distributed.run
 --nproc-per-node N ...`, one rank per GPU -- or plainly as `python bench.py --gpus N`, which then launches itself that way)
-the SAME global batch is sharded over the ranks (strong scaling: 8192 envs per
-GPU at N=8); the data path has NO collective -- envs never interact -- and torch.distributed
-(RCCL) is used only for the barrier and the max-over-ranks time.
+every rank steps the configuration's batch on its own GPU (`--scaling weak`, the default: the path shards into independent envs,
+so per-GPU work is fixed and the global batch is N x 65536; rank r owns the global envs [r x 65536, (r+1) x 65536) -- seeds and
+synthetic state are functions of the global env index), and the SAME run then measures the configuration's batch split over the
+ranks (BASELINE.json configs[3] read literally: 8192 envs per GPU at N=8) and carries it in the line as `strong`
+(`--scaling strong` makes that the headline instead).  The data path has NO collective -- envs never interact (SURVEY.md section
+8e) -- and torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
 
 Timing.  W untimed warm-up steps, one untimed calibration replay, then the timed region: a hipGraph holding a whole
 number of K-step blocks is replayed until the region is >= 50 ms (a K-step region alone would be ~0.5 ms at the
@@ -21,7 +24,9 @@ t (what a policy that needs all B observations of step t before step t+1 gets; t
 `pipelined`: the same steps issued as independent chains of sub-shard launches (BatchedMultiGridEnv.capture_steps(sub_shards=
 "auto"), the product's own policy: mgx_sub_shards) -- valid for open-loop actions or a double-buffered actor loop.
 
-Prints ONE JSON line on rank 0.  Extra objects (N=1 only, except `roofline`):
+Prints ONE JSON line on rank 0.  Extra objects (N=1 only, except `roofline`, `pipelined` and -- N>1 -- `strong`):
+  strong              (N>1, weak runs) the configuration's batch split over the N GPUs: value, ms_per_step, per-rank min / max,
+                      roofline of that launch
   roofline            the fused kernel on the timed workload, by the literal definition: algorithmic bytes per launch (SURVEY.md
                       8d) / average launch duration from HIP events over the timed region on the launch stream (one launch per
                       step, back to back; rocprofv3's average for the kernel: profiles/); `traffic` = HBM bytes per launch from the
@@ -542,6 +547,11 @@ def main():
                     help="graph mode: the chains the HEADLINE steps the batch as (default 1: lock-step, one launch per step; 0 = "
                          "the product's policy, BatchedMultiGridEnv.sub_shards_hint).  The pipelined variant is reported "
                          "beside the headline either way")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak (default) = every GPU steps the configuration's batch (per-GPU work fixed, the global batch "
+                         "grows with N; envs are independent, no collective); strong = the configuration's batch split over the "
+                         "N GPUs (BASELINE.json configs[3] read literally: 65 536 envs over 8 GPUs).  A weak run also measures "
+                         "the strong point and carries it in the line as `strong`")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement + its roofline")
     args = ap.parse_args()
@@ -587,8 +597,9 @@ def main():
         return float(t.item())
 
     name = args.workload
-    G = args.global_batch or workloads.GLOBAL_BATCH[name]
-    first_env, B = shard_range(G, rank, world)                   # strong scaling: the named global batch over the ranks
+    G0 = args.global_batch or workloads.GLOBAL_BATCH[name]       # the configuration's batch
+    G = G0 * world if args.scaling == "weak" else G0             # weak: that batch on EVERY GPU; strong: split over the GPUs
+    first_env, B = shard_range(G, rank, world)                   # (seeds / synthetic state are functions of the GLOBAL env index)
     wl = workloads.make(name, batch=B, first_env=first_env, global_batch=G)
     spec, A = wl.spec, wl.spec.num_agents
     env = wl.make_env(device, auto_reset=AUTO_RESET)
@@ -604,14 +615,17 @@ def main():
     out = {
         "metric": "agent-steps/sec", "value": round(G * A * S / wall_max), "unit": "agent-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall_max * 1e3 / S, 6), "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": round(wall_max * 1e3 / S, 6), "higher_is_better": True, "scaling": args.scaling,
         "ms_per_step_ranks": {"min": round(wall_min * 1e3 / S, 6), "max": round(wall_max * 1e3 / S, 6)},
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "timed_steps": S, "timed_region_ms": round(wall_max * 1e3, 3),
         "config": {"workload": wl.title + ", uniform random actions 0..6", "name": name,
                    "global_batch": G, "batch_per_gpu": B, "agents": A, "grid": f"{spec.width}x{spec.height}",
                    "view_size": spec.view_size, "mode": args.mode,
-                   "parallelism": f"env-sharded x{world} (strong scaling of the global batch), no collective",
+                   "configuration_batch": G0,
+                   "parallelism": (f"env-sharded x{world}, no collective: " +
+                                   (f"weak scaling, the configuration's {G0} envs on every GPU" if args.scaling == "weak" else
+                                    f"strong scaling, the configuration's {G0} envs split over the GPUs")),
                    "sub_shards": P,
                    "semantics": ("lock-step: one launch of the fused kernel per step of the whole per-GPU batch, step t+1 behind "
                                  "step t" if P == 1 else
@@ -638,6 +652,24 @@ def main():
         pp["value"] = round(G * A * m2["timed_steps"] / all_max(m2["wall_s"]))
         if rank == 0:
             out["pipelined"] = pp
+    if world > 1 and args.scaling == "weak":                    # the strong point of the same configuration, same run (all ranks)
+        f2, B2 = shard_range(G0, rank, world)
+        wl2 = workloads.make(name, batch=B2, first_env=f2, global_batch=G0)
+        env2 = wl2.make_env(device, auto_reset=AUTO_RESET)
+        m3 = measure_steps(env2, args.steps, args.warmup, args.mode, barrier, seed=4321 + rank,
+                           agree=lambda n: int(all_max(float(n))), sub_shards=1)
+        env2.check_errors()
+        w3max, w3min, S3 = all_max(m3["wall_s"]), -all_max(-m3["wall_s"]), m3["timed_steps"]
+        if rank == 0:
+            out["strong"] = {"global_batch": G0, "batch_per_gpu": B2, "value": round(G0 * A * S3 / w3max), "unit": "agent-steps/s",
+                             "ms_per_step": round(w3max * 1e3 / S3, 6),
+                             "ms_per_step_ranks": {"min": round(w3min * 1e3 / S3, 6), "max": round(w3max * 1e3 / S3, 6)},
+                             "timed_steps": S3, "launch": env2.backend.launch_info(B2),
+                             "roofline": step_roofline(name, spec, B2, m3["event_ms"] / S3),
+                             "note": "the configuration's batch split over the GPUs (BASELINE.json configs[3] read literally), "
+                                     "lock step, measured in this run after the headline: at an N-th of the batch a launch is a "
+                                     "lone wavefront's instruction chain + the launch boundary, not throughput (DESIGN.md §6)"}
+        del env2
     if rank == 0:
         out["roofline"]["cache_resident"] = bool(B * A * spec.bytes_step() < 200e6)
         if B * A * spec.bytes_step() < 200e6:

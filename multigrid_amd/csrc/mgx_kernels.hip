@@ -71,8 +71,9 @@ int g_debug_skip = 0;
 int g_debug_G = 0;
 int g_debug_wpb = 0;
 int g_debug_grp = 0;
+int g_debug_lds_pad = 0;
 #else
-constexpr int g_debug_skip = 0, g_debug_G = 0, g_debug_wpb = 0, g_debug_grp = 0;
+constexpr int g_debug_skip = 0, g_debug_G = 0, g_debug_wpb = 0, g_debug_grp = 0, g_debug_lds_pad = 0;
 #endif
 
 #if MGX_BOUNDS_CHECK
@@ -88,6 +89,7 @@ int g_span_next = 0;
 
 int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *occupancy) {
     KernelArgs ka = ka_in;
+    lds_bytes += g_debug_lds_pad;
 #if MGX_BOUNDS_CHECK
     if (!g_bounds) {
         hipError_t eb = hipMalloc(reinterpret_cast<void **>(&g_bounds), 8);
@@ -224,6 +226,7 @@ int mgx_last_hip_error(void) { return g_last_hip_error; }
 void mgx_debug_skip_phases(int mask) { g_debug_skip = mask; }
 void mgx_debug_set_envs_per_wavefront(int G) { g_debug_G = G; }
 void mgx_debug_set_waves_per_workgroup(int n) { g_debug_wpb = n; }
+void mgx_debug_set_lds_pad(int bytes) { g_debug_lds_pad = bytes; }   // unused LDS bytes per workgroup: limits the wavefronts a CU holds at a time
 void mgx_debug_set_group(int g) { g_debug_grp = g; }               // 4 / 8: force the small-group latency instantiation, 16: forbid it
 #endif
 #if MGX_BOUNDS_CHECK

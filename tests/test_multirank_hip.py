@@ -46,28 +46,49 @@ def test_hip_ranks_equal_single_process(tmp_path, name, G, T, N):
 
 
 def test_bench_under_two_ranks_prints_strong_scaling_line():
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--scaling", "strong"])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "strong" not in d
+    assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 32768
+    assert "roofline" in d and "configs" not in d and "cpu_baseline" not in d      # extras are N=1 only
+
+
+def test_bench_under_two_ranks_weak_line_carries_the_strong_point():
+    """The default for N > 1: every rank steps the configuration's 65 536 envs (weak scaling; `value` = all ranks' agent-steps over
+    the slowest rank's time), and the same run measures the configuration's batch split over the ranks as `strong`."""
     out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
-    assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 32768
-    assert "roofline" in d and "configs" not in d and "cpu_baseline" not in d      # extras are N=1 only
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2 * 65536 and d["config"]["batch_per_gpu"] == 65536 and d["config"]["configuration_batch"] == 65536
+    assert abs(d["value"] - 2 * 65536 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    assert d["roofline"]["algorithmic_bytes"] == 65536 * 4 * 339
+    st = d["strong"]
+    assert st["global_batch"] == 65536 and st["batch_per_gpu"] == 32768 and st["roofline"]["algorithmic_bytes"] == 32768 * 4 * 339
+    assert abs(st["value"] - 65536 * 4 / (st["ms_per_step"] / 1e3)) / st["value"] < 0.01
+    assert "configs" not in d and "cpu_baseline" not in d
 
 
 def test_bench_under_eight_ranks_prints_the_8_gpu_line():
     """`bench.py --gpus 8` as the driver launches it (one rank per GPU; here all eight on device 0): the first real SCALE run
-    must not fail on plumbing.  8192 envs of C4 per rank, lock-step, no pipelined variant at that size."""
+    must not fail on plumbing.  65 536 envs of C4 on every rank (weak scaling), then the 8192-env split as `strong`."""
     out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], nproc=8, timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
-    assert d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 8192 and d["config"]["sub_shards"] == 1
-    assert "roofline" in d and d["roofline"]["algorithmic_bytes"] == 8192 * 4 * 339 and "pipelined" not in d
-    assert abs(d["value"] - 65536 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 8 * 65536 and d["config"]["batch_per_gpu"] == 65536 and d["config"]["sub_shards"] == 1
+    assert "roofline" in d and d["roofline"]["algorithmic_bytes"] == 65536 * 4 * 339
+    assert abs(d["value"] - 8 * 65536 * 4 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    st = d["strong"]                                                        # BASELINE.json configs[3] read literally, same run
+    assert st["global_batch"] == 65536 and st["batch_per_gpu"] == 8192 and st["roofline"]["algorithmic_bytes"] == 8192 * 4 * 339
+    assert st["launch"]["fixed_shape"] == 1 and abs(st["value"] - 65536 * 4 / (st["ms_per_step"] / 1e3)) / st["value"] < 0.01
 
 
 def test_plain_bench_gpus_8_launches_itself():
@@ -82,5 +103,5 @@ def test_plain_bench_gpus_8_launches_itself():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["config"]["batch_per_gpu"] == 8192 and d["scaling"] == "strong"
+    assert d["n_gpus"] == 8 and d["config"]["batch_per_gpu"] == 65536 and d["scaling"] == "weak" and d["strong"]["batch_per_gpu"] == 8192
     assert d["ms_per_step_ranks"]["min"] <= d["ms_per_step_ranks"]["max"] == d["ms_per_step"]
