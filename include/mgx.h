@@ -291,7 +291,11 @@ typedef struct MgxGenStage {
                                      generators need; more when the generator runs beside the steps: see `external`) */
     int32_t external;             /* ABI 8: 1 = the step's launch carries NO generator wavefronts: the caller runs them as their own
                                      launches on a stream beside the steps' (mgx_stage_generate), a few steps ahead of the truncation --
-                                     off the step's critical path altogether */
+                                     off the step's critical path altogether.  2 = the same, and the caller enqueues those launches on
+                                     the steps' OWN stream, between two steps: no generator ever runs beside a step, so the step publishes
+                                     its snapshot with plain stores (the kernel boundary orders them) instead of an agent-scope release --
+                                     which writes the XCD's L2 back, ~1.5 us for the wavefront that takes a snapshot.  Do NOT pass 2 with
+                                     generator launches on another stream. */
 } MgxGenStage;
 
 typedef struct MgxLayoutGen {

@@ -669,14 +669,14 @@ class BatchedMultiGridEnv:
                        True / "between" (default)  `lead` steps before an env truncates its step takes a snapshot of np_random; every
                                     lead/2 steps ONE generator launch (mgx_stage_generate) between two steps serves the pending
                                     snapshots into per-env slots; the truncating step adopts its slot (a copy).  Measured at C3 with the
-                                    episodes out of phase: 12.0 us per step, against 15.6 in-launch and 16.5 unstaged (pool: 7.3)
+                                    episodes out of phase: 9.7 us per step, against 15.6 in-launch and 16.6 unstaged (pool: 7.3)
                        "side"       the same generator launches on a stream of their own beside the steps (a parallel branch of a
                                     captured graph): measured slower than "between" (14.2 us): the fork / join of the branches costs
                                     more than the generator's few microseconds every lead/2 steps
                        "in_launch"  round 3's form: generator wavefronts appended to every step's launch, two steps ahead
                        False        no staging: every finished env is generated in the tail of its step
                      (`step()` and `capture_steps()` issue the generator launches; `rollout()` does it inside mgx_step_ex)
-        lead         steps between the snapshot and the truncation (default: max_steps / 4, at most 64; 2 for "in_launch")
+        lead         steps between the snapshot and the truncation (default: max_steps / 4, at most 128; 2 for "in_launch")
         """
         sp = self.spec
         if kind == "blockedunlockpickup":
@@ -718,10 +718,10 @@ class BatchedMultiGridEnv:
             tag = torch.zeros((B, 4), dtype=torch.int32, device=dev)
             tag[:, 0] = -1
             side = staged in ("side", "between")
-            lead = int(lead) if lead is not None else (max(2, min(64, sp.max_steps // 4)) if side else 2)
+            lead = int(lead) if lead is not None else (max(2, min(128, sp.max_steps // 4)) if side else 2)
             if not 2 <= lead < sp.max_steps or (side and lead < 4):
                 side, lead, staged = False, 2, "in_launch"      # (episodes too short to look that far ahead: the in-launch form)
-            self._gen["stage"] = {"lead": lead, "external": side, "stream": torch.cuda.Stream(dev) if side and staged == "side" and dev.type == "cuda" else None,
+            self._gen["stage"] = {"lead": lead, "external": (2 if staged == "between" else 1) if side else 0, "stream": torch.cuda.Stream(dev) if side and staged == "side" and dev.type == "cuda" else None,
                                   "grid": torch.zeros((B, sp.height, sp.width), dtype=torch.int16, device=dev),
                                   "agents": torch.zeros((B, sp.num_agents, 8), dtype=torch.uint8, device=dev),
                                   "aux": torch.zeros((B, 16), dtype=torch.uint8, device=dev) if sp.env_kind != "empty" else None,

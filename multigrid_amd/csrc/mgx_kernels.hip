@@ -425,6 +425,7 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
             if (occupancy) { MgxStepArgs one = sa; one.steps = 1; return step_common(spec, batch, one, stream, occupancy); }
             const int64_t BA = batch * spec->num_agents, V2 = (int64_t)spec->view_size * spec->view_size * (one_hot ? 21 : 3);
             MgxLayoutGen gen_t = *gen;
+            if (gen_t.stage.external) gen_t.stage.external = 2;                 // (the generator launches below share the steps' stream)
             for (int32_t t = 0; t < sa.steps; ++t) {
                 MgxStepArgs one = sa;
                 one.steps = 1;
@@ -471,6 +472,7 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
                 return MGX_ERR_INVALID_ARGUMENT;
             if (st.lead < 0 || st.lead >= spec->max_steps) return MGX_ERR_INVALID_ARGUMENT;
             if (st.lead < 2) st.lead = 2;
+            if (st.external < 0 || st.external > 2) return MGX_ERR_INVALID_ARGUMENT;
             if (!st.external) {                                  // generator wavefronts behind the step's own workgroups
                 const int wpb = threads / 64;
                 const int64_t gen_waves = (batch + 63) / 64;

@@ -207,6 +207,20 @@ MGX_HD uint64_t pcg64_draw_at(const uint64_t *rng, const uint64_t *jump_k, uint6
     return ((x >> rot) | (x << ((64u - rot) & 63u))) >> 11;
 }
 
+// The state n units further on, a unit being the jump `unit` = (M^k, C_k) of k draws: binary powering of the affine map
+// s -> M^k s + C_k inc (the maps commute: all are powers of one LCG step), 2 log2(n) compositions instead of n steps.
+MGX_HD void pcg64_advance(uint64_t &s_lo, uint64_t &s_hi, uint64_t inc_lo, uint64_t inc_hi, const uint64_t *unit, uint32_t n) {
+    typedef unsigned __int128 u128;
+    u128 bm = ((u128)unit[1] << 64) | unit[0], bc = ((u128)unit[3] << 64) | unit[2], am = 1, ac = 0;
+    for (; n != 0; n >>= 1) {
+        if (n & 1u) { ac = ac * bm + bc; am = am * bm; }
+        bc = bc * bm + bc;
+        bm = bm * bm;
+    }
+    const u128 st = (((u128)s_hi << 64) | s_lo) * am + (((u128)inc_hi << 64) | inc_lo) * ac;
+    s_lo = (uint64_t)st; s_hi = (uint64_t)(st >> 64);
+}
+
 // rank of draw `a` among the env's A draws = its position in argsort (stable; ties ~2^-53)   base.py:399
 MGX_HD int draw_rank(const uint64_t *rnd, int A, int a) {
     const uint64_t ra = rnd[a];

@@ -171,7 +171,7 @@ class HipBackend:
         st = gen.get("stage")
         if st is not None:                      # staged generation of truncation resets (include/mgx.h: MgxGenStage)
             g.stage = _lib.MgxGenStage(st["grid"].data_ptr(), st["agents"].data_ptr(), _ptr(st.get("aux")), st["words"].data_ptr(),
-                                       st["tag"].data_ptr(), int(st["phase"][0]), int(st.get("lead", 2)), int(bool(st.get("external"))))
+                                       st["tag"].data_ptr(), int(st["phase"][0]), int(st.get("lead", 2)), int(st.get("external") or 0))
         return g
 
     def step_args(self, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,

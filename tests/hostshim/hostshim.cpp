@@ -179,3 +179,9 @@ extern "C" int shim_pool_index(int64_t first_env, int64_t b, int32_t ep, int32_t
     return pool_index(first_env, b, ep, K, M);
 }
 
+
+// the staged generator's fast-forward (mgx_rules.h: pcg64_advance): state[0..1] after n units of k draws each, inc = state[2..3]
+extern "C" void shim_pcg64_advance(uint64_t *state4, int k, uint32_t n) {
+    const uint64_t unit[4] = {kJump.w[k][0], kJump.w[k][1], kJump.w[k][2], kJump.w[k][3]};
+    pcg64_advance(state4[0], state4[1], state4[2], state4[3], unit, n);
+}

@@ -103,3 +103,22 @@ def test_pool_index_by_multiplication_is_the_exact_remainder():
                     assert L.shim_pool_index(first, b, ep, K) == (first + b + ep * 7919) % K, (first, b, ep, K)
                     cases += 1
     assert cases > 20000
+
+
+def test_pcg64_advance_equals_that_many_numpy_draws():
+    """mgx_rules.h: pcg64_advance -- what the staged generator uses to carry a snapshot of env.np_random `lead` steps forward (A draws
+    per step, multigrid/base.py:399) -- against numpy's own generator advanced draw by draw."""
+    import ctypes as C
+    L = hostshim.lib()
+    L.shim_pcg64_advance.restype = None
+    L.shim_pcg64_advance.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_uint32]
+    m = (1 << 64) - 1
+    for seed, k, n in [(0, 2, 64), (1, 2, 128), (2, 4, 1), (3, 4, 127), (4, 3, 1000), (5, 16, 575), (6, 1, 0), (7, 32, 4097)]:
+        g = np.random.Generator(np.random.PCG64(seed))
+        st = g.bit_generator.state["state"]
+        w = (C.c_uint64 * 4)(st["state"] & m, st["state"] >> 64, st["inc"] & m, st["inc"] >> 64)
+        L.shim_pcg64_advance(w, k, n)
+        if n * k:
+            g.random(n * k)
+        st = g.bit_generator.state["state"]
+        assert (int(w[0]), int(w[1]), int(w[2]), int(w[3])) == (st["state"] & m, st["state"] >> 64, st["inc"] & m, st["inc"] >> 64), (seed, k, n)

@@ -14,18 +14,20 @@ lib.mgx_debug_read_span_flags.argtypes = [ctypes.POINTER(ctypes.c_ubyte), ctypes
 dev = torch.device("cuda", 0)
 B = 16384
 wl = workloads.make("c3", batch=B, first_env=0, global_batch=B)
-for staged in (True, False):
+for staged, out_of_phase in (("pool", True), (True, True), (True, False), (False, True)):
     env = wl.make_env(dev, auto_reset=True)
-    env.set_layout_generator("blockedunlockpickup", layout_seed=3, room_size=6, staged=staged)
+    if staged != "pool":                                    # ("pool": the fused auto-reset from the host-made layout pool, for scale)
+        env.set_layout_generator("blockedunlockpickup", layout_seed=3, room_size=6, staged=staged)
     acts = bench.random_actions(64, B, 2, dev, 7)
     # episodes out of phase: a steady ~28 truncations per step (B / max_steps) instead of all of them in one
-    env.step_count.copy_(torch.randint(0, env.spec.max_steps - 3, (B,), device=dev, dtype=torch.int32,
+    if out_of_phase:
+      env.step_count.copy_(torch.randint(0, env.spec.max_steps - 3, (B,), device=dev, dtype=torch.int32,
                                        generator=torch.Generator(device=dev).manual_seed(1)))
     for t in range(40):
         env.step(acts[t % 64], auto_reset=True)
     torch.cuda.synchronize()
     r_ = bench.measure_steps(env, 20, 5, "graph", lambda: None, 7)
-    print(f"staged={staged}: graph replay {r_['event_ms'] * 1e3 / r_['timed_steps']:.2f} us per step, episodes finished {int(env.episode.sum())}")
+    print(f"staged={staged} {'out of phase' if out_of_phase else 'in phase (no env ends in these launches)'}: graph replay {r_['event_ms'] * 1e3 / r_['timed_steps']:.2f} us per step, episodes finished {int(env.episode.sum())}")
     D, F = [], []
     for r in range(12):
         lib.mgx_debug_span_reset()
@@ -45,6 +47,8 @@ for staged in (True, False):
     D, F = np.concatenate(D), np.concatenate(F)
     d = D[:, 1] - D[:, 0]
     pc = lambda x: " ".join(f"{int(np.percentile(x, q)):6d}" for q in (1, 50, 90, 99, 100)) if len(x) else "-"
-    for name, m in (("step waves, nothing in the tail", F == 0), ("adopted a staged episode (1)", (F & 1) != 0), ("generated in the tail (2)", (F & 2) != 0),
+    print(f"   wavefronts begin (ns after the launch's first) p1 p50 p90 p99 max {pc(D[:, 0])}")
+    for name, m in (("step waves, nothing in the tail", (F & 15) == 0), ("adopted a staged episode (1)", (F & 1) != 0), ("generated in the tail (2)", (F & 2) != 0),
+                    ("left a snapshot (4), nothing else", (F & 7) == 4),
                     ("generator waves that generated (8)", (F & 8) != 0)):
         print(f"   {name:36s} {int(m.sum()):6d} waves: duration p1 p50 p90 p99 max {pc(d[m])}   end {pc(D[m, 1])}")

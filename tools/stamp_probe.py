@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase latency of ONE wavefront of the fused step kernel from in-kernel shader-clock stamps (profiling aid).
 Needs a library built with -DMGX_TIMESTAMPS=1 in place of multigrid_amd/lib/libmgx.so (tools/altlib_sweep.sh style).
-Usage (GPU box): python tools/stamp_probe.py [batch ...]"""
+Usage (GPU box): [MGX_WORKLOAD=c3 [MGX_GEN=1]] python tools/stamp_probe.py [batch ...]"""
 import ctypes
 import os
 import sys
@@ -21,6 +21,8 @@ spec = bench.workload_spec()
 names = ["start", "P0", "P0end", "AR", "P1a", "P1s", "P1s_end", "P1hook", "P1d", "P2", "P3", "P4", "P5", "P5end", "P5'", "P5end'", "end"]
 for B in [int(x) for x in sys.argv[1:]] or [4096]:
     env = bench.make_env(spec, B, dev, 0)
+    if os.environ.get("MGX_GEN"):               # the step with episode starts generated on the device (c3; staged unless MGX_GEN=unstaged)
+        env.set_layout_generator("blockedunlockpickup", layout_seed=3, room_size=6, staged=os.environ["MGX_GEN"] != "unstaged")
     acts = bench.random_actions(64, B, spec.num_agents, dev, 7)
     li = env.backend.launch_info(B)
     nw = (B + li["envs_per_wavefront"] - 1) // li["envs_per_wavefront"]
@@ -34,6 +36,8 @@ for B in [int(x) for x in sys.argv[1:]] or [4096]:
         acc = None
         reps = 20
         for r in range(reps):
+            if os.environ.get("MGX_GEN_ALL"):       # every env truncates with this step: every wavefront generates in its tail
+                env.step_count.fill_(env.spec.max_steps - 1)
             env.step(acts[20 + r], auto_reset=bench.AUTO_RESET)
             torch.cuda.synchronize()
             lib.mgx_debug_read_stamps(buf, wave)
