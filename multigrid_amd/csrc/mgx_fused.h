@@ -506,20 +506,29 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
             cell[S0 + n][it] = raw[n][it];
         }
         uint64_t cur;
+        // (a pass with at most 32 cells -- the 17 cells of the second pass of a 9x9 view -- has no high word: one writelane)
+        const bool prev_hi = V2 - 64 * pit > 32;
         if (k == 0) {
             asm volatile("v_cmp_lt_i16_e64 %0, -1, %1\n\ts_nop 1" : "=s"(cur) : "v"(raw[n][it]));   // (only one compare follows it)
-        } else {
+        } else if (prev_hi) {
             asm volatile("v_cmp_lt_i16_e64 %0, -1, %3\n\tv_writelane_b32 %1, %4, %6\n\tv_writelane_b32 %2, %5, %6"
                          : "=&s"(cur), "+v"(sbLo[pit]), "+v"(sbHi[pit])
                          : "v"(raw[n][it]), "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + pn));
+        } else {
+            asm volatile("v_cmp_lt_i16_e64 %0, -1, %2\n\ts_nop 0\n\tv_writelane_b32 %1, %3, %4"
+                         : "=&s"(cur), "+v"(sbLo[pit])
+                         : "v"(raw[n][it]), "s"((uint32_t)pend), "n"(S0 + pn));
         }
         const uint64_t act_mask = (V2 - 64 * it >= 64) ? kAll : ((1ull << ((V2 - 64 * it) & 63)) - 1ull);
         pend = cur & act_mask;                                               // (an SALU op, or nothing)
     }
     {
         constexpr int pn = (N * NW - 1) / NW, pit = (N * NW - 1) - pn * NW;
-        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                     : "+v"(sbLo[pit]), "+v"(sbHi[pit]) : "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + pn));
+        if constexpr (V2 - 64 * pit > 32)
+            asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                         : "+v"(sbLo[pit]), "+v"(sbHi[pit]) : "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + pn));
+        else
+            asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(sbLo[pit]) : "s"((uint32_t)pend), "n"(S0 + pn));
     }
 }
 
