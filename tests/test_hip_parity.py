@@ -68,6 +68,9 @@ CASES = [
     ("a2_v15", EnvSpec(24, 24, 2, 15, max_steps=40), 65, 6),
     ("a32_v7", EnvSpec(12, 12, 32, 7, max_steps=40), 37, 6),
     ("single_env", EnvSpec(8, 8, 2, 7, max_steps=256), 1, 20),
+    # the largest grids the format allows (sides <= 254: DESIGN.md section 7): one env's tile is 72 / 129 KB of a CU's 160 KB of LDS
+    ("big_grid_200x180_a3_v7", EnvSpec(200, 180, 3, 7, max_steps=40), 9, 4),
+    ("max_grid_254x254_a2_v5", EnvSpec(254, 254, 2, 5, max_steps=20), 5, 3),
 ]
 
 
