@@ -229,6 +229,7 @@ class BatchedMultiGridEnv:
         """Install an initial state (numpy arrays or tensors in the product layout).  A single env's state
         (no batch dim) is broadcast to the whole batch.  This is also the parity-injection point: the
         reference's `Grid.state` / `AgentState` go through layouts.grid_to_product / pack_agents."""
+        self._no_session("load_state")
         sp, B = self.spec, self.batch
 
         def prep(x, shape, dtype):
@@ -276,6 +277,7 @@ class BatchedMultiGridEnv:
         (multigrid/base.py:269).  Keyed on the pair so that consecutive experiment seeds share no stream (seed + index
         would give env b under seed s+1 the stream of env b+1 under seed s), and a pure function of the GLOBAL env index
         so that sharding does not change any env's stream."""
+        self._no_session("seed")
         self.join()
         idx = self.first_env + np.arange(self.batch)
         self.rng.copy_(torch.from_numpy(rnglib.words_from_seed_and_index(seed, idx).view(np.int64)))
@@ -283,6 +285,7 @@ class BatchedMultiGridEnv:
 
     def seed_synthetic(self, seed: int):
         """Benchmark-grade seeding: valid PCG64 states from a hash of the global env index (fast for large B)."""
+        self._no_session("seed_synthetic")
         self.join()
         words = rnglib.synthetic_words(self.batch, seed, self.first_env)
         self.rng.copy_(torch.from_numpy(words.view(np.int64)))
@@ -617,6 +620,7 @@ class BatchedMultiGridEnv:
 
     def set_layout_pool(self, grids, agents, auxs=None):
         """Pool of K pre-generated episode starts for `reset_done()`: u8[K,H,W,3], u8[K,A,8], u8[K,16] | None."""
+        self._no_session("set_layout_pool")
         sp = self.spec
         g = torch.as_tensor(np.asarray(grids), dtype=torch.uint8)
         a = torch.as_tensor(np.asarray(agents), dtype=torch.uint8)
@@ -678,6 +682,7 @@ class BatchedMultiGridEnv:
                      (`step()` and `capture_steps()` issue the generator launches; `rollout()` does it inside mgx_step_ex)
         lead         steps between the snapshot and the truncation (default: max_steps / 4, at most 128; 2 for "in_launch")
         """
+        self._no_session("set_layout_generator")
         sp = self.spec
         if kind == "blockedunlockpickup":
             if sp.env_kind != "blockedunlockpickup" or (sp.width, sp.height) != (2 * room_size - 1, room_size):
@@ -760,8 +765,15 @@ class BatchedMultiGridEnv:
 
     def is_done(self) -> torch.Tensor:
         """multigrid/base.py:534-539 per env: bool[B]."""
+        self._no_session("is_done")
         truncated = self.step_count >= self.spec.max_steps
         return truncated | (self.agents[:, :, 4] != 0).all(dim=1)
+
+    def _no_session(self, what: str):
+        """The state tensors are stale while a persistent session is open (the state lives in its launch, which writes it back when
+        it ends): reading or replacing them then is a mistake, not a race to win."""
+        if self._session is not None:
+            raise RuntimeError(f"{what}: a persistent session is open -- the env state lives in its launch until it is closed")
 
     def _need_state(self):
         if not self._loaded:
@@ -779,6 +791,7 @@ class BatchedMultiGridEnv:
     def state_dict(self) -> dict:
         """Everything a resumed run needs to continue bit-identically: the env state, and -- when auto-reset is in use --
         the layout pool, the per-env episode counters and the last `was_reset`."""
+        self._no_session("state_dict")
         self.join()
         sd = {"spec": self.spec.as_dict(), "first_env": self.first_env,
               "grid": self.grid.cpu().clone(), "agents": self.agents.cpu().clone(),
@@ -799,6 +812,7 @@ class BatchedMultiGridEnv:
         return sd
 
     def load_state_dict(self, sd: dict):
+        self._no_session("load_state_dict")
         if EnvSpec.from_dict(sd["spec"]) != self.spec:
             raise ValueError("state_dict was saved for a different EnvSpec")
         if int(sd.get("first_env", self.first_env)) != self.first_env:

@@ -170,3 +170,10 @@ def test_persistent_refuses_what_it_cannot_hold():
     with env2.persistent(max_steps=4, auto_reset=True):
         with pytest.raises(RuntimeError, match="persistent session is open"):
             env2.step(torch.zeros((4096, 4), dtype=torch.int8, device=dev()))
+        # ... and so is everything that reads or replaces the state tensors: they are stale until the launch writes them back
+        for call in (env2.state_dict, lambda: env2.seed(3), lambda: env2.seed_synthetic(3), env2.is_done, env2.gen_obs,
+                     lambda: env2.load_state_dict({}), lambda: env2.set_layout_pool(None, None),
+                     lambda: env2.load_state(None, None)):
+            with pytest.raises(RuntimeError, match="persistent session is open"):
+                call()
+    env2.state_dict(); env2.is_done()                  # (closed: available again)
