@@ -161,6 +161,15 @@ class PersistentSession:
                 raise
         return False
 
+    def __del__(self):
+        # a session dropped without close(): ask the launch to stop (it would otherwise wait out its timeout on the device); the env
+        # stays marked as having a session -- its state tensors are only valid once somebody has joined the launch's stream
+        try:
+            if getattr(self, "open", False):
+                self.ctrl[0:1].fill_(1)
+        except Exception:               # noqa: BLE001  (interpreter shutdown, device gone: nothing to do)
+            pass
+
 
 class BatchedMultiGridEnv:
     def __init__(self, spec: EnvSpec, batch: int, device="cuda", *, first_env: int = 0, backend=None, specialise=None):
