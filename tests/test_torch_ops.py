@@ -202,6 +202,61 @@ def test_out_variants_allocate_nothing_and_equal_the_allocating_ops():
                                o["term"], o["trunc"])
 
 
+def test_bound_step_equals_the_out_variant_and_checks_only_the_actions():
+    """torch.ops.mgx.bind_step / step_bound / unbind_step: the pointers of a step resolved and checked once, then (handle, actions)
+    per call -- for a caller that steps the same tensors in a closed loop (multigrid/base.py:303-346 called per step;
+    multigrid/rllib/__init__.py:59-63).  Same bytes as step_autoreset_out, with the fused auto-reset and the one-hot form."""
+    wl = workloads.make("c2", batch=1024, global_batch=1024)
+    spec = wl.spec
+    ints = ops.spec_to_ints(spec)
+    e1, e2 = wl.make_env(torch.device(DEV), auto_reset=True), wl.make_env(torch.device(DEV), auto_reset=True)
+    for e in (e1, e2):
+        e.step_count.fill_(spec.max_steps - 3)
+    B, A, v = 1024, spec.num_agents, spec.view_size
+
+    def outs(last):
+        return [torch.zeros((B, A, v, v, last), dtype=torch.uint8, device=DEV), torch.zeros((B, A), dtype=torch.uint8, device=DEV),
+                torch.zeros((B, A), dtype=torch.float64, device=DEV), torch.zeros((B, A), dtype=torch.uint8, device=DEV),
+                torch.zeros((B,), dtype=torch.uint8, device=DEV), torch.zeros((B,), dtype=torch.uint8, device=DEV)]
+    o1, o2 = outs(3), outs(3)
+    pg, pa, _ = e1._pool
+    h = torch.ops.mgx.bind_step(e2.cells, e2.agents, e2.rng, e2.step_count, None, e2.err, ints, o2[0], o2[1], o2[2], o2[3], o2[4],
+                                pg, pa, None, e2.episode, 0, o2[5], False)
+    assert isinstance(h, int) and h >= 0
+    for t in range(8):
+        act = torch.from_numpy(util.random_actions(B, A, seed=t)).to(DEV)
+        torch.ops.mgx.step_autoreset_out(e1.cells, e1.agents, e1.rng, e1.step_count, act, None, e1.err, pg, pa, None, e1.episode, 0,
+                                         ints, *o1)
+        before = torch.cuda.memory_allocated()
+        assert torch.ops.mgx.step_bound(h, act) is None and torch.cuda.memory_allocated() == before
+        for w, g in zip(o1, o2):
+            assert torch.equal(w, g), t
+    assert torch.equal(e1.cells, e2.cells) and torch.equal(e1.agents, e2.agents) and torch.equal(e1.rng, e2.rng)
+    assert torch.equal(e1.episode, e2.episode) and int(e1.episode.sum()) >= B
+    with pytest.raises(ValueError, match="actions"):
+        torch.ops.mgx.step_bound(h, torch.zeros((B, A + 1), dtype=torch.int8, device=DEV))
+    with pytest.raises(TypeError, match="actions"):
+        torch.ops.mgx.step_bound(h, torch.zeros((B, A), dtype=torch.int32, device=DEV))
+    torch.ops.mgx.unbind_step(h)
+    with pytest.raises(ValueError, match="no such handle"):
+        torch.ops.mgx.step_bound(h, torch.zeros((B, A), dtype=torch.int8, device=DEV))
+    # the one-hot form without auto-reset; a second handle reuses the freed slot
+    oh1, oh2 = outs(21), outs(21)
+    h2 = torch.ops.mgx.bind_step(e2.cells, e2.agents, e2.rng, e2.step_count, None, e2.err, ints, oh2[0], oh2[1], oh2[2], oh2[3], oh2[4],
+                                 None, None, None, None, 0, None, True)
+    assert h2 == h
+    act = torch.from_numpy(util.random_actions(B, A, seed=77)).to(DEV)
+    torch.ops.mgx.step_one_hot_out(e1.cells, e1.agents, e1.rng, e1.step_count, act, None, e1.err, None, None, None, None, 0, ints,
+                                   oh1[0], oh1[1], oh1[2], oh1[3], oh1[4], None)
+    torch.ops.mgx.step_bound(h2, act)
+    for w, g in zip(oh1[:5], oh2[:5]):
+        assert torch.equal(w, g)
+    torch.ops.mgx.unbind_step(h2)
+    with pytest.raises(TypeError, match="packed grid"):               # byte grids are converted per call: the out-variants take them
+        torch.ops.mgx.bind_step(torch.zeros((B, 16, 16, 3), dtype=torch.uint8, device=DEV), e2.agents, e2.rng, e2.step_count, None, e2.err,
+                                ints, o2[0], o2[1], o2[2], o2[3], o2[4], None, None, None, None, 0, None, False)
+
+
 def test_the_wall_ring_contract_is_enforced_at_the_op_boundary():
     """include/mgx.h: the outer ring of every env's grid is the reference's WALL (what multigrid/utils/obs.py:199-202 shows for
     cells outside the grid; every _gen_grid starts from Grid.wall_rect).  A byte grid that breaks it is reported -- deferred, without

@@ -60,5 +60,10 @@ ar_out = torch.ops.mgx.step_autoreset_out
 timeit("torch.ops.mgx.step_autoreset_out (+ layout pool, was_reset)",
        lambda: ar_out(env.cells, env.agents, env.rng, env.step_count, a0, None, env.err, pg, pa, None, env.episode, 0, ints, env.obs,
                       env.dir, env.reward, env.terminated, env.truncated, env.was_reset))
+h = torch.ops.mgx.bind_step(env.cells, env.agents, env.rng, env.step_count, None, env.err, ints, env.obs, env.dir, env.reward,
+                            env.terminated, env.truncated, pg, pa, None, env.episode, 0, env.was_reset, False)
+step_bound = torch.ops.mgx.step_bound
+timeit("torch.ops.mgx.step_bound (handle, actions): bound once, with auto-reset", lambda: step_bound(h, a0))
+torch.ops.mgx.unbind_step(h)
 x = torch.zeros(16, device=dev)
 timeit("x.add_(1) (a torch elementwise launch, for scale)", lambda: x.add_(1))
