@@ -160,9 +160,13 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only, ka.grp);
     struct { int total; } p{ka.wave_lds};
-    // wavefronts bundled per workgroup: 2 packs a CU's 160 KiB of LDS tighter than 4 once the chip is full (measured
-    // 403 vs 425 us at 1M envs); below that, fewer and larger workgroups launch faster (9.9 vs 10.5 us at 4096 envs)
-    int wpb = ((batch + ka.Gw - 1) / ka.Gw >= 16384) ? 2 : 4;
+    // wavefronts bundled per workgroup: ONE once the chip is full several times over -- single-wavefront workgroups pack a CU's
+    // 160 KiB of LDS tightest and refill a CU one wavefront at a time (round 4, same box: C5 78.1 / 79.0 / 82.2 us for 1 / 2 / 4,
+    // 262 144 envs of C4 59.2 / 60.5 / 60.5, 1 M envs 219.3 / 220.5 / 222.9); below that, fewer and larger workgroups launch
+    // faster (9.9 vs 10.5 us at 4096 envs; C4's 4096 wavefronts: 18.9 for 4 against 19.2 for 1)
+    // (... for the plain step's wavefronts, which hold more than 8 KiB of LDS each; the gen_obs kernel's small slices and the
+    // one-hot step stay at 2: 1 M envs gen_obs 203 us for 1 against 190-193 for 2, fused one-hot step 1.03-1.06 ms against 0.99)
+    int wpb = ((batch + ka.Gw - 1) / ka.Gw >= 16384) ? ((p.total > 8192 && !one_hot && !obs_only) ? 1 : 2) : 4;
     while (wpb > 1 && wpb * p.total > 64 * 1024) wpb >>= 1;
     if (g_debug_wpb > 0) wpb = g_debug_wpb;
     threads = 64 * wpb;
