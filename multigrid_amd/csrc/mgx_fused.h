@@ -287,7 +287,10 @@ struct LdsCarve {
     __host__ __device__ __attribute__((always_inline)) int tile() const { return roll ? own_out() + out_bytes() : own_out(); }   // grid bytes, skew + over-read
     __host__ __device__ __attribute__((always_inline)) int out() const { return roll ? own_out() : tile(); }
     __host__ __device__ __attribute__((always_inline)) int total() const {
-        const int t = tile_bytes + 32 > out_bytes() || roll ? tile_bytes + 32 : out_bytes();
+        // (the tile's 32 bytes of skew + over-read exist only when a wavefront's grid bytes are not whole 16-byte vectors: a 64x64
+        // env's 8 KiB tile + 512 bytes of slots is then exactly 17 x 512 bytes of LDS)
+        const int tile_pad = (tile_bytes & 15) ? 32 : 0;
+        const int t = tile_bytes + tile_pad > out_bytes() || roll ? tile_bytes + tile_pad : out_bytes();
         return (tile() + t + 15) & ~15;
     }
 };
