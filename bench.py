@@ -7,11 +7,12 @@ One "step" = one `MultiGridEnv.step` over the whole per-GPU batch = one launch o
 Headline workload = BASELINE.json's north-star configuration C4: MultiGrid-Empty-16x16-v0, agents=4, view_size=7,
 batch=65536 envs -- all of it on one GPU at N=1 (it is ~100 MB).  For N>1 (launched by `python -m torch.distributed.run
 --nproc-per-node N ...`, one rank per GPU -- or plainly as `python bench.py --gpus N`, which then launches itself that way)
-every rank steps the configuration's batch on its own GPU (`--scaling weak`, the default: the path shards into independent envs,
-so per-GPU work is fixed and the global batch is N x 65536; rank r owns the global envs [r x 65536, (r+1) x 65536) -- seeds and
-synthetic state are functions of the global env index), and the SAME run then measures the configuration's batch split over the
-ranks (BASELINE.json configs[3] read literally: 8192 envs per GPU at N=8) and carries it in the line as `strong`
-(`--scaling strong` makes that the headline instead).  The data path has NO collective -- envs never interact (SURVEY.md section
+the configuration's batch is SPLIT over the ranks (`--scaling strong`, the default since round 5: BASELINE.json configs[3] read
+literally -- 65536 envs sharded across the GPUs, 8192 per GPU at N=8, the shape the north star's 1e8 agent-steps/s target is stated
+on; rank r owns the global envs [r x 65536/N, (r+1) x 65536/N) -- seeds and synthetic state are functions of the global env
+index), and the SAME run then measures the weak point -- the configuration's batch on EVERY GPU, global batch N x 65536, flat by
+construction -- and carries it in the line as `weak` (`--scaling weak` makes that the headline and carries the split as
+`strong`).  The data path has NO collective -- envs never interact (SURVEY.md section
 8e) -- and torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
 
 Timing.  W untimed warm-up steps, one untimed calibration replay, then the timed region: a hipGraph holding a whole
@@ -24,9 +25,9 @@ t (what a policy that needs all B observations of step t before step t+1 gets; t
 `pipelined`: the same steps issued as independent chains of sub-shard launches (BatchedMultiGridEnv.capture_steps(sub_shards=
 "auto"), the product's own policy: mgx_sub_shards) -- valid for open-loop actions or a double-buffered actor loop.
 
-Prints ONE JSON line on rank 0.  Extra objects (N=1 only, except `roofline`, `pipelined` and -- N>1 -- `strong`):
-  strong              (N>1, weak runs) the configuration's batch split over the N GPUs: value, ms_per_step, per-rank min / max,
-                      roofline of that launch
+Prints ONE JSON line on rank 0.  Extra objects (N=1 only, except `roofline`, `pipelined` and -- N>1 -- `weak` / `strong`):
+  weak / strong       (N>1) the scaling point that is NOT the headline, measured in the same run: value, ms_per_step, per-rank
+                      min / max, roofline of that launch (`weak` beside the default strong headline)
   roofline            the fused kernel on the timed workload, by the literal definition: algorithmic bytes per launch (SURVEY.md
                       8d) / average launch duration from HIP events over the timed region on the launch stream (one launch per
                       step, back to back; rocprofv3's average for the kernel: profiles/); `traffic` = HBM bytes per launch from the
@@ -547,11 +548,12 @@ def main():
                     help="graph mode: the chains the HEADLINE steps the batch as (default 1: lock-step, one launch per step; 0 = "
                          "the product's policy, BatchedMultiGridEnv.sub_shards_hint).  The pipelined variant is reported "
                          "beside the headline either way")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak (default) = every GPU steps the configuration's batch (per-GPU work fixed, the global batch "
-                         "grows with N; envs are independent, no collective); strong = the configuration's batch split over the "
-                         "N GPUs (BASELINE.json configs[3] read literally: 65 536 envs over 8 GPUs).  A weak run also measures "
-                         "the strong point and carries it in the line as `strong`")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong (default) = the configuration's batch split over the N GPUs (BASELINE.json configs[3] read "
+                         "literally: 65 536 envs over 8 GPUs, the shape the 1e8 agent-steps/s target is stated on); weak = every "
+                         "GPU steps the configuration's batch (per-GPU work fixed, the global batch grows with N; envs are "
+                         "independent, no collective).  The run also measures the OTHER point and carries it in the line as "
+                         "`weak` / `strong`")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement + its roofline")
     args = ap.parse_args()
@@ -652,23 +654,28 @@ def main():
         pp["value"] = round(G * A * m2["timed_steps"] / all_max(m2["wall_s"]))
         if rank == 0:
             out["pipelined"] = pp
-    if world > 1 and args.scaling == "weak":                    # the strong point of the same configuration, same run (all ranks)
-        f2, B2 = shard_range(G0, rank, world)
-        wl2 = workloads.make(name, batch=B2, first_env=f2, global_batch=G0)
+    if world > 1:               # the OTHER scaling point of the same configuration, same run (all ranks): `weak` beside a strong
+                                # headline (the default), `strong` beside a weak one
+        other = "weak" if args.scaling == "strong" else "strong"
+        Go = G0 * world if other == "weak" else G0
+        f2, B2 = shard_range(Go, rank, world)
+        wl2 = workloads.make(name, batch=B2, first_env=f2, global_batch=Go)
         env2 = wl2.make_env(device, auto_reset=AUTO_RESET)
         m3 = measure_steps(env2, args.steps, args.warmup, args.mode, barrier, seed=4321 + rank,
                            agree=lambda n: int(all_max(float(n))), sub_shards=1)
         env2.check_errors()
         w3max, w3min, S3 = all_max(m3["wall_s"]), -all_max(-m3["wall_s"]), m3["timed_steps"]
         if rank == 0:
-            out["strong"] = {"global_batch": G0, "batch_per_gpu": B2, "value": round(G0 * A * S3 / w3max), "unit": "agent-steps/s",
-                             "ms_per_step": round(w3max * 1e3 / S3, 6),
-                             "ms_per_step_ranks": {"min": round(w3min * 1e3 / S3, 6), "max": round(w3max * 1e3 / S3, 6)},
-                             "timed_steps": S3, "launch": env2.backend.launch_info(B2),
-                             "roofline": step_roofline(name, spec, B2, m3["event_ms"] / S3),
-                             "note": "the configuration's batch split over the GPUs (BASELINE.json configs[3] read literally), "
-                                     "lock step, measured in this run after the headline: at an N-th of the batch a launch is a "
-                                     "lone wavefront's instruction chain + the launch boundary, not throughput (DESIGN.md §6)"}
+            out[other] = {"global_batch": Go, "batch_per_gpu": B2, "value": round(Go * A * S3 / w3max), "unit": "agent-steps/s",
+                          "scaling": other, "ms_per_step": round(w3max * 1e3 / S3, 6),
+                          "ms_per_step_ranks": {"min": round(w3min * 1e3 / S3, 6), "max": round(w3max * 1e3 / S3, 6)},
+                          "timed_steps": S3, "launch": env2.backend.launch_info(B2),
+                          "roofline": step_roofline(name, spec, B2, m3["event_ms"] / S3),
+                          "note": ("the configuration's batch on EVERY GPU (per-GPU work fixed: flat by construction, no rank waits "
+                                   "for another), lock step, measured in this run after the headline" if other == "weak" else
+                                   "the configuration's batch split over the GPUs (BASELINE.json configs[3] read literally), "
+                                   "lock step, measured in this run after the headline: at an N-th of the batch a launch is a "
+                                   "lone wavefront's instruction chain + the launch boundary, not throughput (DESIGN.md §6)")}
         del env2
     if rank == 0:
         out["roofline"]["cache_resident"] = bool(B * A * spec.bytes_step() < 200e6)

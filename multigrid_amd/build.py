@@ -48,8 +48,13 @@ def hipcc() -> str:
 
 
 def flags(defines=()) -> list[str]:
-    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-            *[f"-D{d}" for d in defines]]
+    # (hipcc 7.2's greedy register allocator crashes at -O3 on the persistent kernels of the three largest views when the bounds
+    # checks or the debug knobs are compiled in; those units of those builds are compiled at -O2, which does not -- so the checked
+    # build carries EVERY instantiation the product ships.  The product library is -O3 throughout.)
+    big_view = any(d.startswith("MGX_INST_V=") and int(d.split("=")[1]) >= 11 for d in defines)
+    instrumented = any(d.split("=")[0] in ("MGX_BOUNDS_CHECK", "MGX_DEBUG_KNOBS") for d in defines)
+    return [f"--offload-arch={ARCH}", "-O2" if big_view and instrumented else "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+            "-Wall", *[f"-D{d}" for d in defines]]
 
 
 def source_hash(defines=()) -> str:
@@ -166,7 +171,7 @@ def build_timestamps_lib(force: bool = False, verbose: bool = False) -> str:
     """lib/libmgx_ts.so: -DMGX_TIMESTAMPS=1 (every wavefront records its begin / end in s_memrealtime ticks, one block of
     records per launch; one wavefront records the shader clock at every phase marker) + the debug knobs, for
     tools/span_probe.py, tools/stamp_probe.py and tools/chain_overlap.py.  Built on demand, never by build()."""
-    return build_lib(force, verbose, LIB_TS, ("MGX_DEBUG_KNOBS=1", "MGX_TIMESTAMPS=1", "MGX_SINGLE_TU=1"))
+    return build_lib(force, verbose, LIB_TS, ("MGX_DEBUG_KNOBS=1", "MGX_TIMESTAMPS=1", "MGX_SINGLE_TU=1", "MGX_NO_BIG_PERSIST=1"))
 
 
 def build_spans_lib(force: bool = False, verbose: bool = False, only_v: int = 7) -> str:

@@ -205,6 +205,9 @@ typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 #ifndef MGX_SLOTS_SMALL_VIEW
 #define MGX_SLOTS_SMALL_VIEW 64
 #endif
+#ifndef MGX_NO_BIG_PERSIST
+#define MGX_NO_BIG_PERSIST 0
+#endif
 #ifndef MGX_NO_FIXED_SHAPES
 #define MGX_NO_FIXED_SHAPES 0     // 1: build without the shape-specialised instantiations (kShapes below): A/B builds
 #endif
@@ -450,11 +453,28 @@ __device__ __forceinline__ uint64_t state_is_open(uint32_t c) {
     return m;
 }
 
+// Remainder packing (round 5).  A 9x9 view is 64 + 17 cells: its second lane pass used 17 of 64 lanes.  The 17-cell remainders
+// of THREE views now share one pass (3 x 17 = 51 lanes): lane l of such a pass is cell 64 + l % 17 of the pass's view l / 17, so
+// 16 views take 16 + 6 passes through P2 / P4 instead of 32.  Per-view data that used to be wave-uniform in the second pass
+// becomes per-lane: the view record is read at a lane-varying address (three distinct addresses per instruction), the staging
+// address carries the view's offset; the see-behind ballot of a shared pass is split by fixed lane ranges on the scalar unit
+// (one v_writelane per view, as before), and P4 joins three views' 17-bit visibility words into the pass's lane predicate.
+// Only 9x9 views have a remainder small enough (3 R <= 64); every other view size keeps one view per pass.
+#ifndef MGX_PACK3
+#define MGX_PACK3 1
+#endif
+template <int V> constexpr bool kPack3 = (MGX_PACK3 != 0) && (MGX_P4_B16 != 0) && (MGX_P4_PERM != 0) && (V * V > 64) && (V * V <= 128)
+                                         && 3 * (V * V - 64) <= 64;
+constexpr int pack3_passes(int n) { return (n + 2) / 3; }      // remainder passes of a block of n view slots
+
 template <int V, int NIT>
 struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V + i
     uint32_t pk[NIT];       // (fw, la) as an i16 pair: forward distance V-1-j in the low half, lateral offset i - V/2 in the high
     int q3[NIT];
     bool act[NIT], own[NIT];
+    // kPack3<V>: entry [1] describes the lane's cell of a SHARED remainder pass -- cell 64 + lane % R of view `sub` = lane / R of
+    // the pass (R = V*V - 64); q3[1] includes the view's offset sub * V*V*3 in the staging area, act[1] = lane < 3 R
+    int sub16;              // sub * sizeof(ViewRec): the lane's record relative to the pass's first view
 };
 
 // ---- P2 for slots [S0, S0+N): one lane per cell: rotate-to-facing gather from the LDS tile, out-of-bounds -> wall
@@ -535,6 +555,93 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
     }
 }
 
+// ---- P2 for slots [S0, S0+N) of a view size with packed remainders (kPack3<V>): one full pass per view (cells 0..63), then one
+// pass per THREE views for their remainders.  Remainder pass p of the block covers slots S0 + 3p .. S0 + 3p + 2 and leaves its
+// cells in cell[pk3_reg(S0, N, p)][1], one view's cell per lane, in the low half of the register (never two per register).
+template <int N> constexpr int pk3_reg(int S0, int p) { return S0 / N * pack3_passes(N) + p; }
+
+template <int V, int NW, int S0, int N, int VPW, bool HALF>
+__device__ __forceinline__ void gather_group_pk3(const KernelArgs &a, const int wave, const ViewRec *rec,
+                                                 const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
+                                                 uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+    static_assert(NW == 2, "packed remainders: views of 65..128 cells");
+    constexpr int R = V * V - 64, NP = pack3_passes(N);
+    constexpr int NH = N >= 16 ? N / 2 : N;
+    uint32_t raw[N], rawR[NP];
+#pragma unroll
+    for (int h0 = 0; h0 < N; h0 += NH) {
+        ViewRec r[NH];
+#pragma unroll
+        for (int n = 0; n < NH; ++n) r[n] = rec[S0 + h0 + n];                // broadcast reads
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+            uint32_t t, addr;
+            asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(lc.pk[0]), "v"(r[n].lo));
+            asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(r[n].hi));
+            asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "v"(r[n].steps), "v"(r[n].origin));
+            MGX_CHECK_LDS_ADDR(4, addr, 2);
+            raw[h0 + n] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+        }
+        if (h0 + NH < N) __builtin_amdgcn_sched_barrier(0);
+    }
+    // the remainder passes: every lane reads the record of ITS view (the last pass of the block may hold fewer than three views:
+    // the lanes of the missing ones re-read the last view's record and are dropped from the ballot)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        constexpr int kLast = N - 3 * (NP - 1);                                  // views of the block's last pass: 1..3
+        const int ns = p == NP - 1 ? kLast : 3;
+        const int sub16 = ns == 3 ? lc.sub16 : min(lc.sub16, (ns - 1) * (int)sizeof(ViewRec));
+        const ViewRec r = *reinterpret_cast<const ViewRec *>(reinterpret_cast<const uint8_t *>(rec + S0 + 3 * p) + sub16);
+        uint32_t t, addr;
+        asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(lc.pk[1]), "v"(r.lo));
+        asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(r.hi));
+        asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "v"(r.steps), "v"(r.origin));
+        if (lc.act[1]) MGX_CHECK_LDS_ADDR(4, addr, 2);
+        rawR[p] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+    }
+    // see-behind ballots of the full passes: compare of view n, then the two writelanes of view n-1 (the v_writelane data hazard,
+    // gather_group below)
+    uint64_t pend = 0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        if constexpr (HALF) {
+            if ((n & 1) == 0) cell[(S0 + n) >> 1][0] = raw[n] | (raw[n + 1] << 16);
+        } else {
+            cell[S0 + n][0] = raw[n];
+        }
+        uint64_t cur;
+        if (n == 0) {
+            asm volatile("v_cmp_lt_i16_e64 %0, -1, %1\n\ts_nop 1" : "=s"(cur) : "v"(raw[n]));
+        } else {
+            asm volatile("v_cmp_lt_i16_e64 %0, -1, %3\n\tv_writelane_b32 %1, %4, %6\n\tv_writelane_b32 %2, %5, %6"
+                         : "=&s"(cur), "+v"(sbLo[0]), "+v"(sbHi[0])
+                         : "v"(raw[n]), "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + n - 1));
+        }
+        pend = cur;
+    }
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                 : "+v"(sbLo[0]), "+v"(sbHi[0]) : "s"((uint32_t)pend), "s"((uint32_t)(pend >> 32)), "n"(S0 + N - 1));
+    // ... of the shared passes: the pass's 64-bit ballot is cut into its views' R-bit words on the scalar unit, so every v_writelane
+    // reads an SGPR that a SCALAR instruction wrote (no hazard)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        constexpr int kLast = N - 3 * (NP - 1);
+        const int ns = p == NP - 1 ? kLast : 3;
+        cell[pk3_reg<N>(S0, p)][1] = rawR[p];
+        uint64_t cur;
+        asm volatile("v_cmp_lt_i16_e64 %0, -1, %1" : "=s"(cur) : "v"(rawR[p]));
+        constexpr uint32_t kWord = (1u << R) - 1u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q < ns) {
+                const uint32_t part = (uint32_t)(cur >> (R * q)) & kWord;
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(sbLo[1]) : "s"(part), "n"(S0 + 3 * p + q));
+            }
+        }
+    }
+    (void)sbHi;
+}
+
 #ifndef MGX_GROUP
 #define MGX_GROUP 16
 #endif
@@ -546,7 +653,10 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
                                            uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
-        if (S0 < NVc) gather_group<V, NW, S0, G, VPW, HALF>(a, wave, rec, lc, cell, sbLo, sbHi);
+        if (S0 < NVc) {
+            if constexpr (kPack3<V>) gather_group_pk3<V, NW, S0, G, VPW, HALF>(a, wave, rec, lc, cell, sbLo, sbHi);
+            else gather_group<V, NW, S0, G, VPW, HALF>(a, wave, rec, lc, cell, sbLo, sbHi);
+        }
         gather_all<V, NW, VPW, HALF, G, S0 + G>(a, wave, NVc, rec, lc, cell, sbLo, sbHi);
     }
 }
@@ -720,9 +830,10 @@ inline int launch_view(int mode, const KernelArgs &ka, int threads, int lds_byte
     case 1: return launch_mode<V, 1, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 2: return launch_mode<V, 2, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 3:                                                                                                // persistent stepping
-        // (the checked build and the tools' build leave out the persistent kernels of the three largest views: hipcc 7.2 crashes
-        // on them with the bounds checks / the debug knobs compiled in; the product library has them all)
-        if constexpr ((MGX_BOUNDS_CHECK != 0 || MGX_DEBUG_KNOBS != 0) && V >= 11) return MGX_ERR_UNSUPPORTED;
+        // (hipcc 7.2 crashes at -O3 on the persistent kernels of the three largest views with the bounds checks / the debug knobs
+        // compiled in.  The checked and the tools' builds compile those units at -O2 (multigrid_amd/build.py: flags) and carry
+        // them; only the single-translation-unit timestamps build, which wants -O3 code for its stamps, leaves them out.)
+        if constexpr (MGX_NO_BIG_PERSIST != 0 && V >= 11) return MGX_ERR_UNSUPPORTED;
         else return launch_mode<V, 3, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 4: return launch_mode<V, 0, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
     case 5: return launch_mode<V, 1, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);

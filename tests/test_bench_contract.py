@@ -21,7 +21,8 @@ def test_bench_prints_the_contract_line():
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 5
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None    # (N = 1: no other point)
+    assert "weak" not in d and "strong" not in d
     assert d["dtype"] == "u8" and d["data"] == "synthetic" and "workload" in d["config"]
     assert "valid" not in d                                     # the product library, no debug knobs
     # the headline is the north-star configuration: Empty-16x16, 4 agents, 65536 envs, all on this GPU
