@@ -73,15 +73,21 @@ def tool_workload() -> str:
     return os.environ.get("MGX_WORKLOAD", "c2")
 
 
+def tool_cell_bytes():
+    """(tools/) MGX_CELL_BYTES=1|2 forces the grid's cell format; unset = the configuration's own (compact cells for C5)."""
+    cb = os.environ.get("MGX_CELL_BYTES")
+    return int(cb) if cb else None
+
+
 def workload_spec():
-    return workloads.spec_of(tool_workload())
+    return workloads.spec_of(tool_workload(), tool_cell_bytes())
 
 
 def make_env(spec, batch, device, first_env=0):
     """(tools/) `batch` envs of the MGX_WORKLOAD configuration starting at global env `first_env`."""
     name = tool_workload()
     wl = workloads.make(name, batch=batch, first_env=first_env,
-                        global_batch=max(workloads.GLOBAL_BATCH[name], first_env + batch))
+                        global_batch=max(workloads.GLOBAL_BATCH[name], first_env + batch), cell_bytes=tool_cell_bytes())
     assert wl.spec == spec
     return wl.make_env(device, auto_reset=AUTO_RESET)
 
@@ -174,7 +180,9 @@ def roofline(alg_bytes_per_launch, ms, traffic=None):
 def step_roofline(wl_name, spec, B, ms_launch):
     """Roofline of the fused step kernel, literal definition: one launch of B envs over its own duration."""
     alg = B * spec.num_agents * spec.bytes_step()
-    rf = roofline(alg, ms_launch, pmc_traffic(f"{wl_name}_step", B))
+    # (the counter traffic of C5 on 16-bit cells -- the configuration's own format is the compact one -- has its own key)
+    key = f"{wl_name}_wide" if (wl_name == "c5" and spec.cell_bytes == 2) else wl_name
+    rf = roofline(alg, ms_launch, pmc_traffic(f"{key}_step", B))
     rf.update(kernel=f"mgx_fused_kernel<{spec.view_size},step,autoreset>", ms_per_launch=round(ms_launch, 5),
               bytes_per_agent_step=spec.bytes_step(), algorithmic_bytes=alg,
               traffic_unit="bytes per launch (rocprofv3 PMC, profiles/traffic.json)")
@@ -214,12 +222,12 @@ def sub_shard_launch_ms(env, P, device):
     return kernel_time_ms(step, 200, device, warm=50)
 
 
-def config_point(name, device, K, warmup, device_generated=False, steady=False):
+def config_point(name, device, K, warmup, device_generated=False, steady=False, cell_bytes=None):
     """One of the other BASELINE.json configurations, all of it on this GPU, timed like the headline (lock-step: one launch per
     step); `pipelined` beside it when the product's policy suggests sub-shards for it.
     device_generated: episode starts are generated ON THE DEVICE (the reference's _gen_grid with numpy-exact draws, in the
     tail of the step's own launch: mgx_step_generate) instead of picked from the host-made layout pool."""
-    wl = workloads.make(name)
+    wl = workloads.make(name, cell_bytes=cell_bytes)
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     if device_generated:
         # (truncation resets staged by generator launches between the steps, 128 steps ahead: set_layout_generator's default)
@@ -233,7 +241,8 @@ def config_point(name, device, K, warmup, device_generated=False, steady=False):
     B, A = wl.batch, wl.spec.num_agents
     ms = m["event_ms"] / m["timed_steps"]
     out = {"workload": wl.title, "batch": B, "agents": A, "grid": f"{wl.spec.width}x{wl.spec.height}",
-           "view_size": wl.spec.view_size, "ms_per_step": round(m["wall_s"] * 1e3 / m["timed_steps"], 6),
+           "view_size": wl.spec.view_size, "cell_bytes": wl.spec.cell_bytes,
+           "ms_per_step": round(m["wall_s"] * 1e3 / m["timed_steps"], 6),
            "value": round(B * A * m["timed_steps"] / m["wall_s"]), "unit": "agent-steps/s",
            "timed_steps": m["timed_steps"],
            "layout_pool": ("generated on the device in the step's own launch (mgx_step_generate)"
@@ -621,7 +630,7 @@ def main():
         "ms_per_step_ranks": {"min": round(wall_min * 1e3 / S, 6), "max": round(wall_max * 1e3 / S, 6)},
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "timed_steps": S, "timed_region_ms": round(wall_max * 1e3, 3),
-        "config": {"workload": wl.title + ", uniform random actions 0..6", "name": name,
+        "config": {"workload": wl.title + ", uniform random actions 0..6", "name": name, "cell_bytes": spec.cell_bytes,
                    "global_batch": G, "batch_per_gpu": B, "agents": A, "grid": f"{spec.width}x{spec.height}",
                    "view_size": spec.view_size, "mode": args.mode,
                    "configuration_batch": G0,
@@ -686,6 +695,8 @@ def main():
             del env
             torch.cuda.empty_cache()
             out["configs"] = {c: config_point(c, device, 256, 50) for c in ("c2", "c3", "c5") if c != name}
+            if name != "c5":      # C5 is stepped on COMPACT cells (include/mgx.h: MgxCell8); the same workload on the 16-bit cells beside it
+                out["configs"]["c5_wide_cells"] = config_point("c5", device, 256, 50, cell_bytes=2)
             out["configs"]["c3_device_generated"] = config_point("c3", device, 256, 50, device_generated=True)
             out["configs"]["c3_device_generated_steady"] = config_point("c3", device, 256, 50, device_generated=True, steady=True)
             out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}

@@ -14,7 +14,8 @@
  *   grid        u16[B, H, W]      PACKED cells (MgxCell): cell (x, y) of env b at (b*H + y)*W + x -- the [y][x] transpose of
  *                                 the reference's Grid.state (W,H,3) (multigrid/core/grid.py:54), each (type, color, state)
  *                                 triple in 16 bits:
- *                                     [3:0] type   [10:8] color   [13:12] state   [15] opaque   (other bits zero)
+ *                                     [3:0] type   [10:8] color   [13:12] state   [15] opaque
+ *                                     [6:4] + {[7], [11], [14]}: what a BOX holds (ABI 9, below); zero on every other cell
  *                                 opaque = 1 for a cell one cannot see through (multigrid/utils/obs.py:46-63: a wall, or a door
  *                                 that is not open); it is part of the format (the kernels keep it up to date on every cell
  *                                 they write).  Two bytes per cell instead of the reference's three int64: a third less grid
@@ -22,6 +23,16 @@
  *                                 convert from / to u8[B,H,W,3] (type, color, state) bytes on the device; values the 16 bits
  *                                 cannot hold (type > 15, color > 7, state > 3 -- the reference has types 0-10, colors 0-5,
  *                                 states 0-2 and directions 0-3) are reported by mgx_pack_grid.
+ *                                 BOX CONTENTS (ABI 9).  A box may hold an object (multigrid/core/world_object.py:574-605:
+ *                                 Box(color, contains); Box.toggle replaces the box by its content).  Neither Grid.state nor an
+ *                                 observation shows it, so it rides in bits the triple leaves free: in the (type, color, state)
+ *                                 BYTES (mgx_pack_grid* input, mgx_unpack_grid output, an agent row's carried cell) the state
+ *                                 byte of a box is  state | kind << 2 | content colour << 5,  kind = 0 nothing, 1 key, 2 ball,
+ *                                 3 goal, 4 floor, 5 lava, 6 wall, 7 door (closed and unlocked, as Door(color) constructs it);
+ *                                 in the packed cell: kind in [6:4], colour in {[7], [11], [14]}.  The kernels carry it through
+ *                                 pickup / drop and put the content on the grid when the box is toggled; observations and
+ *                                 mgx_full_obs show the box as (box, color, 0) whatever it holds.  A box in a box and doors in
+ *                                 other states are not representable (the host refuses them: multigrid_amd.world.Box).
  *                                 PRECONDITION: the outer ring of cells (x = 0, x = W-1, y = 0, y = H-1) of every env is the
  *                                 reference's WALL = (wall, grey, 0) (multigrid/utils/obs.py:14).  Every env of the reference
  *                                 starts from Grid.wall_rect(0, 0, W, H) (multigrid/core/grid.py:183-218; envs/empty.py:158,
@@ -33,7 +44,8 @@
  *                                 import (multigrid_amd/layouts.py: check_walled).
  *   agents      u8 [B, A, 8]      packed AgentState row (multigrid/core/agent.py:222-232, 72 B -> 8 B):
  *                                 [0]=color [1]=dir [2]=x [3]=y [4]=terminated [5]=carry.type [6]=carry.color
- *                                 [7]=carry.state ; "carrying nothing" = the empty cell (1,0,0) (agent.py:337-346).
+ *                                 [7]=carry.state (a carried box: | its content << 2, see "grid") ; "carrying nothing" = the
+ *                                 empty cell (1,0,0) (agent.py:337-346).
  *   rng         u64[B, 4]         per-env numpy PCG64 state of `env.np_random`: [state_lo, state_hi, inc_lo, inc_hi].
  *                                 Advanced by A draws per step when A > 1 (multigrid/base.py:396-399).
  *   step_count  i32[B]            multigrid/base.py:292, 333
@@ -81,7 +93,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 8
+#define MGX_ABI_VERSION 9
 
 enum {
     MGX_OK = 0,
@@ -97,6 +109,22 @@ enum { MGX_KIND_EMPTY = 0, MGX_KIND_BLOCKEDUNLOCKPICKUP = 1, MGX_KIND_REDBLUEDOO
 
 typedef uint16_t MgxCell;        /* packed grid cell, see "grid" above */
 #define MGX_CELL_BYTES 2
+
+/* (ABI 9) COMPACT cells: the grid as ONE byte per cell, for large grids -- MgxSpec.cell_bytes = 1.  A step streams an env's whole
+ * grid for its agents' views, so on a 64x64 grid (BASELINE.json configs[4]) the grid is half of all the bytes the step moves and
+ * its LDS tile decides how many envs a wavefront can own: at one byte per cell the traffic falls by a third and a wavefront
+ * steps two such envs instead of one.  A (type, color, state) triple holds 4 + 3 + 2 bits, but only doors (state) and the agent
+ * overlay (direction) use the third field, so type and state are coded JOINTLY:
+ *     [3:0] tcode   0..10 = the reference's type index with state 0 (4 = an OPEN door, 10 = an agent facing right);
+ *                   11 = closed door, 12 = locked door; 13, 14, 15 = agent facing down / left / up
+ *     [6:4] color   [7] opaque (as in MgxCell: a wall, or a door that is not open)
+ * WALL = (wall, grey, 0) is 0xD2.  Wherever this header says `MgxCell *grid` (grid, pool_grid) an engine whose spec has
+ * cell_bytes = 1 takes MgxCell8[B,H,W] through the same parameter (cast).  Served in this format: mgx_gen_obs, mgx_step,
+ * mgx_step_autoreset, mgx_step_ex (steps = 1, no one_hot, no generate), mgx_step_chains / mgx_sub_shards, mgx_reset_done,
+ * mgx_full_obs, mgx_check_grid, mgx_launch_info and the conversions mgx_pack_grid8_env / mgx_unpack_grid8; every other entry
+ * point returns MGX_ERR_UNSUPPORTED for such a spec (rollouts, one-hot output, device-side generation and persistent stepping
+ * keep the 16-bit cells).  Same results bit for bit in either format (tests/test_compact_cells.py). */
+typedef uint8_t MgxCell8;
 
 #define MGX_MAX_AGENTS 32
 #define MGX_MAX_VIEW 15
@@ -115,6 +143,7 @@ typedef struct MgxSpec {
     int32_t success_any;         /* success_termination_mode == 'any' (multigrid/base.py:97) */
     int32_t failure_any;         /* failure_termination_mode == 'any' (multigrid/base.py:98) */
     int32_t env_kind;            /* MGX_KIND_*: which subclass step() hook runs after the base step */
+    int32_t cell_bytes;          /* ABI 9: the grid's cell format: 0 or 2 = MgxCell (16 bits), 1 = MgxCell8 (compact, see above) */
 } MgxSpec;
 
 /* Launch geometry chosen for (spec, batch); for diagnostics, benchmarks and DESIGN.md tables. */
@@ -180,6 +209,11 @@ int mgx_unpack_grid(const MgxCell *packed, int64_t n_cells, uint8_t *cells3, voi
 int mgx_pack_grid_env(const uint8_t *cells3, int64_t batch, int32_t height, int32_t width, MgxCell *packed, int32_t *bad,
                       void *stream);
 int mgx_check_grid(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const uint8_t *agents, int32_t *bad, void *stream);
+/* (ABI 9) the same conversions for COMPACT cells (MgxCell8, spec->cell_bytes = 1): bad[0] also counts what only the compact
+ * format cannot hold (a state on anything but a door / an agent overlay). */
+int mgx_pack_grid8_env(const uint8_t *cells3, int64_t batch, int32_t height, int32_t width, MgxCell8 *packed, int32_t *bad,
+                       void *stream);
+int mgx_unpack_grid8(const MgxCell8 *packed, int64_t n_cells, uint8_t *cells3, void *stream);
 
 /* Geometry mgx_gen_obs / mgx_step / mgx_rollout would use. */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
@@ -26,7 +26,7 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
            "mgx_rollout_autoreset", "mgx_gen_obs_one_hot", "mgx_step_one_hot",
            "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid",
            "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards",
-           "mgx_pack_grid_env", "mgx_check_grid", "mgx_shape_key", "mgx_shape_register", "mgx_stage_generate",
+           "mgx_pack_grid_env", "mgx_check_grid", "mgx_pack_grid8_env", "mgx_unpack_grid8", "mgx_shape_key", "mgx_shape_register", "mgx_stage_generate",
            "mgx_persistent_waves", "mgx_step_persistent", "mgx_persistent_post", "mgx_persistent_wait", "mgx_persistent_feed")
 
 
@@ -131,6 +131,10 @@ def lib() -> C.CDLL:
     L.mgx_unpack_grid.argtypes = [vp, i64, vp, vp]
     L.mgx_pack_grid_env.restype = C.c_int
     L.mgx_pack_grid_env.argtypes = [vp, i64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.mgx_pack_grid8_env.restype = C.c_int
+    L.mgx_pack_grid8_env.argtypes = [vp, i64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.mgx_unpack_grid8.restype = C.c_int
+    L.mgx_unpack_grid8.argtypes = [vp, i64, vp, vp]
     L.mgx_check_grid.restype = C.c_int
     L.mgx_check_grid.argtypes = [C.POINTER(MgxSpecC), i64, vp, vp, vp, vp]
     L.mgx_launch_info.restype = C.c_int

@@ -45,8 +45,8 @@ class PersistentSession:
     a per-wavefront flag behind the step's outputs.  For batches in the latency regime (C2, C4's 8-GPU share, C3), where the launch
     boundary and the state reload are a third of a step.  Made by `BatchedMultiGridEnv.persistent()`; use as a context manager.
 
+        obs, dirs = env.gen_obs()                 # (the first observation: BEFORE the session takes the state over)
         with env.persistent(max_steps=T) as ps:
-            obs, dirs, *_ = env.gen_obs(), ...
             for t in range(T):
                 obs, dirs, reward, terminated, truncated = ps.step(policy(obs))      # == env.step(...) bit for bit
 
@@ -194,7 +194,8 @@ class BatchedMultiGridEnv:
             backend = HipBackend(spec, self.device)
         self.backend = backend
         B, A, dev = self.batch, spec.num_agents, self.device
-        self.cells = torch.zeros(spec.cells_shape(B), dtype=torch.int16, device=dev)    # packed cells (MgxCell bit patterns)
+        # packed cells: MgxCell bit patterns (i16), or -- spec.cell_bytes == 1 -- the compact MgxCell8 bytes (include/mgx.h)
+        self.cells = torch.zeros(spec.cells_shape(B), dtype=torch.uint8 if spec.compact else torch.int16, device=dev)
         self.agents = torch.zeros(spec.agents_shape(B), dtype=torch.uint8, device=dev)
         self.rng = torch.zeros((B, 4), dtype=torch.int64, device=dev)
         self.step_count = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -229,9 +230,18 @@ class BatchedMultiGridEnv:
     @property
     def grid(self) -> torch.Tensor:
         """The grid as (type, color, state) bytes u8[B,H,W,3] ([y][x]: layouts.grid_from_product gives the reference's
-        Grid.state) -- unpacked from `cells` on every access; for inspection, tests and checkpoints, not the hot path."""
+        Grid.state) -- unpacked from `cells` on every access; for inspection, tests and checkpoints, not the hot path.  A box that
+        holds something carries it in the upper bits of its state byte (include/mgx.h "BOX CONTENTS"; `& 3` is what Grid.state
+        shows)."""
         c = self.cells.to(torch.int32)
-        return torch.stack((c & 0xF, (c >> 8) & 0x7, (c >> 12) & 0x3), dim=-1).to(torch.uint8)
+        if self.spec.compact:                                # MgxCell8: joint (type, state) code | color << 4 | opaque << 7
+            tc = c & 0xF
+            door = (tc == 11) | (tc == 12)
+            t = torch.where(tc <= 10, tc, torch.where(door, torch.full_like(tc, 4), torch.full_like(tc, 10)))
+            st = torch.where(tc <= 10, torch.zeros_like(tc), torch.where(door, tc - 10, tc - 12))
+            return torch.stack((t, (c >> 4) & 0x7, st), dim=-1).to(torch.uint8)
+        content = ((c >> 4) & 0xF) | (((c >> 11) & 1) << 4) | (((c >> 14) & 1) << 5)      # a box's content (include/mgx.h)
+        return torch.stack((c & 0xF, (c >> 8) & 0x7, ((c >> 12) & 0x3) | (content << 2)), dim=-1).to(torch.uint8)
 
     # ------------------------------------------------------------------------------------------ state in
     def load_state(self, grid, agents, rng=None, aux=None, step_count=None, validate: bool = True, target=None):
@@ -257,7 +267,7 @@ class BatchedMultiGridEnv:
             an = a.cpu().numpy()
             if (an[..., 2] >= sp.width).any() or (an[..., 3] >= sp.height).any() or (an[..., 1] > 3).any():
                 raise ValueError("agent position / direction out of range")
-        self.cells.copy_(torch.from_numpy(layouts.pack_cells(g.cpu().numpy()).view(np.int16)))
+        self.cells.copy_(torch.from_numpy(layouts.pack_cells_for(sp, g.cpu().numpy())))
         self.agents.copy_(a)
         if rng is not None:
             r = np.asarray(rng.cpu() if torch.is_tensor(rng) else rng)
@@ -319,6 +329,7 @@ class BatchedMultiGridEnv:
         self._need_state()
         self.join()
         if one_hot:
+            self._need_wide_cells("one-hot output")
             self.backend.gen_obs(self.batch, self.cells, self.agents, self._one_hot_buffer(), self.dir, one_hot=True)
             return self._one_hot, self.dir
         self.backend.gen_obs(self.batch, self.cells, self.agents, self.obs, self.dir)
@@ -378,6 +389,8 @@ class BatchedMultiGridEnv:
         if hook_order is not None and (hook_order.dtype is not torch.uint8 or hook_order.shape != self._act_shape
                                        or hook_order.device != self.cells.device or not hook_order.is_contiguous()):
             raise ValueError(f"hook_order must be a contiguous uint8 tensor of shape {tuple(self._act_shape)} on {self.cells.device}")
+        if one_hot:
+            self._need_wide_cells("one-hot output")
         generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
         if generate:
             # on-device generation: the envs whose episode ends with THIS step are regenerated right after it (in the tail
@@ -581,6 +594,7 @@ class BatchedMultiGridEnv:
         step kernel (as T calls of `step(auto_reset=True)`).  one_hot=True: 'obs' is the one-hot observation u8[T,B,A,v,v,21]
         (multigrid/wrappers.py:158-190), written by the same launch."""
         self._need_state()
+        self._need_wide_cells("rollout (the steps of one launch)")
         self.join()
         sp, B = self.spec, self.batch
         if actions.dtype != torch.int8 or actions.dim() != 3 or tuple(actions.shape[1:]) != (B, sp.num_agents) \
@@ -646,7 +660,7 @@ class BatchedMultiGridEnv:
         elif sp.env_kind != "empty":
             raise ValueError(f"env_kind {sp.env_kind!r} needs per-layout aux")
         self.join()
-        cells = torch.from_numpy(layouts.pack_cells(g.numpy()).view(np.int16))
+        cells = torch.from_numpy(layouts.pack_cells_for(sp, g.numpy()))
         old = getattr(self, "_pool", None)
         if (getattr(self, "_gen", None) is None and old is not None and old[0].shape == cells.shape and old[1].shape == a.shape
                 and (old[2] is None) == (t is None)):
@@ -693,6 +707,7 @@ class BatchedMultiGridEnv:
         """
         self._no_session("set_layout_generator")
         sp = self.spec
+        self._need_wide_cells("set_layout_generator (device-side episode generation)")
         if kind == "blockedunlockpickup":
             if sp.env_kind != "blockedunlockpickup" or (sp.width, sp.height) != (2 * room_size - 1, room_size):
                 raise ValueError("blockedunlockpickup generator: the spec must be a BlockedUnlockPickup grid of (2*room_size-1) x room_size")
@@ -784,6 +799,12 @@ class BatchedMultiGridEnv:
         if self._session is not None:
             raise RuntimeError(f"{what}: a persistent session is open -- the env state lives in its launch until it is closed")
 
+    def _need_wide_cells(self, what: str):
+        """Rollouts, one-hot output, device-side generation and persistent stepping are compiled for the 16-bit cells only."""
+        if self.spec.compact:
+            raise NotImplementedError(f"{what} is not available on compact cells (EnvSpec.cell_bytes = 1: step / gen_obs / auto-reset "
+                                      f"from a layout pool / full_obs); build the env with cell_bytes = 2 for it")
+
     def _need_state(self):
         if not self._loaded:
             raise RuntimeError("no state loaded: call load_state() / reset() first")
@@ -794,6 +815,7 @@ class BatchedMultiGridEnv:
         """A `PersistentSession` over this env: closed-loop stepping with ONE resident launch instead of one launch per step
         (include/mgx.h: mgx_step_persistent).  Same results as `step()` bit for bit.  `max_steps` bounds the launch; every wait
         inside it gives up after `timeout_ms`."""
+        self._need_wide_cells("persistent stepping")
         return PersistentSession(self, max_steps, auto_reset, timeout_ms)
 
     # ------------------------------------------------------------------------------------------ checkpoint
@@ -814,7 +836,7 @@ class BatchedMultiGridEnv:
             sd["was_reset"] = self.was_reset.cpu().clone()
         if getattr(self, "_pool", None) is not None:
             pg, pa, pt = self._pool
-            sd["pool"] = {"grid": torch.from_numpy(layouts.unpack_cells(pg.cpu().numpy())), "agents": pa.cpu().clone(),
+            sd["pool"] = {"grid": torch.from_numpy(layouts.unpack_cells_for(self.spec, pg.cpu().numpy())), "agents": pa.cpu().clone(),
                           "aux": pt.cpu().clone() if pt is not None else None}
             sd["episode"] = self.episode.cpu().clone()
             sd["was_reset"] = self.was_reset.cpu().clone()

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void one_hot_kernel(const uint8_t *__restrict_
 // two buffers share one 16-byte skew.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int G, int wave_lds, int in_buf, uint32_t inv_W,
-                                                       uint32_t inv_HW, int64_t batch, const uint8_t *__restrict__ grid,
+                                                       uint32_t inv_HW, int cb, int64_t batch, const uint8_t *__restrict__ grid,
                                                        const uint8_t *__restrict__ agents, uint8_t *__restrict__ out) {
     extern __shared__ __align__(16) uint8_t lds[];
     const int lane = threadIdx.x & 63;
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
     const int64_t e0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * G;
     if (e0 >= batch) return;
     const int Gc = (int)min((int64_t)G, batch - e0);
-    const int HW = H * W, HWB = HW * kCellBytes, HW3 = HW * 3;
-    // input: packed cells [y][x], 2 bytes each; output: (type, color, state) bytes [x][y] -- each with its own 16-byte skew
+    const int HW = H * W, HWB = HW * cb, HW3 = HW * 3;
+    // input: packed cells [y][x], 2 bytes each (compact cells: 1); output: (type, color, state) bytes [x][y] -- each with its own 16-byte skew
     const int64_t g0 = e0 * HWB, gtotal = batch * (int64_t)HWB;
     const int64_t ga = g0 & ~(int64_t)15;
     const int iskew = (int)(g0 - ga);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
         const int e = (int)__umulhi((uint32_t)i, inv_HW);                                    // i / HW  (i < 2^16)
         const int r = i - e * HW;
         const int y = (int)__umulhi((uint32_t)r, inv_W), xx = r - y * W;                    // r / W
-        const uint32_t c = load_cell(in_cells + i * kCellBytes);
+        const uint32_t c = load_cell_shown(cb, in_cells + i * cb);             // (a box's content is not part of Grid.state)
         uint8_t *d = out_cells + e * HW3 + (xx * H + y) * 3;
         d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
     }
@@ -191,12 +191,15 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
 // ---------------------------------------------------------------------------------------------------------------
 // W, H > 0: the cells are whole env grids [b][y][x] and bad[1] counts the cells of every env's OUTER RING that are not the
 // reference's WALL = (wall, grey, 0) -- the precondition of every kernel that reads the grid (include/mgx.h)
-__global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restrict__ c3, int64_t n, uint16_t *__restrict__ out,
+// C8: the output is COMPACT one-byte cells (include/mgx.h: MgxCell8); bad[0] then also counts a state on anything but a door or an
+// agent overlay, which that format cannot hold
+template <typename OutT, bool C8>
+__global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restrict__ c3, int64_t n, OutT *__restrict__ out,
                                                         int32_t *bad, int W, int H) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i0 >= n) return;
     int nbad = 0, nring = 0;
-    uint16_t v[8];
+    OutT v[8];
     int x = 0, y = 0;
     if (W > 0) { const int r = (int)(i0 % ((int64_t)W * H)); y = r / W; x = r - y * W; }
     // 8 cells = 24 bytes: three 8-byte loads when the chunk is whole and aligned (byte loads otherwise)
@@ -216,8 +219,19 @@ __global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restric
         } else {
             c = (i0 + k < n) ? load_obs_cell(c3 + (i0 + k) * 3) : 0u;
         }
-        nbad += ((c & 0xf0u) != 0) | (((c >> 8) & 0xf8u) != 0) | (((c >> 16) & 0xfcu) != 0);
-        v[k] = (uint16_t)cell_pack(c);
+        // the state byte's upper six bits: a box's content (kind | colour << 3, mgx_rules.h), nothing on any other cell
+        const uint32_t content = (c >> 18) & 0x3fu;
+        nbad += ((c & 0xf0u) != 0) | (((c >> 8) & 0xf8u) != 0)
+              | ((content != 0) & (((c & 0xffu) != (uint32_t)T_BOX) | ((content & 7u) == 0) | ((content >> 3) > 5u)));
+        if constexpr (C8) {
+            nbad += content != 0;                                        // (the compact format has no room for one)
+            const uint32_t t = c & 0xffu;
+            nbad += (((c >> 16) & 3u) != 0) & (t != (uint32_t)T_DOOR) & (t != (uint32_t)T_AGENT);
+            nbad += (t > 10u) & (t < 16u);                               // (types 11..15 would alias the joint codes)
+            v[k] = (OutT)cell8_pack(c);
+        } else {
+            v[k] = (OutT)cell_pack(c);
+        }
         if (W > 0) {
             const bool ring = (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
             nring += (i0 + k < n) & ring & (c != CELL_WALL);
@@ -225,7 +239,12 @@ __global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restric
         }
     }
     if (nring && bad) atomicAdd(bad + 1, nring);
-    if (i0 + 8 <= n && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    if (C8 && i0 + 8 <= n && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+        u32x2 w;
+        w.x = v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+        w.y = v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+        *reinterpret_cast<u32x2 *>(out + i0) = w;
+    } else if (!C8 && i0 + 8 <= n && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         u32x4 w;
         w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
         w.z = v[4] | ((uint32_t)v[5] << 16); w.w = v[6] | ((uint32_t)v[7] << 16);
@@ -238,7 +257,8 @@ __global__ __launch_bounds__(256) void pack_grid_kernel(const uint8_t *__restric
 
 // mgx_check_grid: the state preconditions of the kernels, counted (include/mgx.h).  One thread looks at 8 cells and at one
 // agent row.
-__global__ __launch_bounds__(256) void check_grid_kernel(const uint16_t *__restrict__ cells, int64_t n, int W, int H,
+template <typename CellT, bool C8>
+__global__ __launch_bounds__(256) void check_grid_kernel(const CellT *__restrict__ cells, int64_t n, int W, int H,
                                                          const uint8_t *__restrict__ agents, int64_t n_rows, int A, int32_t *bad) {
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i0 = tid * 8;
@@ -251,11 +271,22 @@ __global__ __launch_bounds__(256) void check_grid_kernel(const uint16_t *__restr
         int64_t b = b0;
         for (int k = 0; k < 8 && i0 + k < n; ++k) {
             const uint32_t p = cells[i0 + k];
-            const uint32_t t = p & 0xfu, c = (p >> 8) & 0x7u, st = (p >> 12) & 0x3u;
-            // reserved bits clear, values the reference has, and the opaque bit what the (type, state) says (obs.py:46-63)
-            const bool fmt = ((p & 0x48f0u) != 0) | (t > (uint32_t)T_AGENT) | (c > 5u) | (st > 2u) | (cell_pack(cell_unpack(p)) != p);
+            bool fmt;
+            if constexpr (C8) {
+                // a code the reference has (no door / overlay state 3: tcode 13..15 are agent overlays, never stored in a grid's
+                // own cells but valid in the format), a colour it has, and the opaque bit what the (type, state) says
+                const uint32_t u = cell8_unpack(p);
+                fmt = (((p >> 4) & 7u) > 5u) | (cell8_pack(u) != p);
+            } else {
+                const uint32_t t = p & 0xfu, c = (p >> 8) & 0x7u, st = (p >> 12) & 0x3u;
+                // content bits only on a box (a kind, a colour the reference has), values the reference has, and the opaque bit
+                // what the (type, state) says (obs.py:46-63)
+                const uint32_t full = cell_unpack_full(p), content = (full >> 18) & 0x3fu;
+                fmt = ((content != 0) & ((t != (uint32_t)T_BOX) | ((content & 7u) == 0) | ((content >> 3) > 5u)))
+                    | (t > (uint32_t)T_AGENT) | (c > 5u) | (st > 2u) | (cell_pack(full) != p);
+            }
             const bool ring = (x == 0) | (x == W - 1) | (y == 0) | (y == H - 1);
-            const bool rbad = ring & (p != CELL16_WALL);
+            const bool rbad = ring & (p != (C8 ? CELL8_WALL : CELL16_WALL));
             nfmt += fmt; nring += rbad;
             if ((fmt | rbad) && b < first) first = b;
             if (++x == W) { x = 0; if (++y == H) { y = 0; ++b; } }
@@ -266,7 +297,9 @@ __global__ __launch_bounds__(256) void check_grid_kernel(const uint16_t *__restr
         const int ax = row[AG_X], ay = row[AG_Y];
         // inside the walls (never on the ring: nothing can stand on a wall), a direction, 0/1 terminated, a packable carried cell
         const bool abad = (ax < 1) | (ax > W - 2) | (ay < 1) | (ay > H - 2) | (row[AG_DIR] > 3) | (row[AG_TERM] > 1) | (row[AG_COLOR] > 5)
-                        | (row[AG_CARRY] > (uint8_t)T_AGENT) | (row[AG_CARRY + 1] > 5) | (row[AG_CARRY + 2] > 2);
+                        | (row[AG_CARRY] > (uint8_t)T_AGENT) | (row[AG_CARRY + 1] > 5) | ((row[AG_CARRY + 2] & 3) > 2)
+                        | ((row[AG_CARRY + 2] >> 2) != 0 && (C8 || row[AG_CARRY] != (uint8_t)T_BOX || ((row[AG_CARRY + 2] >> 2) & 7) == 0
+                                                             || (row[AG_CARRY + 2] >> 5) > 5));      // (a carried box's content)
         nag += abad;
         if (abad && tid / A < first) first = tid / A;
     }
@@ -285,7 +318,7 @@ __global__ __launch_bounds__(256) void unpack_grid_kernel(const uint16_t *__rest
         const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
         uint32_t c[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) c[k] = cell_unpack((pw[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        for (int k = 0; k < 8; ++k) c[k] = cell_unpack_full((pw[k >> 1] >> (16 * (k & 1))) & 0xffffu);   // (with a box's content)
         uint32_t o[6];
         o[0] = c[0] | (c[1] << 24);               o[1] = (c[1] >> 8) | (c[2] << 16);   o[2] = (c[2] >> 16) | (c[3] << 8);
         o[3] = c[4] | (c[5] << 24);               o[4] = (c[5] >> 8) | (c[6] << 16);   o[5] = (c[6] >> 16) | (c[7] << 8);
@@ -294,7 +327,26 @@ __global__ __launch_bounds__(256) void unpack_grid_kernel(const uint16_t *__rest
         for (int k = 0; k < 3; ++k) dst[k] = u32x2{o[2 * k], o[2 * k + 1]};
         return;
     }
-    for (int k = 0; k < 8 && i0 + k < n; ++k) store_obs_cell(c3 + (i0 + k) * 3, cell_unpack(in[i0 + k]));
+    for (int k = 0; k < 8 && i0 + k < n; ++k) store_obs_cell(c3 + (i0 + k) * 3, cell_unpack_full(in[i0 + k]));
+}
+
+__global__ __launch_bounds__(256) void unpack_grid8_kernel(const uint8_t *__restrict__ in, int64_t n, uint8_t *__restrict__ c3) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    if (i0 + 8 <= n && ((reinterpret_cast<uintptr_t>(in) & 7) | (reinterpret_cast<uintptr_t>(c3) & 7)) == 0) {
+        const u32x2 p = *reinterpret_cast<const u32x2 *>(in + i0);        // 8 cells in, 24 bytes out as three 8-byte stores
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = cell8_unpack(((k < 4 ? p.x : p.y) >> (8 * (k & 3))) & 0xffu);
+        uint32_t o[6];
+        o[0] = c[0] | (c[1] << 24);               o[1] = (c[1] >> 8) | (c[2] << 16);   o[2] = (c[2] >> 16) | (c[3] << 8);
+        o[3] = c[4] | (c[5] << 24);               o[4] = (c[5] >> 8) | (c[6] << 16);   o[5] = (c[6] >> 16) | (c[7] << 8);
+        u32x2 *dst = reinterpret_cast<u32x2 *>(c3 + i0 * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dst[k] = u32x2{o[2 * k], o[2 * k + 1]};
+        return;
+    }
+    for (int k = 0; k < 8 && i0 + k < n; ++k) store_obs_cell(c3 + (i0 + k) * 3, cell8_unpack(in[i0 + k]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -613,7 +665,9 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const 
     if (spec->width < 3 || spec->height < 3 || spec->num_agents < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->width > 255 || spec->height > 255) return MGX_ERR_UNSUPPORTED;
     const int HW = spec->width * spec->height;
-    if ((kCellBytes + 3) * HW + 2 * 48 > 64 * 1024) return MGX_ERR_UNSUPPORTED;
+    if (spec->cell_bytes != 0 && spec->cell_bytes != 1 && spec->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
+    const int cb = spec->cell_bytes == 1 ? 1 : kCellBytes;
+    if ((cb + 3) * HW + 2 * 48 > 64 * 1024) return MGX_ERR_UNSUPPORTED;
     if (batch == 0) return MGX_OK;
     if (!grid || !agents || !out || misaligned(agents, 8) || misaligned(grid, 16) || misaligned(out, 16))
         return MGX_ERR_INVALID_ARGUMENT;
@@ -621,7 +675,7 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const 
     if (G < 1) G = 1;
     if (G * HW > 65535) G = 65535 / HW;
     while (G > 1 && (batch + G - 1) / G < 4096) G = (G + 1) / 2;  // small batches: spread over the chip
-    const int in_buf = (G * HW * kCellBytes + 15 + 16 + 15) & ~15;         // skew + over-read pad
+    const int in_buf = (G * HW * cb + 15 + 16 + 15) & ~15;                 // skew + over-read pad
     const int out_buf = (G * HW * 3 + 15 + 16 + 15) & ~15;
     const int wave_lds = in_buf + out_buf;
     int wpb = 4;
@@ -634,7 +688,7 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const 
     const uint32_t inv_HW = (uint32_t)(((1ull << 32) + hw - 1) / hw);
     hipLaunchKernelGGL(full_obs_kernel, dim3((unsigned)blocks), dim3(64 * wpb), (size_t)(wpb * wave_lds),
                        static_cast<hipStream_t>(stream), spec->width, spec->height, spec->num_agents, G, wave_lds, in_buf, inv_W,
-                       inv_HW, batch, reinterpret_cast<const uint8_t *>(grid), agents, out);
+                       inv_HW, cb, batch, reinterpret_cast<const uint8_t *>(grid), agents, out);
     return finish_launch();
 }
 
@@ -644,8 +698,8 @@ int mgx_pack_grid(const uint8_t *cells3, int64_t n_cells, MgxCell *packed, int32
     if (!cells3 || !packed || misaligned(packed, 2) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
     const int64_t blocks = (n_cells + 2047) / 2048;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pack_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3, n_cells,
-                       packed, bad, 0, 0);
+    hipLaunchKernelGGL((pack_grid_kernel<uint16_t, false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3,
+                       n_cells, packed, bad, 0, 0);
     return finish_launch();
 }
 
@@ -657,8 +711,31 @@ int mgx_pack_grid_env(const uint8_t *cells3, int64_t batch, int32_t height, int3
     if (!cells3 || !packed || misaligned(packed, 2) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
     const int64_t blocks = (n_cells + 2047) / 2048;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pack_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3, n_cells,
-                       packed, bad, (int)width, (int)height);
+    hipLaunchKernelGGL((pack_grid_kernel<uint16_t, false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3,
+                       n_cells, packed, bad, (int)width, (int)height);
+    return finish_launch();
+}
+
+int mgx_pack_grid8_env(const uint8_t *cells3, int64_t batch, int32_t height, int32_t width, MgxCell8 *packed, int32_t *bad,
+                       void *stream) {
+    if (batch < 0 || height < 3 || width < 3 || height > 255 || width > 255) return MGX_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return MGX_OK;
+    const int64_t n_cells = batch * height * width;
+    if (!cells3 || !packed || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
+    const int64_t blocks = (n_cells + 2047) / 2048;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((pack_grid_kernel<uint8_t, true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cells3,
+                       n_cells, packed, bad, (int)width, (int)height);
+    return finish_launch();
+}
+
+int mgx_unpack_grid8(const MgxCell8 *packed, int64_t n_cells, uint8_t *cells3, void *stream) {
+    if (n_cells < 0) return MGX_ERR_INVALID_ARGUMENT;
+    if (n_cells == 0) return MGX_OK;
+    if (!cells3 || !packed) return MGX_ERR_INVALID_ARGUMENT;
+    const int64_t blocks = (n_cells + 2047) / 2048;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(unpack_grid8_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), packed, n_cells, cells3);
     return finish_launch();
 }
 
@@ -667,13 +744,20 @@ int mgx_check_grid(const MgxSpec *spec, int64_t batch, const MgxCell *grid, cons
         || spec->num_agents < 1 || spec->num_agents > MGX_MAX_AGENTS)
         return MGX_ERR_INVALID_ARGUMENT;
     if (batch == 0) return MGX_OK;
-    if (!grid || !bad || misaligned(grid, 2) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->cell_bytes != 0 && spec->cell_bytes != 1 && spec->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
+    const bool c8 = spec->cell_bytes == 1;
+    if (!grid || !bad || (!c8 && misaligned(grid, 2)) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
     const int64_t n_cells = batch * spec->height * spec->width, n_rows = agents ? batch * spec->num_agents : 0;
     const int64_t work = std::max((n_cells + 7) / 8, n_rows);
     const int64_t blocks = (work + 255) / 256;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(check_grid_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), grid, n_cells,
-                       (int)spec->width, (int)spec->height, agents, n_rows, (int)spec->num_agents, bad);
+    if (c8)
+        hipLaunchKernelGGL((check_grid_kernel<uint8_t, true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           reinterpret_cast<const uint8_t *>(grid), n_cells, (int)spec->width, (int)spec->height, agents, n_rows,
+                           (int)spec->num_agents, bad);
+    else
+        hipLaunchKernelGGL((check_grid_kernel<uint16_t, false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), grid,
+                           n_cells, (int)spec->width, (int)spec->height, agents, n_rows, (int)spec->num_agents, bad);
     return finish_launch();
 }
 
@@ -697,9 +781,10 @@ int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_
     uint8_t *grid = reinterpret_cast<uint8_t *>(grid_c);
     if (!pool_grid || !pool_agents || !grid || !agents || !step_count || !episode) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(agents, 8) || misaligned(pool_agents, 8) || misaligned(aux, 16) || misaligned(pool_aux, 16)
-        || misaligned(grid, 2) || misaligned(pool_grid, 2))
+        || (spec->cell_bytes != 1 && (misaligned(grid, 2) || misaligned(pool_grid, 2))))
         return MGX_ERR_INVALID_ARGUMENT;
-    const int HW3 = spec->width * spec->height * kCellBytes;      // bytes of one env's grid
+    if (spec->cell_bytes != 0 && spec->cell_bytes != 1 && spec->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
+    const int HW3 = spec->width * spec->height * (spec->cell_bytes == 1 ? 1 : kCellBytes);      // bytes of one env's grid
     const int64_t blocks = (batch + 255) / 256;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     // widest copy unit that divides the layout size and the base addresses

@@ -198,6 +198,7 @@ struct alignas(16) ViewRec { int32_t origin; uint32_t steps, lo, hi; };         
 
 typedef const uint32_t __attribute__((address_space(3))) *lds_u32_ptr;
 typedef const uint16_t __attribute__((address_space(3))) *lds_u16_ptr;
+typedef const int8_t __attribute__((address_space(3))) *lds_i8_ptr;
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef const u32_unaligned __attribute__((address_space(3))) *lds_u32_ua_ptr;
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
@@ -261,10 +262,16 @@ constexpr int kSlotsLatency = 32;        // DMA instantiations
 // fifteen of them in SGPRs from the kernel arguments.  Per-slot arrays first (vpw = slots in use, a multiple of 16).
 // (the members are always_inline: left to the inliner's budget the big GEN kernels called tile() / out() out of line, which put the
 // whole struct in scratch memory and every wavefront of the launch through its set-up)
+// COMPACT cells (include/mgx.h: MgxCell8): the wavefront keeps a 256-entry decode table in its slice, indexed by the SIGNED cell
+// byte -- entry (int8)b holds cell8_unpack(b) = type | color << 8 | state << 16 -- so that P2 turns a gathered byte into the
+// observation's three bytes with one more LDS read (the address is one v_lshl_add from the sign-extended byte the opaque test
+// reads anyway) instead of the ~8 VALU instructions of the arithmetic decode.
+constexpr int kLutBytes = 256 * 4;
 struct LdsCarve {
     int vpw, nw, Gw, A, tile_bytes, round_bytes;   // round_bytes: P4/P5 staging of one round (obs bytes, or one-hot cell masks)
     bool roll;      // mgx_rollout: tile and PCG64 state live across steps (no aliasing of the tile, rng kept in LDS)
     bool has_aux;   // env kinds with hook state
+    bool c8;        // compact cells: + the decode table
     __host__ __device__ __attribute__((always_inline)) int rows() const { return 0; }                               // u64  [vpw]
     // -- per-step temporaries, all dead once P2 has gathered the cells --
     // (the view records, written in P1d, lie over the draws and the rewards, both dead by then)
@@ -286,7 +293,8 @@ struct LdsCarve {
     // P4/P5 staging of one round's obs bytes (skew + pad).  One-step kernels put it over the tile, which is dead once
     // P2 has gathered the cells; the rollout keeps the tile and uses the (equally dead) temporaries' space + its own.
     __host__ __device__ __attribute__((always_inline)) int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
-    __host__ __device__ __attribute__((always_inline)) int own_out() const { return wall() + 16; }
+    __host__ __device__ __attribute__((always_inline)) int lut() const { return wall() + 16; }                         // u32 [256] (compact cells only)
+    __host__ __device__ __attribute__((always_inline)) int own_out() const { return lut() + (c8 ? kLutBytes : 0); }
     __host__ __device__ __attribute__((always_inline)) int tile() const { return roll ? own_out() + out_bytes() : own_out(); }   // grid bytes, skew + over-read
     __host__ __device__ __attribute__((always_inline)) int out() const { return roll ? own_out() : tile(); }
     __host__ __device__ __attribute__((always_inline)) int total() const {
@@ -301,20 +309,22 @@ struct LdsCarve {
 // one_hot: the round's staging holds one 32-bit one-hot mask per cell (+ a pad dword either side) instead of 3 obs bytes
 // `round`: slots staged per P4/P5 round (kRound, or the group size of a small-group latency instantiation)
 __host__ __device__ __attribute__((always_inline)) inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
-                                               bool one_hot = false, int round = kRound) {
-    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * kCellBytes, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
-                    roll, has_aux};
+                                               bool one_hot = false, int round = kRound, int cb = kCellBytes) {
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * cb, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
+                    roll, has_aux, cb == 1};
 }
+inline int cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 1 ? 1 : kCellBytes; }
 
 // `grp`: the group size the launch's instantiation is compiled for (16, or 4 / 8: KernelArgs::grp)
 inline int slots_in_use(const MgxSpec &sp, int Gw, bool narrow = false, int grp = 16) {
     int vpw = (Gw * sp.num_agents + grp - 1) / grp * grp;     // (the kernel is compiled for slots_per_wave(V) slots)
-    return vpw > slots_per_wave(sp.view_size, narrow) ? slots_per_wave(sp.view_size, narrow) : vpw;
+    const int cap = slots_per_wave(sp.view_size, narrow || sp.cell_bytes == 1);   // (compact cells: one decoded cell per register)
+    return vpw > cap ? cap : vpw;
 }
 
 inline int wave_lds_bytes(const MgxSpec &sp, int Gw, bool roll = false, bool one_hot = false, bool obs_only = false, int grp = 16) {
     return make_carve(sp.width, sp.height, sp.num_agents, sp.view_size, Gw, slots_in_use(sp, Gw, roll || obs_only, grp), roll,
-                      sp.env_kind != MGX_KIND_EMPTY, one_hot, grp).total();
+                      sp.env_kind != MGX_KIND_EMPTY, one_hot, grp, cell_bytes_of(sp)).total();
 }
 
 constexpr int kGroupSlots = 16;           // (== kGroup, defined with the gather below)
@@ -327,7 +337,7 @@ constexpr int kLdsWaveBudget = MGX_LDS_WAVE_BUDGET;     // keeps >= 12 wavefront
 // Envs per wavefront: as many as fit the wave's view slots and its LDS budget; fewer when the batch is too small
 // to give every SIMD of the chip a few wavefronts (then latency, not throughput, is what matters).
 inline int choose_Gw(const MgxSpec &sp, int64_t batch, bool roll = false, bool one_hot = false, bool obs_only = false) {
-    int Gw = slots_per_wave(sp.view_size, roll || obs_only) / sp.num_agents;
+    int Gw = slots_per_wave(sp.view_size, roll || obs_only || sp.cell_bytes == 1) / sp.num_agents;
     if (Gw < 1) Gw = 1;
     while (Gw > 1 && wave_lds_bytes(sp, Gw, roll, one_hot, obs_only) > kLdsWaveBudget) --Gw;
     // a power of two: otherwise the tile's 16-byte vectors and the output rows stop lining up with the wave's lanes (round 2:
@@ -356,7 +366,8 @@ inline int choose_group(const MgxSpec &sp, int64_t batch) {
 // BlockedUnlockPickup at 16384 envs 5.08 -> 4.45 us (step 9.6 -> 8.2); the throughput instantiation of C4 gains 1 % (its scalar work
 // runs beside four waves' VALU work) and has none.  The table holds the shapes BASELINE.json names, at the envs-per-wavefront
 // choose_Gw gives them in the latency regime; every other shape, and these at other launch geometries, run the generic kernels.
-struct FixedShape { int W, H, A, Gw; bool hooks; int V; bool dma, stream; };     // (dma / stream: the instantiation family, launch_mode)
+struct FixedShape { int W, H, A, Gw; bool hooks; int V; bool dma, stream; int cb = kCellBytes; };   // (dma / stream: the instantiation
+                                                                                // family, launch_mode; cb: bytes per grid cell)
 constexpr FixedShape kShapes[] = {
     {0, 0, 0, 0, false, 0, false, false},
     {16, 16, 4, 4, false, 7, true, false},      // 1: MultiGrid-Empty-16x16 x 4 agents, up to 8192 envs (C2; C4's share of an 8-GPU node)
@@ -364,6 +375,8 @@ constexpr FixedShape kShapes[] = {
     {11, 6, 2, 8, true, 7, true, false},        // 3: MultiGrid-BlockedUnlockPickup x 2 agents (C3)
     {64, 64, 16, 1, false, 9, false, true},     // 4: the 64x64 grid x 16 agents, 9x9 views of C5 (one env per wavefront, streamed grids:
                                                 //    issue-bound at ~4 wavefronts per SIMD, so it gains less: 84.7 -> 81.5 us)
+    {64, 64, 16, 2, false, 9, false, true, 1},  // 5: the same on COMPACT cells (round 5): two envs per wavefront -- the per-agent phases run
+                                                //    on 32 lanes instead of 16 and the 8 KiB of tiles are again 17 wavefronts per CU
 #ifdef MGX_JIT_SHAPE
     {MGX_JIT_SHAPE},                            // 5: ANY other shape, compiled at run time (hipRTC) from these same headers with its
                                                 //    launch geometry as MGX_JIT_SHAPE (multigrid_amd/jit.py, mgx_shape_register)
@@ -481,10 +494,24 @@ struct LaneConst {          // cell k = lane + 64*it  <->  image[i][j], k = j*V 
 // (obs.py:182-202); see-behind ballot (obs.py:211-233) deposited in lane s of sbLo/sbHi.  The agent's own cell still
 // shows the grid here; lane s patches the carried object in afterwards (P3: its see-behind bit, P4: its bytes).
 // Straight-line over the N slots (no per-slot branch) so that their LDS round trips overlap.
-template <int V, int NW, int S0, int N, int VPW, bool HALF>
+// One gathered cell: the packed 16 bits (zero-extended), or -- compact cells -- the SIGN-extended byte: either way the opaque
+// bit is the sign of the low 16 bits, which is what the see-behind compare reads.
+template <bool C8>
+__device__ __forceinline__ uint32_t gather_read(uint32_t addr) {
+    if constexpr (C8) return (uint32_t)(int32_t)*(lds_i8_ptr)(uintptr_t)addr;
+    else return (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+}
+// compact cells: byte -> (type, color, state) through the wavefront's decode table (LdsCarve::lut; lut_mid = the LDS address of
+// entry 0, entries -128..127 around it)
+__device__ __forceinline__ uint32_t lut_decode(uint32_t raw, uint32_t lut_mid) {
+    return *(lds_u32_ptr)(uintptr_t)(lut_mid + (raw << 2));
+}
+
+template <int V, int NW, int S0, int N, int VPW, bool HALF, bool C8 = false>
 __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave, const ViewRec *rec,
                                              const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
-                                             uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+                                             uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW], const uint32_t lut_mid = 0) {
+    static_assert(!(HALF && C8), "two cells per register: 16-bit cells only");
     constexpr int V2 = V * V;
     // (the records are fetched half a group at a time: all N of them at once would hold 4 N registers across the block)
     constexpr int NH = N >= 16 ? N / 2 : N;
@@ -505,12 +532,22 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
                 asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(lc.pk[it]), "v"(r[n].lo));
                 asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(r[n].hi));
                 asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "v"(r[n].steps), "v"(r[n].origin));
-                if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr, 2);
-                // one aligned 16-bit read per cell (ds_read_u16)
-                raw[h0 + n][it] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+                if (lc.act[it]) MGX_CHECK_LDS_ADDR(4, addr, C8 ? 1 : 2);
+                // one aligned 16-bit read per cell (ds_read_u16; compact cells: ds_read_i8)
+                raw[h0 + n][it] = gather_read<C8>(addr);
             }
         }
         if (h0 + NH < N) __builtin_amdgcn_sched_barrier(0);
+    }
+    [[maybe_unused]] uint32_t dec[C8 ? N : 1][NW];
+    if constexpr (C8) {
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                if (lc.act[it]) MGX_CHECK_LDS_ADDR(9, lut_mid + (raw[n][it] << 2), 4);
+                dec[n][it] = lut_decode(raw[n][it], lut_mid);
+            }
     }
     // obs.py:46-63 see_behind as a lane mask: the cell's opaque bit is the sign of its 16 bits -- ONE compare per cell, whose
     // SGPR pair goes straight into lane s of sbLo / sbHi.  HARDWARE HAZARD (found on gfx950, not in the ISA manual's table,
@@ -525,6 +562,8 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
         constexpr uint64_t kAll = ~0ull;
         if constexpr (HALF) {
             if ((n & 1) == 0) cell[(S0 + n) >> 1][it] = raw[n][it] | (raw[n + 1][it] << 16);    // two slots' cells per register
+        } else if constexpr (C8) {
+            cell[S0 + n][it] = dec[n][it];
         } else {
             cell[S0 + n][it] = raw[n][it];
         }
@@ -560,11 +599,12 @@ __device__ __forceinline__ void gather_group(const KernelArgs &a, const int wave
 // cells in cell[pk3_reg(S0, N, p)][1], one view's cell per lane, in the low half of the register (never two per register).
 template <int N> constexpr int pk3_reg(int S0, int p) { return S0 / N * pack3_passes(N) + p; }
 
-template <int V, int NW, int S0, int N, int VPW, bool HALF>
+template <int V, int NW, int S0, int N, int VPW, bool HALF, bool C8 = false>
 __device__ __forceinline__ void gather_group_pk3(const KernelArgs &a, const int wave, const ViewRec *rec,
                                                  const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
-                                                 uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+                                                 uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW], const uint32_t lut_mid = 0) {
     static_assert(NW == 2, "packed remainders: views of 65..128 cells");
+    static_assert(!(HALF && C8), "two cells per register: 16-bit cells only");
     constexpr int R = V * V - 64, NP = pack3_passes(N);
     constexpr int NH = N >= 16 ? N / 2 : N;
     uint32_t raw[N], rawR[NP];
@@ -579,8 +619,8 @@ __device__ __forceinline__ void gather_group_pk3(const KernelArgs &a, const int 
             asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(lc.pk[0]), "v"(r[n].lo));
             asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(r[n].hi));
             asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "v"(r[n].steps), "v"(r[n].origin));
-            MGX_CHECK_LDS_ADDR(4, addr, 2);
-            raw[h0 + n] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+            MGX_CHECK_LDS_ADDR(4, addr, C8 ? 1 : 2);
+            raw[h0 + n] = gather_read<C8>(addr);
         }
         if (h0 + NH < N) __builtin_amdgcn_sched_barrier(0);
     }
@@ -596,8 +636,21 @@ __device__ __forceinline__ void gather_group_pk3(const KernelArgs &a, const int 
         asm("v_pk_max_i16 %0, %1, %2" : "=v"(t) : "v"(lc.pk[1]), "v"(r.lo));
         asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(r.hi));
         asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(addr) : "v"(t), "v"(r.steps), "v"(r.origin));
-        if (lc.act[1]) MGX_CHECK_LDS_ADDR(4, addr, 2);
-        rawR[p] = (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
+        if (lc.act[1]) MGX_CHECK_LDS_ADDR(4, addr, C8 ? 1 : 2);
+        rawR[p] = gather_read<C8>(addr);
+    }
+    [[maybe_unused]] uint32_t dec[C8 ? N : 1], decR[C8 ? NP : 1];
+    if constexpr (C8) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            MGX_CHECK_LDS_ADDR(9, lut_mid + (raw[n] << 2), 4);
+            dec[n] = lut_decode(raw[n], lut_mid);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (lc.act[1]) MGX_CHECK_LDS_ADDR(9, lut_mid + (rawR[p] << 2), 4);
+            decR[p] = lut_decode(rawR[p], lut_mid);
+        }
     }
     // see-behind ballots of the full passes: compare of view n, then the two writelanes of view n-1 (the v_writelane data hazard,
     // gather_group below)
@@ -606,6 +659,8 @@ __device__ __forceinline__ void gather_group_pk3(const KernelArgs &a, const int 
     for (int n = 0; n < N; ++n) {
         if constexpr (HALF) {
             if ((n & 1) == 0) cell[(S0 + n) >> 1][0] = raw[n] | (raw[n + 1] << 16);
+        } else if constexpr (C8) {
+            cell[S0 + n][0] = dec[n];
         } else {
             cell[S0 + n][0] = raw[n];
         }
@@ -627,7 +682,8 @@ __device__ __forceinline__ void gather_group_pk3(const KernelArgs &a, const int 
     for (int p = 0; p < NP; ++p) {
         constexpr int kLast = N - 3 * (NP - 1);
         const int ns = p == NP - 1 ? kLast : 3;
-        cell[pk3_reg<N>(S0, p)][1] = rawR[p];
+        if constexpr (C8) cell[pk3_reg<N>(S0, p)][1] = decR[p];
+        else cell[pk3_reg<N>(S0, p)][1] = rawR[p];
         uint64_t cur;
         asm volatile("v_cmp_lt_i16_e64 %0, -1, %1" : "=s"(cur) : "v"(rawR[p]));
         constexpr uint32_t kWord = (1u << R) - 1u;
@@ -647,17 +703,17 @@ __device__ __forceinline__ void gather_group_pk3(const KernelArgs &a, const int 
 #endif
 constexpr int kGroup = MGX_GROUP;      // slots gathered (P2) / written (P4) as one straight-line block
 
-template <int V, int NW, int VPW, bool HALF, int G, int S0 = 0>
+template <int V, int NW, int VPW, bool HALF, int G, bool C8 = false, int S0 = 0>
 __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, int NVc, const ViewRec *rec,
                                            const LaneConst<V, NW> &lc, uint32_t (&cell)[HALF ? VPW / 2 : VPW][NW],
-                                           uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW]) {
+                                           uint32_t (&sbLo)[NW], uint32_t (&sbHi)[NW], const uint32_t lut_mid = 0) {
     if constexpr (S0 < VPW) {
         // whole groups only: P1d pads the records of a ragged last group with views of nothing (all lanes outside the grid)
         if (S0 < NVc) {
-            if constexpr (kPack3<V>) gather_group_pk3<V, NW, S0, G, VPW, HALF>(a, wave, rec, lc, cell, sbLo, sbHi);
-            else gather_group<V, NW, S0, G, VPW, HALF>(a, wave, rec, lc, cell, sbLo, sbHi);
+            if constexpr (kPack3<V>) gather_group_pk3<V, NW, S0, G, VPW, HALF, C8>(a, wave, rec, lc, cell, sbLo, sbHi, lut_mid);
+            else gather_group<V, NW, S0, G, VPW, HALF, C8>(a, wave, rec, lc, cell, sbLo, sbHi, lut_mid);
         }
-        gather_all<V, NW, VPW, HALF, G, S0 + G>(a, wave, NVc, rec, lc, cell, sbLo, sbHi);
+        gather_all<V, NW, VPW, HALF, G, C8, S0 + G>(a, wave, NVc, rec, lc, cell, sbLo, sbHi, lut_mid);
     }
 }
 
@@ -675,8 +731,10 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // after the step: the reference's _gen_grid on the device, mgx_layout_gen.h).
 // STREAM: the grid tensor is larger than the Infinity Cache can keep between steps: non-temporal tile loads.
 // DMA: the tile is loaded HBM -> LDS by LDS-DMA (small launches: P0).
+// C8: the grid is held as COMPACT one-byte cells (include/mgx.h: MgxCell8; MgxSpec.cell_bytes = 1): one-step and gen_obs kernels of
+// the throughput / streamed families only.
 template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false, bool DMA = (MGX_LDS_DMA != 0),
-          int GRP = kGroup, int SHAPE = 0>
+          int GRP = kGroup, int SHAPE = 0, bool C8 = false>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
 #include "mgx_fused_body.inc"
 }
@@ -685,7 +743,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 // register allocator lands on 78 or 86 depending on unrelated code (measured: 196 vs 204 us at 1M envs).  Its own entry point
 // carries the occupancy request; the step kernels are issue-bound and take the registers they want (forcing them costs
 // spills).  (A shared __device__ function for the body perturbs the other kernels' allocation by ~10 VGPRs: hence the include.)
-template <int V, bool OH, bool STREAM, bool DMA>
+template <int V, bool OH, bool STREAM, bool DMA, bool C8 = false>
 __global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(6)))
 void mgx_obs_kernel(const KernelArgs a) {
     constexpr int MODE = 0, GRP = kGroup, SHAPE = 0;
@@ -718,7 +776,8 @@ inline int match_fixed_shape(const KernelArgs &ka, bool hooks, bool persist = fa
         if (ka.sp.view_size == f.V
             && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw && hooks == f.hooks
             && ka.vpw == shape_slots(f)
-            && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), persist, f.hooks, false, kGroup).total())
+            && cell_bytes_of(ka.sp) == f.cb
+            && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), persist, f.hooks, false, kGroup, f.cb).total())
             return k;
     }
     return 0;
@@ -729,8 +788,59 @@ inline int match_fixed_shape(const KernelArgs &ka, bool hooks, bool persist = fa
 // the host derived, exactly like the built-in kShapes entries.  fn[ar]: the plain step without / with the fused auto-reset.
 struct JitShape { FixedShape f; int vpw, wave_lds; hipFunction_t fn[2]; };
 const JitShape *jit_shape_lookup(const KernelArgs &ka, bool hooks);
+// Compact cells (C8): the plain step / gen_obs of the throughput and streamed families -- hooks and auto-reset included, no one-hot,
+// generation, rollout or latency (LDS-DMA) instantiation: fill_args never asks for one on such a spec.
+template <int V, int MODE, bool STREAM>
+inline int launch_compact(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
+    if constexpr (MODE > 1) {
+        return MGX_ERR_UNSUPPORTED;
+    } else {
+        if constexpr (!STREAM) {
+            if (ka.flags & 1) return launch_compact<V, MODE, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+        }
+        if (ka.grp != kGroup || (ka.flags & 2) || ka.vpw > 32) return MGX_ERR_INVALID_ARGUMENT;     // (32 view slots: one decoded cell per register)
+        void (*kern)(const KernelArgs) = nullptr;
+        const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;
+        const bool ar = MODE != 0 && ka.pool_grid != nullptr;
+        constexpr bool S = MODE != 0;
+        if constexpr (MODE == 1 && V == 9 && STREAM && !MGX_NO_FIXED_SHAPES) {
+            if (match_fixed_shape(ka, hooks) == 5)
+                kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, true, false, kGroup, 5, true>
+                          : mgx_fused_kernel<V, 1, false, false, false, false, true, false, kGroup, 5, true>;
+        }
+        if (!kern) {
+            if constexpr (MODE == 0 && V <= 7)
+                kern = mgx_obs_kernel<V, false, STREAM, false, true>;
+            else
+                kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, false, false, STREAM, false, kGroup, 0, true>
+                                   : mgx_fused_kernel<V, MODE, S, false, false, false, STREAM, false, kGroup, 0, true>)
+                             : (ar ? mgx_fused_kernel<V, MODE, false, S, false, false, STREAM, false, kGroup, 0, true>
+                                   : mgx_fused_kernel<V, MODE, false, false, false, false, STREAM, false, kGroup, 0, true>);
+        }
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) { *hip_err = (int)e; (void)hipGetLastError(); return MGX_ERR_LAUNCH; }
+        }
+        if (occupancy) {
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, reinterpret_cast<const void *>(kern), threads,
+                                                                        (size_t)lds_bytes);
+            if (e != hipSuccess) { *hip_err = (int)e; (void)hipGetLastError(); return MGX_ERR_LAUNCH; }
+            return MGX_OK;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, stream, ka);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+        return MGX_OK;
+    }
+}
+
 template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false, int GRP = kGroup>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
+    if (ka.sp.cell_bytes == 1) {                            // compact cells: their own, smaller family
+        if constexpr (!OH && !GEN && !STREAM && !DMA && GRP == kGroup)
+            return launch_compact<V, MODE, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+        else return MGX_ERR_UNSUPPORTED;
+    }
     if constexpr (!STREAM && !DMA && MODE < 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
         if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
         if constexpr (!OH) {

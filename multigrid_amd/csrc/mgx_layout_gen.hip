@@ -94,6 +94,7 @@ int mgx_reset_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *g
     if (spec->width < 3 || spec->height < 3 || spec->num_agents < 1 || spec->num_agents > MGX_MAX_AGENTS)
         return MGX_ERR_INVALID_ARGUMENT;
     if (spec->width > 254 || spec->height > 254) return MGX_ERR_UNSUPPORTED;         // positions are bytes, 0xff = off the grid
+    if (spec->cell_bytes == 1) return MGX_ERR_UNSUPPORTED;                           // (generation writes 16-bit cells)
     if (batch == 0) return MGX_OK;
     if (!gen->blank || !gen->gen_state || !grid || !agents || !rng || !step_count || !episode) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(agents, 8) || misaligned(rng, 8) || misaligned(gen->gen_state, 8) || misaligned(aux, 16)

@@ -30,12 +30,20 @@ enum : int { AG_COLOR = 0, AG_DIR = 1, AG_X = 2, AG_Y = 3, AG_TERM = 4, AG_CARRY
 
 // A cell as the rules see it ("logical" cell, also the obs / carried-object byte order), little-endian in 24 bits:
 // type | color << 8 | state << 16.
+// (round 5) A BOX may hold an object (multigrid/core/world_object.py:574-605: Box.contains; Box.toggle replaces the box by it).
+// Neither Grid.state nor an observation shows the content -- it is an attribute of the Python object -- so it travels in the six
+// bits of the state BYTE that the 2-bit state leaves free: bits [23:18] of the logical cell = content kind [20:18] | content
+// colour [23:21].  Kinds: 0 nothing, 1 key, 2 ball, 3 goal, 4 floor, 5 lava, 6 wall, 7 door (closed, unlocked: what Door(color)
+// constructs); a box in a box and doors in other states are refused where grids enter (world.Box).  Everything that SHOWS a cell
+// (observations, full_obs, Grid.state) takes the low 18 bits: kCellShown.
+constexpr uint32_t kCellShown = 0x0003ffffu;
 constexpr uint32_t CELL_EMPTY = 1u;                       // (1,0,0)  world_object.py:131-137
 constexpr uint32_t CELL_WALL = 2u | (5u << 8);            // (2,5,0)  obs.py:14
 constexpr uint32_t CELL_UNSEEN = 0u;                      // (0,0,0)  obs.py:15
 
 // A cell as the GRID stores it (HBM and the LDS tile; include/mgx.h "packed cell"), 16 bits:
-//   [3:0] type   [10:8] color   [13:12] state   [15] opaque = !see_behind(cell)   (all other bits zero)
+//   [3:0] type   [10:8] color   [13:12] state   [15] opaque = !see_behind(cell)
+//   [7:4], [11], [14]: a box's content (kind [6:4], colour {[7], [11], [14]}), zero on every other cell
 // Two bytes instead of three cut the grid stream by a third and make every cell an aligned 16-bit LDS access (no dword pair
 // + v_alignbyte); the opaque bit is the sign of the sign-extended load, so the see-behind ballot of the gather is ONE compare.
 constexpr int kCellBytes = MGX_CELL_BYTES;
@@ -45,10 +53,18 @@ constexpr uint32_t CELL16_WALL = 0x8502u;                 // cell_pack(CELL_WALL
 MGX_HD int dir_dx(int d) { return (d == 0) - (d == 2); }
 MGX_HD int dir_dy(int d) { return (d == 1) - (d == 3); }
 
-// multigrid/utils/obs.py:46-63 see_behind, on a packed cell
+// multigrid/utils/obs.py:46-63 see_behind, on a logical cell
+MGX_HD uint32_t cell_state(uint32_t c) { return (c >> 16) & 3u; }
 MGX_HD bool see_behind(uint32_t c) {
     const uint32_t t = c & 0xffu;
-    return !(t == T_WALL || (t == T_DOOR && ((c >> 16) & 0xffu) != S_OPEN));
+    return !(t == T_WALL || (t == T_DOOR && cell_state(c) != S_OPEN));
+}
+// What a toggled box leaves on its cell (world_object.py:599-605: env.grid.set(*pos, self.contains)): the content as a cell,
+// EMPTY for a box that holds nothing.  Kind -> type by a nibble table; only the door kind has a state (closed).
+MGX_HD uint32_t box_content_cell(uint32_t box) {
+    const uint32_t kind = (box >> 18) & 7u, color = (box >> 21) & 7u;
+    const uint32_t type = (0x42938651u >> (4u * kind)) & 0xfu;            // empty, key, ball, goal, floor, lava, wall, door
+    return type | (color << 8) | ((kind == 7u ? (uint32_t)S_CLOSED : 0u) << 16);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -145,19 +161,54 @@ MGX_HD uint64_t row_set_carry(uint64_t r, uint32_t c) { return (r & 0xffffffffff
 // logical <-> packed.  Values outside the packed ranges (type > 15, color > 7, state > 3) do not occur in the reference
 // (types 0-10, colors 0-5, states 0-2 / directions 0-3) and are refused where grids enter (mgx_pack_grid reports them).
 MGX_HD uint32_t cell_pack(uint32_t c) {
-    return (c & 0x070fu) | ((c >> 4) & 0x3000u) | (see_behind(c) ? 0u : 0x8000u);
+    return (c & 0x070fu) | ((c >> 4) & 0x3000u) | (see_behind(c) ? 0u : 0x8000u)
+         | ((c >> 14) & 0x00f0u) | ((c >> 11) & 0x0800u) | ((c >> 9) & 0x4000u);     // content: [21:18] -> [7:4], [22] -> [11], [23] -> [14]
 }
+// what a cell SHOWS (observations, full_obs): (type, color, state)
 MGX_HD uint32_t cell_unpack(uint32_t p) { return (p & 0x070fu) | ((p & 0x3000u) << 4); }
+// ... and with a box's content, for the rules
+MGX_HD uint32_t cell_unpack_full(uint32_t p) {
+    return cell_unpack(p) | ((p & 0x00f0u) << 14) | ((p & 0x0800u) << 11) | ((p & 0x4000u) << 9);
+}
 // the agent overlay cell (10, color, dir) of a packed agent row (obs.py:163-173); never opaque
 MGX_HD uint32_t agent_cell16(uint64_t row) {
     return (uint32_t)T_AGENT | (((uint32_t)row & 0x7u) << 8) | ((((uint32_t)row >> 8) & 0x3u) << 12);
 }
 
+// COMPACT cells (include/mgx.h: MgxCell8, MgxSpec.cell_bytes = 1): one byte, type and state coded jointly --
+//   [3:0] tcode: 0..10 = type with state 0 | 11, 12 = door closed, locked | 13..15 = agent overlay facing 1..3   [6:4] color   [7] opaque
+// Only doors and the agent overlay have a state in the reference, so nothing is lost; mgx_pack_grid8_env counts anything else.
+constexpr uint32_t CELL8_WALL = 0xD2u;                    // cell8_pack(CELL_WALL)
+MGX_HD uint32_t cell8_pack(uint32_t c) {
+    const uint32_t t = c & 0xffu, st = (c >> 16) & 3u;
+    const uint32_t tc = (st == 0u) ? t : ((t == (uint32_t)T_DOOR) ? 10u + st : 12u + st);
+    return (tc & 15u) | (((c >> 8) & 7u) << 4) | (see_behind(c) ? 0u : 0x80u);
+}
+MGX_HD uint32_t cell8_unpack(uint32_t p) {
+    const uint32_t tc = p & 15u;
+    const bool hi = tc > 10u, door = tc < 13u;
+    const uint32_t type = hi ? (door ? (uint32_t)T_DOOR : (uint32_t)T_AGENT) : tc;
+    const uint32_t st = hi ? (door ? tc - 10u : tc - 12u) : 0u;
+    return type | (((p >> 4) & 7u) << 8) | (st << 16);
+}
+MGX_HD uint32_t agent_cell8(uint64_t row) {
+    const uint32_t d = ((uint32_t)row >> 8) & 3u;
+    return (d == 0u ? (uint32_t)T_AGENT : 12u + d) | (((uint32_t)row & 7u) << 4);
+}
+
 // grid cells (tile / HBM): 2 bytes, aligned
 MGX_HD uint32_t load_cell16(const uint8_t *p) { return *reinterpret_cast<const uint16_t *>(p); }
 MGX_HD void store_cell16(uint8_t *p, uint32_t c16) { *reinterpret_cast<uint16_t *>(p) = (uint16_t)c16; }
-MGX_HD uint32_t load_cell(const uint8_t *p) { return cell_unpack(load_cell16(p)); }
+MGX_HD uint32_t load_cell(const uint8_t *p) { return cell_unpack_full(load_cell16(p)); }
 MGX_HD void store_cell(uint8_t *p, uint32_t c) { store_cell16(p, cell_pack(c)); }
+// ... in the engine's cell format: `cb` = bytes per cell, 2 (MgxCell) or 1 (MgxCell8).  In the kernels it is a compile-time
+// constant of the instantiation, so the selects fold away.
+MGX_HD uint32_t load_cell_raw(int cb, const uint8_t *p) { return cb == 1 ? (uint32_t)*p : load_cell16(p); }
+MGX_HD void store_cell_raw(int cb, uint8_t *p, uint32_t raw) { if (cb == 1) *p = (uint8_t)raw; else store_cell16(p, raw); }
+MGX_HD uint32_t load_cell(int cb, const uint8_t *p) { return cb == 1 ? cell8_unpack(*p) : cell_unpack_full(load_cell16(p)); }
+MGX_HD uint32_t load_cell_shown(int cb, const uint8_t *p) { return cb == 1 ? cell8_unpack(*p) : cell_unpack(load_cell16(p)); }
+MGX_HD void store_cell(int cb, uint8_t *p, uint32_t c) { if (cb == 1) *p = (uint8_t)cell8_pack(c); else store_cell16(p, cell_pack(c)); }
+MGX_HD uint32_t agent_cell_raw(int cb, uint64_t row) { return cb == 1 ? agent_cell8(row) : agent_cell16(row); }
 // observation cells: the reference's 3 bytes (type, color, state), any alignment
 MGX_HD uint32_t load_obs_cell(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
 MGX_HD void store_obs_cell(uint8_t *p, uint32_t c) { p[0] = (uint8_t)c; p[1] = (uint8_t)(c >> 8); p[2] = (uint8_t)(c >> 16); }
@@ -240,11 +291,12 @@ MGX_HD int draw_rank(const uint64_t *rnd, int A, int a) {
 struct StepCfg {
     int W, H, A, max_steps;
     bool allow_overlap, joint_reward, success_any, failure_any;
+    int cb;               // bytes per grid cell: 2 (MgxCell) or 1 (MgxCell8)
 };
 
 MGX_HD StepCfg make_cfg(const MgxSpec &sp) {
     return StepCfg{sp.width, sp.height, sp.num_agents, sp.max_steps, sp.allow_agent_overlap != 0,
-                   sp.joint_reward != 0, sp.success_any != 0, sp.failure_any != 0};
+                   sp.joint_reward != 0, sp.success_any != 0, sp.failure_any != 0, sp.cell_bytes == 1 ? 1 : kCellBytes};
 }
 
 MGX_HD void set_terminated(uint64_t *rows, int A, int i, bool all) {
@@ -302,9 +354,9 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     const int d = row_dir(row), x = row_x(row), y = row_y(row);
     const int fx = x + dir_dx(d), fy = y + dir_dy(d);                       // agent.py:111-118
     const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
-    ev.off = inb ? (fy * cf.W + fx) * kCellBytes : 0;
-    const uint32_t cell = load_cell(tile + ev.off);
-    const uint32_t type = cell & 0xff, gstate = (cell >> 16) & 0xff;
+    ev.off = inb ? (fy * cf.W + fx) * cf.cb : 0;
+    const uint32_t cell = load_cell(cf.cb, tile + ev.off);
+    const uint32_t type = cell & 0xff, gstate = cell_state(cell);
     const bool stale = inb & (ev.off == stale_off);
     const uint32_t state = stale ? (uint32_t)S_CLOSED : gstate;             // the WorldObj's own state
     const uint32_t carry = row_carry(row), ctype = carry & 0xff;
@@ -327,7 +379,7 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     // base.py:439-446 pickup; world_object.py:518, 556, 587 can_pickup
     const bool pick = on_cell & (action == ACT_PICKUP) & (ctype == T_EMPTY)
                     & ((type == T_KEY) | (type == T_BALL) | (type == T_BOX));
-    // base.py:462-467 toggle; world_object.py:458-474 Door.toggle, 599-605 Box.toggle (contains is None)
+    // base.py:462-467 toggle; world_object.py:458-474 Door.toggle, 599-605 Box.toggle (the box is replaced by what it holds)
     const bool tog = on_cell & (action == ACT_TOGGLE);
     const bool unlock = (ctype == T_KEY) & (((carry >> 8) & 0xff) == ((cell >> 8) & 0xff));
     const uint32_t ns = (state == S_LOCKED) ? (unlock ? (uint32_t)S_OPEN : state)
@@ -337,7 +389,8 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
 
     uint32_t ncell = cell;
     ncell = door ? ((cell & 0xffffu) | (ns << 16)) : ncell;
-    ncell = (pick | box) ? CELL_EMPTY : ncell;
+    ncell = pick ? CELL_EMPTY : ncell;
+    ncell = box ? box_content_cell(cell) : ncell;
     ncell = drop ? carry : ncell;
     ev.ncell = ncell;
     const uint32_t ncarry = pick ? cell : (drop ? CELL_EMPTY : carry);
@@ -355,7 +408,7 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
 // The reference's loop (base.py:402-474): agents act one after the other in `ord`, each seeing the previous ones' effects.
 // `stale` points at the env's stale-door flag (aux[4] of a RedBlueDoors env) or is NULL.
 MGX_HD int stale_offset(const StepCfg &cf, const uint8_t *aux, int env_kind) {
-    return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.W + aux[0]) * kCellBytes : -1;
+    return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.W + aux[0]) * cf.cb : -1;
 }
 
 // ONE iteration of that loop: agent `i` takes its turn against the CURRENT tile and rows and its effects are committed.
@@ -369,7 +422,7 @@ MGX_HD bool agent_turn(const StepCfg &cf, uint8_t *tile, uint64_t *rows, int i, 
     const AgentEval ev = eval_agent(cf, tile, rows, action, rows[i], alive, so);
     if (ev.go) rows[i] = ev.nrow;
     if (ev.unstale) aux[4] = 0;
-    if (ev.writes) { store_cell(tile + ev.off, ev.ncell); dirty(ev.off); }
+    if (ev.writes) { store_cell(cf.cb, tile + ev.off, ev.ncell); dirty(ev.off); }
     if (ev.success) on_success(cf, rows, i, step_count, rew);                // base.py:433-434
     if (ev.failure) set_terminated(rows, cf.A, i, cf.failure_any);           // base.py:435-436, 509-532
     return ev.bad;
@@ -472,15 +525,15 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
         for (int a = 0; a < A; ++a)
             if ((row_carry(rows[a]) & 0xffffu) == want) on_success(cf, rows, a, step_count, rew);
     } else if (env_kind == MGX_KIND_REDBLUEDOORS) {
-        const int boff = (aux[1] * cf.W + aux[0]) * kCellBytes, roff = (aux[3] * cf.W + aux[2]) * kCellBytes;
+        const int boff = (aux[1] * cf.W + aux[0]) * cf.cb, roff = (aux[3] * cf.W + aux[2]) * cf.cb;
         for (int ko = 0; ko < A; ++ko) {                                        // `for agent_id, action in actions.items()`
             const int a = order ? (int)order[ko] : ko;
             if (a >= A || act[a] != ACT_TOGGLE) continue;
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if (fx != aux[0] || fy != aux[1]) continue;                         // fwd_obj == self.blue_door
-            if (((load_cell(tile + boff) >> 16) & 0xff) != S_OPEN || aux[4]) continue;                   // ... and self.blue_door.is_open (the OBJECT)
-            if (((load_cell(tile + roff) >> 16) & 0xff) == S_OPEN) {
+            if (cell_state(load_cell(cf.cb, tile + boff)) != S_OPEN || aux[4]) continue;                   // ... and self.blue_door.is_open (the OBJECT)
+            if (cell_state(load_cell(cf.cb, tile + roff)) == S_OPEN) {
                 on_success(cf, rows, a, step_count, rew);
             } else {
                 set_terminated(rows, A, a, cf.failure_any);                      // on_failure
@@ -502,8 +555,8 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;
-            const uint32_t c = load_cell(tile + (fy * cf.W + fx) * kCellBytes);
-            if ((c & 0xff) != T_DOOR || ((c >> 16) & 0xff) == S_LOCKED) continue;                   // isinstance(Door) and not is_locked
+            const uint32_t c = load_cell(cf.cb, tile + (fy * cf.W + fx) * cf.cb);
+            if ((c & 0xff) != T_DOOR || cell_state(c) == S_LOCKED) continue;                   // isinstance(Door) and not is_locked
             int k = -1;
             if (geo) {
                 const int side = (fx == 2 * (rs - 1)) ? 1 : ((fx == rs - 1) ? 0 : -1);
@@ -538,7 +591,7 @@ MGX_HD void overlay_agents(const StepCfg &cf, uint8_t *tile, const uint64_t *row
         if (row_term(r)) continue;
         const int x = row_x(r), y = row_y(r);
         if (x >= cf.W || y >= cf.H) continue;
-        store_cell16(tile + (y * cf.W + x) * kCellBytes, agent_cell16(r));
+        store_cell_raw(cf.cb, tile + (y * cf.W + x) * cf.cb, agent_cell_raw(cf.cb, r));
     }
 }
 
@@ -556,7 +609,7 @@ MGX_HD int overlay_offset(const StepCfg &cf, const uint64_t *rows, int ai) {
     }
     const int x = row_x(r), y = row_y(r);
     if (row_term(r) | shadowed | (x >= cf.W) | (y >= cf.H)) return -1;
-    return (y * cf.W + x) * kCellBytes;
+    return (y * cf.W + x) * cf.cb;
 }
 
 // Layout of a restarting env (include/mgx.h: MgxAutoReset): (first_env + b + episode * 7919) mod K.  The 64-bit remainder costs
@@ -589,12 +642,12 @@ MGX_HD int pool_index(int64_t first_env, int64_t b, int32_t ep, int32_t K, uint6
 struct ViewGeom { int origin, stepF, stepL, fmax, imin, imax; };
 
 template <int V>
-MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d) {
+MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d, int cb = kCellBytes) {
     const int dx = dir_dx(d), dy = dir_dy(d), h = V / 2;
     ViewGeom g;
-    g.origin = (y * W + x) * kCellBytes;
-    g.stepF = (dy * W + dx) * kCellBytes;
-    g.stepL = (dx * W - dy) * kCellBytes;
+    g.origin = (y * W + x) * cb;
+    g.stepF = (dy * W + dx) * cb;
+    g.stepL = (dx * W - dy) * cb;
     // room ahead and to both sides, as selects (one lane per view: the lanes hold all four directions)
     const bool d0 = d == 0, d1 = d == 1, d2 = d == 2;
     g.fmax = d0 ? W - 1 - x : (d1 ? H - 1 - y : (d2 ? x : y));

@@ -40,8 +40,11 @@ using at::Tensor;
 using OptTensor = std::optional<Tensor>;
 
 MgxSpec spec_from(at::IntArrayRef v) {
-    TORCH_CHECK(v.size() == 11, "mgx: spec must have 11 ints (struct MgxSpec, include/mgx.h), got ", v.size());
-    MgxSpec s;
+    TORCH_CHECK(v.size() == 11 || v.size() == 12, "mgx: spec must have 11 ints (struct MgxSpec, include/mgx.h; a 12th = cell_bytes), got ",
+                v.size());
+    MgxSpec s{};
+    // (the operator library works on the 16-bit MgxCell tensors; the compact one-byte format is served by the C ABI itself)
+    TORCH_CHECK(v.size() == 11 || v[11] == 0 || v[11] == MGX_CELL_BYTES, "mgx: the torch ops take 16-bit cells (cell_bytes 0 or 2), got ", v[11]);
     s.width = (int32_t)v[0]; s.height = (int32_t)v[1]; s.num_agents = (int32_t)v[2]; s.view_size = (int32_t)v[3];
     s.max_steps = (int32_t)v[4]; s.see_through_walls = (int32_t)v[5]; s.allow_agent_overlap = (int32_t)v[6];
     s.joint_reward = (int32_t)v[7]; s.success_any = (int32_t)v[8]; s.failure_any = (int32_t)v[9]; s.env_kind = (int32_t)v[10];

@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import hashlib
 import os
+import subprocess
 
 from . import _lib, build
 from .spec import EnvSpec
@@ -54,7 +55,7 @@ def source_for(key: MgxShapeKey) -> str:
     kern = """
 extern "C" __global__ __launch_bounds__(kMaxThreads) void %s(const KernelArgs a) {
     constexpr int V = %d, MODE = 1, GRP = kGroup, SHAPE = kNumShapes - 1;
-    constexpr bool HOOKS = %s, AR = %s, OH = false, GEN = false, STREAM = %s, DMA = %s;
+    constexpr bool HOOKS = %s, AR = %s, OH = false, GEN = false, STREAM = %s, DMA = %s, C8 = false;
 #include "mgx_fused_body.inc"
 }
 """
@@ -65,10 +66,31 @@ extern "C" __global__ __launch_bounds__(kMaxThreads) void %s(const KernelArgs a)
             + "}  // namespace mgx_fused\n")
 
 
+_TOOLCHAIN = None
+
+
+def _toolchain_tag() -> str:
+    """What identifies the compiler behind a cached code object: the ROCm tree's version file and libhiprtc's own file name
+    (hiprtcVersion needs the library mapped, which this process avoids: see compile_shape)."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        tag = [os.path.realpath(rocm)]
+        for rel in (".info/version", "lib/libhiprtc.so"):
+            p = os.path.join(rocm, rel)
+            try:
+                tag.append(open(p).read().strip() if rel.startswith(".info") else os.path.realpath(p))
+            except OSError:
+                tag.append("?")
+        _TOOLCHAIN = "|".join(tag)
+    return _TOOLCHAIN
+
+
 def _content_hash(src: str) -> str:
     h = hashlib.sha256()
     h.update(src.encode())
     h.update(" ".join(_OPTIONS).encode())
+    h.update(_toolchain_tag().encode())               # (a code object of another hipRTC / ROCm is not reused)
     for name in _SOURCES:
         with open(os.path.join(build.CSRC, name), "rb") as fh:
             h.update(fh.read())
@@ -147,7 +169,8 @@ def ensure_shape(spec: EnvSpec, batch: int, device=None, latency_only: bool = Tr
             return "unavailable"
         try:
             code = code_object_for(key)
-        except (RuntimeError, OSError) as e:     # (a hipRTC that cannot compile the kernel: the generic instantiation keeps running)
+        except (RuntimeError, OSError, subprocess.SubprocessError) as e:     # (a hipRTC that cannot compile the kernel, or one that
+            # ran into the worker's timeout: the generic instantiation keeps running)
             import warnings
             warnings.warn(f"multigrid_amd.jit: {str(e)[:300]}")
             return "unavailable"

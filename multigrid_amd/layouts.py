@@ -101,22 +101,67 @@ def grid_from_product(grid_hwc: np.ndarray) -> np.ndarray:
 def pack_cells(grid_hwc: np.ndarray) -> np.ndarray:
     """(type, color, state) bytes u8[...,3] -> the device's packed cells u16[...] (include/mgx.h MgxCell):
     [3:0] type | [10:8] color | [13:12] state | [15] opaque, opaque = not see_behind (multigrid/utils/obs.py:46-63: a wall,
-    or a door that is not open).  Values the 16 bits cannot hold (the reference has none) are refused."""
+    or a door that is not open).  A BOX's state byte may carry what the box holds (include/mgx.h "BOX CONTENTS": state | kind << 2
+    | colour << 5): kind -> bits [6:4], colour -> bits 7, 11, 14.  Values the 16 bits cannot hold (the reference has none) are
+    refused."""
     g = np.asarray(grid_hwc)
     if g.shape[-1] != 3:
         raise ValueError("pack_cells expects (type, color, state) triples in the last axis")
-    t, c, s = (g[..., k].astype(np.uint16) for k in range(3))
-    if (t > 15).any() or (c > 7).any() or (s > 3).any():
+    t, c, sb = (g[..., k].astype(np.uint16) for k in range(3))
+    s, kind, ccol = sb & 3, (sb >> 2) & 7, (sb >> 5) & 7
+    if (t > 15).any() or (c > 7).any():
         raise ValueError("cell value outside the packed format (type <= 15, color <= 7, state <= 3)")
+    has = (sb >> 2) != 0
+    if (has & ((t != Type.box) | (kind == 0) | (ccol > 5))).any():
+        raise ValueError("cell value outside the packed format: a state byte above 3 is a BOX's content (kind 1..7, colour <= 5)")
     opaque = (t == Type.wall) | ((t == Type.door) & (s != State.open))
-    return (t | (c << 8) | (s << 12) | (opaque.astype(np.uint16) << 15)).astype(np.uint16)
+    content = (kind << 4) | ((ccol & 1) << 7) | (((ccol >> 1) & 1) << 11) | (((ccol >> 2) & 1) << 14)
+    return (t | (c << 8) | (s << 12) | (opaque.astype(np.uint16) << 15) | content).astype(np.uint16)
 
 
 def unpack_cells(cells: np.ndarray) -> np.ndarray:
     """Packed cells u16[...] (or their int16 view) -> (type, color, state) bytes u8[...,3]."""
     p = np.asarray(cells)
     p = p.view(np.uint16) if p.dtype == np.int16 else p.astype(np.uint16)
-    return np.stack((p & 0xf, (p >> 8) & 0x7, (p >> 12) & 0x3), axis=-1).astype(np.uint8)
+    content = ((p >> 4) & 0xf) | (((p >> 11) & 1) << 4) | (((p >> 14) & 1) << 5)          # a box's content: kind | colour << 3
+    return np.stack((p & 0xf, (p >> 8) & 0x7, ((p >> 12) & 0x3) | (content << 2)), axis=-1).astype(np.uint8)
+
+
+def pack_cells8(grid_hwc: np.ndarray) -> np.ndarray:
+    """(type, color, state) bytes u8[...,3] -> COMPACT cells u8[...] (include/mgx.h MgxCell8): tcode [3:0] | color [6:4] | opaque [7],
+    tcode = type for state 0, 11 / 12 = closed / locked door, 13..15 = agent overlay facing 1..3.  Refuses what one byte cannot
+    hold: a state on anything but a door or an agent overlay."""
+    g = np.asarray(grid_hwc)
+    if g.shape[-1] != 3:
+        raise ValueError("pack_cells8 expects (type, color, state) triples in the last axis")
+    t, c, s = (g[..., k].astype(np.uint16) for k in range(3))
+    if (t > int(Type.agent)).any() or (c > 7).any() or (s > 3).any():
+        raise ValueError("cell value outside the compact format's range (type <= 10, color <= 7, state <= 3; a box's content "
+                         "needs the 16-bit cells)")
+    if ((s != 0) & (t != int(Type.door)) & (t != int(Type.agent))).any():
+        raise ValueError("the compact cell format holds a state only on doors and agent overlays")
+    tc = np.where(s == 0, t, np.where(t == int(Type.door), 10 + s, 12 + s))
+    opaque = (t == int(Type.wall)) | ((t == int(Type.door)) & (s != 0))
+    return (tc | (c << 4) | (opaque.astype(np.uint16) << 7)).astype(np.uint8)
+
+
+def unpack_cells8(cells: np.ndarray) -> np.ndarray:
+    """COMPACT cells u8[...] -> (type, color, state) bytes u8[...,3]."""
+    p = np.asarray(cells).astype(np.uint8).astype(np.int32)
+    tc = p & 15
+    door = (tc == 11) | (tc == 12)
+    t = np.where(tc <= 10, tc, np.where(door, int(Type.door), int(Type.agent)))
+    s = np.where(tc <= 10, 0, np.where(door, tc - 10, tc - 12))
+    return np.stack((t, (p >> 4) & 7, s), axis=-1).astype(np.uint8)
+
+
+def pack_cells_for(spec, grid_hwc: np.ndarray) -> np.ndarray:
+    """The device's cell tensor content for `spec` (its `cell_bytes`): i16 / u8 bit patterns."""
+    return pack_cells8(grid_hwc) if spec.cell_bytes == 1 else pack_cells(grid_hwc).view(np.int16)
+
+
+def unpack_cells_for(spec, cells: np.ndarray) -> np.ndarray:
+    return unpack_cells8(cells) if spec.cell_bytes == 1 else unpack_cells(cells)
 
 
 # ---- multigrid/base.py:604-697 -------------------------------------------------------------------------

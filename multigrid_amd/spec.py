@@ -19,7 +19,7 @@ class MgxSpecC(C.Structure):
     """`struct MgxSpec` of include/mgx.h."""
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "num_agents", "view_size", "max_steps", "see_through_walls",
-        "allow_agent_overlap", "joint_reward", "success_any", "failure_any", "env_kind")]
+        "allow_agent_overlap", "joint_reward", "success_any", "failure_any", "env_kind", "cell_bytes")]
 
 
 @dataclass(frozen=True)
@@ -35,6 +35,11 @@ class EnvSpec:
     success_termination_mode: str = "any"    # multigrid/base.py:97
     failure_termination_mode: str = "all"    # multigrid/base.py:98
     env_kind: str = "empty"
+    #: bytes per grid cell on the device (include/mgx.h): 2 = MgxCell (16 bits, every entry point), 1 = MgxCell8 (compact cells for
+    #: LARGE grids -- type and state coded jointly in one byte: a third less traffic per step and twice the envs per wavefront on
+    #: a 64x64 grid; served by step / gen_obs / auto-reset from a layout pool / full_obs, not by rollouts, one-hot output, device
+    #: generation or persistent stepping).  Same results bit for bit either way.
+    cell_bytes: int = 2
 
     def __post_init__(self):
         # multigrid/core/agent.py:78-79
@@ -57,6 +62,8 @@ class EnvSpec:
             raise ValueError(f"view_size must be <= {MAX_VIEW}")
         if self.width > 255 or self.height > 255:
             raise ValueError("grid sides must be <= 255 (positions are stored as uint8)")
+        if self.cell_bytes not in (1, 2):
+            raise ValueError("cell_bytes must be 2 (MgxCell) or 1 (MgxCell8, compact cells)")
 
     # ---- shapes of the device tensors (include/mgx.h) ----
     def grid_shape(self, batch: int):
@@ -64,8 +71,12 @@ class EnvSpec:
         return (batch, self.height, self.width, 3)
 
     def cells_shape(self, batch: int):
-        """packed 16-bit cells: the form the device holds (include/mgx.h MgxCell)"""
+        """packed cells: the form the device holds (include/mgx.h MgxCell, or MgxCell8 when cell_bytes == 1)"""
         return (batch, self.height, self.width)
+
+    @property
+    def compact(self) -> bool:
+        return self.cell_bytes == 1
 
     def agents_shape(self, batch: int):
         return (batch, self.num_agents, 8)
@@ -88,7 +99,7 @@ class EnvSpec:
             allow_agent_overlap=int(self.allow_agent_overlap), joint_reward=int(self.joint_reward),
             success_any=int(self.success_termination_mode == "any"),
             failure_any=int(self.failure_termination_mode == "any"),
-            env_kind=ENV_KINDS[self.env_kind])
+            env_kind=ENV_KINDS[self.env_kind], cell_bytes=self.cell_bytes)
 
     # ---- algorithmic HBM bytes per agent-step ----
     def bytes_gen_obs(self) -> int:

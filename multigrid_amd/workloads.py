@@ -9,7 +9,9 @@ parity tests and the profiling tools.
     C4  C2 at 65536 envs (the north-star configuration)
     C5  custom 64x64 walled grid, goal at (62,62), 16 agents, view 9, 32768 envs, WITH occluders: 5 % of the interior
         cells are walls, plus 8 doors (4 closed, 2 locked, 2 open), 4 keys, 2 balls, 2 boxes per layout; a pool of K = 64
-        such layouts from `numpy.random.default_rng(5)`; agent starts / directions are random free interior cells
+        such layouts from `numpy.random.default_rng(5)`; agent starts / directions are random free interior cells.
+        Held on the device as COMPACT one-byte cells (EnvSpec.cell_bytes = 1, include/mgx.h: MgxCell8 -- the format for large
+        grids; `make("c5", cell_bytes=2)` gives the same workload on 16-bit cells)
 
 Everything is a pure function of the GLOBAL env index (layout choice, agent starts, PCG64 words), so a shard
 [first_env, first_env + batch) of a workload is bit-identical to the same envs inside the whole batch.
@@ -65,7 +67,11 @@ TITLES = {
 }
 
 
-def spec_of(name: str) -> EnvSpec:
+def spec_of(name: str, cell_bytes: int | None = None) -> EnvSpec:
+    """The configuration's EnvSpec.  `cell_bytes`: None = the format the configuration is stepped in (compact cells for the
+    64x64 grid of C5, 16-bit cells for the others), or 1 / 2 to force one."""
+    if cell_bytes is not None:
+        return dataclasses.replace(spec_of(name), cell_bytes=int(cell_bytes))
     if name == "c1":        # multigrid/envs/__init__.py:44, empty.py:145 (max_steps = 4 * size^2)
         return EnvSpec(8, 8, 2, 7, max_steps=4 * 8 * 8)
     if name in ("c2", "c4"):  # multigrid/envs/__init__.py:46
@@ -73,7 +79,7 @@ def spec_of(name: str) -> EnvSpec:
     if name == "c3":        # multigrid/envs/blockedunlockpickup.py:104-136: room_size 6, max_steps 16 * room_size^2, joint
         return EnvSpec(11, 6, 2, 7, max_steps=16 * 6 * 6, joint_reward=True, env_kind="blockedunlockpickup")
     if name == "c5":
-        return EnvSpec(64, 64, 16, 9, max_steps=4 * 64 * 64)
+        return EnvSpec(64, 64, 16, 9, max_steps=4 * 64 * 64, cell_bytes=1)
     raise ValueError(f"unknown workload {name!r} (c1..c5)")
 
 
@@ -136,10 +142,10 @@ def _free_cells(g: np.ndarray):
 
 
 def make(name: str, batch: int | None = None, first_env: int = 0, global_batch: int | None = None,
-         seed: int = SEED) -> Workload:
+         seed: int = SEED, cell_bytes: int | None = None) -> Workload:
     """The shard [first_env, first_env + batch) of workload `name` at `global_batch` envs (default: the configuration's
-    own batch, all of it)."""
-    spec = spec_of(name)
+    own batch, all of it).  `cell_bytes`: see spec_of."""
+    spec = spec_of(name, cell_bytes)
     G = GLOBAL_BATCH[name] if global_batch is None else int(global_batch)
     B = G - first_env if batch is None else int(batch)
     if first_env < 0 or B < 0 or first_env + B > G:

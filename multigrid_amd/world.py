@@ -9,8 +9,10 @@ array `(W, H, 3)` indexed `[x, y]` like the reference's `Grid.state` (grid.py:54
 returns, the grid is checked (outer wall ring, packable values), packed and uploaded, and the HIP kernels own it
 (multigrid_amd/env.py: MultiGridEnv.reset).
 
-Limits, stated where they bite: `Box(contains=...)` other than None is refused (the device's 16-bit cell has no room for a
-content; every env of the reference uses empty boxes); user-defined object TYPES (the reference's dynamic enum extension,
+`Box(color, contains=obj)` (world_object.py:574-605) is carried to the device in the spare bits of the box's cell (include/mgx.h
+"BOX CONTENTS": a content kind + colour): a key, ball, goal, floor, lava, wall or a closed unlocked door; toggling the box puts
+the content on the grid, as `Box.toggle` does.  Limits, stated where they bite: a box inside a box and a door that is open or
+locked inside a box are refused (`content_code`); user-defined object TYPES (the reference's dynamic enum extension,
 multigrid/utils/enum.py:51-64) do not exist.
 """
 from __future__ import annotations
@@ -111,7 +113,8 @@ class WorldObj:
 
     @staticmethod
     def from_array(arr) -> "WorldObj | None":
-        """world_object.py:139-160: None for an empty cell."""
+        """world_object.py:139-160: None for an empty cell.  A box cell's state value may carry its content (include/mgx.h "BOX
+        CONTENTS": state | kind << 2 | colour << 5): the Box comes back holding it."""
         t = int(arr[0])
         if t == Type.empty:
             return None
@@ -120,7 +123,9 @@ class WorldObj:
             raise ValueError(f"Unknown object type: {t}")
         obj = cls.__new__(cls)
         WorldObj.__init__(obj, type=Type(t))
-        obj._v = [int(arr[0]), int(arr[1]), int(arr[2])]
+        obj._v = [int(arr[0]), int(arr[1]), int(arr[2]) & 3]
+        if t == Type.box and int(arr[2]) >> 2:
+            obj.contains = content_from_code(int(arr[2]) >> 2)
         return obj
 
     @staticmethod
@@ -135,6 +140,11 @@ class WorldObj:
         return False
 
     def can_contain(self) -> bool:
+        return False
+
+    def toggle(self, env, agent, pos) -> bool:
+        """world_object.py:215-233: what the toggle action does to this object (the device applies the same table, csrc/mgx_rules.h:
+        eval_agent); here on whatever grid `env.grid` is -- the host grid inside `_gen_grid`, the device-backed view otherwise."""
         return False
 
 
@@ -203,6 +213,20 @@ class Door(WorldObj):
     def can_overlap(self) -> bool:
         return self.is_open
 
+    def toggle(self, env, agent, pos) -> bool:
+        """world_object.py:458-474"""
+        if self.is_locked:
+            carried = agent.state.carrying
+            if isinstance(carried, Key) and carried.color == self.color:
+                self.is_locked = False
+                self.is_open = True
+                env.grid.update(*pos)
+                return True
+            return False
+        self.is_open = not self.is_open
+        env.grid.update(*pos)
+        return True
+
 
 class Key(WorldObj):
     def __init__(self, color=Color.blue):                            # world_object.py:509-510
@@ -222,17 +246,50 @@ class Ball(WorldObj):
 
 class Box(WorldObj):
     def __init__(self, color=Color.yellow, contains=None):           # world_object.py:574-585
-        if contains is not None:
-            raise NotImplementedError(
-                "multigrid_amd: Box(contains=...) is not supported -- the device's packed 16-bit cell cannot hold a box's content "
-                "(Box.toggle would have to put it on the grid, world_object.py:599-605); every env of the reference uses empty boxes")
         super().__init__(color=color)
+        if contains is not None:
+            content_code(contains)                                   # (refuses what the device's cell cannot hold, by name)
+        self.contains = contains
 
     def can_pickup(self) -> bool:
         return True
 
     def can_contain(self) -> bool:
         return True
+
+    def toggle(self, env, agent, pos) -> bool:
+        """world_object.py:599-605: the box is replaced by what it holds."""
+        env.grid.set(*pos, self.contains)
+        return True
+
+
+#: content kinds of include/mgx.h "BOX CONTENTS" (0 = nothing)
+_CONTENT_KINDS = (None, Type.key, Type.ball, Type.goal, Type.floor, Type.lava, Type.wall, Type.door)
+
+
+def content_code(obj) -> int:
+    """What a box holds as the device carries it: kind | colour << 3 (include/mgx.h "BOX CONTENTS"); 0 for None."""
+    if obj is None:
+        return 0
+    if not isinstance(obj, WorldObj):
+        raise TypeError(f"Box(contains=...) takes a WorldObj or None, got {type(obj).__name__}")
+    if obj.type == Type.box:
+        raise NotImplementedError("multigrid_amd: a box inside a box is not supported (the device's cell holds ONE level of content: "
+                                  "a kind and a colour, include/mgx.h)")
+    if obj.type == Type.door and obj.state != State.closed:
+        raise NotImplementedError("multigrid_amd: a door inside a box must be closed and unlocked (what Door(color) constructs): the "
+                                  "device's cell has no room for the content's state (include/mgx.h)")
+    if obj.type not in _CONTENT_KINDS[1:]:
+        raise NotImplementedError(f"multigrid_amd: a {obj.type.name} cannot be a box's content (include/mgx.h)")
+    return _CONTENT_KINDS.index(obj.type) | (int(obj.color) << 3)
+
+
+def content_from_code(code: int) -> "WorldObj | None":
+    kind, color = code & 7, (code >> 3) & 7
+    if kind == 0:
+        return None
+    t = _CONTENT_KINDS[kind]
+    return WorldObj.from_array((int(t), color, int(State.closed) if t == Type.door else 0))
 
 
 _TYPE_TO_CLASS = {int(Type.goal): Goal, int(Type.floor): Floor, int(Type.lava): Lava, int(Type.wall): Wall, int(Type.door): Door,
@@ -295,9 +352,29 @@ class Grid:
         self.vert_wall(x, y, h)
         self.vert_wall(x + w - 1, y, h)
 
+    def state_with_contents(self) -> np.ndarray:
+        """`state` with every box's content in the upper bits of its state value (include/mgx.h "BOX CONTENTS"): the form grids
+        are uploaded in.  Contents are attributes of the objects, so only boxes that were `set` as objects have one."""
+        out = self.state.copy()
+        for (x, y), obj in self.world_objects.items():
+            if isinstance(obj, Box) and obj.contains is not None and int(out[x, y, 0]) == Type.box:
+                out[x, y, 2] = (int(out[x, y, 2]) & 3) | (content_code(obj.contains) << 2)
+        return out
+
     def encode(self, vis_mask=None) -> np.ndarray:
         """grid.py:310-330 without agents: the state itself (masked cells -> (0, 0, 0))."""
         out = self.state.copy()
         if vis_mask is not None:
             out[~np.asarray(vis_mask, dtype=bool)] = 0
         return out
+
+    @staticmethod
+    def decode(array) -> "tuple[Grid, np.ndarray]":
+        """grid.py:327-349: an encoding (W, H, 3) back into a `Grid` + the mask of the cells it shows (type != unseen)."""
+        array = np.asarray(array)
+        width, height, dim = array.shape
+        assert dim == WorldObj.dim
+        vis_mask = array[..., WorldObj.TYPE] != int(Type.unseen)
+        grid = Grid(width, height)
+        grid.state[vis_mask] = array[vis_mask]
+        return grid, vis_mask

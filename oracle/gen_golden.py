@@ -77,6 +77,40 @@ def narrow(a):
     return a
 
 
+#: Box.contains (multigrid/core/world_object.py:574-605) is an attribute of the Python object: neither Grid.state nor the agent
+#: rows show it.  The fixtures record it where the product's byte layouts carry it (include/mgx.h "BOX CONTENTS"): in the upper
+#: bits of the box cell's STATE value, state | kind << 2 | colour << 5.  Every fixture without a filled box is unchanged by this.
+_CONTENT_KIND = {"key": 1, "ball": 2, "goal": 3, "floor": 4, "lava": 5, "wall": 6, "door": 7}
+
+
+def content_code(obj) -> int:
+    inner = getattr(obj, "contains", None)
+    if inner is None:
+        return 0
+    name = inner.type.value if hasattr(inner.type, "value") else str(inner.type)
+    assert name in _CONTENT_KIND, f"box content {name!r} has no code"
+    assert name != "door" or int(inner[2]) == 1, "a door in a box: closed and unlocked only"
+    return _CONTENT_KIND[name] | (int(inner[1]) << 3)
+
+
+def grid_with_contents(env) -> np.ndarray:
+    """env.grid.state (W,H,3) + what the boxes lying on the grid hold."""
+    st = env.grid.state.copy()
+    for x, y in np.argwhere(st[..., 0] == 7):
+        st[x, y, 2] |= content_code(env.grid.get(int(x), int(y))) << 2
+    return st
+
+
+def agents_with_contents(env) -> np.ndarray:
+    """env.agent_states (A,9) + what the boxes being carried hold."""
+    rows = np.asarray(env.agent_states).copy()
+    for agent in env.agents:
+        carried = agent.state.carrying
+        if carried is not None and int(carried[0]) == 7:
+            rows[agent.index, 8] |= content_code(carried) << 2
+    return rows
+
+
 def make_env(name, **kwargs):
     cls, cfg = ref_envs.CONFIGURATIONS[name]
     # pin the construction-time (layout) generator so regeneration is reproducible; see standins/gymnasium
@@ -123,8 +157,8 @@ def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, scri
         obs0 = env.gen_obs()
     A = env.num_agents
     rec = dict(
-        grid0=narrow(env.grid.state.copy()),
-        agents0=narrow(np.asarray(env.agent_states).copy()),
+        grid0=narrow(grid_with_contents(env)),
+        agents0=narrow(agents_with_contents(env)),
         rng0=rng_words(env.np_random),
         obs0=narrow(np.stack([obs0[i]["image"] for i in range(A)])),
         dir0=narrow(np.array([int(obs0[i]["direction"]) for i in range(A)])),
@@ -149,8 +183,8 @@ def record(fname, env, kind, seed, T, action_rng, p_missing=0.0, edit=None, scri
         log["terminated"].append([bool(term[i]) for i in range(A)])
         log["truncated"].append(bool(trunc[0]))
         assert len(set(bool(trunc[i]) for i in range(A))) == 1
-        log["grid"].append(env.grid.state.copy())
-        log["agents"].append(np.asarray(env.agent_states).copy())
+        log["grid"].append(grid_with_contents(env))
+        log["agents"].append(agents_with_contents(env))
     rec["actions"] = actions
     if dict_orders is not None:
         rec["hook_order"] = np.asarray(dict_orders, dtype=np.uint8)[:T]
@@ -284,6 +318,8 @@ def main():
     record_hook_envs()
     record_dict_order()
     record_custom()          # (last: every make_env() before it keeps the construction seed it always had)
+    record_custom_steps()    # (round 5, behind everything older for the same reason)
+    record_box_rollout()
 
 
 def face(env, i, target_xy, carrying=None):
@@ -534,6 +570,86 @@ def record_custom():
         np.savez_compressed(path, **rec)
         ntypes = sorted(set(int(v) for v in np.asarray(grids)[..., 0].ravel()))
         print(f"{fname:34s} resets={len(reset_seeds)} cell types seen={ntypes} {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def record_custom_steps():
+    """User-defined envs stepped for whole episodes over the REAL reference (tests/custom_envs.py: STEP_CASES): boxes that hold
+    things (Box.contains, world_object.py:574-605) and a `step` override that ends episodes through `on_success` / `on_failure`
+    (base.py:478-532) the way the reference's own envs do.  Per reset: the initial state, then every step's actions, outputs and
+    post-step state (box contents folded into the state values, see grid_with_contents)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import custom_envs
+    classes = custom_envs.define(custom_envs.multigrid_namespace())
+    for fname, (cname, kw, T) in custom_envs.STEP_CASES.items():
+        cls = classes[cname]
+        _MAKE_COUNT[0] += 1
+        cls._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
+        env = cls(**kw)
+        A = env.num_agents
+        reset_seeds = [11, -1, 5, 77]
+        ar = np.random.default_rng(13)
+        rec = dict(construct_seed=np.array(cls._default_seed), reset_seeds=np.array(reset_seeds),
+                   spec_json=np.array(json.dumps(spec_of_noreset(env, "empty"))))
+        keys = ("grid0", "agents0", "rng0", "obs0", "actions", "obs", "reward", "terminated", "truncated", "grid", "agents")
+        log = {k: [] for k in keys}
+        events = dict(success=0, failure=0, opened=0)
+        for sd in reset_seeds:
+            obs, _ = env.reset(seed=None if sd < 0 else sd)
+            log["grid0"].append(grid_with_contents(env)); log["agents0"].append(agents_with_contents(env))
+            log["rng0"].append(rng_words(env.np_random))
+            log["obs0"].append(np.stack([obs[i]["image"] for i in range(A)]))
+            # walk, pick up, drop and toggle a lot: boxes get opened and carried, balls fetched, the trap door opened
+            acts = ar.choice(7, size=(T, A), p=[0.12, 0.12, 0.36, 0.12, 0.08, 0.17, 0.03]).astype(np.int8)
+            acts[ar.random((T, A)) < 0.04] = -1
+            if cname == "BoxTreasureEnv":
+                acts[0, 0] = 5                                   # agent 0 starts facing the key box: open it, take the key
+                acts[1, 0] = 3
+            ep = {k: [] for k in ("obs", "reward", "terminated", "truncated", "grid", "agents")}
+            for t in range(T):
+                nbox = int((env.grid.state[..., 0] == 7).sum())
+                o, r, tm, tr, _ = env.step({i: int(acts[t, i]) for i in range(A) if acts[t, i] >= 0})
+                ep["obs"].append(np.stack([o[i]["image"] for i in range(A)]))
+                ep["reward"].append([float(r[i]) for i in range(A)]); ep["terminated"].append([bool(tm[i]) for i in range(A)])
+                ep["truncated"].append(bool(tr[0]))
+                ep["grid"].append(grid_with_contents(env)); ep["agents"].append(agents_with_contents(env))
+                events["success"] += any(float(r[i]) > 0 for i in range(A))
+                events["failure"] += any(bool(tm[i]) and float(r[i]) == 0 for i in range(A)) and not any(float(r[i]) > 0 for i in range(A))
+                carried = sum(a.state.carrying is not None and int(a.state.carrying[0]) == 7 for a in env.agents)
+                events["opened"] += int(nbox > int((env.grid.state[..., 0] == 7).sum()) + carried)
+            log["actions"].append(acts)
+            for k, v in ep.items():
+                log[k].append(v)
+        for k in keys:
+            arr = np.asarray(log[k])
+            rec[k] = arr.astype(np.float64) if k == "reward" else (arr if k in ("rng0", "actions") else narrow(arr))
+        path = os.path.join(OUT, fname + ".npz")
+        np.savez_compressed(path, **rec)
+        print(f"{fname:34s} episodes={len(reset_seeds)} x {T} steps events={events} {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def record_box_rollout():
+    """A rollout fixture in the format of `record` from the BoxTreasureEnv of tests/custom_envs.py: replayed by every golden test
+    (oracle, host rules, the HIP kernels through the C ABI) like the fixtures of the reference's own envs.  Agent 0 opens the box
+    that holds the purple key, takes the key, walks to the locked purple door and unlocks it (scripted); the others act at random
+    (toggle / pickup / drop heavy), so boxes are opened, carried and opened elsewhere."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import custom_envs
+    cls = custom_envs.define(custom_envs.multigrid_namespace())["BoxTreasureEnv"]
+    _MAKE_COUNT[0] += 1
+    cls._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
+    env = cls(size=9, agents=3)
+    T = 160
+    ar = np.random.default_rng(31)
+    script = ar.choice(7, size=(T, 3), p=[0.12, 0.12, 0.36, 0.12, 0.08, 0.17, 0.03]).astype(np.int8)
+    # agent 0: (1, 6) facing down at the key box (1, 7): toggle (box -> key), pickup, turn left (-> facing right/east), forward x3 to
+    # (4 - 1, 6)... the door sits at (4, 4): up two cells first
+    env.reset(seed=9)
+    assert tuple(int(v) for v in env.agents[0].state.pos) == (1, 6) and int(env.agents[0].state.dir) == 1
+    plan = [5, 3, 0, 0, 2, 2, 1, 2, 2, 5, 2, 2]      # toggle, pickup, left, left (facing up), fwd, fwd (1,4), right (facing east), fwd, fwd (3,4), toggle door, fwd, fwd
+    script[:len(plan), 0] = plan
+    record("boxkey_a3", env, "empty", 9, T, None, script=script,
+           note="BoxTreasureEnv (tests/custom_envs.py): boxes that hold a key / ball / goal / door / lava; agent 0 opens the key box, "
+                "takes the key and unlocks the purple door")
 
 
 def spec_of_noreset(env, kind):

@@ -163,11 +163,14 @@ static void gen_obs_grid(const int64_t *grid_state, const int64_t *agent_state, 
                 else if (rot == 3) { i_rot = v - j - 1; j_rot = i; }
                 const int64_t *src = (x >= 0 && x < W && y >= 0 && y < H)
                     ? grid_encoding + ((size_t)x * H + y) * 3 : WALL_ENCODING;
-                memcpy(img + ((size_t)i_rot * v + j_rot) * 3, src, 3 * sizeof(int64_t));
+                int64_t *dst = img + ((size_t)i_rot * v + j_rot) * 3;
+                memcpy(dst, src, 3 * sizeof(int64_t));
+                dst[2] &= 3;                                          /* (a box's content is not part of Grid.state: below) */
             }
         }
         /* obs.py:207: the agent sees what it carries at its own cell */
         memcpy(img + ((size_t)(v / 2) * v + (v - 1)) * 3, s + AS_CARRY, 3 * sizeof(int64_t));
+        img[((size_t)(v / 2) * v + (v - 1)) * 3 + 2] &= 3;
     }
 }
 
@@ -251,6 +254,18 @@ static int can_overlap(const int64_t *c) {
 /* world_object.py:203-207 (base False), 518-522 Key, 556-560 Ball, 587-591 Box */
 static int can_pickup(const int64_t *c) { return c[0] == T_KEY || c[0] == T_BALL || c[0] == T_BOX; }
 
+/* Box.contains (multigrid/core/world_object.py:574-585): an attribute of the Python object that neither Grid.state nor an
+ * observation shows.  This restatement keeps it where the product's byte layouts do (include/mgx.h "BOX CONTENTS"): in the upper
+ * bits of the box cell's STATE value, state | kind << 2 | colour << 5, kind = 0 nothing, 1 key, 2 ball, 3 goal, 4 floor,
+ * 5 lava, 6 wall, 7 door (closed, as Door(color) constructs it).  It moves with the cell through pickup / drop (the reference
+ * moves the object), is masked wherever the reference reads Grid.state (observations, full_obs), and Box.toggle
+ * (world_object.py:599-605: env.grid.set(*pos, self.contains)) puts it on the grid. */
+static void box_content(const int64_t *box, int64_t *out) {
+    static const int64_t kind_type[8] = {T_EMPTY, T_KEY, T_BALL, T_GOAL, T_FLOOR, T_LAVA, T_WALL, T_DOOR};
+    const int64_t kind = (box[2] >> 2) & 7, color = (box[2] >> 5) & 7;
+    out[0] = kind_type[kind]; out[1] = kind ? color : 0; out[2] = (kind == 7) ? S_CLOSED : 0;
+}
+
 /* base.py:426-427 / 454-455: any agent (terminated or not, any index) standing on (x,y) */
 static int agent_present(const int64_t *agent_state, int A, int64_t x, int64_t y) {
     for (int a = 0; a < A; ++a)
@@ -318,7 +333,9 @@ static int handle_actions(const MgoSpec *sp, int64_t *grid_state, int64_t *agent
                     if (stale) aux[4] = 0;
                 }
             } else if (cell[0] == T_BOX) {                             /* world_object.py:599-605 Box.toggle */
-                memcpy(cell, EMPTY_ENCODING, 3 * sizeof(int64_t));    /* contains is None in scope */
+                int64_t content[3];
+                box_content(cell, content);                           /* env.grid.set(*pos, self.contains); None -> empty */
+                memcpy(cell, content, 3 * sizeof(int64_t));
             }
             break;
         case A_DONE: break;                                            /* base.py:470-471 */
@@ -491,6 +508,7 @@ int mgo_one_hot(const int64_t *x, int64_t n_cells, const int64_t *dim_sizes, uin
  * for agent in agents: img[agent.state.pos] = agent.encode() (agent.py:135-148).  Reference layout (W,H,3). */
 int mgo_full_obs(const int64_t *grid_state, const int64_t *agent_state, int W, int H, int A, int64_t *img) {
     memcpy(img, grid_state, sizeof(int64_t) * (size_t)W * H * 3);
+    for (size_t k = 0; k < (size_t)W * H; ++k) img[3 * k + 2] &= 3;    /* (Grid.state holds no box content) */
     for (int a = 0; a < A; ++a) {
         const int64_t *s = agent_state + (size_t)a * AS_DIM;
         int64_t *c = img + ((size_t)s[AS_X] * H + s[AS_Y]) * 3;

@@ -16,14 +16,16 @@ def multigrid_amd_namespace():
     import multigrid_amd as m
     from multigrid_amd import core
     return SimpleNamespace(MultiGridEnv=m.MultiGridEnv, Grid=core.Grid, Goal=core.Goal, Wall=core.Wall, Door=core.Door, Key=core.Key,
-                           Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction)
+                           Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction,
+                           Action=core.Action)
 
 
 def multigrid_namespace():
     from multigrid.base import MultiGridEnv
     from multigrid import core
     return SimpleNamespace(MultiGridEnv=MultiGridEnv, Grid=core.Grid, Goal=core.Goal, Wall=core.Wall, Door=core.Door, Key=core.Key,
-                           Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction)
+                           Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction,
+                           Action=core.Action)
 
 
 def define(ns):
@@ -90,11 +92,85 @@ def define(ns):
             for agent in self.agents:
                 self.place_agent(agent)
 
-    return {"TwoRoomsEnv": TwoRoomsEnv, "ScatterEnv": ScatterEnv}
+    class BoxTreasureEnv(ns.MultiGridEnv):
+        """Boxes that HOLD things (Box(color, contains=...), multigrid/core/world_object.py:574-605): the key of the locked door
+        between the two rooms is in a box, other boxes hold a ball, a goal, a closed door, nothing.  Toggling a box replaces it by
+        its content; a box can be carried away first and opened elsewhere.  Agents are placed through the `Agent` aliases
+        (`agent.pos = ...`, `agent.dir = ...`, agent.py:100-109)."""
+
+        def __init__(self, size=9, **kwargs):
+            super().__init__(mission_space="open the boxes", grid_size=size, max_steps=5 * size * size, **kwargs)
+
+        def _gen_grid(self, width, height):
+            self.grid = ns.Grid(width, height)
+            self.grid.wall_rect(0, 0, width, height)
+            mid = width // 2
+            self.grid.vert_wall(mid, 0)
+            self.door = ns.Door(ns.Color.purple, is_locked=True)
+            self.put_obj(self.door, mid, height // 2)
+            self.put_obj(ns.Goal(), width - 2, 1)
+            self.key_box = ns.Box(ns.Color.yellow, contains=ns.Key(ns.Color.purple))
+            self.put_obj(self.key_box, 1, height - 2)
+            self.put_obj(ns.Box(ns.Color.red, contains=ns.Ball(ns.Color.blue)), 2, 1)
+            self.put_obj(ns.Box(ns.Color.green), 3, 3)                                   # holds nothing
+            self.place_obj(ns.Box(self._rand_color(), contains=ns.Goal(ns.Color.grey)), top=(1, 1), size=(mid - 1, height - 2))
+            self.place_obj(ns.Box(ns.Color.blue, contains=ns.Door(ns.Color.red)), top=(mid + 1, 1), size=(mid - 1, height - 2))
+            self.place_obj(ns.Box(ns.Color.grey, contains=ns.Lava()), top=(mid + 1, 1), size=(mid - 1, height - 2))
+            for agent in self.agents:
+                if agent.index == 0:
+                    agent.pos = (1, height - 3)                                          # right above the key box, facing it
+                    agent.dir = ns.Direction.down
+                else:
+                    self.place_agent(agent, top=(1, 1), size=(mid - 1, height - 2))
+
+    class FetchTrapEnv(ns.MultiGridEnv):
+        """An env that ends its episodes the way the reference's own envs do (envs/blockedunlockpickup.py:166-175,
+        envs/redbluedoors.py:170-187): a `step` override on top of the base step -- success for whoever carries THE purple ball
+        (object identity, not the green decoy), failure for whoever toggles the red trap door open."""
+
+        def __init__(self, size=8, **kwargs):
+            super().__init__(mission_space="fetch the purple ball, leave the red door shut", grid_size=size,
+                             max_steps=3 * size * size, **kwargs)
+
+        def _gen_grid(self, width, height):
+            self.grid = ns.Grid(width, height)
+            self.grid.wall_rect(0, 0, width, height)
+            self.grid.horz_wall(0, height - 3)
+            self.trap = ns.Door(ns.Color.red)
+            self.put_obj(self.trap, self._rand_int(1, width - 1), height - 3)
+            self.ball = ns.Ball(ns.Color.purple)
+            self.place_obj(self.ball, top=(1, 1), size=(width - 2, height - 4))
+            self.decoy = ns.Ball(ns.Color.green)
+            self.place_obj(self.decoy, top=(1, 1), size=(width - 2, height - 4))
+            for agent in self.agents:
+                self.place_agent(agent, top=(1, 1), size=(width - 2, height - 4))
+
+        def step(self, actions):
+            obs, reward, terminated, truncated, info = super().step(actions)
+            for agent in self.agents:
+                if agent.state.carrying == self.ball:
+                    self.on_success(agent, reward, terminated)
+            for agent_id, action in actions.items():
+                if action == ns.Action.toggle:
+                    agent = self.agents[agent_id]
+                    if self.grid.get(*agent.front_pos) == self.trap and self.trap.is_open:
+                        self.on_failure(agent, reward, terminated)
+            return obs, reward, terminated, truncated, info
+
+    return {"TwoRoomsEnv": TwoRoomsEnv, "ScatterEnv": ScatterEnv, "BoxTreasureEnv": BoxTreasureEnv, "FetchTrapEnv": FetchTrapEnv}
 
 
 #: fixture name -> (class name, constructor kwargs)
 CASES = {
     "custom_tworooms_a3": ("TwoRoomsEnv", dict(size=11, agents=3)),
     "custom_scatter_a2_v5": ("ScatterEnv", dict(width=13, height=9, agents=2, agent_view_size=5, allow_agent_overlap=False)),
+}
+
+#: step-sequence fixtures (oracle/gen_golden.py: record_custom_steps; tests/test_custom_envs.py: _replay_steps):
+#: fixture name -> (class name, constructor kwargs, steps per episode)
+STEP_CASES = {
+    "customsteps_boxtreasure_a3": ("BoxTreasureEnv", dict(size=9, agents=3), 120),
+    "customsteps_fetchtrap_a2": ("FetchTrapEnv", dict(size=8, agents=2), 90),
+    "customsteps_fetchtrap_a3_all": ("FetchTrapEnv", dict(size=8, agents=3, success_termination_mode="all",
+                                                          failure_termination_mode="any", joint_reward=True), 90),
 }

@@ -43,8 +43,10 @@ def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=Fals
     Returns dict(obs, reward, terminated, truncated, order, rc, n_dirty)."""
     sc = spec.to_c()
     A, v = spec.num_agents, spec.view_size
-    # the rules work on packed 16-bit cells (include/mgx.h MgxCell); the tests speak (type, color, state) bytes
-    tile3, tile = tile, np.ascontiguousarray(_layouts().pack_cells(tile))
+    # the rules work on packed cells (include/mgx.h MgxCell, or MgxCell8 for spec.cell_bytes == 1); the tests speak (type, color,
+    # state) bytes
+    L = _layouts()
+    tile3, tile = tile, np.ascontiguousarray(L.pack_cells_for(spec, tile))
     over = np.empty_like(tile)
     rew = np.empty(A, np.float64); term = np.empty(A, np.uint8); trunc = np.zeros(1, np.uint8)
     order = np.empty(A, np.uint8); nd = C.c_int32(0); scnt = C.c_int32(int(step_count))
@@ -56,8 +58,8 @@ def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=Fals
                              _p(np.ascontiguousarray(hook_order, dtype=np.uint8), C.c_uint8) if hook_order is not None else None)
     obs = np.empty((A, v, v, 3), np.uint8)
     assert lib().shim_obs_env(C.byref(sc), _p(over, C.c_uint8), _p(rows, C.c_uint64), _p(obs, C.c_uint8)) == 0
-    assert np.array_equal(_layouts().pack_cells(_layouts().unpack_cells(tile)), tile), "opaque bits out of date"
-    tile3[...] = _layouts().unpack_cells(tile)
+    assert np.array_equal(L.pack_cells_for(spec, L.unpack_cells_for(spec, tile)), tile), "opaque bits out of date"
+    tile3[...] = L.unpack_cells_for(spec, tile)
     return dict(obs=obs, reward=rew, terminated=term, truncated=int(trunc[0]), order=order, rc=rc,
                 n_dirty=nd.value, step_count=scnt.value, serial=nd.value < 0)
 
@@ -65,7 +67,7 @@ def step_env(spec, tile, rows8, act, rng4, step_count, target, force_serial=Fals
 def obs_env(spec, tile, rows8):
     sc = spec.to_c()
     A, v = spec.num_agents, spec.view_size
-    over = np.ascontiguousarray(_layouts().pack_cells(tile))
+    over = np.ascontiguousarray(_layouts().pack_cells_for(spec, tile))
     rows = np.ascontiguousarray(rows8).view(np.uint64).reshape(A)
     lib().shim_overlay(C.byref(sc), _p(over, C.c_uint8), _p(rows, C.c_uint64))
     obs = np.empty((A, v, v, 3), np.uint8)

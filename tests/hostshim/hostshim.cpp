@@ -24,7 +24,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
                              uint8_t *terminated /* A out */, uint8_t *truncated, uint8_t *order_out,
                              int32_t *n_dirty, int force_serial, const uint8_t *hook_order /* A, or NULL */) {
     const StepCfg cf = make_cfg(*sp);
-    const int A = cf.A, HWB = cf.H * cf.W * kCellBytes;
+    const int A = cf.A, HWB = cf.H * cf.W * cf.cb;          // (cf.cb: 2 = MgxCell, 1 = the compact MgxCell8; include/mgx.h)
     std::vector<uint64_t> rnd(A);
     std::vector<uint8_t> ord(A, 0);
     for (int a = 0; a < A; ++a) rew[a] = 0.0;
@@ -71,7 +71,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
             if (acts[ai]) {
                 if (ev[ai].go) rows[ai] = ev[ai].nrow;
                 if (ev[ai].unstale) aux[4] = 0;
-                if (ev[ai].writes) { store_cell(tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
+                if (ev[ai].writes) { store_cell(cf.cb, tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
             }
             if (cf.joint_reward ? joint_success : (acts[ai] & ev[ai].success)) rew[ai] = r;
             if ((acts[ai] & event_ends_self(cf, ev[ai])) | (m_ends_all != 0))
@@ -93,7 +93,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
             const int ai = ord[k];
             if (ev[ai].go) rows[ai] = ev[ai].nrow;
             if (ev[ai].unstale) aux[4] = 0;
-            if (ev[ai].writes) { store_cell(tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
+            if (ev[ai].writes) { store_cell(cf.cb, tile + ev[ai].off, ev[ai].ncell); dirty(ev[ai].off); }
         }
         rc = handle_actions(cf, tile, rows, act, ord.data(), rew, sc, dirty, aux, sp->env_kind, cut);
     }
@@ -109,7 +109,7 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
     for (int a = 0; a < A; ++a) terminated[a] = (uint8_t)(row_term(rows[a]) | forced);
     std::memcpy(tile_overlaid, tile, HWB);
     for (int ai = 0; ai < A; ++ai)
-        if (ovl[ai] >= 0) store_cell16(tile_overlaid + ovl[ai], agent_cell16(rows[ai]));
+        if (ovl[ai] >= 0) store_cell_raw(cf.cb, tile_overlaid + ovl[ai], agent_cell_raw(cf.cb, rows[ai]));
     {   // must equal the reference's ascending loop (overlay_agents) run on the pre-hook rows
         std::vector<uint8_t> ref(tile, tile + HWB);
         overlay_agents(cf, ref.data(), pre_rows.data());
@@ -122,10 +122,10 @@ extern "C" int shim_step_env(const MgxSpec *sp, uint8_t *tile /* H*W packed cell
 template <int V>
 static void obs_env(const MgxSpec *sp, const uint8_t *tile, const uint64_t *rows, uint8_t *obs) {
     constexpr int V2 = V * V, NW = (V2 + 63) / 64;
-    const int A = sp->num_agents, W = sp->width, H = sp->height;
+    const int A = sp->num_agents, W = sp->width, H = sp->height, cb = make_cfg(*sp).cb;
     for (int a = 0; a < A; ++a) {
         const uint64_t row = rows[a];
-        const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row));
+        const ViewGeom g = view_geom<V>(W, H, row_x(row), row_y(row), row_dir(row), cb);
         uint64_t inb[NW], sb[NW], vis[NW];
         inbounds_mask<V, NW>(g, inb);
         const ViewClamp vc = view_clamp<V>(g, W, H, row_x(row), row_y(row));   // what the kernel's P2 gathers with
@@ -135,10 +135,15 @@ static void obs_env(const MgxSpec *sp, const uint8_t *tile, const uint64_t *rows
             const int j = k / V, i = k - j * V, la = i - V / 2, fw = V - 1 - j;
             const bool in = (inb[k >> 6] >> (k & 63)) & 1;
             // (the kernel: the clamped offset, or the WALL cell for an agent outside the grid; must agree with the mask form)
-            uint32_t c = vc.valid ? load_cell(tile + clamped_offset(g.origin, vc, fw, la)) : (uint32_t)CELL_WALL;
-            const uint32_t c_mask = in ? load_cell(tile + g.origin + fw * g.stepF + la * g.stepL) : (uint32_t)CELL_WALL;
+            // (what a cell SHOWS: a box's content is not part of it -- the kernel's P4 masks the same bits)
+            uint32_t c = vc.valid ? load_cell_shown(cb, tile + clamped_offset(g.origin, vc, fw, la)) : (uint32_t)CELL_WALL;
+            const uint32_t c_mask = in ? load_cell_shown(cb, tile + g.origin + fw * g.stepF + la * g.stepL) : (uint32_t)CELL_WALL;
             if (c != c_mask) std::abort();
-            if (i == V / 2 && j == V - 1) c = row_carry(row);
+            if (vc.valid) {      // the gather's see-behind test is the raw cell's opaque bit (sign of the 16 bits / of the byte)
+                const uint32_t raw = load_cell_raw(cb, tile + clamped_offset(g.origin, vc, fw, la));
+                if ((((raw >> (cb == 1 ? 7 : 15)) & 1u) != 0) == see_behind(c)) std::abort();
+            }
+            if (i == V / 2 && j == V - 1) c = row_carry(row) & kCellShown;
             if (see_behind(c)) sb[k >> 6] |= 1ull << (k & 63);
             cells[i * V + j] = c;
         }

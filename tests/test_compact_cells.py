@@ -1,0 +1,230 @@
+"""COMPACT one-byte grid cells (include/mgx.h: MgxCell8, EnvSpec.cell_bytes = 1 -- the format for large grids: type and state
+coded jointly, a third less traffic per step and twice the envs per wavefront at 64x64) against the oracle, which knows nothing
+about cell formats, and against the 16-bit format: the same results bit for bit.
+
+`-m gpu`: the HIP kernels through the C ABI (random states on every view size incl. the packed remainders of 9x9 views, the
+throughput / streamed families, hooks, the fused auto-reset, sub-shard chains, full_obs, check_grid, pack / unpack) and C5 at its
+full size in BOTH formats.  `-m "not gpu"`: the host side of the format (packing, BatchedMultiGridEnv on the oracle backend, what is
+refused)."""
+import dataclasses
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from multigrid_amd import BatchedMultiGridEnv, EnvSpec, layouts, workloads
+from oracle import binding as ob
+from tests import util
+
+DEV = "cuda:0"
+
+
+def compact(spec: EnvSpec) -> EnvSpec:
+    return dataclasses.replace(spec, cell_bytes=1)
+
+
+# ---------------------------------------------------------------------------------------------------- CPU: host side of the format
+def test_env_on_the_oracle_backend_holds_compact_cells_and_steps_like_the_wide_one():
+    spec = EnvSpec(12, 10, 3, 7, max_steps=50)
+    B = 16
+    st = util.random_state(spec, B, seed=5)
+    envs = []
+    for sp in (spec, compact(spec)):
+        env = BatchedMultiGridEnv(sp, B, "cpu", backend=util.OracleBackend(sp))
+        env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+        envs.append(env)
+    wide, comp = envs
+    assert wide.cells.dtype == torch.int16 and comp.cells.dtype == torch.uint8
+    np.testing.assert_array_equal(comp.cells.numpy(), layouts.pack_cells8(st["grid"]))
+    np.testing.assert_array_equal(comp.grid.numpy(), st["grid"])                  # the unpacked view, both formats
+    np.testing.assert_array_equal(wide.grid.numpy(), st["grid"])
+    for t in range(8):
+        act = torch.from_numpy(util.random_actions(B, 3, seed=t))
+        a, b = wide.step(act), comp.step(act)
+        for x, y in zip(a, b):
+            assert x.numpy().tobytes() == y.numpy().tobytes()
+        np.testing.assert_array_equal(wide.grid.numpy(), comp.grid.numpy())
+    sd = comp.state_dict()
+    assert sd["spec"]["cell_bytes"] == 1 and sd["grid"].shape == (B, 10, 12, 3)
+    other = BatchedMultiGridEnv(compact(spec), B, "cpu", backend=util.OracleBackend(compact(spec)))
+    other.load_state_dict(sd)
+    np.testing.assert_array_equal(other.cells.numpy(), comp.cells.numpy())
+
+
+def test_what_compact_cells_do_not_serve_is_refused_by_name():
+    sp = compact(EnvSpec(16, 16, 2, 7, max_steps=50))
+    env = BatchedMultiGridEnv(sp, 4, "cpu", backend=util.OracleBackend(sp))
+    st = util.random_state(sp, 4, seed=1)
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    act = torch.zeros((4, 2), dtype=torch.int8)
+    with pytest.raises(NotImplementedError, match="compact cells"):
+        env.rollout(act[None])
+    with pytest.raises(NotImplementedError, match="compact cells"):
+        env.step(act, one_hot=True)
+    with pytest.raises(NotImplementedError, match="compact cells"):
+        env.set_layout_generator("empty_fixed")
+    with pytest.raises(NotImplementedError, match="compact cells"):
+        env.persistent(4)
+    with pytest.raises(ValueError):
+        EnvSpec(8, 8, cell_bytes=3)
+    bad = st["grid"].copy()
+    bad[0, 3, 3] = (5, 1, 1)                                   # a key with a state: the compact format has no code for it
+    with pytest.raises(ValueError, match="compact"):
+        env.load_state(bad, st["agents"], st["rng"], st["target"], st["step_count"])
+
+
+def test_c_abi_refuses_the_unsupported_entry_points_without_a_gpu():
+    """Argument validation runs before any HIP call (tests/test_capi.py does the same for the other checks)."""
+    import ctypes as C
+    from multigrid_amd import _lib
+    L = _lib.lib()
+    sc = compact(EnvSpec(64, 64, 16, 9)).to_c()
+    assert L.mgx_rollout(C.byref(sc), 8, 0, *([None] * 13)) == _lib.ERR_UNSUPPORTED          # (steps = 0: the spec check alone)
+    key = (C.c_int32 * 16)()
+    assert L.mgx_shape_key(C.byref(sc), 64, key) == _lib.ERR_UNSUPPORTED
+    sc.cell_bytes = 5
+    info = _lib.MgxLaunchInfo()
+    assert L.mgx_launch_info(C.byref(sc), 64, C.byref(info)) == _lib.ERR_INVALID_ARGUMENT
+    # two 64x64 envs per wavefront on compact cells, one on the 16-bit ones (the per-agent phases then run on 32 lanes, not 16)
+    assert _lib.launch_info(compact(EnvSpec(64, 64, 16, 9)), 32768)["envs_per_wavefront"] == 2
+    assert _lib.launch_info(EnvSpec(64, 64, 16, 9), 32768)["envs_per_wavefront"] == 1
+    assert _lib.launch_info(compact(EnvSpec(64, 64, 16, 9)), 32768)["fixed_shape"] == 5
+
+
+# ---------------------------------------------------------------------------------------------------- GPU: the kernels
+gpu = pytest.mark.gpu
+
+CASES = [
+    ("c8_C5_64x64_a16_v9", EnvSpec(64, 64, 16, 9, max_steps=16384), 515, 6),
+    ("c8_C2_empty16_a4_v7", EnvSpec(16, 16, 4, 7, max_steps=1024), 4096, 10),
+    ("c8_bup_11x6_a2", EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup"), 3001, 10),
+    ("c8_ragged_a3_v5_nooverlap", EnvSpec(9, 7, 3, 5, max_steps=50, allow_agent_overlap=False, failure_termination_mode="any"), 1001, 12),
+    ("c8_a1_v3_seethrough", EnvSpec(8, 8, 1, 3, max_steps=30, see_through_walls=True), 777, 8),
+    ("c8_a2_v9_seethrough", EnvSpec(10, 8, 2, 9, max_steps=30, see_through_walls=True), 130, 8),
+    ("c8_a5_v11_all_joint", EnvSpec(13, 12, 5, 11, max_steps=40, success_termination_mode="all", joint_reward=True), 333, 8),
+    ("c8_a7_v13", EnvSpec(20, 17, 7, 13, max_steps=40), 129, 5),
+    ("c8_a2_v15", EnvSpec(24, 24, 2, 15, max_steps=40), 65, 5),
+    ("c8_a32_v7", EnvSpec(12, 12, 32, 7, max_steps=40), 37, 5),
+    ("c8_a17_v9_odd", EnvSpec(31, 23, 17, 9, max_steps=40), 203, 5),
+    ("c8_single_env", EnvSpec(8, 8, 2, 7, max_steps=256), 1, 12),
+    ("c8_max_grid_254x254_a2_v5", EnvSpec(254, 254, 2, 5, max_steps=20), 5, 3),
+]
+
+
+@gpu
+@pytest.mark.parametrize("name,spec,B,T", CASES, ids=[c[0] for c in CASES])
+def test_compact_random_states_vs_oracle(name, spec, B, T):
+    from tests.test_hip_parity import test_random_states_vs_oracle
+    test_random_states_vs_oracle(name, compact(spec), B, T)
+
+
+THROUGHPUT = [
+    ("c8t_a2_v9", EnvSpec(10, 8, 2, 9, max_steps=30), 40001, 4),
+    ("c8t_a16_v9_48x48", EnvSpec(48, 48, 16, 9, max_steps=60), 6001, 3),
+    ("c8t_bup_a2_v7", EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup"), 70003, 4),
+    ("c8t_a5_v11", EnvSpec(13, 12, 5, 11, max_steps=40), 13001, 3),
+    ("c8t_a7_v7", EnvSpec(12, 12, 7, 7, max_steps=40), 20011, 4),
+]
+
+
+@gpu
+@pytest.mark.parametrize("name,spec,B,T", THROUGHPUT, ids=[c[0] for c in THROUGHPUT])
+def test_compact_throughput_and_auto_reset_vs_oracle(name, spec, B, T):
+    from tests.test_hip_parity import test_throughput_instantiations_vs_oracle
+    test_throughput_instantiations_vs_oracle(name, compact(spec), B, T)
+
+
+@gpu
+def test_compact_equals_wide_on_the_same_states_and_actions():
+    """Both formats through the HIP kernels, same state, same actions: every output and the whole state byte for byte."""
+    spec = EnvSpec(40, 36, 9, 9, max_steps=200)
+    B = 2003
+    st = util.random_state(spec, B, seed=9)
+    envs = []
+    for sp in (spec, compact(spec)):
+        env = BatchedMultiGridEnv(sp, B, DEV)
+        env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+        envs.append(env)
+    wide, comp = envs
+    np.testing.assert_array_equal(comp.cells.cpu().numpy(), layouts.pack_cells8(st["grid"]))
+    for t in range(12):
+        act = torch.from_numpy(util.random_actions(B, spec.num_agents, seed=300 + t)).to(DEV)
+        a, b = wide.step(act), comp.step(act)
+        for x, y in zip(a, b):
+            assert x.cpu().numpy().tobytes() == y.cpu().numpy().tobytes(), f"step {t}"
+        np.testing.assert_array_equal(wide.grid.cpu().numpy(), comp.grid.cpu().numpy())
+        np.testing.assert_array_equal(wide.agents.cpu().numpy(), comp.agents.cpu().numpy())
+        # the compact cells stay canonical: what the packer makes of the unpacked grid (opaque bits up to date)
+        np.testing.assert_array_equal(comp.cells.cpu().numpy(), layouts.pack_cells8(comp.grid.cpu().numpy()))
+    np.testing.assert_array_equal(wide.full_obs().cpu().numpy(), comp.full_obs().cpu().numpy())
+    wide.check_errors(); comp.check_errors()
+
+
+@gpu
+def test_compact_pack_unpack_check_kernels():
+    import ctypes as C
+    from multigrid_amd import _lib
+    L = _lib.lib()
+    spec = compact(EnvSpec(30, 20, 3, 7, max_steps=50))
+    B = 257
+    st = util.random_state(spec, B, seed=3)
+    g3 = torch.from_numpy(st["grid"]).to(DEV)
+    cells = torch.zeros((B, 20, 30), dtype=torch.uint8, device=DEV)
+    bad = torch.zeros(2, dtype=torch.int32, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.mgx_pack_grid8_env(g3.data_ptr(), B, 20, 30, cells.data_ptr(), bad.data_ptr(), s) == 0
+    assert bad.cpu().tolist() == [0, 0]
+    np.testing.assert_array_equal(cells.cpu().numpy(), layouts.pack_cells8(st["grid"]))
+    back = torch.zeros_like(g3)
+    assert L.mgx_unpack_grid8(cells.data_ptr(), cells.numel(), back.data_ptr(), s) == 0
+    np.testing.assert_array_equal(back.cpu().numpy(), st["grid"])
+    # a state on a ball and a hole in the wall ring are counted
+    g3[5, 4, 4] = torch.tensor([6, 1, 2], dtype=torch.uint8)
+    g3[7, 0, 3] = torch.tensor([1, 0, 0], dtype=torch.uint8)
+    assert L.mgx_pack_grid8_env(g3.data_ptr(), B, 20, 30, cells.data_ptr(), bad.data_ptr(), s) == 0
+    assert bad.cpu().tolist() == [1, 1]
+    # mgx_check_grid on compact state: clean, then a broken opaque bit and an agent on the ring
+    sc = spec.to_c()
+    chk = torch.tensor([0, 0, 0, 2 ** 31 - 1], dtype=torch.int32, device=DEV)
+    good = torch.from_numpy(layouts.pack_cells8(st["grid"])).to(DEV)
+    agents = torch.from_numpy(st["agents"]).to(DEV)
+    assert L.mgx_check_grid(C.byref(sc), B, good.data_ptr(), agents.data_ptr(), chk.data_ptr(), s) == 0
+    assert chk.cpu().tolist() == [0, 0, 0, 2 ** 31 - 1]
+    good[11, 5, 5] = 0x82 ^ 0x80                               # a wall without its opaque bit
+    agents[13, 0, 2] = 0
+    assert L.mgx_check_grid(C.byref(sc), B, good.data_ptr(), agents.data_ptr(), chk.data_ptr(), s) == 0
+    assert chk.cpu().tolist() == [1, 0, 1, 11]
+
+
+@gpu
+def test_compact_sub_shard_chains_equal_one_launch():
+    spec = compact(EnvSpec(48, 48, 8, 9, max_steps=100))
+    B = 4096
+    st = util.random_state(spec, B, seed=21)
+    a, b = (BatchedMultiGridEnv(spec, B, DEV) for _ in range(2))
+    for env in (a, b):
+        env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    for t in range(5):
+        act = torch.from_numpy(util.random_actions(B, 8, seed=t)).to(DEV)
+        a.step(act)
+        b.step(act, sub_shards=2)
+    b.join()
+    for name in ("cells", "agents", "rng", "step_count", "obs", "reward", "terminated", "truncated"):
+        assert getattr(a, name).cpu().numpy().tobytes() == getattr(b, name).cpu().numpy().tobytes(), name
+
+
+@gpu
+def test_c5_full_size_on_both_cell_formats_vs_oracle():
+    """BASELINE.json configs[4] at its full size, every step, every output and the whole state, fused auto-reset: on the compact
+    cells the bench times it on (two envs per wavefront, the shape-specialised kernel) and on the 16-bit cells."""
+    from tests.test_full_size import run_vs_oracle
+    wl = workloads.make("c5")
+    assert wl.batch == 32768 and wl.spec.cell_bytes == 1
+    env = wl.make_env(DEV)
+    li = env.backend.launch_info(wl.batch)
+    assert li["envs_per_wavefront"] == 2 and li["fixed_shape"] == 5, li
+    run_vs_oracle(wl, T=8, seed=55)
+    wl2 = workloads.make("c5", cell_bytes=2)
+    assert wl2.spec.cell_bytes == 2 and wl2.make_env(DEV).backend.launch_info(wl2.batch)["fixed_shape"] == 4
+    run_vs_oracle(wl2, T=4, seed=56)

@@ -51,6 +51,75 @@ def test_user_defined_gen_grid_matches_reference_on_gpu(path):
     _replay(path, device="cuda")
 
 
+def _replay_steps(path, **env_kw):
+    """Whole episodes of a user-defined env (tests/custom_envs.py: STEP_CASES) against what the REAL reference did with the same
+    class body: every step's observations, rewards, terminations, truncations, and the post-step grid and agent rows -- box
+    contents included (the fixture folds them into the state values, include/mgx.h "BOX CONTENTS")."""
+    from multigrid_amd import layouts
+    z = np.load(path)
+    cname, kw, T = custom_envs.STEP_CASES[os.path.basename(path)[:-4]]
+    cls = custom_envs.define(custom_envs.multigrid_amd_namespace())[cname]
+    env = cls(layout_seed=int(z["construct_seed"]), **kw, **env_kw)
+    A = env.num_agents
+    n_reward = n_term = 0
+    for k, sd in enumerate(z["reset_seeds"]):
+        obs, _ = env.reset(seed=None if sd < 0 else int(sd))
+        ctx = f"episode {k}"
+        np.testing.assert_array_equal(env.grid._cells(), z["grid0"][k].astype(np.int64), err_msg=ctx)
+        np.testing.assert_array_equal(layouts.unpack_agents(env._benv.agents[0].cpu().numpy()), z["agents0"][k].astype(np.int64), err_msg=ctx)
+        np.testing.assert_array_equal(env.grid.state, z["grid0"][k].astype(np.int64) & np.array([255, 255, 3]), err_msg=ctx)
+        for i in range(A):
+            np.testing.assert_array_equal(obs[i]["image"], z["obs0"][k][i], err_msg=ctx)
+        for t in range(T):
+            acts = {i: int(z["actions"][k][t, i]) for i in range(A) if z["actions"][k][t, i] >= 0}
+            o, r, tm, tr, _ = env.step(acts)
+            c = f"{ctx} step {t}"
+            for i in range(A):
+                np.testing.assert_array_equal(o[i]["image"], z["obs"][k][t][i], err_msg=c)
+                assert float(r[i]) == float(z["reward"][k][t][i]), (c, i, r, z["reward"][k][t])
+                assert bool(tm[i]) == bool(z["terminated"][k][t][i]), (c, i, tm, z["terminated"][k][t])
+                assert bool(tr[i]) == bool(z["truncated"][k][t]), c
+            np.testing.assert_array_equal(env.grid._cells(), z["grid"][k][t].astype(np.int64), err_msg=c)
+            np.testing.assert_array_equal(layouts.unpack_agents(env._benv.agents[0].cpu().numpy()), z["agents"][k][t].astype(np.int64),
+                                          err_msg=c)
+            n_reward += any(float(r[i]) > 0 for i in range(A)); n_term += any(bool(tm[i]) for i in range(A))
+    return env, n_reward, n_term
+
+
+@pytest.mark.parametrize("path", util.CUSTOM_STEPS_GOLDEN, ids=util.CUSTOM_STEPS_IDS)
+def test_user_defined_step_hooks_and_box_contents_match_reference_on_cpu(path):
+    env, n_reward, n_term = _replay_steps(path, device="cpu", _backend=lambda spec: util.OracleBackend(spec))
+    if "fetchtrap" in path:
+        assert n_reward > 10 and n_term > 10                       # the `step` override's on_success / on_failure did fire
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", util.CUSTOM_STEPS_GOLDEN, ids=util.CUSTOM_STEPS_IDS)
+def test_user_defined_step_hooks_and_box_contents_match_reference_on_gpu(path):
+    _replay_steps(path, device="cuda")
+
+
+def test_boxes_hold_things_as_in_the_reference():
+    """multigrid/core/world_object.py:574-605"""
+    key = core.Key("purple")
+    box = core.Box("yellow", contains=key)
+    assert box.contains is key and box.encode() == (core.Type.box, core.Color.yellow, 0)          # the encoding does not show it
+    g = core.Grid(5, 5)
+    g.set(2, 2, box)
+    assert g.state[2, 2].tolist() == [7, 4, 0] and g.state_with_contents()[2, 2].tolist() == [7, 4, (1 | 3 << 3) << 2]
+    back = core.WorldObj.from_array(g.state_with_contents()[2, 2])
+    assert isinstance(back, core.Box) and isinstance(back.contains, core.Key) and back.contains.color == core.Color.purple
+    assert core.Box(contains=core.Door("red")).contains.state == core.State.closed
+    with pytest.raises(NotImplementedError, match="box inside a box"):
+        core.Box(contains=core.Box())
+    with pytest.raises(NotImplementedError, match="closed and unlocked"):
+        core.Box(contains=core.Door("red", is_locked=True))
+
+    class Env:                                                       # Box.toggle / Door.toggle on a host grid (world_object.py:215)
+        grid = g
+    assert box.toggle(Env, None, (2, 2)) is True and g.get(2, 2) is key
+
+
 def test_world_objects_have_the_reference_encodings_and_predicates():
     """multigrid/core/world_object.py:279-616 (constructor defaults, encodings) and :197-233 + overrides (predicates)."""
     C, T, S = core.Color, core.Type, core.State
@@ -73,8 +142,6 @@ def test_world_objects_have_the_reference_encodings_and_predicates():
     assert isinstance(core.WorldObj(type="goal", color="green"), core.Goal)
     assert core.WorldObj.from_array([1, 0, 0]) is None and isinstance(core.WorldObj.decode(4, 2, 1), core.Door)
     assert np.asarray(core.Key("yellow")).tolist() == [5, 4, 0] and tuple(core.Key("yellow")) == (5, 4, 0)
-    with pytest.raises(NotImplementedError, match="contains"):
-        core.Box(contains=core.Key())
     with pytest.raises(ValueError):
         core.Key("magenta")
 

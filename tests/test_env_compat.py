@@ -133,7 +133,9 @@ def test_attribute_surface():
     assert env.observation_space[2]["image"].shape == (5, 5, 3) and env.action_space[0].n == 7
     assert env.agents[0].observation_space["direction"].n == 4
     assert not env.is_done()
-    assert env.grid.get(14, 14) == (8, 1, 0) and env.grid.get(1, 1) is None
+    goal = env.grid.get(14, 14)                                    # a WorldObj, as the reference hands out (grid.py:102-117)
+    assert isinstance(goal, mg.Goal) and goal.encode() == (8, 1, 0) and env.grid.get(1, 1) is None
+    assert env.grid.get(14, 14) is goal                            # ... and the same object on every look (identity: world_object.py:126)
     with pytest.raises(AssertionError):
         make("MultiGrid-Empty-8x8-v0", agent_view_size=4)     # agent.py:78
     with pytest.raises(NotImplementedError):
@@ -361,3 +363,47 @@ def test_locked_hallway_with_more_rooms_than_colours():
         env.step({i: (t + i) % 7 for i in range(3)})
     with pytest.raises(ValueError):
         LockedHallwayEnv(num_rooms=18, agents=2, device="cpu", _backend=backend_factory)
+
+
+def test_public_names_of_the_reference_data_model_exist():
+    """tests/golden/public_names.json (oracle/gen_public_names.py: `dir()` of the reference's classes, names only): everything user
+    code written against multigrid.base.MultiGridEnv / multigrid.core.{Agent, AgentState, Grid, WorldObj, Door, Box} can touch is
+    there under the same name -- rendering aside (out of scope: SURVEY.md section 2)."""
+    import json
+    import os
+    from multigrid_amd import core, env as envmod, world
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "public_names.json")) as fh:
+        names = json.load(fh)
+    rendering = {"render", "render_tile", "get_frame", "get_full_render", "get_pov_render"}
+    ours = {"MultiGridEnv": mg.MultiGridEnv, "Agent": core.Agent, "AgentState": core.AgentState, "Grid": world.Grid,
+            "WorldObj": core.WorldObj, "Door": core.Door, "Box": core.Box}
+    for cls_name, wanted in names.items():
+        missing = [n for n in wanted if n not in rendering and not hasattr(ours[cls_name], n)]
+        assert not missing, (cls_name, missing)
+    # ... and the device-backed `env.grid` answers to the reference's Grid accessors too
+    for n in names["Grid"]:
+        if n not in rendering and n not in ("horz_wall", "vert_wall", "wall_rect"):          # (layout builders: _gen_grid's host Grid)
+            assert hasattr(envmod.GridView, n), n
+    assert core.AgentState.POS == slice(3, 5) and core.AgentState.CARRYING == slice(6, 9) and core.AgentState.dim == 9
+    assert (core.AgentState.TYPE, core.AgentState.COLOR, core.AgentState.DIR, core.AgentState.TERMINATED) == (0, 1, 2, 5)
+
+
+def test_agent_aliases_write_through_and_reset():
+    """multigrid/core/agent.py:100-133: `agent.pos = ...` / `agent.dir = ...` / `agent.terminated = ...` set the state (here: on the
+    device), `Agent.reset` un-places a free agent."""
+    env = mg.make("MultiGrid-Empty-8x8-v0", agents=2, device="cpu", _backend=lambda spec: util.OracleBackend(spec))
+    env.reset(seed=1)
+    a = env.agents[1]
+    a.pos = (3, 4); a.dir = 2
+    assert a.pos == (3, 4) and int(a.dir) == 2 and env.agent_states[1].pos == (3, 4)
+    obs = env.gen_obs()
+    assert obs[1]["direction"] == 2
+    a.terminated = True
+    assert env.agents[1].terminated and not env.agents[0].terminated and not env.is_done()
+    env.agent_states.terminated = True                            # base.py:494: on_success in mode 'any'
+    assert env.is_done()
+    from multigrid_amd import core
+    free = core.Agent(0)
+    free.state.pos = (2, 2)
+    free.reset("go")
+    assert free.pos == (-1, -1) and free.state.dir == -1 and free.mission == "go" and free.carrying is None

@@ -74,7 +74,7 @@ def test_fused_one_hot_step_vs_oracle(name, spec, B, T):
 @pytest.mark.parametrize("name,B", [("c2", 4096), ("c3", 5000), ("c5", 300)])
 def test_fused_one_hot_autoreset_equals_step_then_one_hot(name, B):
     """mgx_step_one_hot with auto-reset == mgx_step_autoreset followed by mgx_one_hot, on every output and the state."""
-    wl = workloads.make(name, batch=B)
+    wl = workloads.make(name, batch=B, cell_bytes=2)           # (one-hot output: 16-bit cells; C5's own format is the compact one)
     a, b = wl.make_env(DEV), wl.make_env(DEV)
     if name != "c5":
         a.step_count.fill_(wl.spec.max_steps - 3); b.step_count.fill_(wl.spec.max_steps - 3)      # restarts on the way
@@ -153,7 +153,7 @@ def test_one_hot_with_device_generation_in_one_launch(kind):
 def test_rollout_with_one_hot_output_equals_steps(name, B, T):
     """mgx_rollout with one-hot observations (T steps, one launch, u8[T,B,A,v,v,21]) == T x mgx_step_one_hot, with the fused
     auto-reset on the way; also through torch.ops.mgx.rollout_one_hot vs the oracle."""
-    wl = workloads.make(name, batch=B)
+    wl = workloads.make(name, batch=B, cell_bytes=2)           # (rollouts and one-hot output: 16-bit cells)
     a, b = wl.make_env(DEV), wl.make_env(DEV)
     if name != "c5":
         a.step_count.fill_(wl.spec.max_steps - 3); b.step_count.fill_(wl.spec.max_steps - 3)

@@ -14,7 +14,7 @@ import pytest
 from oracle import binding as ob
 
 GOLDEN = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-          if not os.path.basename(p).startswith(("layout_", "wrappers_", "custom_"))]
+          if not os.path.basename(p).startswith(("layout_", "wrappers_", "custom_", "customsteps_"))]
 
 
 def load(path):

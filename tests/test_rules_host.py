@@ -2,6 +2,8 @@
 (jump-ahead PCG64, ranking argsort, handle_actions, overlay, hooks, view geometry, in-bounds masks, the closed
 form visibility flood) -- against the oracle, via the g++-built host shim.  The kernels' own parallel plumbing
 (LDS staging, ballot, byte packing) is covered by the -m gpu parity tests."""
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -58,6 +60,36 @@ def test_rules_match_oracle_on_random_states(spec, force_serial):
         assert n_serial < n_total, (n_serial, n_total)          # the order-free path is exercised ...
         if spec.num_agents >= 5 or not spec.allow_agent_overlap:
             assert n_serial > 0, (n_serial, n_total)            # ... and so is the fallback (cell conflicts, presence)
+
+
+COMPACT = [dataclasses.replace(s, cell_bytes=1) for s in (CASES[0], CASES[1], CASES[2], CASES[6], CASES[9])] + [
+    EnvSpec(8, 8, 2, 7, max_steps=40, env_kind="redbluedoors", cell_bytes=1)]
+
+
+@pytest.mark.parametrize("force_serial", [False, True], ids=["fastpath", "serial"])
+@pytest.mark.parametrize("spec", COMPACT, ids=lambda s: f"{s.width}x{s.height}_a{s.num_agents}_v{s.view_size}_{s.env_kind}")
+def test_rules_on_compact_cells_match_oracle(spec, force_serial):
+    """The same rules on COMPACT one-byte cells (include/mgx.h: MgxCell8, EnvSpec.cell_bytes = 1: type and state coded jointly):
+    the host shim packs the tile that way, the rules read / write it through the format-aware accessors, and every output and the
+    whole post-step state must equal the oracle's -- which knows nothing about cell formats."""
+    if spec.env_kind == "redbluedoors":
+        pytest.skip("random states of the hook envs come from their own generators (tests/test_hip_parity.py on the GPU)")
+    test_rules_match_oracle_on_random_states(spec, force_serial)
+
+
+def test_compact_cell_codes_round_trip():
+    from multigrid_amd import layouts
+    cells = [(t, c, 0) for t in range(11) for c in range(6)] + [(4, c, s) for c in range(6) for s in (1, 2)] \
+        + [(10, c, d) for c in range(6) for d in (1, 2, 3)]
+    g = np.array(cells, dtype=np.uint8)
+    p = layouts.pack_cells8(g)
+    assert len(set(p.tolist())) == len(cells)                         # distinct codes
+    np.testing.assert_array_equal(layouts.unpack_cells8(p), g)
+    assert p[cells.index((2, 5, 0))] == 0xD2                           # WALL
+    opaque = np.array([(t == 2) or (t == 4 and s != 0) for t, c, s in cells])
+    np.testing.assert_array_equal((p & 0x80) != 0, opaque)
+    with pytest.raises(ValueError):
+        layouts.pack_cells8(np.array([[5, 1, 1]], dtype=np.uint8))    # a state on a key: not representable
 
 
 @pytest.mark.parametrize("path", util.GOLDEN, ids=util.GOLDEN_IDS)

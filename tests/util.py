@@ -15,7 +15,7 @@ from oracle import binding as ob
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _ALL = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 #: rollout fixtures (state + actions + per-step outputs) and reset/layout fixtures, both written by oracle/gen_golden.py
-GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith(("layout_", "wrappers_", "custom_"))]
+GOLDEN = [p for p in _ALL if not os.path.basename(p).startswith(("layout_", "wrappers_", "custom_", "customsteps_"))]
 GOLDEN_IDS = [os.path.basename(p)[:-4] for p in GOLDEN]
 LAYOUT_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("layout_")]
 LAYOUT_IDS = [os.path.basename(p)[:-4] for p in LAYOUT_GOLDEN]
@@ -26,6 +26,10 @@ LAYOUT_ENV_IDS = {"layout_bup_a2": "MultiGrid-BlockedUnlockPickup-v0", "layout_b
 #: reset sequences of the user-defined envs of tests/custom_envs.py, recorded over the reference (oracle/gen_golden.py: record_custom)
 CUSTOM_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("custom_")]
 CUSTOM_IDS = [os.path.basename(p)[:-4] for p in CUSTOM_GOLDEN]
+#: whole episodes of user-defined envs (boxes that hold things, `step` overrides with on_success / on_failure) over the reference
+#: (oracle/gen_golden.py: record_custom_steps)
+CUSTOM_STEPS_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("customsteps_")]
+CUSTOM_STEPS_IDS = [os.path.basename(p)[:-4] for p in CUSTOM_STEPS_GOLDEN]
 WRAPPER_GOLDEN = [p for p in _ALL if os.path.basename(p).startswith("wrappers_")]
 WRAPPER_IDS = [os.path.basename(p)[:-4] for p in WRAPPER_GOLDEN]
 
@@ -144,15 +148,13 @@ class OracleBackend:
     def __init__(self, spec: EnvSpec, nthreads: int = 1):
         self.spec, self.d, self.nthreads = spec, spec.as_dict(), nthreads
 
-    # `grid` arrives as BatchedMultiGridEnv holds it: packed cells (int16 MgxCell bit patterns); the oracle works on the
-    # reference's (type, color, state) triples
-    @staticmethod
-    def _g3(grid):
-        return layouts.unpack_cells(grid.numpy())
+    # `grid` arrives as BatchedMultiGridEnv holds it: packed cells (int16 MgxCell bit patterns, or the compact MgxCell8 bytes of
+    # a spec with cell_bytes == 1); the oracle works on the reference's (type, color, state) triples
+    def _g3(self, grid):
+        return layouts.unpack_cells_for(self.spec, grid.numpy())
 
-    @staticmethod
-    def _store(grid, g3):
-        grid.copy_(torch.from_numpy(layouts.pack_cells(g3).view(np.int16)))
+    def _store(self, grid, g3):
+        grid.copy_(torch.from_numpy(layouts.pack_cells_for(self.spec, g3)))
 
     def gen_obs(self, B, grid, agents, obs, dirs, one_hot: bool = False):
         assert not one_hot
@@ -191,7 +193,7 @@ class OracleBackend:
         for b in range(B):
             out[b] = torch.from_numpy(ob.full_obs(layouts.grid_from_product(g[b]), layouts.unpack_agents(a[b])).astype(np.uint8))
 
-    def reset_done(self, B, first_env, pool, grid, agents, step_count, target, episode, was_reset):
+    def reset_done(self, B, first_env, pool, grid, agents, step_count, target, episode, was_reset):       # (cells copied as they are)
         pg, pa, pt = pool
         K = pg.shape[0]
         for b in range(B):

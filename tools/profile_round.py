@@ -25,16 +25,17 @@ WARM_LARGE = 250      # the 1M-env point: steady state of the rollout (tools/tim
 
 #: (key, MGX_WORKLOAD, batch, extra env)
 POINTS = [("c2", "c2", 4096, {}), ("c3", "c3", 16384, {}), ("c4", "c4", 65536, {}), ("c5", "c5", 32768, {}),
+          ("c5_wide", "c5", 32768, {"MGX_CELL_BYTES": "2"}),      # C5 on the 16-bit cells (its own format is the compact one)
           ("c4_share8", "c4", 8192, {}), ("c4_part", "c4", 16384, {}), ("c5_part", "c5", 16384, {}),      # the sub-shard launches of bench.py (C4: 4 chains, C5: 2)
           ("large", "c4", 1 << 20, {"MGX_ONE_HOT_STEP": "1"})]
 
 
 def kind_of(name: str):
     m = re.search(r"mgx_obs_kernel<([^>]*)>", name)
-    if m:                                   # <V, OH, STREAM, DMA>: gen_obs for views up to 7x7 (its own entry point)
+    if m:                                   # <V, OH, STREAM, DMA, C8>: gen_obs for views up to 7x7 (its own entry point)
         return "gen_obs" + ("_one_hot" if m.group(1).split(",")[1].strip() == "true" else "")
     m = re.search(r"mgx_fused_kernel<([^>]*)>", name)
-    if m:                                   # <V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA>
+    if m:                                   # <V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA, GRP, SHAPE, C8>
         t = [x.strip() for x in m.group(1).split(",")] + ["false"] * 8
         return ({"0": "gen_obs", "1": "step", "2": "rollout"}[t[1]] + ("_one_hot" if t[4] == "true" else "")
                 + ("_generate" if t[5] == "true" else ""))
