@@ -192,7 +192,10 @@ def step_roofline(wl_name, spec, B, ms_launch):
 def pipelined_point(wl_name, spec, env, K, device, barrier, seed, P, wall_scale=None, min_region_ms=30.0, agree=None, G=None):
     """The same steps as P independent chains of sub-shard launches (capture_steps(sub_shards=P))."""
     B, A = env.batch, spec.num_agents
-    m = measure_steps(env, K, 0, "graph", barrier, seed=seed, min_region_ms=min_region_ms, sub_shards=P, agree=agree)
+    # (graphs of at most ~256 steps per chain, replayed: a replay's host side has to feed P queues, and on graphs of thousands of
+    # kernel nodes it no longer keeps up -- profiles/r5_chain_policy.txt)
+    Kp = K if K <= 256 else 250
+    m = measure_steps(env, Kp, 0, "graph", barrier, seed=seed, min_region_ms=min_region_ms, sub_shards=P, agree=agree)
     ms_step = m["event_ms"] / m["timed_steps"]
     ms_launch = sub_shard_launch_ms(env, P, device)
     alg = B * A * spec.bytes_step()

@@ -103,7 +103,29 @@ enum {
     MGX_ERR_LAUNCH = -4            /* hipLaunchKernel failed; see mgx_last_hip_error() */
 };
 
-enum { MGX_KIND_EMPTY = 0, MGX_KIND_BLOCKEDUNLOCKPICKUP = 1, MGX_KIND_REDBLUEDOORS = 2, MGX_KIND_LOCKEDHALLWAY = 3 };
+enum { MGX_KIND_EMPTY = 0, MGX_KIND_BLOCKEDUNLOCKPICKUP = 1, MGX_KIND_REDBLUEDOORS = 2, MGX_KIND_LOCKEDHALLWAY = 3,
+       MGX_KIND_RULES = 4 };     /* ABI 9: a declarative step() hook, see MgxHookRule */
+
+/* (ABI 9) MGX_KIND_RULES: the step() post-hook of a USER-DEFINED env, declared instead of compiled in.  The reference's envs
+ * end their episodes in a `step` override that runs after the base step: `if agent.state.carrying == self.obj:
+ * self.on_success(...)` (multigrid/envs/blockedunlockpickup.py:166-175), `if action == toggle and fwd_obj == self.blue_door ...:
+ * self.on_failure(...)` (multigrid/envs/redbluedoors.py:170-187).  Both shapes as a table in the env's `aux`:
+ *     aux[0] = n, the number of rules (<= MGX_MAX_RULES); rule k = the five bytes aux[1 + 5k ..]: { op, a, b, effect, cond }
+ *       op      MGX_RULE_CARRIES    an agent carries an object of type a and colour b   (`agent.state.carrying == self.obj`)
+ *               MGX_RULE_TOGGLES_AT an agent's action this step was `toggle` and the cell in front of it is (x, y) = (a, b)
+ *                                   (`fwd_obj == self.door` for an object that does not move)
+ *       effect  MGX_EFFECT_SUCCESS  on_success(agent): terminated (mode 'any': every agent), reward (multigrid/base.py:478-507)
+ *               MGX_EFFECT_FAILURE  on_failure(agent)                                        (multigrid/base.py:509-532)
+ *       cond    TOGGLES_AT only: MGX_COND_ALWAYS, MGX_COND_DOOR_OPEN / MGX_COND_DOOR_SHUT = only while the cell at (x, y) holds a
+ *               door that is open / not open AFTER the step (`self.door.is_open`)
+ * Evaluated after the base step on the post-step state, rule by rule in table order; within a CARRIES rule the agents in index
+ * order (`for agent in self.agents`), within a TOGGLES_AT rule in `hook_order` (`for agent_id, action in actions.items()`).  As with
+ * the compiled hooks the observation of the step is rendered BEFORE the hook; `terminated` / `reward` reflect it.  BlockedUnlockPickup
+ * is the one-rule table { CARRIES, box, colour, SUCCESS } (tests/test_rule_hooks.py holds it against the compiled kind). */
+#define MGX_MAX_RULES 3
+enum { MGX_RULE_CARRIES = 1, MGX_RULE_TOGGLES_AT = 2 };
+enum { MGX_EFFECT_SUCCESS = 1, MGX_EFFECT_FAILURE = 2 };
+enum { MGX_COND_ALWAYS = 0, MGX_COND_DOOR_OPEN = 1, MGX_COND_DOOR_SHUT = 2 };
 
 #define MGX_AUX_BYTES 16
 
@@ -429,16 +451,17 @@ int mgx_step_ex(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, voi
 /* Sub-shard stepping.  A launch that fills the chip in one round of wavefronts first loads (no wave has data to work on), then
  * computes, then drains, and the next step's launch cannot start before the last wave has gone; envs are independent, so the
  * same step can be issued as `parts` launches over consecutive blocks of the batch on `parts` streams, and consecutive calls
- * then form `parts` independent CHAINS of launches whose bubbles are filled by the other chains' waves (C4: 20.9 -> 15.7 us per
- * step of 65536 envs).  Blocks are cut at multiples of 64 envs; per-env seeds, auto-reset layouts and generated episodes follow
+ * then form `parts` independent CHAINS of launches whose bubbles are filled by the other chains' waves (C4: 18.6 -> 16.0-16.7 us per
+ * step of 65536 envs as two chains).  Blocks are cut at multiples of 64 envs; per-env seeds, auto-reset layouts and generated episodes follow
  * the global env index (auto_reset->first_env + block offset), so the results are bit-identical to mgx_step_ex on the whole batch.
  *   streams      `parts` HIP streams (hipStream_t cast to void*), one per chain
  *   fork_event   a hipEvent_t (cast to void*) the caller recorded on the stream that produced `actions`, or NULL: every chain's
  *                stream waits for it before its launch.  The call does NOT join: the outputs of block k are complete when
  *                streams[k] reaches this point (the caller makes its consumer wait on the streams it needs).
  * steps must be 1.  mgx_sub_shards() suggests `parts` for (spec, batch, options of `args`) on the current device: 1 when the
- * launch is less than two wavefronts per SIMD of the chip (splitting only shortens short launches), 4 when the whole batch is
- * about one round of resident wavefronts (occupancy of the kernel x CUs of the device), else 2.  `args` may be NULL (plain step). */
+ * launch is less than two wavefronts per SIMD of the chip (splitting only shortens short launches), else 2 (round 5: two chains
+ * hold their gain on every box and graph length measured -- C4 18.6 -> 16.0-16.7 us, C5 61.5 -> 47 us --, four swing between
+ * 15.3 and 18.6 with the host side of the graph replay: profiles/r5_chain_policy.txt).  `args` may be NULL (plain step). */
 int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t parts, void *const *streams,
                     void *fork_event);
 int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, int32_t *parts);

@@ -129,7 +129,7 @@ int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot
     if (sp->width < 3 || sp->height < 3 || sp->num_agents < 1 || sp->max_steps < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
-    if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_LOCKEDHALLWAY) return MGX_ERR_UNSUPPORTED;
+    if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_RULES) return MGX_ERR_UNSUPPORTED;
     if (sp->cell_bytes != 0 && sp->cell_bytes != 1 && sp->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
     // compact cells (include/mgx.h: MgxCell8): the plain step and gen_obs; rollouts and one-hot output keep the 16-bit cells
     if (sp->cell_bytes == 1 && (roll || one_hot)) return MGX_ERR_UNSUPPORTED;
@@ -647,12 +647,14 @@ int mgx_sub_shards(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, 
     // below two wavefronts per SIMD (or a view per lane of two waves per SIMD) a launch is a lone wave's instruction chain:
     // splitting it only adds launches
     if (nwaves < 2 * (int64_t)simds || batch * spec->num_agents < 64 * (int64_t)simds) return MGX_OK;
-    int occ = 0;
-    rc = step_common(spec, batch, sa, nullptr, &occ);                  // workgroups of THIS instantiation resident per CU
-    if (rc) return rc;
-    const int64_t resident = (int64_t)cus * (occ > 0 ? occ : 1) * (threads / 64);
-    const double rounds = (double)nwaves / (double)resident;
-    *parts = (rounds >= 0.75 && rounds <= 1.5) ? 4 : 2;               // about ONE round: load / compute / drain in lock step
+    // Two chains.  Round 3 answered 4 when the whole batch is about ONE round of resident wavefronts (C4: 65536 envs = 4096 wavefronts
+    // at 16 per CU); measured again in round 5 on two boxes and over graph lengths (profiles/r5_chain_policy.txt): four chains of
+    // C4 run anywhere between 15.3 and 17.7 us per step of the batch -- their advantage hangs on how fast the host side of a graph
+    // replay feeds four queues, and it is gone on graphs of 4000+ kernel nodes (18.2-18.6, the "regression" of round 4's bench
+    // line, which timed 1000-step graphs where round 3's timed 260-step ones) -- while two chains stay at 16.0-16.7 us on every
+    // box and graph length up to 2 x 1000 nodes (lock step: 18.6-18.8); C5: 47.0 / 47.6 / 48.1 us for 2 / 3 / 4 chains (61.5 in
+    // lock step).  The policy is the form that holds.
+    *parts = 2;
     const int64_t max_parts = batch / kSubShardAlign;
     if (*parts > max_parts) *parts = (int32_t)(max_parts < 1 ? 1 : max_parts);
     return MGX_OK;

@@ -580,6 +580,34 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
         int cnt = 0;
         for (int k = 0; k < nd; ++k) cnt += (mask >> k) & 1u;
         aux[15] = (uint8_t)(cnt == target);      // len(unlocked_doors) == len(rooms): `terminations` only, not agent state
+    } else if (env_kind == MGX_KIND_RULES) {
+        // the declared hook of a user-defined env (include/mgx.h: MGX_KIND_RULES): rule by rule in table order
+        const int n = aux[0] < MGX_MAX_RULES ? aux[0] : MGX_MAX_RULES;
+        for (int k = 0; k < n; ++k) {
+            const uint8_t *r = aux + 1 + 5 * k;
+            const int op = r[0], effect = r[3], cond = r[4];
+            for (int ko = 0; ko < A; ++ko) {
+                bool hit = false;
+                int a = ko;
+                if (op == MGX_RULE_CARRIES) {                                    // `for agent in self.agents: if carrying == obj`
+                    hit = (row_carry(rows[a]) & 0xffffu) == ((uint32_t)r[1] | ((uint32_t)r[2] << 8));
+                } else if (op == MGX_RULE_TOGGLES_AT) {                          // `for agent_id, action in actions.items()`
+                    a = order ? (int)order[ko] : ko;
+                    if (a >= A || act[a] != ACT_TOGGLE) continue;
+                    const uint64_t row = rows[a];
+                    const int d = row_dir(row), fx = row_x(row) + dir_dx(d), fy = row_y(row) + dir_dy(d);
+                    hit = (fx == r[1]) & (fy == r[2]);
+                    if (hit && cond != MGX_COND_ALWAYS) {
+                        const uint32_t c = load_cell(cf.cb, tile + (r[2] * cf.W + r[1]) * cf.cb);
+                        const bool open = ((c & 0xff) == T_DOOR) & (cell_state(c) == S_OPEN);
+                        hit = (c & 0xff) == T_DOOR && (cond == MGX_COND_DOOR_OPEN ? open : !open);
+                    }
+                }
+                if (!hit) continue;
+                if (effect == MGX_EFFECT_SUCCESS) on_success(cf, rows, a, step_count, rew);
+                else if (effect == MGX_EFFECT_FAILURE) set_terminated(rows, A, a, cf.failure_any);
+            }
+        }
     }
 }
 

@@ -355,14 +355,28 @@ struct BoundStep {
     std::vector<Tensor> keep;          // every bound tensor: the launch reads / writes their storage
     bool live = false;
 };
+// A handle = slot | generation << 20.  Slots are reused; the generation a slot was handed out with is part of the handle, so a
+// stale handle (kept past its unbind_step) is refused instead of silently stepping whatever was bound into the slot since.  A
+// call copies the shared_ptr under the lock and holds it for its duration: a concurrent unbind_step cannot free the struct, or
+// the tensors it keeps alive, under a launch that is being set up.
 std::mutex g_bound_mutex;
-std::vector<std::unique_ptr<BoundStep>> g_bound;
+std::vector<std::shared_ptr<BoundStep>> g_bound;
+std::vector<int64_t> g_bound_gen;
+constexpr int64_t kSlotBits = 20;
+
+std::shared_ptr<BoundStep> bound_at(int64_t handle, const char *who) {
+    const int64_t slot = handle & ((int64_t(1) << kSlotBits) - 1), gen = handle >> kSlotBits;
+    std::lock_guard<std::mutex> lock(g_bound_mutex);
+    TORCH_CHECK_VALUE(handle >= 0 && slot < (int64_t)g_bound.size() && g_bound[slot] && g_bound_gen[slot] == gen,
+                      "mgx: ", who, ": no such handle ", handle, " (never bound, or unbound since)");
+    return g_bound[slot];
+}
 
 int64_t bind_step(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, OptTensor aux, Tensor err, at::IntArrayRef spec,
                   Tensor obs, Tensor dirs, Tensor reward, Tensor terminated, Tensor truncated, const OptTensor &pool_grid,
                   const OptTensor &pool_agents, const OptTensor &pool_aux, OptTensor episode, int64_t first_env, OptTensor was_reset,
                   bool one_hot) {
-    auto b = std::make_unique<BoundStep>();
+    auto b = std::make_shared<BoundStep>();
     b->sc = spec_from(spec);
     const MgxSpec &sc = b->sc;
     DeviceGuard g(grid);
@@ -406,18 +420,15 @@ int64_t bind_step(Tensor grid, Tensor agents, Tensor rng, Tensor step_count, Opt
     b->live = true;
     std::lock_guard<std::mutex> lock(g_bound_mutex);
     for (size_t i = 0; i < g_bound.size(); ++i)
-        if (!g_bound[i]) { g_bound[i] = std::move(b); return (int64_t)i; }
+        if (!g_bound[i]) { g_bound[i] = std::move(b); return (int64_t)i | (++g_bound_gen[i] << kSlotBits); }
+    TORCH_CHECK((int64_t)g_bound.size() < (int64_t(1) << kSlotBits), "mgx: bind_step: too many bound steps");
     g_bound.push_back(std::move(b));
+    g_bound_gen.push_back(0);
     return (int64_t)g_bound.size() - 1;
 }
 
 void step_bound(int64_t handle, const Tensor &actions) {
-    BoundStep *b;
-    {
-        std::lock_guard<std::mutex> lock(g_bound_mutex);
-        TORCH_CHECK_VALUE(handle >= 0 && handle < (int64_t)g_bound.size() && g_bound[handle], "mgx: step_bound: no such handle ", handle);
-        b = g_bound[handle].get();
-    }
+    const std::shared_ptr<BoundStep> b = bound_at(handle, "step_bound");      // (held until the launch is enqueued)
     TORCH_CHECK(actions.device() == b->device, "mgx: `actions` is on ", actions.device(), " but the bound state is on ", b->device);
     TORCH_CHECK_TYPE(actions.scalar_type() == at::kChar, "mgx: `actions` must be int8, got ", actions.scalar_type());
     TORCH_CHECK_VALUE(actions.is_contiguous() && actions.dim() == 2 && actions.size(0) == b->B && actions.size(1) == b->A,
@@ -429,9 +440,9 @@ void step_bound(int64_t handle, const Tensor &actions) {
 }
 
 void unbind_step(int64_t handle) {
+    (void)bound_at(handle, "unbind_step");
     std::lock_guard<std::mutex> lock(g_bound_mutex);
-    TORCH_CHECK_VALUE(handle >= 0 && handle < (int64_t)g_bound.size() && g_bound[handle], "mgx: unbind_step: no such handle ", handle);
-    g_bound[handle].reset();
+    g_bound[handle & ((int64_t(1) << kSlotBits) - 1)].reset();
 }
 
 // out-variants: nothing is allocated; the outputs are written into the caller's tensors

@@ -423,6 +423,24 @@ class _RoomGrid:
         return self.grid.to_product(), pack_agents(self.ag)
 
 
+def rules_aux(rules) -> np.ndarray:
+    """The hook table of an `env_kind="rules"` env (include/mgx.h: MGX_KIND_RULES) as its aux u8[16]: a user-defined env's
+    `step` post-hook, declared.  `rules`: up to 3 tuples, evaluated in order after the base step --
+        ("carries", type, color, "success" | "failure")                  `if agent.state.carrying == self.obj: self.on_...(agent)`
+        ("toggles_at", x, y, "success" | "failure"[, "open" | "shut"])   `if action == toggle and fwd_obj == self.door [and (not)
+                                                                          self.door.is_open]: self.on_...(agent)`
+    BlockedUnlockPickup's hook (envs/blockedunlockpickup.py:166-175) is `[("carries", Type.box, color, "success")]`."""
+    if len(rules) > 3:
+        raise ValueError("at most 3 rules fit the env's 16 bytes of hook state")
+    aux = np.zeros(16, dtype=np.uint8)
+    aux[0] = len(rules)
+    for k, r in enumerate(rules):
+        op = {"carries": 1, "toggles_at": 2}[r[0]]
+        cond = {"always": 0, "open": 1, "shut": 2}[r[4]] if len(r) > 4 else 0
+        aux[1 + 5 * k:6 + 5 * k] = (op, int(r[1]), int(r[2]), {"success": 1, "failure": 2}[r[3]], cond)
+    return aux
+
+
 def make_aux(kind: str, grid_hwc: np.ndarray, target=None) -> np.ndarray:
     """The 16-byte hook state of include/mgx.h for a freshly generated layout."""
     aux = np.zeros(16, dtype=np.uint8)

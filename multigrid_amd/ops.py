@@ -258,6 +258,11 @@ class HipBackend:
 
         gen_c = keep[1]
         phase = generate[0]["stage"]["phase"] if generate is not None and generate[0].get("stage") is not None else None
+        if phase is not None and gen_c.stage.external:
+            # the chains issue no generator launches of their own (nobody sits between the steps of a chain): the pending snapshots are
+            # served by generator wavefronts inside every chain's launch instead (MgxGenStage.external = 0, the in-launch form), so a
+            # staged slot is there to adopt when the env truncates -- with `external` left set the requests would never be served
+            gen_c.stage.external = 0
 
         def step(actions, fork_event, hook_order=None):
             sa.actions = actions.data_ptr()

@@ -9,7 +9,7 @@ import ctypes as C
 import dataclasses
 from dataclasses import dataclass
 
-ENV_KINDS = {"empty": 0, "blockedunlockpickup": 1, "redbluedoors": 2, "lockedhallway": 3}
+ENV_KINDS = {"empty": 0, "blockedunlockpickup": 1, "redbluedoors": 2, "lockedhallway": 3, "rules": 4}
 AUX_BYTES = 16
 MAX_AGENTS = 32
 MAX_VIEW = 15

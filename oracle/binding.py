@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmgx_oracle.so")
 
-KIND = {"empty": 0, "blockedunlockpickup": 1, "redbluedoors": 2, "lockedhallway": 3}
+KIND = {"empty": 0, "blockedunlockpickup": 1, "redbluedoors": 2, "lockedhallway": 3, "rules": 4}
 AUX = 16
 ERR_UNKNOWN_ACTION = -2
 

@@ -43,7 +43,7 @@ static const int64_t WALL_ENCODING[3] = { T_WALL, C_GREY, 0 };
 static const int64_t UNSEEN_ENCODING[3] = { T_UNSEEN, 0, 0 };
 static const int64_t EMPTY_ENCODING[3] = { T_EMPTY, 0, 0 }; /* world_object.py:131-137 */
 
-enum { KIND_EMPTY = 0, KIND_BLOCKEDUNLOCKPICKUP = 1, KIND_REDBLUEDOORS = 2, KIND_LOCKEDHALLWAY = 3 };
+enum { KIND_EMPTY = 0, KIND_BLOCKEDUNLOCKPICKUP = 1, KIND_REDBLUEDOORS = 2, KIND_LOCKEDHALLWAY = 3, KIND_RULES = 4 };
 
 /* Per-env hook state `aux` (int64[16]), mirroring the attributes the env subclasses keep:
  *   BlockedUnlockPickup  [0..2] = self.obj encoding                        (envs/blockedunlockpickup.py:147)
@@ -378,6 +378,45 @@ int mgo_step_ref(const MgoSpec *sp, int64_t *grid_state, int64_t *agent_state, u
                 /* on_success writes the terminations dict it is handed (base.py:498-501) */
                 if (sp->success_any) { for (int b = 0; b < A; ++b) terminated[b] = 1; }
                 else terminated[a] = 1;
+            }
+        }
+    }
+    if (sp->env_kind == KIND_RULES) {
+        /* A user-defined env's step() hook in its declared form (include/mgx.h: MGX_KIND_RULES): the two shapes the reference's own
+         * hooks have -- `if agent.state.carrying == self.obj: on_success` (blockedunlockpickup.py:170-173) and `if action == toggle
+         * and fwd_obj == self.door [and self.door.is_open]: on_failure / on_success` (redbluedoors.py:176-185) -- as a table:
+         * aux[0] = n, rule k = aux[1 + 5k ..] = { op, a, b, effect, cond }.  on_success / on_failure are the reference's
+         * (base.py:478-532), restated above. */
+        const int64_t *aux = target;
+        const int H = sp->height, n = aux[0] < 3 ? (int)aux[0] : 3;
+        for (int k = 0; k < n; ++k) {
+            const int64_t *r = aux + 1 + 5 * k;
+            for (int ko = 0; ko < A; ++ko) {
+                int a = ko, hit = 0;
+                if (r[0] == 1) {                                       /* CARRIES(type, colour): `for agent in self.agents` */
+                    const int64_t *c = agent_state + (size_t)a * AS_DIM + AS_CARRY;
+                    hit = c[0] == r[1] && c[1] == r[2];
+                } else if (r[0] == 2) {                                /* TOGGLES_AT(x, y): `for agent_id, action in actions.items()` */
+                    a = hook_order ? hook_order[ko] : ko;
+                    if (a >= A || actions[a] != A_TOGGLE) continue;
+                    const int64_t *s = agent_state + (size_t)a * AS_DIM;
+                    int64_t fx = s[AS_X], fy = s[AS_Y];
+                    if (s[AS_DIR] >= 0 && s[AS_DIR] < 4) { fx += DIR_TO_VEC[s[AS_DIR]][0]; fy += DIR_TO_VEC[s[AS_DIR]][1]; }
+                    hit = fx == r[1] && fy == r[2];
+                    if (hit && r[4] != 0) {                            /* `and self.door.is_open` / `and not ...` */
+                        const int64_t *c = grid_state + ((size_t)r[1] * H + r[2]) * 3;
+                        const int open = c[0] == T_DOOR && (c[2] & 3) == S_OPEN;
+                        hit = c[0] == T_DOOR && (r[4] == 1 ? open : !open);
+                    }
+                }
+                if (!hit) continue;
+                if (r[3] == 1) {
+                    on_success(sp, agent_state, a, *step_count, rewards);
+                    if (sp->success_any) { for (int b = 0; b < A; ++b) terminated[b] = 1; } else terminated[a] = 1;
+                } else if (r[3] == 2) {
+                    on_failure(sp, agent_state, a);
+                    if (sp->failure_any) { for (int b = 0; b < A; ++b) terminated[b] = 1; } else terminated[a] = 1;
+                }
             }
         }
     }

@@ -39,6 +39,6 @@ def test_bench_prints_the_contract_line():
     assert d["config"]["sub_shards"] == 1 and r["algorithmic_bytes"] == 65536 * 4 * 339
     assert abs(r["ms_per_launch"] - d["ms_per_step"]) / d["ms_per_step"] < 0.1
     p = d["pipelined"]
-    assert p["sub_shards"] == 4 and p["launch"]["batch"] * 4 == 65536
+    assert p["sub_shards"] == 2 and p["launch"]["batch"] * 2 == 65536          # (mgx_sub_shards' answer: two chains, round 5)
     assert p["value"] > d["value"] * 0.9 and p["launch"]["frac"] < p["step_frac"]
     assert abs(p["step_frac"] - p["launch"]["frac"] * p["mean_launches_in_flight"]) < 0.02

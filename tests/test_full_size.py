@@ -85,7 +85,8 @@ def test_c4_full_size_vs_oracle():
 
 @pytest.mark.parametrize("form", ["graph", "eager_chains"])
 def test_c4_full_size_four_chains_vs_oracle(form):
-    """EXACTLY what bench.py times as the pipelined headline: C4 at 65 536 envs stepped as 4 independent chains of 16 384-env
+    """The sub-sharded forms at full size (bench.py's `pipelined` point is the policy's two chains; four are the finer cut, and
+    the unjoined eager steps below run the policy's own): C4 at 65 536 envs stepped as 4 independent chains of 16 384-env
     launches (capture_steps(sub_shards=4): four parallel branches of one hipGraph; or step(..., sub_shards=4): mgx_step_chains on
     four streams), auto-reset fused in -- against the ORACLE, every output and the whole state:
       * a one-step 4-chain graph replayed per step with fresh actions: every step's outputs and post-step state;
@@ -95,7 +96,7 @@ def test_c4_full_size_four_chains_vs_oracle(form):
     assert wl.batch == 65536
     spec, B, A = wl.spec, wl.batch, wl.spec.num_agents
     env = wl.make_env(DEV, auto_reset=True)
-    assert env.sub_shards_hint(auto_reset=True) == 4                     # (what sub_shards="auto" resolves to on an MI355X)
+    assert env.sub_shards_hint(auto_reset=True) == 2                     # (what sub_shards="auto" resolves to on an MI355X: round 5)
     ref = dict(grid=wl.grid.copy(), agents=wl.agents.copy(), rng=wl.rng.copy(), step_count=np.zeros(B, np.int32), aux=None)
     episode = np.zeros(B, np.int32)
     sd, nt = spec.as_dict(), ob.max_threads()
@@ -123,7 +124,7 @@ def test_c4_full_size_four_chains_vs_oracle(form):
     T1, T2 = 6, 12
     if form == "graph":
         buf = torch.zeros((1, B, A), dtype=torch.int8, device=DEV)
-        g1 = env.capture_steps(buf, auto_reset=True, sub_shards="auto")
+        g1 = env.capture_steps(buf, auto_reset=True, sub_shards=4)
         assert g1.sub_shards == 4
         for t in range(T1):
             act = r.integers(0, 7, size=(B, A)).astype(np.int8)

@@ -244,7 +244,9 @@ def test_bound_step_equals_the_out_variant_and_checks_only_the_actions():
     oh1, oh2 = outs(21), outs(21)
     h2 = torch.ops.mgx.bind_step(e2.cells, e2.agents, e2.rng, e2.step_count, None, e2.err, ints, oh2[0], oh2[1], oh2[2], oh2[3], oh2[4],
                                  None, None, None, None, 0, None, True)
-    assert h2 == h
+    assert h2 != h and (h2 & 0xFFFFF) == (h & 0xFFFFF)          # the same slot under a new generation: ...
+    with pytest.raises(ValueError, match="no such handle"):        # ... the stale handle does not step what now lives there
+        torch.ops.mgx.step_bound(h, torch.zeros((B, A), dtype=torch.int8, device=DEV))
     act = torch.from_numpy(util.random_actions(B, A, seed=77)).to(DEV)
     torch.ops.mgx.step_one_hot_out(e1.cells, e1.agents, e1.rng, e1.step_count, act, None, e1.err, None, None, None, None, 0, ints,
                                    oh1[0], oh1[1], oh1[2], oh1[3], oh1[4], None)
