@@ -568,6 +568,9 @@ def main():
                          "`weak` / `strong`")
     ap.add_argument("--large-batch", type=int, default=1 << 20)
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement + its roofline")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the sub-sharded variant beside the headline (profiling: its launches are instances of the same kernel "
+                         "at half the batch and would mix into the kernel's rocprofv3 statistics)")
     args = ap.parse_args()
     global AUTO_RESET
     AUTO_RESET = not args.no_auto_reset
@@ -660,7 +663,7 @@ def main():
         else:                                                   # (--sub-shards: the literal per-launch number stays the `frac`)
             out["roofline"] = step_roofline(name, spec, B // P, sub_shard_launch_ms(env, P, device))
             out["roofline"]["step_frac"] = round(B * A * spec.bytes_step() / (m["event_ms"] / S * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    if P == 1 and hint > 1 and args.mode == "graph":            # the pipelined variant beside the lock-step headline (all ranks)
+    if P == 1 and hint > 1 and args.mode == "graph" and not args.no_pipelined:   # the pipelined variant beside the lock-step headline (all ranks)
         m2, pp = pipelined_point(name, spec, env, args.steps, device, barrier, 99 + rank, hint, min_region_ms=25.0,
                                  agree=lambda n: int(all_max(float(n))))
         pp["value"] = round(G * A * m2["timed_steps"] / all_max(m2["wall_s"]))

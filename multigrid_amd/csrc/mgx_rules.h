@@ -158,17 +158,38 @@ MGX_HD uint64_t row_set_pos(uint64_t r, int x, int y) {
 }
 MGX_HD uint64_t row_set_carry(uint64_t r, uint32_t c) { return (r & 0xffffffffffull) | ((uint64_t)c << 40); }
 
+// "does any lane of the wavefront ...": box contents are rare, so the instructions that carry them sit behind a wave-uniform
+// branch (one ballot) instead of on every agent's chain; on the host (tests/hostshim) it is the condition itself
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGX_ANY_LANE(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+#else
+#define MGX_ANY_LANE(cond) (cond)
+#endif
+
 // logical <-> packed.  Values outside the packed ranges (type > 15, color > 7, state > 3) do not occur in the reference
 // (types 0-10, colors 0-5, states 0-2 / directions 0-3) and are refused where grids enter (mgx_pack_grid reports them).
 MGX_HD uint32_t cell_pack(uint32_t c) {
-    return (c & 0x070fu) | ((c >> 4) & 0x3000u) | (see_behind(c) ? 0u : 0x8000u)
-         | ((c >> 14) & 0x00f0u) | ((c >> 11) & 0x0800u) | ((c >> 9) & 0x4000u);     // content: [21:18] -> [7:4], [22] -> [11], [23] -> [14]
+    uint32_t p = (c & 0x070fu) | ((c >> 4) & 0x3000u) | (see_behind(c) ? 0u : 0x8000u);
+    if (MGX_ANY_LANE((c >> 18) != 0))                                     // content: [21:18] -> [7:4], [22] -> [11], [23] -> [14]
+        p |= ((c >> 14) & 0x00f0u) | ((c >> 11) & 0x0800u) | ((c >> 9) & 0x4000u);
+    return p;
 }
 // what a cell SHOWS (observations, full_obs): (type, color, state)
 MGX_HD uint32_t cell_unpack(uint32_t p) { return (p & 0x070fu) | ((p & 0x3000u) << 4); }
 // ... and with a box's content, for the rules
+// (-DMGX_BOX_CONTENTS=0 / -DMGX_RULES_KIND=0: A/B builds without the round-5 additions to the per-agent phase, tools/variant_bench.sh)
+#ifndef MGX_BOX_CONTENTS
+#define MGX_BOX_CONTENTS 1
+#endif
+#ifndef MGX_RULES_KIND
+#define MGX_RULES_KIND 1
+#endif
 MGX_HD uint32_t cell_unpack_full(uint32_t p) {
+#if MGX_BOX_CONTENTS
     return cell_unpack(p) | ((p & 0x00f0u) << 14) | ((p & 0x0800u) << 11) | ((p & 0x4000u) << 9);
+#else
+    return cell_unpack(p);
+#endif
 }
 // the agent overlay cell (10, color, dir) of a packed agent row (obs.py:163-173); never opaque
 MGX_HD uint32_t agent_cell16(uint64_t row) {
@@ -355,7 +376,8 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     const int fx = x + dir_dx(d), fy = y + dir_dy(d);                       // agent.py:111-118
     const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
     ev.off = inb ? (fy * cf.W + fx) * cf.cb : 0;
-    const uint32_t cell = load_cell(cf.cb, tile + ev.off);
+    const uint32_t raw = load_cell_raw(cf.cb, tile + ev.off);
+    const uint32_t cell = cf.cb == 1 ? cell8_unpack(raw) : cell_unpack(raw);       // what the cell shows (a box's content: below)
     const uint32_t type = cell & 0xff, gstate = cell_state(cell);
     const bool stale = inb & (ev.off == stale_off);
     const uint32_t state = stale ? (uint32_t)S_CLOSED : gstate;             // the WorldObj's own state
@@ -389,11 +411,16 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
 
     uint32_t ncell = cell;
     ncell = door ? ((cell & 0xffffu) | (ns << 16)) : ncell;
-    ncell = pick ? CELL_EMPTY : ncell;
-    ncell = box ? box_content_cell(cell) : ncell;
-    ncell = drop ? carry : ncell;
+    ncell = (pick | box) ? CELL_EMPTY : ncell;
+    ncell = drop ? carry : ncell;                                            // (a carried box takes its content along: `carry` has it)
+    uint32_t ncarry = pick ? cell : (drop ? CELL_EMPTY : carry);
+    // a box that holds something (world_object.py:574-605): picked up with its content, replaced by it when toggled
+    if (MGX_ANY_LANE((cf.cb != 1) & ((raw & 0x48f0u) != 0) & (pick | box))) {
+        const uint32_t full = cell_unpack_full(raw);
+        ncell = box ? box_content_cell(full) : ncell;
+        ncarry = pick ? full : ncarry;
+    }
     ev.ncell = ncell;
-    const uint32_t ncarry = pick ? cell : (drop ? CELL_EMPTY : carry);
     uint64_t nrow = row_set_dir(row, nd);
     nrow = row_set_pos(nrow, fwd ? fx : x, fwd ? fy : y);
     ev.nrow = row_set_carry(nrow, ncarry);
@@ -580,6 +607,7 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
         int cnt = 0;
         for (int k = 0; k < nd; ++k) cnt += (mask >> k) & 1u;
         aux[15] = (uint8_t)(cnt == target);      // len(unlocked_doors) == len(rooms): `terminations` only, not agent state
+#if MGX_RULES_KIND
     } else if (env_kind == MGX_KIND_RULES) {
         // the declared hook of a user-defined env (include/mgx.h: MGX_KIND_RULES): rule by rule in table order
         const int n = aux[0] < MGX_MAX_RULES ? aux[0] : MGX_MAX_RULES;
@@ -608,6 +636,7 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
                 else if (effect == MGX_EFFECT_FAILURE) set_terminated(rows, A, a, cf.failure_any);
             }
         }
+#endif
     }
 }
 

@@ -26,7 +26,7 @@ WARM_LARGE = 250      # the 1M-env point: steady state of the rollout (tools/tim
 #: (key, MGX_WORKLOAD, batch, extra env)
 POINTS = [("c2", "c2", 4096, {}), ("c3", "c3", 16384, {}), ("c4", "c4", 65536, {}), ("c5", "c5", 32768, {}),
           ("c5_wide", "c5", 32768, {"MGX_CELL_BYTES": "2"}),      # C5 on the 16-bit cells (its own format is the compact one)
-          ("c4_share8", "c4", 8192, {}), ("c4_part", "c4", 16384, {}), ("c5_part", "c5", 16384, {}),      # the sub-shard launches of bench.py (C4: 4 chains, C5: 2)
+          ("c4_share8", "c4", 8192, {}), ("c4_part", "c4", 32768, {}), ("c5_part", "c5", 16384, {}),      # the sub-shard launches of bench.py (two chains)
           ("large", "c4", 1 << 20, {"MGX_ONE_HOT_STEP": "1"})]
 
 
@@ -82,7 +82,10 @@ lines, traffic = [], {"_comment": "HBM-side traffic per launch from rocprofv3 --
                                   "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated per the same guide.",
                       "round": TAG}
 quick = "--quick" in sys.argv
+ONLY = next((a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")), None)   # --only=c4_part,bench: just these
 for key, wl, B, xenv in POINTS:
+    if ONLY is not None and key not in ONLY:
+        continue
     e = dict(MGX_WORKLOAD=wl, **xenv)
     if B < (1 << 20):
         e["MGX_GRAPH"] = "1"                 # the configurations' steps run as hipGraph replays, as bench.py times them
@@ -115,13 +118,14 @@ d = os.path.join(OUT, "bench_trace")
 log = os.path.join(OUT, "bench_under_rocprof.json")
 with open(log, "a" if PARSE_ONLY else "w") as fh:
     subprocess.run(["true"] if PARSE_ONLY else ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--",
-                    sys.executable, "bench.py", "--no-extras"], env=ENV, cwd=ROOT, stdout=fh, stderr=subprocess.DEVNULL)
+                    sys.executable, "bench.py", "--no-extras", "--no-pipelined"], env=ENV, cwd=ROOT, stdout=fh, stderr=subprocess.DEVNULL)
 rows = []
 for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 with open(os.path.join(OUT, "bench_kernel_stats.txt"), "w") as fh:
-    fh.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-extras   (C4: 65536 envs on one GPU)\n")
+    fh.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-extras --no-pipelined   (C4: 65536 envs on one GPU, lock step only:\n"
+             "# the sub-sharded variant launches the same kernel at half the batch and would mix into its average)\n")
     for r in rows[:6]:
         fh.write(f"{r['Name'][:100]:100s} calls={r['Calls']:>6s} avg_ns={float(r['AverageNs']):10.1f} min_ns={r['MinNs']} "
                  f"total_ns={r['TotalDurationNs']} pct={r['Percentage']}\n")
@@ -129,6 +133,6 @@ txt = "\n".join(lines)
 open(os.path.join(OUT, "summary.txt"), "w").write(
     f"# tools/profile_round.py {TAG}: rocprofv3 kernel-trace, first {WARM} launches of each kernel discarded; the steps of the\n"
     f"# configurations (B < 1M) are hipGraph replays, as bench.py times them; separate --pmc passes (FETCH_SIZE, WRITE_SIZE)\n" + txt + "\n")
-json.dump(traffic, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(OUT, "traffic_only.json" if ONLY is not None else "traffic.json"), "w"), indent=1)
 print(txt)
 print(open(os.path.join(OUT, "bench_kernel_stats.txt")).read())
