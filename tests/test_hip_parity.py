@@ -156,6 +156,41 @@ def test_throughput_instantiations_vs_oracle(name, spec, B, T):
     env.check_errors()
 
 
+BOX_CASES = [
+    ("boxes_a4_v7", EnvSpec(12, 12, 4, 7, max_steps=200), 3000, 16),
+    ("boxes_a2_v9_nooverlap", EnvSpec(14, 9, 2, 9, max_steps=200, allow_agent_overlap=False), 777, 12),
+    ("boxes_a3_v5_throughput", EnvSpec(8, 8, 3, 5, max_steps=200), 60001, 6),
+    ("boxes_a16_v9", EnvSpec(40, 40, 16, 9, max_steps=200), 300, 6),
+]
+
+
+@pytest.mark.parametrize("name,spec,B,T", BOX_CASES, ids=[c[0] for c in BOX_CASES])
+def test_boxes_that_hold_things_vs_oracle(name, spec, B, T):
+    """Box.contains (multigrid/core/world_object.py:574-605; include/mgx.h "BOX CONTENTS"): random states dense in boxes, most of
+    them -- on the grid and in the agents' hands -- holding something; pickup-, drop- and toggle-heavy actions.  Every output and
+    the whole state (contents included) against the oracle, whose restatement is pinned by the reference's `boxkey_a3` fixture."""
+    st = util.random_state(spec, B, seed=zlib.crc32(name.encode()) % 10000, density=0.35, carry_p=0.5, box_contents_p=0.7)
+    assert (st["grid"][..., 2] > 3).sum() > B // 4 and (st["agents"][..., 7] > 3).sum() > B // 50
+    env = BatchedMultiGridEnv(spec, B, dev())
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    ref = {k: v.copy() for k, v in st.items()}
+    r = np.random.default_rng(5)
+    n_opened = 0
+    for t in range(T):
+        act = r.choice(7, size=(B, spec.num_agents), p=[0.1, 0.1, 0.25, 0.2, 0.15, 0.18, 0.02]).astype(np.int8)
+        boxes_before = int((ref["grid"][..., 0] == 7).sum() + (ref["agents"][..., 5] == 7).sum())
+        want = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["target"], nthreads=8)
+        n_opened += boxes_before - int((ref["grid"][..., 0] == 7).sum() + (ref["agents"][..., 5] == 7).sum())
+        got = env.step(torch.from_numpy(act).to(dev()))
+        for g, w in zip(got, want):
+            assert g.cpu().numpy().tobytes() == w.tobytes(), f"{name} step {t}"
+        np.testing.assert_array_equal(env.grid.cpu().numpy(), ref["grid"], err_msg=f"{name} step {t}")
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"], err_msg=f"{name} step {t}")
+    assert n_opened > B // 20, n_opened
+    assert (env.obs[..., 2] > 3).sum() == 0                        # no observation ever shows a content
+    env.check_errors()
+
+
 def test_torch_ops_registered_and_match():
     import multigrid_amd.ops as ops
     spec = EnvSpec(16, 16, 4, 7, max_steps=1024)

@@ -71,9 +71,10 @@ golden_target = golden_aux
 
 
 def random_state(spec: EnvSpec, B: int, seed: int, density: float = 0.25, terminated_p: float = 0.05,
-                 carry_p: float = 0.3):
+                 carry_p: float = 0.3, box_contents_p: float = 0.0):
     """Random walled grids with every object type, agents on overlappable cells (possibly stacked),
-    some carrying, some already terminated.  Product layout."""
+    some carrying, some already terminated.  Product layout.  box_contents_p: the share of the boxes -- lying around and carried
+    -- that hold something (include/mgx.h "BOX CONTENTS": the state byte's upper bits)."""
     r = np.random.default_rng(seed)
     H, W, A = spec.height, spec.width, spec.num_agents
     grid = np.zeros((B, H, W, 3), dtype=np.uint8)
@@ -105,6 +106,13 @@ def random_state(spec: EnvSpec, B: int, seed: int, density: float = 0.25, termin
     carry[..., 1] = r.integers(0, 6, size=(B, A))
     has = r.random((B, A)) < carry_p
     agents[..., 5:8] = np.where(has[..., None], carry, np.array([1, 0, 0], dtype=np.uint8))
+    if box_contents_p > 0:
+        rc = np.random.default_rng(seed + 2)
+        for arr in (grid, agents[..., 5:8]):
+            is_box = arr[..., 0] == 7
+            code = (rc.integers(1, 8, size=is_box.shape) | (rc.integers(0, 6, size=is_box.shape) << 3)).astype(np.uint8)
+            fill = is_box & (rc.random(is_box.shape) < box_contents_p)
+            arr[..., 2] = np.where(fill, arr[..., 2] | (code << 2), arr[..., 2])
     rng = np.random.default_rng(seed + 1).integers(0, 2 ** 63, size=(B, 4), dtype=np.int64).astype(np.uint64)
     rng[:, 2] |= np.uint64(1)
     step_count = r.integers(0, max(1, spec.max_steps), size=B).astype(np.int32)

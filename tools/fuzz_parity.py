@@ -45,8 +45,9 @@ while time.time() < t_end:
         B = max(1, int(4e7 / (W * H * A)))
     T = int(r.integers(3, 14))
     seed = int(r.integers(0, 1 << 30))
+    contents = float(r.choice([0.0, 0.0, 0.6]))       # boxes that hold things (Box.contains, include/mgx.h "BOX CONTENTS")
     st = util.random_state(spec, B, seed=seed, density=float(r.choice([0.0, 0.1, 0.3, 0.5])),
-                           terminated_p=float(r.choice([0.0, 0.05, 0.3])))
+                           terminated_p=float(r.choice([0.0, 0.05, 0.3])), box_contents_p=contents)
     hook = r.random() < 0.15 and fixed is None
     if hook:                                    # a hook env kind on generated layouts: BlockedUnlockPickup, 2..4 agents
         A = int(r.integers(2, 5)); B = min(B, 300)
@@ -65,6 +66,14 @@ while time.time() < t_end:
     env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
     roll = BatchedMultiGridEnv(spec, B, dev, first_env=first_env)
     roll.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    # the same state on COMPACT one-byte cells (include/mgx.h: MgxCell8), stepped beside it -- when nothing in it needs the 16-bit
+    # cells (a box that holds something)
+    comp = None
+    if contents == 0.0 and r.random() < 0.6:
+        import dataclasses
+        comp = BatchedMultiGridEnv(dataclasses.replace(spec, cell_bytes=1), B, dev, first_env=first_env)
+        comp.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    n_comp = (n_comp if n_case else 0) + (comp is not None)
     ref = {k: v.copy() for k, v in st.items()}
     sd = spec.as_dict()
     acts = np.stack([util.random_actions(B, A, seed=seed + 1 + t) for t in range(T)])
@@ -75,8 +84,10 @@ while time.time() < t_end:
     ar = bool(r.random() < 0.5) and not hook
     if ar:
         K = int(r.integers(1, 6))
-        pool = util.random_state(spec, K, seed=seed + 77, terminated_p=0.0, density=0.3)
+        pool = util.random_state(spec, K, seed=seed + 77, terminated_p=0.0, density=0.3, box_contents_p=contents)
         env.set_layout_pool(pool["grid"], pool["agents"]); roll.set_layout_pool(pool["grid"], pool["agents"])
+        if comp is not None:
+            comp.set_layout_pool(pool["grid"], pool["agents"])
         episode = np.zeros(B, dtype=np.int64)
     rr = roll.rollout(torch.from_numpy(acts).to(dev), auto_reset=ar)
     ctx = f"case {n_case}: {spec} B={B} T={T} seed={seed} auto_reset={ar} fixed_shape={env.backend.launch_info(B).get('fixed_shape')}"
@@ -100,6 +111,13 @@ while time.time() < t_end:
                 print("MISMATCH rollout step", t, key, ctx); sys.exit(1)
         if env.grid.cpu().numpy().tobytes() != ref["grid"].tobytes() or env.agents.cpu().numpy().tobytes() != ref["agents"].tobytes():
             print("MISMATCH state at step", t, ctx); sys.exit(1)
+        if comp is not None:
+            gotc = comp.step(torch.from_numpy(acts[t]).to(dev), auto_reset=ar)
+            for g, w, key in zip(gotc, want, ("obs", "dir", "reward", "terminated", "truncated")):
+                if g.cpu().numpy().tobytes() != w.tobytes():
+                    print("MISMATCH compact cells, step", t, key, ctx); sys.exit(1)
+            if comp.grid.cpu().numpy().tobytes() != ref["grid"].tobytes() or comp.agents.cpu().numpy().tobytes() != ref["agents"].tobytes():
+                print("MISMATCH compact cells, state at step", t, ctx); sys.exit(1)
     for e in (env, roll):
         if e.grid.cpu().numpy().tobytes() != ref["grid"].tobytes() or e.agents.cpu().numpy().tobytes() != ref["agents"].tobytes() \
                 or e.step_count.cpu().numpy().tobytes() != ref["step_count"].tobytes() \
@@ -110,9 +128,11 @@ while time.time() < t_end:
     if env.gen_obs(one_hot=True)[0].cpu().numpy().tobytes() != ob.one_hot(o_plain.cpu().numpy()).tobytes():
         print("MISMATCH one-hot gen_obs", ctx); sys.exit(1)
     env.check_errors(); roll.check_errors()
+    if comp is not None:
+        comp.check_errors()
     n_case += 1; n_steps += T * B
-    del env, roll
-print(f"{n_case} cases, {n_steps} env-steps, {n_fixed} cases on a shape-specialised instantiation: clean")
+    del env, roll, comp
+print(f"{n_case} cases, {n_steps} env-steps, {n_fixed} cases on a shape-specialised instantiation, {n_comp} also on compact cells: clean")
 from multigrid_amd import _lib  # noqa: E402
 if hasattr(_lib.lib(), "mgx_debug_bounds_violations"):            # the checked build (MGX_LIBMGX=.../libmgx_chk.so)
     import ctypes
