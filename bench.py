@@ -469,8 +469,9 @@ def persistent_point(name, base, batch, device, T=400):
 
 
 def byte_grid_overhead(wl, device):
-    """The step through torch.ops.mgx.step_out on the reference's grid form, u8[B,H,W,3] (packed on the way in, unpacked into the
-    caller's tensor on the way out: two more streaming kernels per call), against the same op on packed cells."""
+    """The step through torch.ops.mgx.step_out on the reference's grid form, u8[B,H,W,3] -- since round 5 handed to the kernel as it is
+    (MgxSpec.cell_bytes = 3: packed into the LDS tile by the step's own P0, changed cells written back as bytes) --, against the same
+    op on packed cells."""
     from multigrid_amd import ops
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     ints = ops.spec_to_ints(wl.spec)
@@ -492,8 +493,8 @@ def byte_grid_overhead(wl, device):
     torch.cuda.empty_cache()
     return {"workload": wl.name, "batch": wl.batch, "packed_cells_ms_per_step": round(t_p, 5), "byte_grid_ms_per_step": round(t_b, 5),
             "overhead_ms": round(t_b - t_p, 5),
-            "note": "torch.ops.mgx.step_out eager, no auto-reset; byte grid u8[B,H,W,3] = mgx_pack_grid_env (with the wall-ring check) + "
-                    "the step + mgx_unpack_grid per call"}
+            "note": "torch.ops.mgx.step_out eager, no auto-reset; byte grid u8[B,H,W,3] = the same launch with the conversion (and the "
+                    "wall-ring check) in its load phase (round 4: a pack and an unpack launch around the step, +36..43 us)"}
 
 
 def cpu_baseline(wl, threads, budget_s, sample_envs):

@@ -148,6 +148,14 @@ typedef uint16_t MgxCell;        /* packed grid cell, see "grid" above */
  * keep the 16-bit cells).  Same results bit for bit in either format (tests/test_compact_cells.py). */
 typedef uint8_t MgxCell8;
 
+/* (ABI 9) BYTE grids: MgxSpec.cell_bytes = 3 -- the grid tensors (grid, pool_grid) ARE the reference's triples, u8[B,H,W,3]
+ * (type, color, state | a box's content << 2), the tensor BASELINE.json's north star names.  The step / gen_obs kernels pack them
+ * into their 16-bit LDS tile as the bytes arrive and write changed cells back as three bytes, so a caller that holds its state in
+ * the reference's form pays the conversion inside the step's own launch (C4, 65536 envs: 26.6 us against 18.7 on packed cells)
+ * instead of a pack and an unpack launch around it (55..62 us).  Served: mgx_gen_obs, mgx_step, mgx_step_autoreset, mgx_step_ex (steps = 1, no one_hot, no generate),
+ * mgx_step_chains / mgx_sub_shards, mgx_reset_done, mgx_full_obs, mgx_launch_info; MgxStepArgs.grid_bad receives what
+ * mgx_pack_grid_env would have counted.  Everything else: MGX_ERR_UNSUPPORTED.  Same results bit for bit. */
+
 #define MGX_MAX_AGENTS 32
 #define MGX_MAX_VIEW 15
 #define MGX_AGENT_STRIDE 8
@@ -165,7 +173,8 @@ typedef struct MgxSpec {
     int32_t success_any;         /* success_termination_mode == 'any' (multigrid/base.py:97) */
     int32_t failure_any;         /* failure_termination_mode == 'any' (multigrid/base.py:98) */
     int32_t env_kind;            /* MGX_KIND_*: which subclass step() hook runs after the base step */
-    int32_t cell_bytes;          /* ABI 9: the grid's cell format: 0 or 2 = MgxCell (16 bits), 1 = MgxCell8 (compact, see above) */
+    int32_t cell_bytes;          /* ABI 9: the grid's cell format: 0 or 2 = MgxCell (16 bits), 1 = MgxCell8 (compact, see above),
+                                    3 = the reference's byte triples u8[B,H,W,3] (see above) */
 } MgxSpec;
 
 /* Launch geometry chosen for (spec, batch); for diagnostics, benchmarks and DESIGN.md tables. */
@@ -444,6 +453,9 @@ typedef struct MgxStepArgs {
     const MgxLayoutGen *generate;
     int32_t *episode;            /* `generate`: i32[B], in/out */
     uint8_t *was_reset;          /* `generate`: u8[B] (or [T,B]), may be NULL */
+    int32_t *grid_bad;           /* ABI 9, byte grids (MgxSpec.cell_bytes = 3) only, may be NULL: i32[2], the caller zeroes it --
+                                    [0] += cell values the packed format cannot hold, [1] += outer-ring cells that are not WALL
+                                    (the counters of mgx_pack_grid_env; nothing synchronises) */
 } MgxStepArgs;
 
 int mgx_step_ex(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args, void *stream);

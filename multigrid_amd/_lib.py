@@ -62,7 +62,7 @@ class MgxStepArgs(C.Structure):
                 ("truncated", C.c_void_p), ("err", C.c_void_p),
                 ("steps", C.c_int32), ("one_hot", C.c_int32),
                 ("auto_reset", C.POINTER(MgxAutoReset)), ("generate", C.POINTER(MgxLayoutGen)),
-                ("episode", C.c_void_p), ("was_reset", C.c_void_p)]
+                ("episode", C.c_void_p), ("was_reset", C.c_void_p), ("grid_bad", C.c_void_p)]
 
 
 class MgxPersistent(C.Structure):

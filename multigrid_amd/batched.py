@@ -195,7 +195,8 @@ class BatchedMultiGridEnv:
         self.backend = backend
         B, A, dev = self.batch, spec.num_agents, self.device
         # packed cells: MgxCell bit patterns (i16), or -- spec.cell_bytes == 1 -- the compact MgxCell8 bytes (include/mgx.h)
-        self.cells = torch.zeros(spec.cells_shape(B), dtype=torch.uint8 if spec.compact else torch.int16, device=dev)
+        # (spec.cell_bytes == 3: the reference's byte triples themselves, u8[B,H,W,3])
+        self.cells = torch.zeros(spec.cells_shape(B), dtype=torch.uint8 if spec.cell_bytes != 2 else torch.int16, device=dev)
         self.agents = torch.zeros(spec.agents_shape(B), dtype=torch.uint8, device=dev)
         self.rng = torch.zeros((B, 4), dtype=torch.int64, device=dev)
         self.step_count = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -233,8 +234,10 @@ class BatchedMultiGridEnv:
         Grid.state) -- unpacked from `cells` on every access; for inspection, tests and checkpoints, not the hot path.  A box that
         holds something carries it in the upper bits of its state byte (include/mgx.h "BOX CONTENTS"; `& 3` is what Grid.state
         shows)."""
+        if self.spec.cell_bytes == 3:
+            return self.cells
         c = self.cells.to(torch.int32)
-        if self.spec.compact:                                # MgxCell8: joint (type, state) code | color << 4 | opaque << 7
+        if self.spec.cell_bytes == 1:                        # MgxCell8: joint (type, state) code | color << 4 | opaque << 7
             tc = c & 0xF
             door = (tc == 11) | (tc == 12)
             t = torch.where(tc <= 10, tc, torch.where(door, torch.full_like(tc, 4), torch.full_like(tc, 10)))
@@ -781,6 +784,13 @@ class BatchedMultiGridEnv:
     def check_errors(self):
         """Synchronises and raises ValueError if any env met an unknown action since the last check."""
         self.join()
+        gb = getattr(self.backend, "_grid_bad", None)
+        if gb is not None:                       # byte grids: what the step kernels counted while packing them
+            unpackable, ring = (int(v) for v in gb.cpu())
+            if unpackable or ring:
+                gb.zero_()
+                raise ValueError(f"the byte grid held {ring} outer-ring cell(s) that are not WALL = (wall, grey, 0) and {unpackable} "
+                                 f"cell value(s) the packed format cannot hold (include/mgx.h)")
         count, first = (int(v) for v in self.err.cpu())
         if count:
             self._reset_err()
@@ -802,8 +812,8 @@ class BatchedMultiGridEnv:
     def _need_wide_cells(self, what: str):
         """Rollouts, one-hot output, device-side generation and persistent stepping are compiled for the 16-bit cells only."""
         if self.spec.compact:
-            raise NotImplementedError(f"{what} is not available on compact cells (EnvSpec.cell_bytes = 1: step / gen_obs / auto-reset "
-                                      f"from a layout pool / full_obs); build the env with cell_bytes = 2 for it")
+            raise NotImplementedError(f"{what} is not available on compact cells / byte grids (EnvSpec.cell_bytes = 1 or 3: step / "
+                                      f"gen_obs / auto-reset from a layout pool / full_obs); build the env with cell_bytes = 2 for it")
 
     def _need_state(self):
         if not self._loaded:

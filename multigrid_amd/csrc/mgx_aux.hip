@@ -665,8 +665,8 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const 
     if (spec->width < 3 || spec->height < 3 || spec->num_agents < 1) return MGX_ERR_INVALID_ARGUMENT;
     if (spec->width > 255 || spec->height > 255) return MGX_ERR_UNSUPPORTED;
     const int HW = spec->width * spec->height;
-    if (spec->cell_bytes != 0 && spec->cell_bytes != 1 && spec->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
-    const int cb = spec->cell_bytes == 1 ? 1 : kCellBytes;
+    if (spec->cell_bytes < 0 || spec->cell_bytes > 3) return MGX_ERR_INVALID_ARGUMENT;
+    const int cb = spec->cell_bytes == 1 ? 1 : (spec->cell_bytes == 3 ? 3 : kCellBytes);
     if ((cb + 3) * HW + 2 * 48 > 64 * 1024) return MGX_ERR_UNSUPPORTED;
     if (batch == 0) return MGX_OK;
     if (!grid || !agents || !out || misaligned(agents, 8) || misaligned(grid, 16) || misaligned(out, 16))
@@ -744,7 +744,8 @@ int mgx_check_grid(const MgxSpec *spec, int64_t batch, const MgxCell *grid, cons
         || spec->num_agents < 1 || spec->num_agents > MGX_MAX_AGENTS)
         return MGX_ERR_INVALID_ARGUMENT;
     if (batch == 0) return MGX_OK;
-    if (spec->cell_bytes != 0 && spec->cell_bytes != 1 && spec->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->cell_bytes < 0 || spec->cell_bytes > 3) return MGX_ERR_INVALID_ARGUMENT;
+    if (spec->cell_bytes == 3) return MGX_ERR_UNSUPPORTED;           // (byte grids are checked where they are packed: MgxStepArgs.grid_bad)
     const bool c8 = spec->cell_bytes == 1;
     if (!grid || !bad || (!c8 && misaligned(grid, 2)) || misaligned(bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
     const int64_t n_cells = batch * spec->height * spec->width, n_rows = agents ? batch * spec->num_agents : 0;
@@ -781,10 +782,10 @@ int mgx_reset_done(const MgxSpec *spec, int64_t batch, int64_t first_env, int32_
     uint8_t *grid = reinterpret_cast<uint8_t *>(grid_c);
     if (!pool_grid || !pool_agents || !grid || !agents || !step_count || !episode) return MGX_ERR_INVALID_ARGUMENT;
     if (misaligned(agents, 8) || misaligned(pool_agents, 8) || misaligned(aux, 16) || misaligned(pool_aux, 16)
-        || (spec->cell_bytes != 1 && (misaligned(grid, 2) || misaligned(pool_grid, 2))))
+        || ((spec->cell_bytes == 0 || spec->cell_bytes == 2) && (misaligned(grid, 2) || misaligned(pool_grid, 2))))
         return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->cell_bytes != 0 && spec->cell_bytes != 1 && spec->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
-    const int HW3 = spec->width * spec->height * (spec->cell_bytes == 1 ? 1 : kCellBytes);      // bytes of one env's grid
+    if (spec->cell_bytes < 0 || spec->cell_bytes > 3) return MGX_ERR_INVALID_ARGUMENT;
+    const int HW3 = spec->width * spec->height * (spec->cell_bytes == 1 ? 1 : (spec->cell_bytes == 3 ? 3 : kCellBytes));   // bytes of one env's grid
     const int64_t blocks = (batch + 255) / 256;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     // widest copy unit that divides the layout size and the base addresses

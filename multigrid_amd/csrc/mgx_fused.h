@@ -103,6 +103,8 @@ struct KernelArgs {
     uint32_t *done;             // u32[wavefronts]
     uint32_t *pctrl;            // u32[MGX_PERSIST_CTRL_WORDS]
     uint32_t timeout_ticks;     // s_memrealtime ticks (100 MHz) a wavefront waits for its granules before it gives up
+    int32_t *grid_bad;  // byte grids (MgxSpec.cell_bytes = 3; MgxStepArgs.grid_bad): i32[2] counters or NULL -- [0] += cell values the packed
+                        // format cannot hold, [1] += outer-ring cells that are not WALL (what mgx_pack_grid_env reports)
     int32_t *bounds;    // -DMGX_BOUNDS_CHECK=1 builds: [0] += LDS accesses outside the wavefront's slice, [1] = last site id
     int32_t span_base;  // -DMGX_TIMESTAMPS=1 builds: first record of this launch in g_span (tools/span_probe.py, tools/chain_overlap.py)
 };
@@ -313,7 +315,8 @@ __host__ __device__ __attribute__((always_inline)) inline LdsCarve make_carve(in
     return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * cb, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
                     roll, has_aux, cb == 1};
 }
-inline int cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 1 ? 1 : kCellBytes; }
+inline int cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 1 ? 1 : kCellBytes; }        // the LDS tile's cells
+inline int grid_cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 3 ? 3 : cell_bytes_of(sp); }   // the HBM tensors' cells
 
 // `grp`: the group size the launch's instantiation is compiled for (16, or 4 / 8: KernelArgs::grp)
 inline int slots_in_use(const MgxSpec &sp, int Gw, bool narrow = false, int grp = 16) {
@@ -733,8 +736,9 @@ __device__ __forceinline__ void gather_all(const KernelArgs &a, const int wave, 
 // DMA: the tile is loaded HBM -> LDS by LDS-DMA (small launches: P0).
 // C8: the grid is held as COMPACT one-byte cells (include/mgx.h: MgxCell8; MgxSpec.cell_bytes = 1): one-step and gen_obs kernels of
 // the throughput / streamed families only.
+// B3: the grid tensors are the reference's byte triples u8[B,H,W,3] (MgxSpec.cell_bytes = 3), packed into the 16-bit tile by P0.
 template <int V, int MODE, bool HOOKS, bool AR, bool OH = false, bool GEN = false, bool STREAM = false, bool DMA = (MGX_LDS_DMA != 0),
-          int GRP = kGroup, int SHAPE = 0, bool C8 = false>
+          int GRP = kGroup, int SHAPE = 0, bool C8 = false, bool B3 = false>
 __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs a) {
 #include "mgx_fused_body.inc"
 }
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 // register allocator lands on 78 or 86 depending on unrelated code (measured: 196 vs 204 us at 1M envs).  Its own entry point
 // carries the occupancy request; the step kernels are issue-bound and take the registers they want (forcing them costs
 // spills).  (A shared __device__ function for the body perturbs the other kernels' allocation by ~10 VGPRs: hence the include.)
-template <int V, bool OH, bool STREAM, bool DMA, bool C8 = false>
+template <int V, bool OH, bool STREAM, bool DMA, bool C8 = false, bool B3 = false>
 __global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(6)))
 void mgx_obs_kernel(const KernelArgs a) {
     constexpr int MODE = 0, GRP = kGroup, SHAPE = 0;
@@ -790,32 +794,36 @@ struct JitShape { FixedShape f; int vpw, wave_lds; hipFunction_t fn[2]; };
 const JitShape *jit_shape_lookup(const KernelArgs &ka, bool hooks);
 // Compact cells (C8): the plain step / gen_obs of the throughput and streamed families -- hooks and auto-reset included, no one-hot,
 // generation, rollout or latency (LDS-DMA) instantiation: fill_args never asks for one on such a spec.
-template <int V, int MODE, bool STREAM>
+// (... and, with C8 = false / B3 = true, the byte-grid family: the same set of kernels for MgxSpec.cell_bytes = 3)
+template <int V, int MODE, bool STREAM, bool C8 = true>
 inline int launch_compact(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
+    constexpr bool B3 = !C8;
     if constexpr (MODE > 1) {
         return MGX_ERR_UNSUPPORTED;
     } else {
         if constexpr (!STREAM) {
-            if (ka.flags & 1) return launch_compact<V, MODE, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+            if (ka.flags & 1) return launch_compact<V, MODE, true, C8>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
         }
-        if (ka.grp != kGroup || (ka.flags & 2) || ka.vpw > 32) return MGX_ERR_INVALID_ARGUMENT;     // (32 view slots: one decoded cell per register)
+        if (ka.grp != kGroup || (ka.flags & 2) || (C8 && ka.vpw > 32)) return MGX_ERR_INVALID_ARGUMENT;     // (C8: 32 view slots: one decoded cell per register)
         void (*kern)(const KernelArgs) = nullptr;
         const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;
         const bool ar = MODE != 0 && ka.pool_grid != nullptr;
         constexpr bool S = MODE != 0;
-        if constexpr (MODE == 1 && V == 9 && STREAM && !MGX_NO_FIXED_SHAPES) {
+        if constexpr (C8 && MODE == 1 && V == 9 && STREAM && !MGX_NO_FIXED_SHAPES) {
             if (match_fixed_shape(ka, hooks) == 5)
                 kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, true, false, kGroup, 5, true>
                           : mgx_fused_kernel<V, 1, false, false, false, false, true, false, kGroup, 5, true>;
         }
         if (!kern) {
-            if constexpr (MODE == 0 && V <= 7)
-                kern = mgx_obs_kernel<V, false, STREAM, false, true>;
+            // (the byte-grid gen_obs holds its conversion's staging registers: it takes the step kernels' entry point, without the
+            // occupancy request of mgx_obs_kernel that would make it spill)
+            if constexpr (MODE == 0 && V <= 7 && !B3)
+                kern = mgx_obs_kernel<V, false, STREAM, false, C8, B3>;
             else
-                kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, false, false, STREAM, false, kGroup, 0, true>
-                                   : mgx_fused_kernel<V, MODE, S, false, false, false, STREAM, false, kGroup, 0, true>)
-                             : (ar ? mgx_fused_kernel<V, MODE, false, S, false, false, STREAM, false, kGroup, 0, true>
-                                   : mgx_fused_kernel<V, MODE, false, false, false, false, STREAM, false, kGroup, 0, true>);
+                kern = hooks ? (ar ? mgx_fused_kernel<V, MODE, S, S, false, false, STREAM, false, kGroup, 0, C8, B3>
+                                   : mgx_fused_kernel<V, MODE, S, false, false, false, STREAM, false, kGroup, 0, C8, B3>)
+                             : (ar ? mgx_fused_kernel<V, MODE, false, S, false, false, STREAM, false, kGroup, 0, C8, B3>
+                                   : mgx_fused_kernel<V, MODE, false, false, false, false, STREAM, false, kGroup, 0, C8, B3>);
         }
         if (lds_bytes > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -836,10 +844,11 @@ inline int launch_compact(const KernelArgs &ka, int threads, int lds_bytes, int6
 
 template <int V, int MODE, bool OH, bool GEN = false, bool STREAM = false, bool DMA = false, int GRP = kGroup>
 inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
-    if (ka.sp.cell_bytes == 1) {                            // compact cells: their own, smaller family
-        if constexpr (!OH && !GEN && !STREAM && !DMA && GRP == kGroup)
-            return launch_compact<V, MODE, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
-        else return MGX_ERR_UNSUPPORTED;
+    if (ka.sp.cell_bytes == 1 || ka.sp.cell_bytes == 3) {  // compact cells / byte grids: their own, smaller families
+        if constexpr (!OH && !GEN && !STREAM && !DMA && GRP == kGroup) {
+            if (ka.sp.cell_bytes == 1) return launch_compact<V, MODE, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+            return launch_compact<V, MODE, false, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+        } else return MGX_ERR_UNSUPPORTED;
     }
     if constexpr (!STREAM && !DMA && MODE < 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)
         if (ka.flags & 1) return launch_mode<V, MODE, OH, GEN, true, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);

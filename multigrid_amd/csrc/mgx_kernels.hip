@@ -130,9 +130,10 @@ int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot
     if (sp->view_size > MGX_MAX_VIEW || sp->num_agents > MGX_MAX_AGENTS) return MGX_ERR_UNSUPPORTED;
     if (sp->width > 255 || sp->height > 255) return MGX_ERR_UNSUPPORTED;             // positions are uint8
     if (sp->env_kind < MGX_KIND_EMPTY || sp->env_kind > MGX_KIND_RULES) return MGX_ERR_UNSUPPORTED;
-    if (sp->cell_bytes != 0 && sp->cell_bytes != 1 && sp->cell_bytes != MGX_CELL_BYTES) return MGX_ERR_INVALID_ARGUMENT;
-    // compact cells (include/mgx.h: MgxCell8): the plain step and gen_obs; rollouts and one-hot output keep the 16-bit cells
-    if (sp->cell_bytes == 1 && (roll || one_hot)) return MGX_ERR_UNSUPPORTED;
+    if (sp->cell_bytes < 0 || sp->cell_bytes > 3) return MGX_ERR_INVALID_ARGUMENT;
+    // compact cells (include/mgx.h: MgxCell8) and byte grids (cell_bytes = 3): the plain step and gen_obs; rollouts and one-hot
+    // output keep the 16-bit cells
+    if ((sp->cell_bytes == 1 || sp->cell_bytes == 3) && (roll || one_hot)) return MGX_ERR_UNSUPPORTED;
     if (wave_lds_bytes(*sp, 1, roll, one_hot, obs_only) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;   // one env must fit one CU's LDS (the
                                                                                      // rollout carve is the larger one)
     return MGX_OK;
@@ -152,13 +153,13 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     ka.grp = kGroup;
     // latency regime: a wavefront that owns ONE small group of view slots (4 or 8) -- fewer slots of P2/P4/P5 on each wave's
     // instruction chain, more wavefronts per SIMD to run them side by side (mgx_fused.h: choose_group)
-    if (step_plain && has_small_groups(sp->view_size, 1, false, false) && sp->num_agents <= 8 && sp->cell_bytes != 1) {
+    if (step_plain && has_small_groups(sp->view_size, 1, false, false) && sp->num_agents <= 8 && sp->cell_bytes != 1 && sp->cell_bytes != 3) {
         const int g = g_debug_grp > 0 ? g_debug_grp : (g_debug_G > 0 ? kGroup : choose_group(*sp, batch));
         if (g < kGroup && sp->num_agents <= g) { ka.grp = g; ka.Gw = g / sp->num_agents; }
     }
     ka.dbg = g_debug_skip;
     // a grid tensor beyond half of the 256 MiB Infinity Cache is streamed (nt tile loads): mgx_fused.h, P0
-    ka.flags = (batch * (int64_t)sp->width * sp->height * cell_bytes_of(*sp) >= (int64_t)128 << 20) ? 1 : 0;
+    ka.flags = (batch * (int64_t)sp->width * sp->height * grid_cell_bytes_of(*sp) >= (int64_t)128 << 20) ? 1 : 0;
     ka.vpw = slots_in_use(*sp, ka.Gw, roll || obs_only, ka.grp);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only, ka.grp);
@@ -177,7 +178,9 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
     // latency regime: LDS-DMA tile loads, 32 view slots with unpacked cell registers (mgx_fused.h: DMA instantiations)
     // (compact cells have no latency instantiation: their launches take the throughput kernel at any size)
-    if ((nwaves <= 2048 || ka.grp < kGroup) && !(ka.flags & 1) && ka.Gw * sp->num_agents <= kSlotsLatency && sp->cell_bytes != 1) ka.flags |= 2;
+    if ((nwaves <= 2048 || ka.grp < kGroup) && !(ka.flags & 1) && ka.Gw * sp->num_agents <= kSlotsLatency && sp->cell_bytes != 1
+        && sp->cell_bytes != 3)
+        ka.flags |= 2;
     if (!(ka.flags & 2) && ka.grp < kGroup) return MGX_ERR_UNSUPPORTED;     // (cannot happen: small groups imply a small grid tensor)
     nwg = (nwaves + wpb - 1) / wpb;
     if (nwg > INT_MAX) return MGX_ERR_UNSUPPORTED;
@@ -307,7 +310,7 @@ int mgx_shape_key(const MgxSpec *spec, int64_t batch, MgxShapeKey *key) {
     int rc = check_spec(spec, batch);
     if (rc) return rc;
     if (!key || batch < 1) return MGX_ERR_INVALID_ARGUMENT;
-    if (spec->cell_bytes == 1) return MGX_ERR_UNSUPPORTED;            // (runtime-compiled shapes: 16-bit cells)
+    if (spec->cell_bytes == 1 || spec->cell_bytes == 3) return MGX_ERR_UNSUPPORTED;            // (runtime-compiled shapes: 16-bit cells)
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
     rc = fill_args(ka, spec, batch, threads, lds, nwg, false, false, false, true);
@@ -423,11 +426,13 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
     ka.actions = sa.actions; ka.hook_order = sa.hook_order;
     ka.aux = sa.aux; ka.obs = sa.obs; ka.dir = sa.dir; ka.reward = sa.reward; ka.terminated = sa.terminated;
     ka.truncated = sa.truncated; ka.err = sa.err;
+    ka.grid_bad = spec->cell_bytes == 3 ? sa.grid_bad : nullptr;
+    if (misaligned(ka.grid_bad, 4)) return MGX_ERR_INVALID_ARGUMENT;
     ka.T = roll ? sa.steps : 1;
     int mode = (roll ? 2 : 1) | (one_hot ? 4 : 0);
     if (gen) {
         if (ar) return MGX_ERR_INVALID_ARGUMENT;
-        if (spec->cell_bytes == 1) return MGX_ERR_UNSUPPORTED;        // (device-side generation writes 16-bit cells)
+        if (spec->cell_bytes == 1 || spec->cell_bytes == 3) return MGX_ERR_UNSUPPORTED;        // (device-side generation writes 16-bit cells)
         if (roll) {
             // steps = T with generation: T launches of the one-step kernel over the [t] slices.  (Generation writes the HBM state;
             // the one-launch rollout keeps the state in LDS between its steps, so the two do not combine into a single launch --
@@ -568,7 +573,7 @@ int mgx_stage_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *g
     int rc = check_spec(spec, batch);
     if (rc) return rc;
     if (batch == 0) return MGX_OK;
-    if (spec->cell_bytes == 1) return MGX_ERR_UNSUPPORTED;
+    if (spec->cell_bytes == 1 || spec->cell_bytes == 3) return MGX_ERR_UNSUPPORTED;
     if (!gen || !rng || !episode || !gen->blank || !gen->gen_state) return MGX_ERR_INVALID_ARGUMENT;
     const MgxGenStage &gs = gen->stage;
     if (!gs.grid || !gs.agents || !gs.words || !gs.tag || (!gs.aux && spec->env_kind != MGX_KIND_EMPTY) || spec->num_agents < 2)
@@ -679,7 +684,7 @@ int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args,
         MgxStepArgs sa = *args;
         MgxAutoReset ar;
         MgxLayoutGen gen;
-        sa.grid = args->grid ? reinterpret_cast<MgxCell *>(reinterpret_cast<uint8_t *>(args->grid) + lo * HW * cell_bytes_of(*spec)) : nullptr;
+        sa.grid = args->grid ? reinterpret_cast<MgxCell *>(reinterpret_cast<uint8_t *>(args->grid) + lo * HW * grid_cell_bytes_of(*spec)) : nullptr;
         sa.agents = args->agents ? args->agents + lo * A * MGX_AGENT_STRIDE : nullptr;
         sa.rng = args->rng ? args->rng + lo * 4 : nullptr;
         sa.step_count = args->step_count ? args->step_count + lo : nullptr;

@@ -227,7 +227,11 @@ MGX_HD void store_cell(uint8_t *p, uint32_t c) { store_cell16(p, cell_pack(c)); 
 MGX_HD uint32_t load_cell_raw(int cb, const uint8_t *p) { return cb == 1 ? (uint32_t)*p : load_cell16(p); }
 MGX_HD void store_cell_raw(int cb, uint8_t *p, uint32_t raw) { if (cb == 1) *p = (uint8_t)raw; else store_cell16(p, raw); }
 MGX_HD uint32_t load_cell(int cb, const uint8_t *p) { return cb == 1 ? cell8_unpack(*p) : cell_unpack_full(load_cell16(p)); }
-MGX_HD uint32_t load_cell_shown(int cb, const uint8_t *p) { return cb == 1 ? cell8_unpack(*p) : cell_unpack(load_cell16(p)); }
+// (cb == 3: the reference's byte triples, as mgx_full_obs reads a byte grid)
+MGX_HD uint32_t load_cell_shown(int cb, const uint8_t *p) {
+    return cb == 1 ? cell8_unpack(*p)
+                   : (cb == 3 ? (((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16)) & 0x0003ffffu) : cell_unpack(load_cell16(p)));
+}
 MGX_HD void store_cell(int cb, uint8_t *p, uint32_t c) { if (cb == 1) *p = (uint8_t)cell8_pack(c); else store_cell16(p, cell_pack(c)); }
 MGX_HD uint32_t agent_cell_raw(int cb, uint64_t row) { return cb == 1 ? agent_cell8(row) : agent_cell16(row); }
 // observation cells: the reference's 3 bytes (type, color, state), any alignment

@@ -91,6 +91,9 @@ struct GridFaults {
     int32_t *host = nullptr;       // pinned copy
     hipEvent_t ev = nullptr;       // recorded behind the copy
     bool pending = false;
+    int unreported = 0;            // fused byte-grid steps (the kernel counts into `dev`) since the last queued report: the copy to the
+                                   // host is queued with the first of them and then every 32nd (it is a DMA op on the step's stream),
+                                   // and by check_errors(), which waits
 };
 std::mutex g_faults_mutex;
 std::map<int, GridFaults> g_faults;
@@ -111,8 +114,15 @@ void raise_faults(GridFaults &f, void *stream) {
 void poll_faults(int device, void *stream, bool wait = false) {
     std::lock_guard<std::mutex> lock(g_faults_mutex);
     auto it = g_faults.find(device);
-    if (it == g_faults.end() || !it->second.pending) return;
+    if (it == g_faults.end()) return;
     GridFaults &f = it->second;
+    if (wait && f.unreported > 0) {                     // counts of fused byte-grid steps that have not been sent for yet
+        TORCH_CHECK(hip_ok(hipMemcpyAsync(f.host, f.dev, 8, hipMemcpyDeviceToHost, (hipStream_t)stream))
+                    && hip_ok(hipEventRecord(f.ev, (hipStream_t)stream)), "mgx: could not queue the grid check's report");
+        f.pending = true;
+        f.unreported = 0;
+    }
+    if (!f.pending) return;
     if (wait) {
         TORCH_CHECK(hip_ok(hipEventSynchronize(f.ev)), "mgx: hipEventSynchronize failed");
     } else if (!hip_ok(hipEventQuery(f.ev))) {          // (hipErrorNotReady is not an error: and must not stay behind as one)
@@ -228,12 +238,29 @@ StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, co
                  const OptTensor &aux, const Tensor &err, at::IntArrayRef spec, int64_t T /* 0 = one step */, bool one_hot,
                  const OptTensor &pool_grid, const OptTensor &pool_agents, const OptTensor &pool_aux, const OptTensor &episode,
                  int64_t first_env, const OptTensor &hook_order, const char *what, const StepOut *pre = nullptr) {
-    const MgxSpec sc = spec_from(spec);
+    MgxSpec sc = spec_from(spec);
     DeviceGuard g(grid);
     poll_faults(grid.device().index(), stream_of(grid));
     bool bytes, pool_bytes = false;
-    const Tensor cells = as_cells(grid, "grid", bytes);
-    const int64_t B = check_state(sc, cells, agents);
+    // A byte grid u8[B,H,W,3] -- the reference's own form -- of a plain step goes to the kernel AS IT IS (MgxSpec.cell_bytes = 3: the
+    // step packs it into its LDS tile while loading it and writes changed cells back as bytes, include/mgx.h): no pack launch in
+    // front, no unpack launch behind.  Rollouts and the one-hot output keep the conversion around the call; so does a byte grid
+    // with a PACKED layout pool (the kernel takes both in one format).
+    const bool fused_bytes = grid.scalar_type() == at::kByte && T == 0 && !one_hot
+                             && (!pool_grid.has_value() || pool_grid->scalar_type() == at::kByte);
+    Tensor cells;
+    int64_t B;
+    if (fused_bytes) {
+        bytes = false;
+        cells = grid;
+        B = grid.dim() > 0 ? grid.size(0) : 0;
+        want(grid, "grid", at::kByte, {B, sc.height, sc.width, 3}, true);
+        want(agents, "agents", at::kByte, {B, sc.num_agents, 8}, true);
+        sc.cell_bytes = 3;
+    } else {
+        cells = as_cells(grid, "grid", bytes);
+        B = check_state(sc, cells, agents);
+    }
     const int64_t A = sc.num_agents, v = sc.view_size;
     want(rng, "rng", at::kLong, {B, 4}, true);
     want(step_count, "step_count", at::kInt, {B}, true);
@@ -273,9 +300,11 @@ StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, co
     MgxAutoReset ar{};
     Tensor pool_cells;
     if (pool_grid.has_value()) {
-        pool_cells = as_cells(*pool_grid, "pool_grid", pool_bytes);
+        if (fused_bytes) pool_cells = *pool_grid;
+        else pool_cells = as_cells(*pool_grid, "pool_grid", pool_bytes);
         const int64_t K = pool_cells.dim() > 0 ? pool_cells.size(0) : 0;
-        want(pool_cells, "pool_grid", at::kShort, {K, sc.height, sc.width}, true);
+        if (fused_bytes) want(pool_cells, "pool_grid", at::kByte, {K, sc.height, sc.width, 3}, true);
+        else want(pool_cells, "pool_grid", at::kShort, {K, sc.height, sc.width}, true);
         TORCH_CHECK_VALUE(pool_agents.has_value() && episode.has_value(), "mgx: auto-reset needs pool_agents and episode");
         want(*pool_agents, "pool_agents", at::kByte, {K, A, 8}, true);
         if (pool_aux.has_value()) want(*pool_aux, "pool_aux", at::kByte, {K, 16}, true);
@@ -288,6 +317,19 @@ StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, co
         sa.auto_reset = &ar;
     } else if (!pre) {
         o.was_reset = at::zeros(lead, agents.options());
+    }
+    if (fused_bytes) {          // the kernel counts what the pack kernel would have (ring, unpackable values); the report is deferred
+        void *st = stream_of(grid);
+        std::lock_guard<std::mutex> lock(g_faults_mutex);
+        GridFaults &f = faults_of(grid.device().index());
+        sa.grid_bad = f.dev;
+        check(mgx_step_ex(&sc, B, &sa, st), what);
+        if ((f.unreported++ & 31) == 0) {
+            TORCH_CHECK(hip_ok(hipMemcpyAsync(f.host, f.dev, 8, hipMemcpyDeviceToHost, (hipStream_t)st))
+                        && hip_ok(hipEventRecord(f.ev, (hipStream_t)st)), "mgx: could not queue the grid check's report");
+            f.pending = true;
+        }
+        return o;
     }
     check(mgx_step_ex(&sc, B, &sa, stream_of(cells)), what);
     if (bytes) cells_back(cells, grid);

@@ -55,7 +55,7 @@ def source_for(key: MgxShapeKey) -> str:
     kern = """
 extern "C" __global__ __launch_bounds__(kMaxThreads) void %s(const KernelArgs a) {
     constexpr int V = %d, MODE = 1, GRP = kGroup, SHAPE = kNumShapes - 1;
-    constexpr bool HOOKS = %s, AR = %s, OH = false, GEN = false, STREAM = %s, DMA = %s, C8 = false;
+    constexpr bool HOOKS = %s, AR = %s, OH = false, GEN = false, STREAM = %s, DMA = %s, C8 = false, B3 = false;
 #include "mgx_fused_body.inc"
 }
 """

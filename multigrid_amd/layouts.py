@@ -157,10 +157,15 @@ def unpack_cells8(cells: np.ndarray) -> np.ndarray:
 
 def pack_cells_for(spec, grid_hwc: np.ndarray) -> np.ndarray:
     """The device's cell tensor content for `spec` (its `cell_bytes`): i16 / u8 bit patterns."""
+    if spec.cell_bytes == 3:                                  # byte grids: the triples themselves (checked like the packed forms)
+        pack_cells(grid_hwc)
+        return np.ascontiguousarray(grid_hwc, dtype=np.uint8)
     return pack_cells8(grid_hwc) if spec.cell_bytes == 1 else pack_cells(grid_hwc).view(np.int16)
 
 
 def unpack_cells_for(spec, cells: np.ndarray) -> np.ndarray:
+    if spec.cell_bytes == 3:
+        return np.asarray(cells, dtype=np.uint8)
     return unpack_cells8(cells) if spec.cell_bytes == 1 else unpack_cells(cells)
 
 

@@ -185,6 +185,8 @@ class HipBackend:
         sa.obs, sa.dir, sa.reward = obs.data_ptr(), _ptr(dirs), reward.data_ptr()
         sa.terminated, sa.truncated = terminated.data_ptr(), truncated.data_ptr()
         sa.steps, sa.one_hot = 1, int(bool(one_hot))
+        if self.spec.cell_bytes == 3:               # byte grids: what the kernel's own packing counts (include/mgx.h: grid_bad)
+            sa.grid_bad = self.grid_bad().data_ptr()
         gen = None
         if ar is not None:
             sa.auto_reset = C.pointer(ar)
@@ -194,6 +196,13 @@ class HipBackend:
             sa.generate = C.pointer(gen)
             sa.episode, sa.was_reset = episode.data_ptr(), _ptr(was_reset)
         return sa, (ar, gen, self.sc)
+
+    def grid_bad(self):
+        """i32[2] on the device: cell values the packed format cannot hold / outer-ring cells that are not WALL, as counted by the
+        step kernel while it packs a byte grid (MgxSpec.cell_bytes = 3); BatchedMultiGridEnv.check_errors() reads it."""
+        if getattr(self, "_grid_bad", None) is None:
+            self._grid_bad = torch.zeros(2, dtype=torch.int32, device=self.device)
+        return self._grid_bad
 
     def bind_step(self, B, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
                   auto_reset=None, one_hot: bool = False, generate=None):

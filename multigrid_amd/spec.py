@@ -38,7 +38,9 @@ class EnvSpec:
     #: bytes per grid cell on the device (include/mgx.h): 2 = MgxCell (16 bits, every entry point), 1 = MgxCell8 (compact cells for
     #: LARGE grids -- type and state coded jointly in one byte: a third less traffic per step and twice the envs per wavefront on
     #: a 64x64 grid; served by step / gen_obs / auto-reset from a layout pool / full_obs, not by rollouts, one-hot output, device
-    #: generation or persistent stepping).  Same results bit for bit either way.
+    #: generation or persistent stepping); 3 = the grid tensor IS the reference's `(type, color, state)` bytes u8[B,H,W,3], packed by
+    #: the step kernel itself as it loads them (for callers that hold their state in that form; same set of entry points as 1).
+    #: Same results bit for bit either way.
     cell_bytes: int = 2
 
     def __post_init__(self):
@@ -62,8 +64,8 @@ class EnvSpec:
             raise ValueError(f"view_size must be <= {MAX_VIEW}")
         if self.width > 255 or self.height > 255:
             raise ValueError("grid sides must be <= 255 (positions are stored as uint8)")
-        if self.cell_bytes not in (1, 2):
-            raise ValueError("cell_bytes must be 2 (MgxCell) or 1 (MgxCell8, compact cells)")
+        if self.cell_bytes not in (1, 2, 3):
+            raise ValueError("cell_bytes must be 2 (MgxCell), 1 (MgxCell8, compact cells) or 3 (the reference's byte triples)")
 
     # ---- shapes of the device tensors (include/mgx.h) ----
     def grid_shape(self, batch: int):
@@ -71,12 +73,13 @@ class EnvSpec:
         return (batch, self.height, self.width, 3)
 
     def cells_shape(self, batch: int):
-        """packed cells: the form the device holds (include/mgx.h MgxCell, or MgxCell8 when cell_bytes == 1)"""
-        return (batch, self.height, self.width)
+        """packed cells: the form the device holds (include/mgx.h MgxCell, MgxCell8 when cell_bytes == 1, the byte triples when 3)"""
+        return (batch, self.height, self.width) + ((3,) if self.cell_bytes == 3 else ())
 
     @property
     def compact(self) -> bool:
-        return self.cell_bytes == 1
+        """a cell format that only the plain step / gen_obs kernels serve (compact cells, byte grids)"""
+        return self.cell_bytes != 2
 
     def agents_shape(self, batch: int):
         return (batch, self.num_agents, 8)

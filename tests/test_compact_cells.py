@@ -67,7 +67,7 @@ def test_what_compact_cells_do_not_serve_is_refused_by_name():
     with pytest.raises(NotImplementedError, match="compact cells"):
         env.persistent(4)
     with pytest.raises(ValueError):
-        EnvSpec(8, 8, cell_bytes=3)
+        EnvSpec(8, 8, cell_bytes=4)
     bad = st["grid"].copy()
     bad[0, 3, 3] = (5, 1, 1)                                   # a key with a state: the compact format has no code for it
     with pytest.raises(ValueError, match="compact"):
@@ -228,3 +228,69 @@ def test_c5_full_size_on_both_cell_formats_vs_oracle():
     wl2 = workloads.make("c5", cell_bytes=2)
     assert wl2.spec.cell_bytes == 2 and wl2.make_env(DEV).backend.launch_info(wl2.batch)["fixed_shape"] == 4
     run_vs_oracle(wl2, T=4, seed=56)
+
+
+# ---------------------------------------------------------------------------------------------------- byte grids (cell_bytes = 3)
+def bytes_spec(spec: EnvSpec) -> EnvSpec:
+    return dataclasses.replace(spec, cell_bytes=3)
+
+
+BYTE_CASES = [
+    ("b3_C2_empty16_a4_v7", EnvSpec(16, 16, 4, 7, max_steps=1024), 4096, 10),
+    ("b3_bup_11x6_a2", EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup"), 3001, 10),     # 198 bytes per env: unaligned
+    ("b3_ragged_a3_v5_nooverlap", EnvSpec(9, 7, 3, 5, max_steps=50, allow_agent_overlap=False, failure_termination_mode="any"), 1001, 10),
+    ("b3_a1_v3_seethrough", EnvSpec(8, 8, 1, 3, max_steps=30, see_through_walls=True), 777, 6),
+    ("b3_C5_64x64_a16_v9", EnvSpec(64, 64, 16, 9, max_steps=16384), 300, 5),
+    ("b3_a5_v11_all_joint", EnvSpec(13, 12, 5, 11, max_steps=40, success_termination_mode="all", joint_reward=True), 333, 6),
+    ("b3_a2_v15", EnvSpec(24, 24, 2, 15, max_steps=40), 65, 4),
+    ("b3_single_env", EnvSpec(8, 8, 2, 7, max_steps=256), 1, 8),
+    ("b3_big_grid_200x180_a3_v7", EnvSpec(200, 180, 3, 7, max_steps=40), 9, 3),
+]
+
+
+@gpu
+@pytest.mark.parametrize("name,spec,B,T", BYTE_CASES, ids=[c[0] for c in BYTE_CASES])
+def test_byte_grid_random_states_vs_oracle(name, spec, B, T):
+    """MgxSpec.cell_bytes = 3: the grid tensor IS the reference's (type, color, state) bytes u8[B,H,W,3]; the step kernel packs it
+    into its LDS tile as it loads it and writes changed cells back as three bytes."""
+    from tests.test_hip_parity import test_random_states_vs_oracle
+    test_random_states_vs_oracle(name, bytes_spec(spec), B, T)
+
+
+@gpu
+@pytest.mark.parametrize("name,spec,B,T", [("b3t_a3_v5", EnvSpec(9, 7, 3, 5, max_steps=50), 50001, 4),
+                                           ("b3t_bup_a2_v7", EnvSpec(11, 6, 2, 7, max_steps=576, joint_reward=True, env_kind="blockedunlockpickup"), 70003, 4),
+                                           ("b3t_a2_v9", EnvSpec(10, 8, 2, 9, max_steps=30), 40001, 3)], ids=["a3_v5", "bup", "a2_v9"])
+def test_byte_grid_throughput_and_auto_reset_vs_oracle(name, spec, B, T):
+    from tests.test_hip_parity import test_throughput_instantiations_vs_oracle
+    test_throughput_instantiations_vs_oracle(name, bytes_spec(spec), B, T)
+
+
+@gpu
+def test_byte_grid_c4_full_size_and_filled_boxes_and_the_ring_count():
+    from tests.test_full_size import run_vs_oracle
+    wl = workloads.make("c4", cell_bytes=3)
+    assert wl.spec.cell_bytes == 3
+    run_vs_oracle(wl, T=10, seed=41)
+    # boxes that hold things travel in the state byte's upper bits
+    spec = bytes_spec(EnvSpec(12, 12, 4, 7, max_steps=200))
+    B = 3000
+    st = util.random_state(spec, B, seed=8, density=0.35, carry_p=0.5, box_contents_p=0.7)
+    env = BatchedMultiGridEnv(spec, B, DEV)
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    ref = {k: v.copy() for k, v in st.items()}
+    r = np.random.default_rng(5)
+    for t in range(10):
+        act = r.choice(7, size=(B, 4), p=[0.1, 0.1, 0.25, 0.2, 0.15, 0.18, 0.02]).astype(np.int8)
+        want = ob.step_batch(spec.as_dict(), ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, ref["target"], nthreads=8)
+        got = env.step(torch.from_numpy(act).to(DEV))
+        for g, w in zip(got, want):
+            assert g.cpu().numpy().tobytes() == w.tobytes(), f"step {t}"
+        np.testing.assert_array_equal(env.cells.cpu().numpy(), ref["grid"], err_msg=f"step {t}")
+    env.check_errors()
+    # a hole in the wall ring and a value the packed format cannot hold are counted by the kernel (MgxStepArgs.grid_bad)
+    env.cells[5, 0, 3] = torch.tensor([1, 0, 0], dtype=torch.uint8, device=DEV)
+    env.cells[9, 4, 4] = torch.tensor([5, 9, 0], dtype=torch.uint8, device=DEV)
+    env.step(torch.zeros((B, 4), dtype=torch.int8, device=DEV))
+    with pytest.raises(ValueError, match="1 outer-ring cell.*1 cell value"):
+        env.check_errors()

