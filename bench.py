@@ -38,6 +38,7 @@ Prints ONE JSON line on rank 0.  Extra objects (N=1 only, except `roofline`, `pi
   configs             the other BASELINE.json GPU configurations (C2, C3 with its layout pool + hook, C5 with occluders),
                       each timed the same way, each with its own roofline
   eager               the same step called from Python once per step (policy-in-the-loop cost: ctypes + launch)
+  cpu_baseline_python_1core  (round 5) SURVEY 8d(i): the pure Python / NumPy per-env restatement (oracle/py_oracle.py) on one host core
   fused_rollout       K steps as ONE mgx_rollout launch (open-loop actions only)
   roofline_large / gen_obs_large / one_hot_large / aux_kernels
                       the kernels at a working set >> the 256 MiB Infinity Cache (HBM-resident regime)
@@ -497,6 +498,30 @@ def byte_grid_overhead(wl, device):
                     "wall-ring check) in its load phase (round 4: a pack and an unpack launch around the step, +36..43 us)"}
 
 
+def cpu_baseline_python(wl, budget_s=4.0, sample_envs=4):
+    """the pure Python / NumPy per-env restatement (oracle/py_oracle.py, pinned to the reference's fixtures) on ONE
+    host core, a few envs of the timed workload -- the stand-in for the reference's own speed, whose two hot kernels are numba
+    functions that run as exactly such interpreter loops without numba (BASELINE.md section 2 measured the real reference at
+    ~5.4e3 agent-steps/s that way)."""
+    from multigrid_amd import layouts
+    from oracle import py_oracle as po
+    n = min(sample_envs, wl.batch)
+    spec, A = wl.spec.as_dict(), wl.spec.num_agents
+    envs = [(layouts.grid_from_product(wl.grid[b]), layouts.unpack_agents(wl.agents[b]), np.random.default_rng(b), 0) for b in range(n)]
+    r = np.random.default_rng(1)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for k, (g, a, rng, sc) in enumerate(envs):
+            out = po.step(spec, g, a, rng, sc, r.integers(0, 7, size=A), None if wl.aux is None else wl.aux[k])
+            envs[k] = (g, a, rng, out[5])
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * A * steps / dt), "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} steps of the first {n} envs of the timed workload ({wl.name}) = {n * A * steps} agent-steps in {dt:.1f} s; "
+                      "oracle/py_oracle.py: the reference's algorithm restated per env in Python / NumPy (interpreter loops for gen_obs "
+                      "and the visibility sweep, as the reference's numba kernels run without numba), no auto-reset"}
+
+
 def cpu_baseline(wl, threads, budget_s, sample_envs):
     """Oracle (C port of the reference algorithm, OpenMP over envs) on this host, bounded sample of the workload."""
     from oracle import binding as ob
@@ -730,6 +755,7 @@ def main():
             from oracle import binding as ob
             out["cpu_baseline"] = cpu_baseline(wl, ob.max_threads(), 8.0, wl.batch)
             out["cpu_baseline_1core"] = cpu_baseline(wl, 1, 6.0, 2048)
+            out["cpu_baseline_python_1core"] = cpu_baseline_python(wl)
         print(json.dumps(out), flush=True)
     barrier()
     if dist is not None:

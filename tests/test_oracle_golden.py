@@ -132,3 +132,37 @@ def test_oracle_wrappers_match_reference():
         for t in range(z["obs"].shape[0]):
             np.testing.assert_array_equal(ob.one_hot(z["obs"][t]), z["one_hot"][t])
             np.testing.assert_array_equal(ob.full_obs(z["grid"][t], z["agents"][t]), z["full"][t].astype(np.int64))
+
+
+PY_GOLDEN = [p for p in GOLDEN if os.path.basename(p).startswith(("empty8_a2_seed0", "empty16_a4_seed1", "empty16_a4_objects", "empty8_a2_unlock",
+                                                                  "bup_a2_seed", "emptyrandom6_a3_nooverlap"))]
+
+
+@pytest.mark.parametrize("path", PY_GOLDEN, ids=[os.path.basename(p)[:-4] for p in PY_GOLDEN])
+def test_python_restatement_replays_reference(path):
+    """oracle/py_oracle.py -- the pure Python / NumPy per-env restatement bench.py times on one host core as the reference's
+    interpreter-speed stand-in -- against what the real reference produced: every output, every step."""
+    from oracle import py_oracle as po
+    z, spec = load(path)
+    assert PY_GOLDEN
+    grid, agents = z["grid0"].astype(np.int64), z["agents0"].astype(np.int64)
+    hs, ls, hi, li = (int(w) for w in z["rng0"])
+    bg = np.random.PCG64()
+    st = bg.state
+    st["state"] = {"state": (hs << 64) | ls, "inc": (hi << 64) | li}
+    st["has_uint32"], st["uinteger"] = 0, 0
+    bg.state = st
+    rng = np.random.Generator(bg)
+    np.testing.assert_array_equal(po.gen_obs(grid, agents, spec["view_size"], spec["see_through_walls"]), z["obs0"])
+    sc = 0
+    T = min(z["actions"].shape[0], 120)
+    for t in range(T):
+        obs, d, rew, term, trunc, sc = po.step(spec, grid, agents, rng, sc, z["actions"][t], spec.get("target"))
+        ctx = f"step {t}"
+        np.testing.assert_array_equal(obs, z["obs"][t], err_msg=ctx)
+        np.testing.assert_array_equal(d, z["direction"][t], err_msg=ctx)
+        assert rew.tobytes() == z["reward"][t].tobytes(), ctx
+        np.testing.assert_array_equal(term.astype(np.uint8), z["terminated"][t], err_msg=ctx)
+        assert bool(trunc) == bool(z["truncated"][t]), ctx
+        np.testing.assert_array_equal(grid, z["grid"][t].astype(np.int64), err_msg=ctx)
+        np.testing.assert_array_equal(agents, z["agents"][t].astype(np.int64), err_msg=ctx)
