@@ -234,7 +234,8 @@ def config_point(name, device, K, warmup, device_generated=False, steady=False, 
     wl = workloads.make(name, cell_bytes=cell_bytes)
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     if device_generated:
-        # (truncation resets staged by generator launches between the steps, 128 steps ahead: set_layout_generator's default)
+        # (set_layout_generator's default: every episode end adopts a candidate made while its episode ran -- one per value of the
+        # generator's np_random draw -- by generator launches between the steps, one every max_steps / 3 steps)
         # steady: the episodes are OUT OF PHASE (uniform over the episode length: what any long rollout settles into -- every step
         # then sees its share of truncations, ~B / max_steps, instead of one burst every max_steps steps)
         env.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6)
@@ -250,7 +251,8 @@ def config_point(name, device, K, warmup, device_generated=False, steady=False, 
            "value": round(B * A * m["timed_steps"] / m["wall_s"]), "unit": "agent-steps/s",
            "timed_steps": m["timed_steps"],
            "layout_pool": ("generated on the device in the step's own launch (mgx_step_generate)"
-                           + "; truncation resets staged 128 steps ahead by generator launches between the steps"
+                           + "; every episode end adopts one of 4 candidates (one per door row) made while the episode ran, by a "
+                             "generator launch between two steps every max_steps / 3 steps (MgxGenStage.candidates)"
                            + ("; episodes out of phase" if steady else ""))
                           if device_generated else int(wl.pool[0].shape[0]),
            "resets_in_region": int(env.episode.sum().item()) if AUTO_RESET else 0,

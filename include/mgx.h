@@ -93,7 +93,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 9
+#define MGX_ABI_VERSION 10
 
 enum {
     MGX_OK = 0,
@@ -361,6 +361,21 @@ typedef struct MgxGenStage {
                                      its snapshot with plain stores (the kernel boundary orders them) instead of an agent-scope release --
                                      which writes the XCD's L2 back, ~1.5 us for the wavefront that takes a snapshot.  Do NOT pass 2 with
                                      generator launches on another stream. */
+    int32_t candidates;           /* ABI 10: K > 0 = EVERY episode end an adoption (needs external == 2).  The layout stream that drives
+                                     place_obj is the construction-time generator: it does not depend on WHEN the
+                                     episode ends -- only the draws from env.np_random do, and the generators make at most one such draw
+                                     (BlockedUnlockPickup: the door's row, roomgrid.py:104-106; the Empty / RedBlueDoors / LockedHallway
+                                     generators none).  So the NEXT episode is generated while the current one runs, once per possible
+                                     value of that draw: K = room_size - 2 candidates (<= 4) for BlockedUnlockPickup, 1 for the others
+                                     (MGX_GEN_PLAYGROUND draws many times: not available).  mgx_stage_generate fills the candidates of every
+                                     env whose slots are not its current episode's (tag[k] != episode; no snapshot, no request, `lead`
+                                     only sets how often the caller launches it); a step that ENDS an episode -- truncation or success /
+                                     failure alike -- makes the draw from np_random as it is then (registers) and adopts the matching
+                                     candidate, requested as soon as the step's rules have run and stored in the tail; an env whose
+                                     candidates are not there yet is generated in the tail.  Same results bit for bit.  The slots then are
+                                       grid MgxCell[B,K,H,W]   agents u8[B,K,A,8]   aux u8[B,K,16]   words u64[B,K,6] (gen_state[0..4] after
+                                       that candidate's generation)   tag i32[B,4]: [k] = the episode whose successor candidate k is
+                                     (-1: none; any content with all tags -1 is valid) */
 } MgxGenStage;
 
 typedef struct MgxLayoutGen {

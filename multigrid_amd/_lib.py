@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
@@ -44,7 +44,7 @@ class MgxAutoReset(C.Structure):
 class MgxGenStage(C.Structure):
     """include/mgx.h: struct MgxGenStage (staged generation of truncation resets)."""
     _fields_ = [("grid", C.c_void_p), ("agents", C.c_void_p), ("aux", C.c_void_p), ("words", C.c_void_p), ("tag", C.c_void_p),
-                ("phase", C.c_int32), ("lead", C.c_int32), ("external", C.c_int32)]
+                ("phase", C.c_int32), ("lead", C.c_int32), ("external", C.c_int32), ("candidates", C.c_int32)]
 
 
 class MgxLayoutGen(C.Structure):

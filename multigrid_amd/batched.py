@@ -320,7 +320,9 @@ class BatchedMultiGridEnv:
         """The env state (np_random, step counts, grids) was replaced from outside: what the staged generator prepared from the
         old state is void (the slots are a cache: dropping them is always valid), and nothing of the old state is in flight."""
         st = (getattr(self, "_gen", None) or {}).get("stage")
-        if st is not None:
+        if st is not None and st.get("candidates"):
+            st["tag"].fill_(-1)
+        elif st is not None:
             st["tag"][:, 0] = -1
             st["tag"][:, 3] = 0
 
@@ -572,10 +574,16 @@ class BatchedMultiGridEnv:
                 for i, sh in enumerate(shards):
                     lo, hi = getattr(sh, "_range", (0, self.batch))
                     with torch.cuda.stream(side if i == 0 else others[i - 1]):
+                        st = (getattr(sh, "_gen", None) or {}).get("stage") if auto_reset else None
+                        before = st.get("launches", 0) if st else 0
                         for t in range(actions.shape[0]):
                             ho = None if hook_order is None else (hook_order[t] if sh is self else hook_order[t, lo:hi])
                             sh.step(actions[t] if sh is self else actions[t, lo:hi], auto_reset=auto_reset, one_hot=one_hot,
                                     hook_order=ho)
+                        # candidates (set_layout_generator): a block shorter than the generator launches' cadence may have caught
+                        # none of them -- and would then never make a candidate, however often it is replayed: it ends with one
+                        if st and st.get("candidates") and len(shards) == 1 and st.get("launches", 0) == before:
+                            sh.backend.stage_generate(sh.batch, sh._gen, sh.rng, sh.episode)
                 for i, sh in enumerate(shards):                              # (generator streams of side-staged envs: join)
                     gs = ((getattr(sh, "_gen", None) or {}).get("stage") or {}).get("stream")
                     if gs is not None:
@@ -696,7 +704,14 @@ class BatchedMultiGridEnv:
         observation is the terminal one and the state tensors already hold the next episode's start.
         staged       how the truncation resets -- known in advance -- are kept off the step's critical path (include/mgx.h: MgxGenStage;
                      same results bit for bit in every mode, the slots are a cache):
-                       True / "between" (default)  `lead` steps before an env truncates its step takes a snapshot of np_random; every
+                       True (default) / "candidates"  EVERY episode end an adoption: the generators draw from env.np_random at most
+                                    once (BlockedUnlockPickup: the door row; the others never), and the placement stream does not
+                                    depend on when the episode ends -- so the next episode is generated while the current one runs,
+                                    once per possible value of that draw (room_size - 2 <= 4 candidates), by one generator launch
+                                    (mgx_stage_generate) every lead/2 steps between two steps; a step that ends an episode -- by
+                                    truncation or by success / failure -- makes the draw and adopts the matching candidate (a copy).
+                                    Playground (many draws) and room sizes above 6 fall back to "between"
+                       "between"    `lead` steps before an env truncates its step takes a snapshot of np_random; every
                                     lead/2 steps ONE generator launch (mgx_stage_generate) between two steps serves the pending
                                     snapshots into per-env slots; the truncating step adopts its slot (a copy).  Measured at C3 with the
                                     episodes out of phase: 9.7 us per step, against 15.6 in-launch and 16.6 unstaged (pool: 7.3)
@@ -706,7 +721,8 @@ class BatchedMultiGridEnv:
                        "in_launch"  round 3's form: generator wavefronts appended to every step's launch, two steps ahead
                        False        no staging: every finished env is generated in the tail of its step
                      (`step()` and `capture_steps()` issue the generator launches; `rollout()` does it inside mgx_step_ex)
-        lead         steps between the snapshot and the truncation (default: max_steps / 4, at most 128; 2 for "in_launch")
+        lead         steps between the snapshot and the truncation (default: max_steps / 4, at most 128; 2 for "in_launch");
+                     "candidates": twice the number of steps between two generator launches (default: 2/3 of max_steps, at most 512)
         """
         self._no_session("set_layout_generator")
         sp = self.spec
@@ -741,11 +757,30 @@ class BatchedMultiGridEnv:
                      "max_hallway_keys": int(max_hallway_keys), "max_keys_per_room": int(max_keys_per_room),
                      "blank": torch.from_numpy(layouts.pack_cells(blank).view(np.int16)).to(self.device).contiguous(),
                      "gen_state": torch.from_numpy(rnglib.layout_gen_state(layout_seed, idx).view(np.int64)).to(self.device)}
+        # candidates per env (include/mgx.h: MgxGenStage.candidates): one per value of the generator's single env.np_random draw
+        cand = {"blockedunlockpickup": int(room_size) - 2, "redbluedoors": 1, "lockedhallway": 1, "empty_fixed": 1,
+                "empty_random": 1}.get(kind, 0)
         if staged is True:
-            staged = "between"
-        if staged not in (False, "between", "side", "in_launch"):
-            raise ValueError(f"staged must be True / 'between' / 'side' / 'in_launch' / False, got {staged!r}")
-        if staged and sp.num_agents > 1:         # the staging slots: a cache, not state (tag -1 = empty)
+            staged = "candidates" if 1 <= cand <= 4 else "between"
+        if staged not in (False, "candidates", "between", "side", "in_launch"):
+            raise ValueError(f"staged must be True / 'candidates' / 'between' / 'side' / 'in_launch' / False, got {staged!r}")
+        if staged == "candidates" and not 1 <= cand <= 4:
+            raise ValueError(f"staged='candidates': the {kind!r} generator draws from env.np_random more than once (or has more than "
+                             f"4 possible draws): use 'between'")
+        if staged == "candidates" and sp.num_agents > 1:
+            B, dev = self.batch, self.device
+            # (here `lead` only sets the generator launches' cadence -- every lead/2 steps, by default a third of max_steps: a launch
+            # costs 15-50 us of the stream's time whatever it finds to do (profiles/r5_candidates.txt), and an episode shorter than
+            # the cadence merely generates in the tail of its last step.  Callers whose episodes are short pass a smaller `lead`.)
+            lead = int(lead) if lead is not None else max(4, min(512, 2 * sp.max_steps // 3))
+            lead = max(2, min(lead, sp.max_steps - 1))
+            self._gen["stage"] = {"lead": lead, "external": 2, "stream": None, "candidates": cand,
+                                  "grid": torch.zeros((B, cand, sp.height, sp.width), dtype=torch.int16, device=dev),
+                                  "agents": torch.zeros((B, cand, sp.num_agents, 8), dtype=torch.uint8, device=dev),
+                                  "aux": torch.zeros((B, cand, 16), dtype=torch.uint8, device=dev) if sp.env_kind != "empty" else None,
+                                  "words": torch.zeros((B, cand, 6), dtype=torch.int64, device=dev),
+                                  "tag": torch.full((B, 4), -1, dtype=torch.int32, device=dev), "phase": [0]}
+        elif staged and sp.num_agents > 1:       # the staging slots: a cache, not state (tag -1 = empty)
             B, dev = self.batch, self.device
             tag = torch.zeros((B, 4), dtype=torch.int32, device=dev)
             tag[:, 0] = -1

@@ -214,6 +214,9 @@ const JitShape *jit_shape_lookup(const KernelArgs &ka, bool hooks) {
 }
 }  // namespace mgx_fused
 
+extern "C" int mgx_internal_stage_candidates(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, const int32_t *episode,
+                                             void *stream);      // mgx_layout_gen.hip (not in include/mgx.h)
+
 extern "C" {
 
 int mgx_abi_version(void) { return MGX_ABI_VERSION; }
@@ -488,6 +491,9 @@ static int step_common(const MgxSpec *spec, int64_t batch, const MgxStepArgs &sa
             if (st.lead < 0 || st.lead >= spec->max_steps) return MGX_ERR_INVALID_ARGUMENT;
             if (st.lead < 2) st.lead = 2;
             if (st.external < 0 || st.external > 2) return MGX_ERR_INVALID_ARGUMENT;
+            // candidates (ABI 10): only with the generator launches between the steps, only what the generator kind offers
+            if (st.candidates < 0 || (st.candidates > 0 && (st.external != 2 || st.candidates != mgx_gen::stage_candidates(gen))))
+                return MGX_ERR_INVALID_ARGUMENT;
             if (!st.external) {                                  // generator wavefronts behind the step's own workgroups
                 const int wpb = threads / 64;
                 const int64_t gen_waves = (batch + 63) / 64;
@@ -596,6 +602,9 @@ int mgx_stage_generate(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *g
     ka.gen.stage.lead = ka.gen.stage.lead < 2 ? 2 : ka.gen.stage.lead;
     ka.gen_first_wg = 0;                                 // every workgroup of this launch is a generator workgroup
     ka.T = 1;
+    if (gs.candidates < 0 || (gs.candidates > 0 && (gs.external != 2 || gs.candidates != mgx_gen::stage_candidates(gen))))
+        return MGX_ERR_INVALID_ARGUMENT;
+    if (gs.candidates > 0) return mgx_internal_stage_candidates(spec, batch, gen, episode, stream);   // (a kernel of its own: mgx_layout_gen.hip)
     const int wpb = threads / 64;
     const int64_t gen_waves = (batch + 63) / 64;
     nwg = (gen_waves + wpb - 1) / wpb;

@@ -46,6 +46,15 @@ inline int check_layout_gen(const MgxSpec *spec, const MgxLayoutGen *gen) {
     }
 }
 
+// MgxGenStage.candidates this generator supports: one per value of its single env.np_random draw (0: not available)
+inline int stage_candidates(const MgxLayoutGen *gen) {
+    switch (gen->kind) {
+    case MGX_GEN_EMPTY_FIXED: case MGX_GEN_EMPTY_RANDOM: case MGX_GEN_REDBLUEDOORS: case MGX_GEN_LOCKEDHALLWAY: return 1;
+    case MGX_GEN_BLOCKEDUNLOCKPICKUP: return gen->room_size - 2 <= 4 ? gen->room_size - 2 : 0;
+    default: return 0;
+    }
+}
+
 // numpy PCG64 + its next_uint32 buffer: s = {state_lo, state_hi, inc_lo, inc_hi}, buf = has_uint32 << 32 | uinteger
 struct NpGen {
     uint64_t s[4];
@@ -191,8 +200,10 @@ struct Placer {
 
 // Agent.reset (agent.py:120-133) + _gen_grid for ONE env, run by one lane.  `grid` / `rows`: the env's slices in HBM (the
 // blank layout is already in `grid`); `apos`: 2 * A bytes of LDS scratch.  Returns the env's new hook state.
+// `door_row` > 0: the value of the generator's ONE draw from env.np_random is given (a candidate of MgxGenStage.candidates: `npr` is
+// not touched); 0: it is drawn.
 __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W, int H, int A, NpGen &lay, NpGen &npr,
-                                                  uint8_t *apos, uint8_t *grid, uint64_t *rows) {
+                                                  uint8_t *apos, uint8_t *grid, uint64_t *rows, int door_row = 0) {
     Placer P;
     P.kind = gen.kind; P.rs = gen.room_size; P.W = W; P.H = H; P.A = A; P.n_obj = 0;
     P.apos = apos;
@@ -337,7 +348,7 @@ __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W
         uint32_t p = P.place(lay, rs - 1, 0, rs, rs, true);                          // box in the right room
         P.put(p & 0xff, p >> 8, (uint32_t)T_BOX | (box_color << 8));
         const uint32_t door_color = (uint32_t)np_integers(lay, 0, 6);
-        const int door_x = rs - 1, door_y = np_integers(npr, 1, rs - 1);            // roomgrid.py:104-106: env.np_random
+        const int door_x = rs - 1, door_y = door_row > 0 ? door_row : np_integers(npr, 1, rs - 1);   // roomgrid.py:104-106: env.np_random
         P.put(door_x, door_y, (uint32_t)T_DOOR | (door_color << 8) | ((uint32_t)S_LOCKED << 16));
         P.put(door_x - 1, door_y, (uint32_t)T_BALL | ((uint32_t)np_integers(lay, 0, 6) << 8));
         p = P.place(lay, 0, 0, rs, rs, true);                                        // key in the left room

@@ -25,6 +25,9 @@
 #include <stdint.h>
 
 #include "mgx_layout_gen.h"
+#ifndef MGX_GEN_PROBE
+#define MGX_GEN_PROBE 0
+#endif
 
 extern "C" void mgx_internal_set_hip_error(int e);      // mgx_kernels.hip: what mgx_last_hip_error() reports
 
@@ -82,9 +85,74 @@ __global__ __launch_bounds__(64) void reset_generate_kernel(const GenArgs a) {
 }
 
 
+// MgxGenStage.candidates (include/mgx.h): one lane per (env, value of the generator's env.np_random draw).  An env whose candidate
+// k is not its CURRENT episode's successor gets it made from the layout stream as that episode's generation left it.  Launched
+// between two steps on their stream (external == 2): nothing reads or writes a slot beside this launch, the kernel boundary
+// publishes it.  KIND is a template argument so that each instantiation carries ONE generator's code: this launch is as long as its
+// slowest wavefront, and that one's time is mostly instruction fetch (profiles/r5_candidates.txt).
+template <int KIND>
+__global__ __launch_bounds__(64) void stage_candidates_kernel(const GenArgs a) {
+    extern __shared__ uint8_t lds[];
+    const int lane = threadIdx.x;
+    const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents, HWB = H * W * kCellBytes;
+    const MgxGenStage &st = a.gen.stage;
+    const int K = st.candidates;
+    const int64_t s0 = (int64_t)blockIdx.x * 64, s = s0 + lane, b = s / K;
+    const int k = (int)(s - b * K);
+    const bool go = b < a.batch && st.tag[b * 4 + k] != a.episode[b];
+    const uint64_t gom = __builtin_amdgcn_ballot_w64(go);
+    if (gom == 0) return;
+    MgxLayoutGen gen = a.gen;
+    gen.kind = KIND;
+    uint8_t *const st_grid = reinterpret_cast<uint8_t *>(st.grid);
+#if !(MGX_GEN_PROBE & 1)
+    copy_blank(gen, st_grid, s0, HWB, gom, lane);
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                           // (the owning lane overwrites cells the other lanes stored)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_wave_barrier();
+    if (!go) return;
+    const uint64_t *gs = gen.gen_state + b * 6;
+    NpGen lay, npr;
+    for (int q = 0; q < 4; ++q) { lay.s[q] = gs[q]; npr.s[q] = 0; }
+    lay.buf = gs[4]; npr.buf = 0;                                                    // (npr: not drawn from -- door_row is given)
+#if MGX_GEN_PROBE & 2
+    const uint4 naux = {0, 0, 0, 0};
+#else
+    const uint4 naux = generate_episode(gen, W, H, A, lay, npr, lds + lane * (2 * A), st_grid + s * HWB,
+                                        reinterpret_cast<uint64_t *>(st.agents) + s * A, k + 1);
+#endif
+    if (st.aux) reinterpret_cast<uint4 *>(st.aux)[s] = naux;
+    uint64_t *const words = st.words + s * 6;
+    for (int q = 0; q < 4; ++q) words[q] = lay.s[q];
+    words[4] = lay.buf;
+    st.tag[b * 4 + k] = a.episode[b];
+}
+
 inline bool misaligned(const void *p, uintptr_t al) { return (reinterpret_cast<uintptr_t>(p) & (al - 1)) != 0; }
 
 }  // namespace
+
+// mgx_stage_generate with MgxGenStage.candidates > 0 (mgx_kernels.hip validated the arguments)
+extern "C" int mgx_internal_stage_candidates(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, const int32_t *episode,
+                                             void *stream) {
+    const int64_t blocks = (batch * gen->stage.candidates + 63) / 64;
+    if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
+    GenArgs ga{*spec, batch, *gen, nullptr, nullptr, nullptr, nullptr, nullptr, const_cast<int32_t *>(episode), nullptr};
+    const size_t lds = (size_t)(64 * 2 * spec->num_agents);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    switch (gen->kind) {
+    case MGX_GEN_EMPTY_FIXED: hipLaunchKernelGGL(stage_candidates_kernel<MGX_GEN_EMPTY_FIXED>, dim3((unsigned)blocks), dim3(64), lds, hs, ga); break;
+    case MGX_GEN_EMPTY_RANDOM: hipLaunchKernelGGL(stage_candidates_kernel<MGX_GEN_EMPTY_RANDOM>, dim3((unsigned)blocks), dim3(64), lds, hs, ga); break;
+    case MGX_GEN_BLOCKEDUNLOCKPICKUP: hipLaunchKernelGGL(stage_candidates_kernel<MGX_GEN_BLOCKEDUNLOCKPICKUP>, dim3((unsigned)blocks), dim3(64), lds, hs, ga); break;
+    case MGX_GEN_REDBLUEDOORS: hipLaunchKernelGGL(stage_candidates_kernel<MGX_GEN_REDBLUEDOORS>, dim3((unsigned)blocks), dim3(64), lds, hs, ga); break;
+    case MGX_GEN_LOCKEDHALLWAY: hipLaunchKernelGGL(stage_candidates_kernel<MGX_GEN_LOCKEDHALLWAY>, dim3((unsigned)blocks), dim3(64), lds, hs, ga); break;
+    default: return MGX_ERR_UNSUPPORTED;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mgx_internal_set_hip_error((int)e); return MGX_ERR_LAUNCH; }
+    return MGX_OK;
+}
 
 extern "C" {
 

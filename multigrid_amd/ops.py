@@ -171,7 +171,8 @@ class HipBackend:
         st = gen.get("stage")
         if st is not None:                      # staged generation of truncation resets (include/mgx.h: MgxGenStage)
             g.stage = _lib.MgxGenStage(st["grid"].data_ptr(), st["agents"].data_ptr(), _ptr(st.get("aux")), st["words"].data_ptr(),
-                                       st["tag"].data_ptr(), int(st["phase"][0]), int(st.get("lead", 2)), int(st.get("external") or 0))
+                                       st["tag"].data_ptr(), int(st["phase"][0]), int(st.get("lead", 2)), int(st.get("external") or 0),
+                                       int(st.get("candidates") or 0))
         return g
 
     def step_args(self, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated, truncated,
@@ -251,8 +252,17 @@ class HipBackend:
                     rc = stage_fn(spec_ref, B, gen_ref, rng_ptr, episode_ptr, handle)
                 if rc:
                     _lib.check(rc, "mgx_stage_generate")
+                stage["launches"] = stage.get("launches", 0) + 1
         step._keep = (sa, keep)
         return step
+
+    def stage_generate(self, B, gen, rng, episode):
+        """mgx_stage_generate on torch's current stream: the staging slots' generator as a launch of its own (include/mgx.h)."""
+        gen_c = self._layout_gen_struct(gen)
+        with torch.cuda.device(rng.device):
+            rc = _lib.lib().mgx_stage_generate(C.byref(self.sc), B, C.byref(gen_c), rng.data_ptr(), episode.data_ptr(), _stream(rng.device))
+        _lib.check(rc, "mgx_stage_generate")
+        gen["stage"]["launches"] = gen["stage"].get("launches", 0) + 1
 
     def bind_chains(self, B, parts, streams, grid, agents, rng, step_count, target, err, obs, dirs, reward, terminated,
                     truncated, auto_reset=None, one_hot: bool = False, generate=None):
@@ -267,6 +277,11 @@ class HipBackend:
 
         gen_c = keep[1]
         phase = generate[0]["stage"]["phase"] if generate is not None and generate[0].get("stage") is not None else None
+        if phase is not None and gen_c.stage.candidates:
+            # (candidates are made by generator launches BETWEEN the steps only: the chains run without staging -- every finished env
+            # generated in the tail of its step; same results)
+            gen_c.stage = _lib.MgxGenStage()
+            phase = None
         if phase is not None and gen_c.stage.external:
             # the chains issue no generator launches of their own (nobody sits between the steps of a chain): the pending snapshots are
             # served by generator wavefronts inside every chain's launch instead (MgxGenStage.external = 0, the in-launch form), so a

@@ -189,13 +189,14 @@ def test_rollout_with_device_generation_equals_steps(one_hot):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["between", "side"])
+@pytest.mark.parametrize("mode", ["candidates", "between", "side"])
 @pytest.mark.parametrize("case", [0, 2, 5], ids=lambda k: CASES[k][0])
 def test_generator_launches_of_their_own_equal_unstaged(case, mode):
-    """MgxGenStage.external (set_layout_generator(staged="between" -- the default -- / "side")): the staging slots are filled by
-    launches of their own (mgx_stage_generate), `lead` steps ahead of each truncation, between the steps or on a stream beside
-    them.  Bit-identical to generating every episode in the tail of its step -- eagerly, as a captured hipGraph and as a rollout --
-    and the slots ARE used (adoptions happen)."""
+    """MgxGenStage.external (set_layout_generator(staged="candidates" -- the default -- / "between" / "side")): the staging slots are
+    filled by launches of their own (mgx_stage_generate) between the steps or on a stream beside them -- one candidate per value of
+    the generator's np_random draw while the current episode runs ("candidates": every episode end adopts), or `lead` steps ahead
+    of each truncation.  Bit-identical to generating every episode in the tail of its step -- eagerly, as a captured hipGraph and
+    as a rollout -- and the slots ARE used (adoptions happen)."""
     name, spec, gen, B = CASES[case]
     if spec.max_steps < 6:
         spec = EnvSpec(**{**spec.as_dict(), "max_steps": 9})
@@ -212,6 +213,7 @@ def test_generator_launches_of_their_own_equal_unstaged(case, mode):
 
     ref, side = make(False), make(mode, lead=4)
     assert side._gen["stage"]["external"] and side._gen["stage"]["lead"] == 4
+    assert bool(side._gen["stage"].get("candidates")) == (mode == "candidates")
     assert (side._gen["stage"]["stream"] is not None) == (mode == "side")
     for t in range(T):
         want = [x.clone() for x in ref.step(acts[t], auto_reset=True)] + [ref.was_reset.clone()]
@@ -238,7 +240,7 @@ def test_generator_launches_of_their_own_equal_unstaged(case, mode):
     side.check_errors(); side2.check_errors()
     # the rollout form issues the generator launches inside mgx_step_ex (T launches over the [t] slices: they must be 16-byte
     # aligned, include/mgx.h)
-    if mode == "between" and (B * spec.num_agents * spec.view_size ** 2 * 3) % 16 == 0:
+    if mode in ("between", "candidates") and (B * spec.num_agents * spec.view_size ** 2 * 3) % 16 == 0:
         ref3, roll = make(False), make(mode, lead=4)
         out = roll.rollout(acts[:K], auto_reset=True)
         for t in range(K):
@@ -250,7 +252,71 @@ def test_generator_launches_of_their_own_equal_unstaged(case, mode):
 
 
 @pytest.mark.gpu
-def test_staged_slots_are_a_cache_not_state():
+def test_every_episode_end_adopts_its_candidate():
+    """MgxGenStage.candidates: an episode that ends EARLY -- here by success: an agent is handed the target box, the
+    BlockedUnlockPickup hook fires on the next step -- adopts the candidate its door-row draw selects, exactly like a truncation.
+    (a) staged == unstaged bit for bit through early ends, truncations and the steps after them; (b) the slots really are what
+    the envs restart from: with every candidate grid overwritten by a marker after the generator launch, the envs that restart
+    -- early-ended and truncated alike -- come out holding the marker."""
+    name, spec, gen, B = CASES[0]
+    spec = EnvSpec(**{**spec.as_dict(), "max_steps": 24})
+    B = 1024
+    dev = "cuda:0"
+    T = 3 * spec.max_steps
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    acts = torch.randint(0, 7, (T, B, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+
+    def make(staged):
+        env = _make(spec, gen, B, dev)
+        env.set_layout_generator(layout_seed=11, staged=staged, lead=4, **gen)
+        env.step_count.copy_(torch.arange(B, device=dev, dtype=torch.int32) % 5)                # a little out of phase
+        return env
+
+    def hand_over_the_box(env, which):
+        """agent 0 of the envs `which` carries the target box from now on (written in place: the state is not 'replaced')"""
+        a = env.agents                                                                          # u8[B, A, 8]: bytes 5..6 = carrying
+        a[which, 0, 5] = 7                                                                      # Type.box
+        a[which, 0, 6] = env.aux[which, 1]                                                      # the target's colour (include/mgx.h)
+
+    early = torch.arange(B, device=dev) % 3 == 0
+    ref, cand = make(False), make("candidates")
+    assert cand._gen["stage"]["candidates"] == 4
+    n_early = 0
+    for t in range(T):
+        if t % 9 == 6:                                       # (at least two generator launches after the last restart)
+            hand_over_the_box(ref, early); hand_over_the_box(cand, early)
+        want = [x.clone() for x in ref.step(acts[t], auto_reset=True)] + [ref.was_reset.clone()]
+        got = list(cand.step(acts[t], auto_reset=True)) + [cand.was_reset]
+        for k, (w, gg) in enumerate(zip(want, got)):
+            assert torch.equal(w, gg), f"step {t} output {k}"
+        n_early += int((cand.was_reset.bool() & ~cand.truncated.bool()).sum())
+    torch.cuda.synchronize()
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(ref, f), getattr(cand, f)), f
+    assert torch.equal(ref._gen["gen_state"], cand._gen["gen_state"])
+    assert n_early > B // 3, n_early                          # success-ended episodes did occur
+    cand.check_errors()
+    # (b) poisoned candidates show up in the restarted envs
+    env = make("candidates")
+    marker = 0x0103                                           # (a valid cell: a floor of colour 1)
+    for t in range(8):
+        env.step(acts[t], auto_reset=True)
+    st = env._gen["stage"]
+    ready = (st["tag"] == env.episode[:, None]).all(dim=1)    # every candidate of the env's current episode is there
+    assert int(ready.sum()) > B // 2
+    st["grid"].fill_(marker)
+    hand_over_the_box(env, early)
+    env.step(acts[8], auto_reset=True)
+    restarted = env.was_reset.bool()
+    took = (env.cells.reshape(B, -1) == marker).all(dim=1)
+    assert int((restarted & early).sum()) > B // 4 and int((restarted & ~early).sum()) >= 0
+    assert torch.equal(took & ready, restarted & ready), "an env whose candidates were ready restarted from somewhere else"
+    assert not bool((took & ~restarted).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("protocol", ["candidates", "between"])
+def test_staged_slots_are_a_cache_not_state(protocol):
     """The staging slots of the truncation resets (include/mgx.h: MgxGenStage) must never change results: staged == unstaged bit for
     bit when (a) the caller replaces np_random / the step counts mid-episode AFTER the snapshot was taken (seed_synthetic, a
     partial load of step counts), and (b) a truncated env is stepped once more WITHOUT auto-reset and only then with it (the slot
@@ -279,7 +345,7 @@ def test_staged_slots_are_a_cache_not_state():
             env._gen["gen_state"].clone()
 
     for scenario in ("reseed", "step_past"):
-        (o1, s1, g1), (o2, s2, g2) = run(True, scenario), run(False, scenario)
+        (o1, s1, g1), (o2, s2, g2) = run(protocol, scenario), run(False, scenario)
         for t, (a, b) in enumerate(zip(o1, o2)):
             for k, (x, y) in enumerate(zip(a, b)):
                 assert torch.equal(x, y), f"{scenario}: step {t} output {k}"

@@ -18,7 +18,11 @@ def run(staged, steady, lead=None):
         env.step_count.copy_(torch.arange(wl.batch, device=dev, dtype=torch.int32) % wl.spec.max_steps)
     m = bench.measure_steps(env, 256, 50, "graph", lambda: None, seed=4321, min_region_ms=30.0)
     return m["event_ms"] / m["timed_steps"] * 1e3, int(env.episode.sum())
+QUICK = (("pool", None), (False, None), ("between", None), ("candidates", 128), ("candidates", 256), ("candidates", None), ("pool", None), ("candidates", None))
+if os.environ.get("MGX_GEN_AB_QUICK") == "2":
+    QUICK = (("pool", None), ("candidates", 512), ("candidates", 384), ("candidates", 256), ("candidates", 512))
 for steady in (False, True):
-    for staged, lead in (("pool", None), (False, None), (True, None), ("side", 16), ("side", 32), ("between", 8), ("between", 16), ("between", 32), ("between", 64)):
+    for staged, lead in QUICK if os.environ.get("MGX_GEN_AB_QUICK") else (("pool", None), (False, None), ("candidates", None), ("candidates", 32), ("candidates", 256), ("between", None), ("between", 32),
+                         ("candidates", None), ("between", None), ("pool", None)):
         us, ep = run(staged, steady, lead)
         print(f"{'out of phase' if steady else 'in phase    '}  staged={str(staged):8s} lead={lead}  {us:6.2f} us/step   episodes ended {ep}", flush=True)
