@@ -118,6 +118,9 @@ struct KernelArgs {
 #ifndef MGX_UA_WRITE
 #define MGX_UA_WRITE 0
 #endif
+#ifndef MGX_EARLY_ARGS
+#define MGX_EARLY_ARGS 1     // 1: the latency family (DMA instantiations, views <= 7x7); 2: every instantiation with views <= 7x7 (C4: -0.5 %, noise)
+#endif
 #ifndef MGX_LATE_ARGS
 #define MGX_LATE_ARGS 1
 #endif
