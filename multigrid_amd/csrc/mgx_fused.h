@@ -119,7 +119,8 @@ struct KernelArgs {
 #define MGX_UA_WRITE 0
 #endif
 #ifndef MGX_EARLY_ARGS
-#define MGX_EARLY_ARGS 1     // 1: the latency family (DMA instantiations, views <= 7x7); 2: every instantiation with views <= 7x7 (C4: -0.5 %, noise)
+#define MGX_EARLY_ARGS 2     // 1: the latency family only (DMA instantiations); 2: every instantiation with views <= 7x7 (the C4
+                             // throughput kernel: 18.63-18.83 -> 18.45-18.54 us, three same-box passes; 9x9 and up: the compiler crashes on it)
 #endif
 #ifndef MGX_LATE_ARGS
 #define MGX_LATE_ARGS 1
