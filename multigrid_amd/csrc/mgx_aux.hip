@@ -112,9 +112,15 @@ __global__ __launch_bounds__(256) void one_hot_kernel(const uint8_t *__restrict_
 // agents there, and streams that buffer out with 16-byte vectors.  Input and output of an env have the same size, so the
 // two buffers share one 16-byte skew.
 // ---------------------------------------------------------------------------------------------------------------
+// CB (template): bytes per grid cell -- 1 compact, 2 packed, 3 the reference's triples.  (As a run-time argument -- round 5's first
+// form -- every cell of the transposition went through the format's branches and the loop through one LDS round trip per
+// iteration: 0.55 -> 0.42 of the roofline.  Now: the format fixed per instantiation, four cells in flight per lane, shifts
+// instead of the two reciprocal multiplies when W is a power of two.)
+template <int CB>
 __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int G, int wave_lds, int in_buf, uint32_t inv_W,
-                                                       uint32_t inv_HW, int cb, int64_t batch, const uint8_t *__restrict__ grid,
+                                                       uint32_t inv_HW, int64_t batch, const uint8_t *__restrict__ grid,
                                                        const uint8_t *__restrict__ agents, uint8_t *__restrict__ out) {
+    constexpr int cb = CB;
     extern __shared__ __align__(16) uint8_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -149,14 +155,30 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
     const uint8_t *in_cells = in_raw + iskew;
     uint8_t *out_cells = out_raw + oskew;
     const int ncell = Gc * HW;
-    for (int i = lane; i < ncell; i += 64) {
-        const int e = (int)__umulhi((uint32_t)i, inv_HW);                                    // i / HW  (i < 2^16)
-        const int r = i - e * HW;
-        const int y = (int)__umulhi((uint32_t)r, inv_W), xx = r - y * W;                    // r / W
-        const uint32_t c = load_cell_shown(cb, in_cells + i * cb);             // (a box's content is not part of Grid.state)
+    const bool pow2 = (W & (W - 1)) == 0 && (HW & (HW - 1)) == 0;                         // (wave-uniform)
+    const int shW = 31 - __builtin_clz((unsigned)W), shHW = 31 - __builtin_clz((unsigned)HW);
+    auto move = [&](const int i, const uint32_t c) {
+        int e, r, y, xx;
+        if (pow2) { e = i >> shHW; r = i & (HW - 1); y = r >> shW; xx = r & (W - 1); }
+        else {
+            e = (int)__umulhi((uint32_t)i, inv_HW);                                         // i / HW  (i < 2^16)
+            r = i - e * HW;
+            y = (int)__umulhi((uint32_t)r, inv_W); xx = r - y * W;                          // r / W
+        }
+        // (one aligned 2-byte store + one byte store instead of three byte stores, as the fused kernel's P4 does, measured SLOWER here:
+        // 0.358 against 0.317 ms at 1 M envs -- the parity selects cost more than the third store)
         uint8_t *d = out_cells + e * HW3 + (xx * H + y) * 3;
         d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
+    };
+    int i = lane;
+    for (; i + 192 < ncell; i += 256) {                                                    // four cells in flight per lane
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = load_cell_shown(cb, in_cells + (i + 64 * u) * cb);   // (a box's content is not part of Grid.state)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) move(i + 64 * u, c[u]);
     }
+    for (; i < ncell; i += 64) move(i, load_cell_shown(cb, in_cells + i * cb));
     wave_sync();
     // (3) agents, index order: a later agent overwrites an earlier one on the same cell, so only the last one writes
     const uint64_t *rows = reinterpret_cast<const uint64_t *>(agents) + e0 * A;
@@ -686,9 +708,10 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const 
     const uint32_t inv_W = (uint32_t)(((1ull << 32) + spec->width - 1) / spec->width);
     const uint32_t hw = (uint32_t)HW;
     const uint32_t inv_HW = (uint32_t)(((1ull << 32) + hw - 1) / hw);
-    hipLaunchKernelGGL(full_obs_kernel, dim3((unsigned)blocks), dim3(64 * wpb), (size_t)(wpb * wave_lds),
+    auto *kern = cb == 1 ? full_obs_kernel<1> : cb == 3 ? full_obs_kernel<3> : full_obs_kernel<2>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), (size_t)(wpb * wave_lds),
                        static_cast<hipStream_t>(stream), spec->width, spec->height, spec->num_agents, G, wave_lds, in_buf, inv_W,
-                       inv_HW, cb, batch, reinterpret_cast<const uint8_t *>(grid), agents, out);
+                       inv_HW, batch, reinterpret_cast<const uint8_t *>(grid), agents, out);
     return finish_launch();
 }
 
