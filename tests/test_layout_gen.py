@@ -315,6 +315,41 @@ def test_every_episode_end_adopts_its_candidate():
 
 
 @pytest.mark.gpu
+def test_a_captured_block_shorter_than_the_generator_cadence_still_makes_candidates():
+    """capture_steps() of fewer steps than lie between two generator launches (set_layout_generator's default cadence is a third of
+    max_steps): the block would contain no generator launch at all and its replays would never make a candidate -- every episode
+    end generated in the tail, silently slow.  The captured block ends with one; results as unstaged either way."""
+    name, spec, gen, B = CASES[0]
+    spec = EnvSpec(**{**spec.as_dict(), "max_steps": 40})
+    B, dev, K = 512, "cuda:0", 8
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    acts = torch.randint(0, 7, (K, B, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+
+    def make(staged):
+        env = _make(spec, gen, B, dev)
+        env.set_layout_generator(layout_seed=11, staged=staged, **gen)
+        env.step_count.copy_(torch.arange(B, device=dev, dtype=torch.int32) % spec.max_steps)
+        return env
+
+    ref, cand = make(False), make("candidates")
+    st = cand._gen["stage"]
+    assert st["candidates"] == 4 and st["lead"] // 2 > K              # no launch of the regular cadence falls into K steps
+    graph = cand.capture_steps(acts, auto_reset=True)
+    for rep in range(12):
+        graph.replay()
+        for t in range(K):
+            ref.step(acts[t], auto_reset=True)
+    torch.cuda.synchronize()
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode", "obs", "reward"):
+        assert torch.equal(getattr(ref, f), getattr(cand, f)), f
+    assert torch.equal(ref._gen["gen_state"], cand._gen["gen_state"])
+    ready = (st["tag"] == cand.episode[:, None]).all(dim=1)
+    assert int(ready.sum()) > B * 3 // 4, int(ready.sum())              # the candidates ARE being made
+    assert int(cand.episode.sum()) > B                                   # ... and episodes did end
+    cand.check_errors()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("protocol", ["candidates", "between"])
 def test_staged_slots_are_a_cache_not_state(protocol):
     """The staging slots of the truncation resets (include/mgx.h: MgxGenStage) must never change results: staged == unstaged bit for
