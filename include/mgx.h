@@ -151,7 +151,7 @@ typedef uint8_t MgxCell8;
 /* (ABI 9) BYTE grids: MgxSpec.cell_bytes = 3 -- the grid tensors (grid, pool_grid) ARE the reference's triples, u8[B,H,W,3]
  * (type, color, state | a box's content << 2), the tensor BASELINE.json's north star names.  The step / gen_obs kernels pack them
  * into their 16-bit LDS tile as the bytes arrive and write changed cells back as three bytes, so a caller that holds its state in
- * the reference's form pays the conversion inside the step's own launch (C4, 65536 envs: 26.6 us against 18.7 on packed cells)
+ * the reference's form pays the conversion inside the step's own launch (C4, 65536 envs: 23.6 us against 18.4 on packed cells)
  * instead of a pack and an unpack launch around it (55..62 us).  Served: mgx_gen_obs, mgx_step, mgx_step_autoreset, mgx_step_ex (steps = 1, no one_hot, no generate),
  * mgx_step_chains / mgx_sub_shards, mgx_reset_done, mgx_full_obs, mgx_launch_info; MgxStepArgs.grid_bad receives what
  * mgx_pack_grid_env would have counted.  Everything else: MGX_ERR_UNSUPPORTED.  Same results bit for bit. */

@@ -294,3 +294,19 @@ def test_byte_grid_c4_full_size_and_filled_boxes_and_the_ring_count():
     env.step(torch.zeros((B, 4), dtype=torch.int8, device=DEV))
     with pytest.raises(ValueError, match="1 outer-ring cell.*1 cell value"):
         env.check_errors()
+    # every edge of the ring is looked at, a corner once; grids whose ring is longer than a wavefront (2W + 2(H-2) > 64) too
+    for W_, H_, B_ in ((12, 12, 300), (30, 21, 70), (7, 5, 1000)):
+        sp = bytes_spec(EnvSpec(W_, H_, 2, 5, max_steps=50))
+        st2 = util.random_state(sp, B_, seed=3, density=0.2)
+        e2 = BatchedMultiGridEnv(sp, B_, DEV)
+        e2.load_state(st2["grid"], st2["agents"], st2["rng"], st2["target"], st2["step_count"])
+        e2.step(torch.zeros((B_, 2), dtype=torch.int8, device=DEV)); e2.check_errors()
+        hole = torch.tensor([1, 0, 0], dtype=torch.uint8, device=DEV)
+        holes = [(0, 0, 0), (1, 0, W_ - 1), (2, H_ - 1, 0), (3, H_ - 1, W_ - 1), (4, 0, W_ // 2), (5, H_ - 1, W_ // 2), (6, H_ // 2, 0),
+                 (7, H_ // 2, W_ - 1), (B_ - 1, 1, 0), (B_ - 1, H_ - 2, W_ - 1), (B_ - 1, 0, 1)]
+        for b_, y_, x_ in holes:
+            e2.cells[b_, y_, x_] = hole
+        e2.cells[8, H_ // 2, W_ // 2] = hole                         # (an interior cell: not the ring's business)
+        e2.step(torch.zeros((B_, 2), dtype=torch.int8, device=DEV))
+        with pytest.raises(ValueError, match=f"{len(holes)} outer-ring cell"):
+            e2.check_errors()
