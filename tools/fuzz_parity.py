@@ -74,6 +74,14 @@ while time.time() < t_end:
         comp = BatchedMultiGridEnv(dataclasses.replace(spec, cell_bytes=1), B, dev, first_env=first_env)
         comp.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
     n_comp = (n_comp if n_case else 0) + (comp is not None)
+    # ... and on the reference's own BYTE triples u8[B,H,W,3] (MgxSpec.cell_bytes = 3: packed in the step kernel's load phase,
+    # written back as bytes; a box's content rides in the state byte)
+    byt = None
+    if r.random() < 0.5:
+        import dataclasses
+        byt = BatchedMultiGridEnv(dataclasses.replace(spec, cell_bytes=3), B, dev, first_env=first_env)
+        byt.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    n_byt = (n_byt if n_case else 0) + (byt is not None)
     ref = {k: v.copy() for k, v in st.items()}
     sd = spec.as_dict()
     acts = np.stack([util.random_actions(B, A, seed=seed + 1 + t) for t in range(T)])
@@ -88,6 +96,8 @@ while time.time() < t_end:
         env.set_layout_pool(pool["grid"], pool["agents"]); roll.set_layout_pool(pool["grid"], pool["agents"])
         if comp is not None:
             comp.set_layout_pool(pool["grid"], pool["agents"])
+        if byt is not None:
+            byt.set_layout_pool(pool["grid"], pool["agents"])
         episode = np.zeros(B, dtype=np.int64)
     rr = roll.rollout(torch.from_numpy(acts).to(dev), auto_reset=ar)
     ctx = f"case {n_case}: {spec} B={B} T={T} seed={seed} auto_reset={ar} fixed_shape={env.backend.launch_info(B).get('fixed_shape')}"
@@ -118,6 +128,15 @@ while time.time() < t_end:
                     print("MISMATCH compact cells, step", t, key, ctx); sys.exit(1)
             if comp.grid.cpu().numpy().tobytes() != ref["grid"].tobytes() or comp.agents.cpu().numpy().tobytes() != ref["agents"].tobytes():
                 print("MISMATCH compact cells, state at step", t, ctx); sys.exit(1)
+        if byt is not None:
+            gotb = byt.step(torch.from_numpy(acts[t]).to(dev), auto_reset=ar)
+            for g, w, key in zip(gotb, want, ("obs", "dir", "reward", "terminated", "truncated")):
+                if g.cpu().numpy().tobytes() != w.tobytes():
+                    print("MISMATCH byte grid, step", t, key, ctx); sys.exit(1)
+            if byt.grid.cpu().numpy().tobytes() != ref["grid"].tobytes() or byt.agents.cpu().numpy().tobytes() != ref["agents"].tobytes():
+                print("MISMATCH byte grid, state at step", t, ctx); sys.exit(1)
+    if byt is not None:
+        byt.check_errors()
     for e in (env, roll):
         if e.grid.cpu().numpy().tobytes() != ref["grid"].tobytes() or e.agents.cpu().numpy().tobytes() != ref["agents"].tobytes() \
                 or e.step_count.cpu().numpy().tobytes() != ref["step_count"].tobytes() \
@@ -132,7 +151,7 @@ while time.time() < t_end:
         comp.check_errors()
     n_case += 1; n_steps += T * B
     del env, roll, comp
-print(f"{n_case} cases, {n_steps} env-steps, {n_fixed} cases on a shape-specialised instantiation, {n_comp} also on compact cells: clean")
+print(f"{n_case} cases, {n_steps} env-steps, {n_fixed} cases on a shape-specialised instantiation, {n_comp} also on compact cells, {n_byt} also on byte grids: clean")
 from multigrid_amd import _lib  # noqa: E402
 if hasattr(_lib.lib(), "mgx_debug_bounds_violations"):            # the checked build (MGX_LIBMGX=.../libmgx_chk.so)
     import ctypes
