@@ -29,9 +29,6 @@
 // cell lanes as LDS broadcasts or SGPR masks, and as few VALU instructions per slot as possible.  Workgroups touch
 // disjoint memory, so the blockIdx -> XCD mapping needs no swizzle.
 #pragma once
-#ifndef MGX_GEN_X
-#define MGX_GEN_X 0      /* experiment knob (tools/build_variants.py): parts of the GEN step left out */
-#endif
 // (hipRTC -- the runtime compilation of shape-specialised kernels, multigrid_amd/jit.py -- has the HIP runtime built in and no
 // system headers)
 #if !defined(__HIPCC_RTC__)

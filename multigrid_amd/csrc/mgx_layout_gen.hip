@@ -25,9 +25,6 @@
 #include <stdint.h>
 
 #include "mgx_layout_gen.h"
-#ifndef MGX_GEN_PROBE
-#define MGX_GEN_PROBE 0
-#endif
 
 extern "C" void mgx_internal_set_hip_error(int e);      // mgx_kernels.hip: what mgx_last_hip_error() reports
 
@@ -105,9 +102,7 @@ __global__ __launch_bounds__(64) void stage_candidates_kernel(const GenArgs a) {
     MgxLayoutGen gen = a.gen;
     gen.kind = KIND;
     uint8_t *const st_grid = reinterpret_cast<uint8_t *>(st.grid);
-#if !(MGX_GEN_PROBE & 1)
     copy_blank(gen, st_grid, s0, HWB, gom, lane);
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                           // (the owning lane overwrites cells the other lanes stored)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_wave_barrier();
@@ -116,12 +111,8 @@ __global__ __launch_bounds__(64) void stage_candidates_kernel(const GenArgs a) {
     NpGen lay, npr;
     for (int q = 0; q < 4; ++q) { lay.s[q] = gs[q]; npr.s[q] = 0; }
     lay.buf = gs[4]; npr.buf = 0;                                                    // (npr: not drawn from -- door_row is given)
-#if MGX_GEN_PROBE & 2
-    const uint4 naux = {0, 0, 0, 0};
-#else
     const uint4 naux = generate_episode(gen, W, H, A, lay, npr, lds + lane * (2 * A), st_grid + s * HWB,
                                         reinterpret_cast<uint64_t *>(st.agents) + s * A, k + 1);
-#endif
     if (st.aux) reinterpret_cast<uint4 *>(st.aux)[s] = naux;
     uint64_t *const words = st.words + s * 6;
     for (int q = 0; q < 4; ++q) words[q] = lay.s[q];
