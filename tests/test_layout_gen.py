@@ -432,6 +432,39 @@ def test_generator_state_round_trip_on_cpu():
     assert torch.equal(a.grid, b.grid) and torch.equal(a._gen["gen_state"], b._gen["gen_state"])
 
 
+def test_staging_protocol_chosen_by_the_generator_kind_on_cpu():
+    """set_layout_generator(staged=True): `candidates` (one slot per value of the generator's single np_random draw, include/mgx.h:
+    MgxGenStage.candidates) for the kinds that draw from env.np_random at most once and offer at most four values; the snapshot
+    protocol otherwise; the slot tensors' shapes; the tags all -1 (nothing staged) -- and dropped again when the state is replaced."""
+    def stage_of(spec, gen, **kw):
+        env = BatchedMultiGridEnv(spec, 8, "cpu", backend=util.OracleBackend(spec))
+        env.set_layout_generator(layout_seed=1, **gen, **kw)
+        return env, env._gen.get("stage")
+    bup = EnvSpec(11, 6, 2, 7, max_steps=90, joint_reward=True, env_kind="blockedunlockpickup")
+    env, st = stage_of(bup, dict(kind="blockedunlockpickup", room_size=6))
+    assert st["candidates"] == 4 and st["external"] == 2 and st["lead"] == 60                 # a launch every max_steps / 3 steps
+    assert tuple(st["grid"].shape) == (8, 4, 6, 11) and tuple(st["agents"].shape) == (8, 4, 2, 8)
+    assert tuple(st["aux"].shape) == (8, 4, 16) and tuple(st["words"].shape) == (8, 4, 6) and bool((st["tag"] == -1).all())
+    st["tag"].fill_(5); env.seed_synthetic(3)
+    assert bool((st["tag"] == -1).all())                                                      # the slots are a cache: dropped
+    _, st = stage_of(EnvSpec(15, 8, 2, 7, max_steps=90, joint_reward=True, env_kind="blockedunlockpickup"),
+                     dict(kind="blockedunlockpickup", room_size=8))
+    assert not st.get("candidates") and st["external"] == 2                                   # 6 door rows: the snapshot protocol
+    for spec, gen in ((EnvSpec(9, 9, 3, 7, max_steps=30), dict(kind="empty_random")),
+                      (EnvSpec(16, 8, 3, 7, max_steps=30, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors"),
+                       dict(kind="redbluedoors")),
+                      (EnvSpec(13, 9, 2, 7, max_steps=30, joint_reward=True, env_kind="lockedhallway"),
+                       dict(kind="lockedhallway", room_size=5))):
+        _, st = stage_of(spec, gen)
+        assert st["candidates"] == 1 and tuple(st["grid"].shape) == (8, 1, spec.height, spec.width)
+    _, st = stage_of(EnvSpec(19, 19, 3, 7, max_steps=30), dict(kind="playground", room_size=7))
+    assert not st.get("candidates")                                                           # many np_random draws
+    with pytest.raises(ValueError, match="candidates"):
+        stage_of(EnvSpec(19, 19, 3, 7, max_steps=30), dict(kind="playground", room_size=7), staged="candidates")
+    _, st = stage_of(EnvSpec(9, 9, 1, 7, max_steps=30), dict(kind="empty_random"))
+    assert st is None                                                                         # one agent: no staging at all
+
+
 def test_oracle_shuffle_equals_numpy():
     """numpy's Generator.shuffle of a Python list (RandomMixin._rand_perm, multigrid/utils/random.py:75-83) restated."""
     r = np.random.default_rng(5)
