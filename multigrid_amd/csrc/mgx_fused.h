@@ -384,6 +384,8 @@ constexpr FixedShape kShapes[] = {
                                                 //    issue-bound at ~4 wavefronts per SIMD, so it gains less: 84.7 -> 81.5 us)
     {64, 64, 16, 2, false, 9, false, true, 1},  // 5: the same on COMPACT cells (round 5): two envs per wavefront -- the per-agent phases run
                                                 //    on 32 lanes instead of 16 and the 8 KiB of tiles are again 17 wavefronts per CU
+    {64, 64, 16, 2, false, 9, false, false, 1}, // 6: ... with the grid left to the caches: C5's 32768 compact grids are 128 MiB, half
+                                                //    of the Infinity Cache, and re-read from there (measured: -1.5 % against nt loads)
 #ifdef MGX_JIT_SHAPE
     {MGX_JIT_SHAPE},                            // 5: ANY other shape, compiled at run time (hipRTC) from these same headers with its
                                                 //    launch geometry as MGX_JIT_SHAPE (multigrid_amd/jit.py, mgx_shape_register)
@@ -817,6 +819,11 @@ inline int launch_compact(const KernelArgs &ka, int threads, int lds_bytes, int6
             if (match_fixed_shape(ka, hooks) == 5)
                 kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, true, false, kGroup, 5, true>
                           : mgx_fused_kernel<V, 1, false, false, false, false, true, false, kGroup, 5, true>;
+        }
+        if constexpr (C8 && MODE == 1 && V == 9 && !STREAM && !MGX_NO_FIXED_SHAPES) {
+            if (match_fixed_shape(ka, hooks) == 6)
+                kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, false, kGroup, 6, true>
+                          : mgx_fused_kernel<V, 1, false, false, false, false, false, false, kGroup, 6, true>;
         }
         if (!kern) {
             // (the byte-grid gen_obs holds its conversion's staging registers: it takes the step kernels' entry point, without the

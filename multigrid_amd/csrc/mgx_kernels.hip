@@ -158,8 +158,9 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
         if (g < kGroup && sp->num_agents <= g) { ka.grp = g; ka.Gw = g / sp->num_agents; }
     }
     ka.dbg = g_debug_skip;
-    // a grid tensor beyond half of the 256 MiB Infinity Cache is streamed (nt tile loads): mgx_fused.h, P0
-    ka.flags = (batch * (int64_t)sp->width * sp->height * grid_cell_bytes_of(*sp) >= (int64_t)128 << 20) ? 1 : 0;
+    // a grid tensor beyond half of the 256 MiB Infinity Cache is streamed (nt tile loads): mgx_fused.h, P0.  (One of exactly half --
+    // C5's 32768 compact 64x64 grids -- is still better left to the caches: 60.4 against 61.1-61.6 us with nt loads.)
+    ka.flags = (batch * (int64_t)sp->width * sp->height * grid_cell_bytes_of(*sp) > (int64_t)128 << 20) ? 1 : 0;
     ka.vpw = slots_in_use(*sp, ka.Gw, roll || obs_only, ka.grp);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only, ka.grp);

@@ -89,7 +89,9 @@ def test_c_abi_refuses_the_unsupported_entry_points_without_a_gpu():
     # two 64x64 envs per wavefront on compact cells, one on the 16-bit ones (the per-agent phases then run on 32 lanes, not 16)
     assert _lib.launch_info(compact(EnvSpec(64, 64, 16, 9)), 32768)["envs_per_wavefront"] == 2
     assert _lib.launch_info(EnvSpec(64, 64, 16, 9), 32768)["envs_per_wavefront"] == 1
-    assert _lib.launch_info(compact(EnvSpec(64, 64, 16, 9)), 32768)["fixed_shape"] == 5
+    # (its shape instantiation: with the grids left to the caches at 128 MiB, streamed past them beyond that)
+    assert _lib.launch_info(compact(EnvSpec(64, 64, 16, 9)), 32768)["fixed_shape"] == 6
+    assert _lib.launch_info(compact(EnvSpec(64, 64, 16, 9)), 65536)["fixed_shape"] == 5
 
 
 # ---------------------------------------------------------------------------------------------------- GPU: the kernels
@@ -223,8 +225,12 @@ def test_c5_full_size_on_both_cell_formats_vs_oracle():
     assert wl.batch == 32768 and wl.spec.cell_bytes == 1
     env = wl.make_env(DEV)
     li = env.backend.launch_info(wl.batch)
-    assert li["envs_per_wavefront"] == 2 and li["fixed_shape"] == 5, li
+    assert li["envs_per_wavefront"] == 2 and li["fixed_shape"] == 6, li
     run_vs_oracle(wl, T=8, seed=55)
+    # ... and beyond 128 MiB of grids the streamed instantiation of the same shape (nt tile loads)
+    wl_big = workloads.make("c5", global_batch=36864)
+    assert wl_big.make_env(DEV).backend.launch_info(wl_big.batch)["fixed_shape"] == 5
+    run_vs_oracle(wl_big, T=3, seed=56)
     wl2 = workloads.make("c5", cell_bytes=2)
     assert wl2.spec.cell_bytes == 2 and wl2.make_env(DEV).backend.launch_info(wl2.batch)["fixed_shape"] == 4
     run_vs_oracle(wl2, T=4, seed=56)
