@@ -719,10 +719,11 @@ int mgx_step_chains(const MgxSpec *spec, int64_t batch, const MgxStepArgs *args,
             gen = *args->generate;
             gen.gen_state = gen.gen_state ? gen.gen_state + lo * 6 : nullptr;
             MgxGenStage &st = gen.stage;
-            st.grid = st.grid ? st.grid + lo * HW : nullptr;
-            st.agents = st.agents ? st.agents + lo * A * MGX_AGENT_STRIDE : nullptr;
-            st.aux = st.aux ? st.aux + lo * MGX_AUX_BYTES : nullptr;
-            st.words = st.words ? st.words + lo * 12 : nullptr;
+            const int64_t K = st.candidates > 0 ? st.candidates : 1;         // (candidates: K slots per env, 6 words each)
+            st.grid = st.grid ? st.grid + lo * K * HW : nullptr;
+            st.agents = st.agents ? st.agents + lo * K * A * MGX_AGENT_STRIDE : nullptr;
+            st.aux = st.aux ? st.aux + lo * K * MGX_AUX_BYTES : nullptr;
+            st.words = st.words ? st.words + lo * (st.candidates > 0 ? 6 * K : 12) : nullptr;
             st.tag = st.tag ? st.tag + lo * 4 : nullptr;
             sa.generate = &gen;
         }

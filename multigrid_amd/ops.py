@@ -277,12 +277,15 @@ class HipBackend:
 
         gen_c = keep[1]
         phase = generate[0]["stage"]["phase"] if generate is not None and generate[0].get("stage") is not None else None
-        if phase is not None and gen_c.stage.candidates:
-            # (candidates are made by generator launches BETWEEN the steps only: the chains run without staging -- every finished env
-            # generated in the tail of its step; same results)
-            gen_c.stage = _lib.MgxGenStage()
-            phase = None
-        if phase is not None and gen_c.stage.external:
+        cand = phase is not None and bool(gen_c.stage.candidates)
+        if cand:
+            # candidates are made by generator launches BETWEEN the steps: every lead/2 steps the chains are joined on the first
+            # stream, ONE generator launch serves the whole batch there, and the chains go on behind it
+            stage = generate[0]["stage"]
+            every = max(1, int(stage.get("lead", 2)) // 2)
+            stage_fn, gen_ref = _lib.lib().mgx_stage_generate, C.byref(gen_c)
+            rng_ptr, episode_ptr = rng.data_ptr(), generate[1].data_ptr()
+        if phase is not None and not cand and gen_c.stage.external:
             # the chains issue no generator launches of their own (nobody sits between the steps of a chain): the pending snapshots are
             # served by generator wavefronts inside every chain's launch instead (MgxGenStage.external = 0, the in-launch form), so a
             # staged slot is there to adopt when the env truncates -- with `external` left set the requests would never be served
@@ -296,8 +299,17 @@ class HipBackend:
                 phase[0] = (phase[0] + 1) & 0x3fffffff
             with torch.cuda.device(dev):
                 rc = fn(spec_ref, B, args_ref, parts, handles, fork_event)
-            if rc:
-                _lib.check(rc, "mgx_step_chains")
+                if rc:
+                    _lib.check(rc, "mgx_step_chains")
+                if cand and phase[0] % every == 0:
+                    for s in streams[1:]:
+                        streams[0].wait_stream(s)
+                    rc = stage_fn(spec_ref, B, gen_ref, rng_ptr, episode_ptr, handles[0])
+                    if rc:
+                        _lib.check(rc, "mgx_stage_generate")
+                    for s in streams[1:]:
+                        s.wait_stream(streams[0])
+                    stage["launches"] = stage.get("launches", 0) + 1
         step._keep = (sa, keep, handles, streams)
         return step
 

@@ -315,6 +315,51 @@ def test_every_episode_end_adopts_its_candidate():
 
 
 @pytest.mark.gpu
+def test_candidates_on_sub_shard_chains():
+    """step(sub_shards=P) (mgx_step_chains: P launches on P streams) and capture_steps(sub_shards=P) with the candidates protocol:
+    the chains are joined every lead/2 steps for ONE generator launch over the whole batch (eager form), the split shards of a
+    captured graph make their own; both equal the unstaged run bit for bit, and the candidates are made and adopted."""
+    name, spec, gen, B = CASES[0]
+    spec = EnvSpec(**{**spec.as_dict(), "max_steps": 11})
+    B, dev = 1000, "cuda:0"
+    T = 4 * spec.max_steps + 1
+    g = torch.Generator(device=dev); g.manual_seed(12)
+    acts = torch.randint(0, 7, (T, B, spec.num_agents), dtype=torch.int8, device=dev, generator=g)
+
+    def make(staged):
+        env = _make(spec, gen, B, dev)
+        env.set_layout_generator(layout_seed=11, staged=staged, lead=4, **gen)
+        env.step_count.copy_(torch.arange(B, device=dev, dtype=torch.int32) % spec.max_steps)
+        return env
+
+    ref, cand = make(False), make("candidates")
+    for t in range(T):
+        want = [x.clone() for x in ref.step(acts[t], auto_reset=True)] + [ref.was_reset.clone()]
+        got = list(cand.step(acts[t], auto_reset=True, sub_shards=3)) + [cand.was_reset]
+        cand.join()
+        for k, (w, gg) in enumerate(zip(want, got)):
+            assert torch.equal(w, gg), f"step {t} output {k}"
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(ref, f), getattr(cand, f)), f
+    assert torch.equal(ref._gen["gen_state"], cand._gen["gen_state"])
+    st = cand._gen["stage"]
+    assert st.get("launches", 0) >= T // 2 - 1 and int((st["tag"] == cand.episode[:, None]).all(dim=1).sum()) > B // 2
+    # the captured form: every split shard makes the candidates of its own slice
+    ref2, cand2 = make(False), make("candidates")
+    K = 2 * spec.max_steps
+    graph = cand2.capture_steps(acts[:K], auto_reset=True, sub_shards=2)
+    for rep in range(2):
+        graph.replay()
+        for t in range(K):
+            ref2.step(acts[t], auto_reset=True)
+    torch.cuda.synchronize()
+    for f in ("cells", "agents", "rng", "step_count", "aux", "episode"):
+        assert torch.equal(getattr(ref2, f), getattr(cand2, f)), f"graph: {f}"
+    assert int((cand2._gen["stage"]["tag"] == cand2.episode[:, None]).all(dim=1).sum()) > B // 2
+    cand.check_errors(); cand2.check_errors()
+
+
+@pytest.mark.gpu
 def test_a_captured_block_shorter_than_the_generator_cadence_still_makes_candidates():
     """capture_steps() of fewer steps than lie between two generator launches (set_layout_generator's default cadence is a third of
     max_steps): the block would contain no generator launch at all and its replays would never make a candidate -- every episode
