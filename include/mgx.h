@@ -323,6 +323,9 @@ int mgx_rollout_autoreset(const MgxSpec *spec, int64_t batch, int32_t steps, con
  *         MGX_GEN_REDBLUEDOORS         multigrid/envs/redbluedoors.py:142-168 (grid 2*size x size: agents placed in the middle
  *                                      room, then the red and the blue door rows drawn; writes aux[0..4]; `blank` = the outer
  *                                      walls + the room's walls, multigrid_amd.layouts.redbluedoors_blank)
+ * A spec whose rooms have no cell to spare for what the generator places in them (e.g. a BlockedUnlockPickup room_size of 4 with two
+ * agents, a Playground of 3x3-cell rooms for its 12 objects) is refused with MGX_ERR_UNSUPPORTED: the reference's place_obj samples
+ * positions without a bound (base.py:604-669) and would never return -- here that lane would hang the device.
  * Given generators in the same state the result is byte-identical to the reference's reset() (pinned through
  * multigrid_amd/layouts.py and the reference's reset fixtures).  step_count := 0, episode += 1, was_reset (may be NULL). */
 enum { MGX_GEN_EMPTY_FIXED = 0, MGX_GEN_EMPTY_RANDOM = 1, MGX_GEN_BLOCKEDUNLOCKPICKUP = 2, MGX_GEN_REDBLUEDOORS = 3,

@@ -14,8 +14,32 @@ namespace mgx_gen {
 using namespace mgx;
 
 // Is (spec, gen) a combination the generators implement?  Shared by mgx_reset_generate and the fused step (MGX_OK or an error).
+// (... and does a layout EXIST with room to spare?  The reference's place_obj samples positions until one fits, without a bound
+// (base.py:604-669, max_tries = inf): in a room too small for what goes into it, it never returns -- and neither would the lane
+// that runs it here, which on a GPU means a hung device.  Such specs are refused: MGX_ERR_UNSUPPORTED.)
 inline int check_layout_gen(const MgxSpec *spec, const MgxLayoutGen *gen) {
-    const int W = spec->width, H = spec->height, rs = gen->room_size;
+    const int W = spec->width, H = spec->height, rs = gen->room_size, A = spec->num_agents;
+    const int room = (rs - 2) * (rs - 2);                       // free cells of one room
+    switch (gen->kind) {
+    case MGX_GEN_EMPTY_RANDOM:
+        if ((W - 2) * (H - 2) - 1 < A + 1) return MGX_ERR_UNSUPPORTED;                 // the agents beside the goal
+        break;
+    case MGX_GEN_BLOCKEDUNLOCKPICKUP:
+        if (rs >= 4 && room < A + 3) return MGX_ERR_UNSUPPORTED;                       // key + ball + the agents in the left room
+        break;
+    case MGX_GEN_REDBLUEDOORS:
+        if ((W / 2 - 2) * (H - 2) < A + 1) return MGX_ERR_UNSUPPORTED;                 // the agents in the middle room
+        break;
+    case MGX_GEN_LOCKEDHALLWAY:
+        if (rs >= 4 && (rs - 2) * (H - 2) < A + gen->max_hallway_keys + 1) return MGX_ERR_UNSUPPORTED;   // hallway: keys + agents
+        if (rs >= 4 && room < gen->max_keys_per_room + 1) return MGX_ERR_UNSUPPORTED;
+        break;
+    case MGX_GEN_PLAYGROUND:
+        if (rs >= 4 && room < 12 + A + 1) return MGX_ERR_UNSUPPORTED;                  // all 12 objects may draw the same room
+        break;
+    default:
+        break;
+    }
     switch (gen->kind) {
     case MGX_GEN_EMPTY_FIXED:
         if (spec->env_kind != MGX_KIND_EMPTY || gen->start_x < 0 || gen->start_x >= W || gen->start_y < 0 || gen->start_y >= H

@@ -510,6 +510,30 @@ def test_staging_protocol_chosen_by_the_generator_kind_on_cpu():
     assert st is None                                                                         # one agent: no staging at all
 
 
+def test_generators_refuse_layouts_without_room_to_spare():
+    """The reference's place_obj samples until a position fits, without a bound (base.py:604-669): in a room too small for what goes
+    into it, it never returns -- on a GPU that lane would hang the device.  The C ABI refuses such specs before any launch
+    (MGX_ERR_UNSUPPORTED from mgx_reset_generate; no GPU needed: the check precedes the launch)."""
+    import ctypes as C
+    from multigrid_amd import _lib
+    L = _lib.lib()
+
+    def rc_of(spec, kind, room_size=0, max_hallway_keys=1, max_keys_per_room=2):
+        sc = spec.to_c()
+        g = _lib.MgxLayoutGen(_lib.GEN_KINDS[kind], room_size, 1, 1, 0, max_hallway_keys, max_keys_per_room, 4096, 4096)
+        fake = 4096                                              # (aligned, never dereferenced: the checks come first)
+        return L.mgx_reset_generate(C.byref(sc), 8, C.byref(g), fake, fake, fake, fake, fake, fake, None, None)
+
+    bup = lambda rs, A: EnvSpec(2 * rs - 1, rs, A, 7, max_steps=9, joint_reward=True, env_kind="blockedunlockpickup")
+    assert rc_of(bup(4, 2), "blockedunlockpickup", 4) == _lib.ERR_UNSUPPORTED        # 2x2 room: key + ball + 2 agents + nothing spare
+    assert rc_of(bup(5, 7), "blockedunlockpickup", 5) == _lib.ERR_UNSUPPORTED
+    assert rc_of(EnvSpec(9, 9, 4, 7, max_steps=9), "playground", 5) == _lib.ERR_UNSUPPORTED      # 12 objects may draw one 3x3 room
+    assert rc_of(EnvSpec(11, 11, 4, 7, max_steps=9), "playground", 6) == _lib.ERR_UNSUPPORTED
+    assert rc_of(EnvSpec(4, 4, 4, 3, max_steps=9), "empty_random") == _lib.ERR_UNSUPPORTED        # 2x2 interior: goal + 4 agents
+    assert rc_of(EnvSpec(8, 4, 4, 3, max_steps=9, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors"),
+                 "redbluedoors") == _lib.ERR_UNSUPPORTED                                          # a 2x2 middle room for 4 agents
+
+
 def test_oracle_shuffle_equals_numpy():
     """numpy's Generator.shuffle of a Python list (RandomMixin._rand_perm, multigrid/utils/random.py:75-83) restated."""
     r = np.random.default_rng(5)
