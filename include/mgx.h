@@ -93,7 +93,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 10
+#define MGX_ABI_VERSION 11
 
 enum {
     MGX_OK = 0,
@@ -246,8 +246,24 @@ int mgx_pack_grid8_env(const uint8_t *cells3, int64_t batch, int32_t height, int
                        void *stream);
 int mgx_unpack_grid8(const MgxCell8 *packed, int64_t n_cells, uint8_t *cells3, void *stream);
 
-/* Geometry mgx_gen_obs / mgx_step / mgx_rollout would use. */
+/* Geometry of the plain step's launch (mgx_step / mgx_step_autoreset; mgx_gen_obs bundles as many envs per wavefront or fewer). */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
+
+/* ABI 11: geometry of the launches that keep the envs' state in LDS between steps -- mgx_rollout* and mgx_step_persistent.
+ * resident_shape > 0: one of the library's RESIDENT instantiations (64 view slots per wavefront, `slices` groups of
+ * `envs_per_slice` envs stepped one after the other by the same wavefront: Empty-16x16 x 4 agents from 16385 envs up; at BASELINE.json
+ * configs[3]'s 65536 envs 2048 wavefronts of 2 x 16 envs, 8 per CU, hold every env's tile on the chip); 0: the ordinary rollout
+ * kernels (32 view slots, one slice).  Same results either way, bit for bit. */
+typedef struct MgxRolloutInfo {
+    int32_t envs_per_slice;
+    int32_t slices;              /* per wavefront; envs per wavefront = envs_per_slice * slices */
+    int32_t wavefronts;          /* that own envs (mgx_step_persistent: the flags of MgxPersistent.done) */
+    int32_t threads_per_workgroup;
+    int32_t workgroups;
+    int32_t lds_bytes;           /* per workgroup */
+    int32_t resident_shape;
+} MgxRolloutInfo;
+int mgx_rollout_info(const MgxSpec *spec, int64_t batch, MgxRolloutInfo *out);
 
 /* Replaces OneHotObsWrapper.one_hot (multigrid/wrappers.py:158-190; the wrapper RLlib registration applies to every
  * env, multigrid/rllib/__init__.py:110-111) for a flat array of cells:

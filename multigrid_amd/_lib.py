@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MGX_LIBMGX") or PRODUCT_LIB_PATH
 def is_product_lib() -> bool:
     return os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 OK, ERR_INVALID_ARGUMENT, ERR_UNKNOWN_ACTION, ERR_UNSUPPORTED, ERR_LAUNCH = 0, -1, -2, -3, -4
 
 #: every symbol include/mgx.h declares
@@ -27,12 +27,19 @@ EXPORTS = ("mgx_abi_version", "mgx_error_string", "mgx_last_hip_error", "mgx_gen
            "mgx_reset_generate", "mgx_step_generate", "mgx_pack_grid", "mgx_unpack_grid",
            "mgx_step_ex", "mgx_step_chains", "mgx_sub_shards",
            "mgx_pack_grid_env", "mgx_check_grid", "mgx_pack_grid8_env", "mgx_unpack_grid8", "mgx_shape_key", "mgx_shape_register", "mgx_stage_generate",
-           "mgx_persistent_waves", "mgx_step_persistent", "mgx_persistent_post", "mgx_persistent_wait", "mgx_persistent_feed")
+           "mgx_persistent_waves", "mgx_step_persistent", "mgx_persistent_post", "mgx_persistent_wait", "mgx_persistent_feed",
+           "mgx_rollout_info")
 
 
 class MgxLaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("envs_per_wavefront", "envs_per_workgroup", "threads_per_workgroup", "workgroups",
                                           "lds_bytes", "slots_per_group", "fixed_shape")]
+
+
+class MgxRolloutInfo(C.Structure):
+    """include/mgx.h: struct MgxRolloutInfo (ABI 11)."""
+    _fields_ = [(n, C.c_int32) for n in ("envs_per_slice", "slices", "wavefronts", "threads_per_workgroup", "workgroups", "lds_bytes",
+                                          "resident_shape")]
 
 
 class MgxAutoReset(C.Structure):
@@ -170,8 +177,19 @@ def check(code: int, what: str):
         raise MgxError(code, what)
 
 
-def launch_info(spec, batch: int) -> dict:
-    info = MgxLaunchInfo()
+def launch_info(spec, batch: int, roll: bool = False) -> dict:
+    """Launch geometry of the plain step (`roll=False`) or of the rollout / persistent launches (`roll=True`: MgxRolloutInfo, with
+    `envs_per_wavefront` added)."""
     sc = spec.to_c()
+    if roll:
+        ri = MgxRolloutInfo()
+        L = lib()
+        L.mgx_rollout_info.restype = C.c_int
+        L.mgx_rollout_info.argtypes = [C.POINTER(MgxSpecC), C.c_int64, C.POINTER(MgxRolloutInfo)]
+        check(L.mgx_rollout_info(C.byref(sc), batch, C.byref(ri)), "mgx_rollout_info")
+        out = {n: getattr(ri, n) for n, _ in MgxRolloutInfo._fields_}
+        out["envs_per_wavefront"] = ri.envs_per_slice * ri.slices
+        return out
+    info = MgxLaunchInfo()
     check(lib().mgx_launch_info(C.byref(sc), batch, C.byref(info)), "mgx_launch_info")
     return {n: getattr(info, n) for n, _ in MgxLaunchInfo._fields_}

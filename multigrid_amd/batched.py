@@ -368,8 +368,8 @@ class BatchedMultiGridEnv:
         hook_order  u8[B,A] or None: per env, agent indices in the insertion order of the caller's actions dict -- the order
                     in which the RedBlueDoors / LockedHallway step hooks visit the agents (`for agent_id, action in
                     actions.items()`, multigrid/envs/redbluedoors.py:176, locked_hallway.py:210).  None = ascending index.
-        sub_shards  1 (default): one launch for the whole batch on the current stream.  P > 1 or "auto" (= what
-                    `sub_shards_hint()` suggests for this device): the step is issued as P launches over consecutive blocks
+        sub_shards  1 (default): one launch for the whole batch on the current stream.  "auto" = `sub_shards_hint(form="eager")`,
+                    which is 1 (per-step calls from Python are host-bound as chains); P > 1: the step is issued as P launches over consecutive blocks
                     of the batch on P side streams (mgx_step_chains) and is NOT joined -- consecutive calls form P independent
                     chains, so one block's load phase runs under another's compute (C4: 20.9 -> ~16 us per step).  The
                     outputs / state are complete after `join()`; any other method of this object joins first.  Same
@@ -403,7 +403,7 @@ class BatchedMultiGridEnv:
             auto_reset = False
         P = 1
         if sub_shards != 1:
-            P = self.sub_shards_hint(auto_reset or generate, one_hot) if sub_shards == "auto" else int(sub_shards)
+            P = self.sub_shards_hint(auto_reset or generate, one_hot, form="eager") if sub_shards == "auto" else int(sub_shards)
             P = max(1, min(P, self.batch // self.SUB_SHARD_ALIGN))
         if self._chains_pending and P != self._chains_P:       # (another cut of the batch over other streams: join the old chains)
             self.join()
@@ -456,10 +456,19 @@ class BatchedMultiGridEnv:
                 cur.wait_stream(st)
             self._chains_pending = False
 
-    def sub_shards_hint(self, auto_reset: bool = False, one_hot: bool = False) -> int:
-        """How many independent chains this env's step is best issued as on its device (mgx_sub_shards: 1 when a launch is
-        less than two wavefronts per SIMD, 4 when the batch is about one round of resident wavefronts, else 2 -- from the
-        kernel's occupancy and the device's CU count, not from constants)."""
+    def sub_shards_hint(self, auto_reset: bool = False, one_hot: bool = False, form: str = "graph") -> int:
+        """How many independent chains this env's step is best issued as on its device.
+
+        form="graph" (`capture_steps(sub_shards="auto")`): mgx_sub_shards -- 1 when a launch is less than two wavefronts per
+        SIMD, else 2, from the kernel's occupancy and the device's CU count, not from constants (C4: 18.6 -> 16.0-16.7 us per step).
+        form="eager" (`step(sub_shards="auto")`): 1.  Issued per step from Python, P launches + P event waits + the allocator's
+        stream bookkeeping cost the host more than a step lasts (C4, two chains: 32 us per step, host-bound, against 18.7 us as one
+        launch: profiles/r5_bench.json `eager.c4_chains`, rounds 3-5 alike), so the chains only pay where the host is out of the
+        loop -- in a captured graph.  An explicit `step(sub_shards=P)` is still honoured."""
+        if form not in ("graph", "eager"):
+            raise ValueError("form must be 'graph' or 'eager'")
+        if form == "eager":
+            return 1
         hint = getattr(self.backend, "sub_shards", None)
         if hint is None:
             return 1

@@ -85,6 +85,8 @@ struct KernelArgs {
     int32_t vpw;
     int32_t grp;        // slots per gather / staging group of the instantiation to launch: 16, or 4 / 8 (small-group latency family)
     int32_t inv_A;      // ceil(2^16 / A): (lane * inv_A) >> 16 == lane / A for lane < 64
+    int32_t ns;         // rollout / persistent launches: slices of Gw envs per wavefront (LdsCarve); 0 = the ordinary kernels, 1 / 2 = a
+                        // resident shape (kShapes[].ns): host-side geometry, the kernels have it as a constant
     // fused auto-reset (mgx_step_autoreset / mgx_rollout_autoreset; include/mgx.h: MgxAutoReset)
     int32_t pool_size;
     int64_t first_env;
@@ -273,26 +275,40 @@ constexpr int kSlotsLatency = 32;        // DMA instantiations
 // observation's three bytes with one more LDS read (the address is one v_lshl_add from the sign-extended byte the opaque test
 // reads anyway) instead of the ~8 VALU instructions of the arithmetic decode.
 constexpr int kLutBytes = 256 * 4;
+// SLICES (round 6; ns > 1, rollout / persistent kernels of the resident shapes only -- kShapes[].ns): a wavefront owns `ns` groups of
+// Gw envs and steps them ONE AFTER THE OTHER, every step.  What lives across steps exists once per slice (agent rows, PCG64 words, step
+// counts, hook state, the grid tile: the `s` argument of the accessors); everything a step only needs while it runs -- view records /
+// draws / rewards, written-cell offsets, actions, visiting order, the jump table, the WALL cell -- exists once per wavefront, and the
+// P4/P5 staging of a round lies over the view records + the written-cell offsets (both dead once P2 has gathered the cells; a round is
+// then 8 view slots).  C4: 1488 + 2 x 9344 = 20176 bytes for 32 envs -> 8 wavefronts per CU hold 65536 envs' tiles on the chip.
 struct LdsCarve {
     int vpw, nw, Gw, A, tile_bytes, round_bytes;   // round_bytes: P4/P5 staging of one round (obs bytes, or one-hot cell masks)
     bool roll;      // mgx_rollout: tile and PCG64 state live across steps (no aliasing of the tile, rng kept in LDS)
     bool has_aux;   // env kinds with hook state
     bool c8;        // compact cells: + the decode table
-    __host__ __device__ __attribute__((always_inline)) int rows() const { return 0; }                               // u64  [vpw]
+    int ns = 1;     // slices per wavefront (above)
+    __host__ __device__ __attribute__((always_inline)) int tile_pad() const { return (tile_bytes & 15) ? 32 : 0; }
+    // -- ns > 1: the shared block [0, sh_end()), then one block of pstride() bytes per slice --
+    __host__ __device__ __attribute__((always_inline)) int sh_end() const { return 22 * vpw + 32 * A + 16; }
+    __host__ __device__ __attribute__((always_inline)) int pstride() const {
+        return 8 * vpw + 32 * Gw + ((4 * Gw + 15) & ~15) + (has_aux ? 16 * Gw : 0) + tile_bytes + tile_pad();
+    }
+    __host__ __device__ __attribute__((always_inline)) int pers(int s) const { return sh_end() + s * pstride(); }
+    __host__ __device__ __attribute__((always_inline)) int rows(int s = 0) const { return ns > 1 ? pers(s) : 0; }   // u64  [vpw]
     // -- per-step temporaries, all dead once P2 has gathered the cells --
     // (the view records, written in P1d, lie over the draws and the rewards, both dead by then)
-    __host__ __device__ __attribute__((always_inline)) int rec() const { return 8 * vpw; }                          // ViewRec [vpw]  (P1d -> P2)
+    __host__ __device__ __attribute__((always_inline)) int rec() const { return ns > 1 ? 0 : 8 * vpw; }            // ViewRec [vpw]  (P1d -> P2)
     __host__ __device__ __attribute__((always_inline)) int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
-    __host__ __device__ __attribute__((always_inline)) int rew() const { return 16 * vpw; }                         // f64  [vpw]     (P0 -> hooks), same space
-    __host__ __device__ __attribute__((always_inline)) int woff() const { return 24 * vpw; }                        // i32  [vpw]     (P1s)
+    __host__ __device__ __attribute__((always_inline)) int rew() const { return rec() + 8 * vpw; }                  // f64  [vpw]     (P0 -> hooks), same space
+    __host__ __device__ __attribute__((always_inline)) int woff() const { return rec() + 16 * vpw; }                // i32  [vpw]     (P1s)
     __host__ __device__ __attribute__((always_inline)) int temps_end() const { return woff() + 4 * vpw; }
     // -- state that lives across phases / steps --
     __host__ __device__ __attribute__((always_inline)) int act() const { return temps_end(); }                      // i8   [vpw]
     __host__ __device__ __attribute__((always_inline)) int ord() const { return act() + vpw; }                      // u8   [vpw]
-    __host__ __device__ __attribute__((always_inline)) int rng() const { return ord() + vpw; }                      // u64  [Gw][4]   (rollout only)
-    __host__ __device__ __attribute__((always_inline)) int scnt() const { return rng() + (roll ? 32 * Gw : 0); }    // i32  [Gw]
-    __host__ __device__ __attribute__((always_inline)) int aux() const { return scnt() + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
-    __host__ __device__ __attribute__((always_inline)) int own_jump() const { return aux() + (has_aux ? 16 * Gw : 0); }
+    __host__ __device__ __attribute__((always_inline)) int rng(int s = 0) const { return ns > 1 ? pers(s) + 8 * vpw : ord() + vpw; }   // u64  [Gw][4]   (rollout only)
+    __host__ __device__ __attribute__((always_inline)) int scnt(int s = 0) const { return rng(s) + (roll ? 32 * Gw : 0); }    // i32  [Gw]
+    __host__ __device__ __attribute__((always_inline)) int aux(int s = 0) const { return scnt(s) + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
+    __host__ __device__ __attribute__((always_inline)) int own_jump() const { return ns > 1 ? ord() + vpw : aux() + (has_aux ? 16 * Gw : 0); }
     __host__ __device__ __attribute__((always_inline)) int jump() const { return own_jump(); }                      // u64  [A][4]: k = 1..A   (rollout only: the
     __host__ __device__ __attribute__((always_inline)) int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one-step kernels keep them in registers)
                                                                                      // wall: one WALL cell + the dword after it
@@ -301,23 +317,27 @@ struct LdsCarve {
     __host__ __device__ __attribute__((always_inline)) int out_bytes() const { return (round_bytes + 32 + 15) & ~15; }
     __host__ __device__ __attribute__((always_inline)) int lut() const { return wall() + 16; }                         // u32 [256] (compact cells only)
     __host__ __device__ __attribute__((always_inline)) int own_out() const { return lut() + (c8 ? kLutBytes : 0); }
-    __host__ __device__ __attribute__((always_inline)) int tile() const { return roll ? own_out() + out_bytes() : own_out(); }   // grid bytes, skew + over-read
-    __host__ __device__ __attribute__((always_inline)) int out() const { return roll ? own_out() : tile(); }
+    __host__ __device__ __attribute__((always_inline)) int tile(int s = 0) const {                                      // grid bytes, skew + over-read
+        return ns > 1 ? aux(s) + (has_aux ? 16 * Gw : 0) : (roll ? own_out() + out_bytes() : own_out());
+    }
+    __host__ __device__ __attribute__((always_inline)) int out() const { return ns > 1 ? rec() : (roll ? own_out() : tile()); }
     __host__ __device__ __attribute__((always_inline)) int total() const {
+        if (ns > 1) return (pers(ns) + 15) & ~15;
         // (the tile's 32 bytes of skew + over-read exist only when a wavefront's grid bytes are not whole 16-byte vectors: a 64x64
         // env's 8 KiB tile + 512 bytes of slots is then exactly 17 x 512 bytes of LDS)
-        const int tile_pad = (tile_bytes & 15) ? 32 : 0;
-        const int t = tile_bytes + tile_pad > out_bytes() || roll ? tile_bytes + tile_pad : out_bytes();
+        const int t = tile_bytes + tile_pad() > out_bytes() || roll ? tile_bytes + tile_pad() : out_bytes();
         return (tile() + t + 15) & ~15;
     }
+    // (ns > 1: the staging must fit the records + the written-cell offsets it lies over)
+    __host__ __device__ __attribute__((always_inline)) bool slices_ok() const { return ns <= 1 || (roll && !c8 && out_bytes() <= 20 * vpw); }
 };
 
 // one_hot: the round's staging holds one 32-bit one-hot mask per cell (+ a pad dword either side) instead of 3 obs bytes
 // `round`: slots staged per P4/P5 round (kRound, or the group size of a small-group latency instantiation)
 __host__ __device__ __attribute__((always_inline)) inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
-                                               bool one_hot = false, int round = kRound, int cb = kCellBytes) {
+                                               bool one_hot = false, int round = kRound, int cb = kCellBytes, int ns = 1) {
     return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * cb, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
-                    roll, has_aux, cb == 1};
+                    roll, has_aux, cb == 1, ns};
 }
 inline int cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 1 ? 1 : kCellBytes; }        // the LDS tile's cells
 inline int grid_cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 3 ? 3 : cell_bytes_of(sp); }   // the HBM tensors' cells
@@ -373,8 +393,9 @@ inline int choose_group(const MgxSpec &sp, int64_t batch) {
 // BlockedUnlockPickup at 16384 envs 5.08 -> 4.45 us (step 9.6 -> 8.2); the throughput instantiation of C4 gains 1 % (its scalar work
 // runs beside four waves' VALU work) and has none.  The table holds the shapes BASELINE.json names, at the envs-per-wavefront
 // choose_Gw gives them in the latency regime; every other shape, and these at other launch geometries, run the generic kernels.
-struct FixedShape { int W, H, A, Gw; bool hooks; int V; bool dma, stream; int cb = kCellBytes; };   // (dma / stream: the instantiation
-                                                                                // family, launch_mode; cb: bytes per grid cell)
+struct FixedShape { int W, H, A, Gw; bool hooks; int V; bool dma, stream; int cb = kCellBytes; int ns = 0; };   // (dma / stream: the
+                                                  // instantiation family, launch_mode; cb: bytes per grid cell; ns > 0: a RESIDENT shape of the
+                                                  // rollout / persistent kernels -- 64 view slots, ns slices per wavefront, LdsCarve)
 constexpr FixedShape kShapes[] = {
     {0, 0, 0, 0, false, 0, false, false},
     {16, 16, 4, 4, false, 7, true, false},      // 1: MultiGrid-Empty-16x16 x 4 agents, up to 8192 envs (C2; C4's share of an 8-GPU node)
@@ -386,13 +407,23 @@ constexpr FixedShape kShapes[] = {
                                                 //    on 32 lanes instead of 16 and the 8 KiB of tiles are again 17 wavefronts per CU
     {64, 64, 16, 2, false, 9, false, false, 1}, // 6: ... with the grid left to the caches: C5's 32768 compact grids are 128 MiB, half
                                                 //    of the Infinity Cache, and re-read from there (measured: -1.5 % against nt loads)
+    // 7, 8 (round 6): the RESIDENT forms of Empty-16x16 x 4 agents for mgx_rollout* / mgx_step_persistent at C4's batch -- 64 view slots
+    // per wavefront with two slots per cell register, as the throughput step kernel; 7: one slice of 16 envs (13216 B of LDS: 12
+    // wavefronts per CU, up to 49152 envs resident), 8: TWO slices = 32 envs per wavefront (20112 B: 8 wavefronts per CU = 2048
+    // wavefronts hold the 65536 envs of C4, tiles and all, for the whole launch)
+    {16, 16, 4, 16, false, 7, false, false, kCellBytes, 1},
+    {16, 16, 4, 16, false, 7, false, false, kCellBytes, 2},
 #ifdef MGX_JIT_SHAPE
     {MGX_JIT_SHAPE},                            // 5: ANY other shape, compiled at run time (hipRTC) from these same headers with its
                                                 //    launch geometry as MGX_JIT_SHAPE (multigrid_amd/jit.py, mgx_shape_register)
 #endif
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
-constexpr int shape_slots(const FixedShape &f) { return (f.Gw * f.A + 15) / 16 * 16; }   // == slots_in_use() (all entries: <= 32 slots)
+constexpr int shape_slots(const FixedShape &f) { return (f.Gw * f.A + 15) / 16 * 16; }   // == slots_in_use() (all entries: <= 32 slots, the
+                                                                                         // resident shapes 64)
+constexpr int kShapeResident1 = 7, kShapeResident2 = 8;
+constexpr int kRoundResident = 8;        // P4/P5 round of the sliced resident kernels (their staging lies over the view records)
+constexpr int shape_round(const FixedShape &f) { return f.ns > 1 ? kRoundResident : kRound; }
 
 static __device__ const JumpTable kJump{};
 
@@ -782,12 +813,28 @@ inline int match_fixed_shape(const KernelArgs &ka, bool hooks, bool persist = fa
     if (MGX_NO_FIXED_SHAPES || ka.grp != kGroup) return 0;
     for (int k = 1; k < kNumShapes; ++k) {
         const FixedShape &f = kShapes[k];
+        if (f.ns > 0) continue;                                                  // (resident shapes: match_resident_shape)
         if (persist ? !f.dma : (((ka.flags & 2) != 0) != f.dma || ((ka.flags & 1) != 0) != f.stream)) continue;
         if (ka.sp.view_size == f.V
             && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw && hooks == f.hooks
             && ka.vpw == shape_slots(f)
             && cell_bytes_of(ka.sp) == f.cb
             && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), persist, f.hooks, false, kGroup, f.cb).total())
+            return k;
+    }
+    return 0;
+}
+
+// ... and which RESIDENT shape (kShapes[].ns > 0) the geometry of a rollout / persistent launch is: fill_args chose it (ka.ns), this
+// re-checks every number the instantiation was compiled for.
+inline int match_resident_shape(const KernelArgs &ka, bool hooks) {
+    if (MGX_NO_FIXED_SHAPES || ka.grp != kGroup || ka.ns < 1) return 0;
+    for (int k = 1; k < kNumShapes; ++k) {
+        const FixedShape &f = kShapes[k];
+        if (f.ns != ka.ns) continue;
+        if (ka.sp.view_size == f.V && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw
+            && hooks == f.hooks && ka.vpw == shape_slots(f) && cell_bytes_of(ka.sp) == f.cb
+            && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), true, f.hooks, false, shape_round(f), f.cb, f.ns).total())
             return k;
     }
     return 0;
@@ -907,6 +954,16 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
         default: break;
         }
     }
+    if constexpr ((MODE == 2 || MODE == 3) && !OH && !GEN && V == 7 && !MGX_NO_FIXED_SHAPES) {
+        // the resident forms of the C4 shape (kShapes 7 / 8: 64 view slots, one or two slices of 16 envs per wavefront)
+        switch (match_resident_shape(ka, hooks)) {
+        case kShapeResident1: kern = ar ? mgx_fused_kernel<V, MODE, false, true, false, false, false, false, kGroup, kShapeResident1>
+                                        : mgx_fused_kernel<V, MODE, false, false, false, false, false, false, kGroup, kShapeResident1>; break;
+        case kShapeResident2: kern = ar ? mgx_fused_kernel<V, MODE, false, true, false, false, false, false, kGroup, kShapeResident2>
+                                        : mgx_fused_kernel<V, MODE, false, false, false, false, false, false, kGroup, kShapeResident2>; break;
+        default: if (ka.ns > 0) return MGX_ERR_INVALID_ARGUMENT;               // (fill_args chose a geometry no instantiation has)
+        }
+    } else if (ka.ns > 0) return MGX_ERR_INVALID_ARGUMENT;
     if constexpr (MODE == 1 && !OH && !GEN && GRP == kGroup && !MGX_NO_FIXED_SHAPES) {
         if (!kern && !occupancy) {
             if (const JitShape *js = jit_shape_lookup(ka, hooks)) {          // a runtime-compiled instantiation of this very geometry

@@ -1,6 +1,7 @@
 // mgx_kernels.hip -- the C ABI of libmgx.so (include/mgx.h): argument checks, launch geometry, dispatch to the fused
 // kernel's per-view-size translation units (mgx_fused.h / mgx_fused_inst.hip).
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -139,6 +140,22 @@ int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot
     return MGX_OK;
 }
 
+// Slices per wavefront of the resident rollout / persistent form (0: the ordinary 32-slot kernels).  Empty-16x16 x 4 agents, 7x7 views,
+// 16-bit cells; by batch: up to 16384 envs the 32-slot kernels are one wavefront or two per SIMD and as fast (tools/rollout_probe.py);
+// up to 49152 envs one slice of 16 envs per wavefront is resident at 12 wavefronts per CU; up to 98304 two slices at 8 per CU; beyond
+// that nothing is resident in one round and the single slice packs the CU tighter.  MGX_RESIDENT_SLICES=0/1/2 overrides (tools).
+int resident_slices(const MgxSpec &sp, int64_t batch) {
+    const FixedShape &f = kShapes[kShapeResident1];
+    if (sp.width != f.W || sp.height != f.H || sp.num_agents != f.A || sp.view_size != f.V || sp.env_kind != MGX_KIND_EMPTY
+        || cell_bytes_of(sp) != f.cb || sp.cell_bytes == 3)
+        return 0;
+    if (const char *e = getenv("MGX_RESIDENT_SLICES")) { if (*e) { const int f_ = atoi(e); return f_ > 2 ? 2 : (f_ < 0 ? 0 : f_); } }   // (read per call: the tests switch it)
+    if (batch <= 16384) return 0;
+    if (batch <= 49152) return 1;
+    if (batch <= 98304) return 2;
+    return 1;
+}
+
 // `step_plain`: the launch is the plain one-step kernel (mode 1 without one-hot / generation): the only one the small-group
 // latency instantiations exist for (mgx_fused.h: has_small_groups)
 int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg,
@@ -164,6 +181,18 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     ka.vpw = slots_in_use(*sp, ka.Gw, roll || obs_only, ka.grp);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only, ka.grp);
+    ka.ns = 0;
+    // RESIDENT shapes of the rollout / persistent kernels (mgx_fused.h: kShapes[].ns > 0; round 6): at the batches where the 32-slot
+    // rollout kernel no longer keeps every env on the chip, Empty-16x16 x 4 agents takes 64 view slots per wavefront and, beyond what
+    // 12 such wavefronts per CU hold, two slices of 16 envs per wavefront (8 per CU: 65536 envs, C4, in 2048 wavefronts)
+    if (roll && !one_hot && !MGX_NO_FIXED_SHAPES && g_debug_G <= 0) {
+        const int ns = resident_slices(*sp, batch);
+        if (ns > 0) {
+            const FixedShape &f = kShapes[ns > 1 ? kShapeResident2 : kShapeResident1];
+            ka.ns = ns; ka.Gw = f.Gw; ka.vpw = shape_slots(f);
+            ka.wave_lds = make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), true, f.hooks, false, shape_round(f), f.cb, f.ns).total();
+        }
+    }
     struct { int total; } p{ka.wave_lds};
     // wavefronts bundled per workgroup: ONE once the chip is full several times over -- single-wavefront workgroups pack a CU's
     // 160 KiB of LDS tightest and refill a CU one wavefront at a time (round 4, same box: C5 78.1 / 79.0 / 82.2 us for 1 / 2 / 4,
@@ -172,11 +201,12 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     // (... for the plain step's wavefronts, which hold more than 8 KiB of LDS each; the gen_obs kernel's small slices and the
     // one-hot step stay at 2: 1 M envs gen_obs 203 us for 1 against 190-193 for 2, fused one-hot step 1.03-1.06 ms against 0.99)
     int wpb = ((batch + ka.Gw - 1) / ka.Gw >= 16384) ? ((p.total > 8192 && !one_hot && !obs_only) ? 1 : 2) : 4;
+    if (ka.ns > 0) wpb = 2;                                   // (resident shapes: 12 / 8 wavefronts per CU as 6 / 4 workgroups)
     while (wpb > 1 && wpb * p.total > 64 * 1024) wpb >>= 1;
     if (g_debug_wpb > 0) wpb = g_debug_wpb;
     threads = 64 * wpb;
     lds_bytes = wpb * p.total;
-    const int64_t nwaves = (batch + ka.Gw - 1) / ka.Gw;
+    const int64_t nwaves = (batch + (int64_t)ka.Gw * std::max(ka.ns, 1) - 1) / ((int64_t)ka.Gw * std::max(ka.ns, 1));
     // latency regime: LDS-DMA tile loads, 32 view slots with unpacked cell registers (mgx_fused.h: DMA instantiations)
     // (compact cells have no latency instantiation: their launches take the throughput kernel at any size)
     if ((nwaves <= 2048 || ka.grp < kGroup) && !(ka.flags & 1) && ka.Gw * sp->num_agents <= kSlotsLatency && sp->cell_bytes != 1
@@ -306,6 +336,25 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     out->slots_per_group = ka.grp;
     out->fixed_shape = match_fixed_shape(ka, spec->env_kind != MGX_KIND_EMPTY);
     if (!out->fixed_shape && jit_shape_lookup(ka, spec->env_kind != MGX_KIND_EMPTY)) out->fixed_shape = MGX_SHAPE_RUNTIME_COMPILED;
+    return MGX_OK;
+}
+
+int mgx_rollout_info(const MgxSpec *spec, int64_t batch, MgxRolloutInfo *out) {
+    int rc = check_spec(spec, batch, true, false);
+    if (rc) return rc;
+    if (!out) return MGX_ERR_INVALID_ARGUMENT;
+    KernelArgs ka{};
+    int threads = 0, lds = 0; int64_t nwg = 0;
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, true, false, false, false);
+    if (rc) return rc;
+    const int64_t epw = (int64_t)ka.Gw * std::max(ka.ns, 1);
+    out->envs_per_slice = ka.Gw;
+    out->slices = std::max(ka.ns, 1);
+    out->wavefronts = (int32_t)((batch + epw - 1) / epw);
+    out->threads_per_workgroup = threads;
+    out->workgroups = (int32_t)nwg;
+    out->lds_bytes = lds;
+    out->resident_shape = match_resident_shape(ka, spec->env_kind != MGX_KIND_EMPTY);
     return MGX_OK;
 }
 
@@ -769,7 +818,8 @@ int mgx_persistent_waves(const MgxSpec *spec, int64_t batch, const MgxStepArgs *
     int threads = 0, lds = 0; int64_t nwg = 0;
     const int rc = persistent_geometry(spec, batch, args, ka, threads, lds, nwg);
     if (rc) return rc;
-    *waves = (int32_t)((batch + ka.Gw - 1) / ka.Gw);        // (the wavefronts that own envs: the ones that publish a flag)
+    const int64_t epw = (int64_t)ka.Gw * std::max(ka.ns, 1);     // envs per wavefront (resident shapes: all of its slices)
+    *waves = (int32_t)((batch + epw - 1) / epw);            // (the wavefronts that own envs: the ones that publish a flag)
     return MGX_OK;
 }
 

@@ -414,7 +414,12 @@ class MultiGridEnv:
     @property
     def agent_states(self) -> AgentStateRow:
         """(A,9) int64 snapshot in the reference's AgentState column order (agent.py:222-232) whose setters write through
-        (`self.agent_states.terminated = True`, base.py:494)."""
+        (`self.agent_states.terminated = True`, base.py:494).  While `_gen_grid` runs: the episode's initial rows, live -- what
+        `RoomGrid._gen_grid` sets (`self.agent_states.pos = ...`, roomgrid.py:232-236) and `reject_next_to` reads (roomgrid.py:45-50)."""
+        if self._gen_agents is not None:
+            rows = self._gen_agents.view(AgentStateRow)
+            rows._env, rows._index, rows._contents = self, None, None
+            return rows
         raw = layouts.unpack_agents(self._benv.agents[0].cpu().numpy())
         content = raw[:, 8] >> 2                                 # carried boxes' contents (include/mgx.h): not part of the row
         raw[:, 8] &= 3

@@ -320,6 +320,9 @@ def main():
     record_custom()          # (last: every make_env() before it keeps the construction seed it always had)
     record_custom_steps()    # (round 5, behind everything older for the same reason)
     record_box_rollout()
+    import custom_envs       # (round 6, likewise: the RoomGrid subclass of tests/custom_envs.py)
+    record_custom(custom_envs.CASES_R6)
+    record_custom_steps(custom_envs.STEP_CASES_R6)
 
 
 def face(env, i, target_xy, carrying=None):
@@ -529,7 +532,7 @@ def record_layouts():
               f"{os.path.getsize(path) / 1024:.1f} KiB")
 
 
-def record_custom():
+def record_custom(cases=None):
     """User-defined envs written against the reference's extension point, `_gen_grid` + `put_obj` / `place_obj` / `place_agent` /
     `Grid.wall_rect / horz_wall / vert_wall` / the WorldObj classes (multigrid/base.py:229-247, 604-697; core/grid.py:78-195;
     core/world_object.py:279-616).  The class bodies are this repo's own (tests/custom_envs.py) and run here over the REAL
@@ -538,7 +541,7 @@ def record_custom():
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import custom_envs
     classes = custom_envs.define(custom_envs.multigrid_namespace())
-    for fname, (cname, kw) in custom_envs.CASES.items():
+    for fname, (cname, kw) in (custom_envs.CASES if cases is None else cases).items():
         cls = classes[cname]
         _MAKE_COUNT[0] += 1
         cls._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
@@ -572,7 +575,7 @@ def record_custom():
         print(f"{fname:34s} resets={len(reset_seeds)} cell types seen={ntypes} {os.path.getsize(path) / 1024:.1f} KiB")
 
 
-def record_custom_steps():
+def record_custom_steps(cases=None):
     """User-defined envs stepped for whole episodes over the REAL reference (tests/custom_envs.py: STEP_CASES): boxes that hold
     things (Box.contains, world_object.py:574-605) and a `step` override that ends episodes through `on_success` / `on_failure`
     (base.py:478-532) the way the reference's own envs do.  Per reset: the initial state, then every step's actions, outputs and
@@ -580,7 +583,7 @@ def record_custom_steps():
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import custom_envs
     classes = custom_envs.define(custom_envs.multigrid_namespace())
-    for fname, (cname, kw, T) in custom_envs.STEP_CASES.items():
+    for fname, (cname, kw, T) in (custom_envs.STEP_CASES if cases is None else cases).items():
         cls = classes[cname]
         _MAKE_COUNT[0] += 1
         cls._default_seed = 0xC0FFEE + _MAKE_COUNT[0]
@@ -606,6 +609,9 @@ def record_custom_steps():
                 acts[1, 0] = 3
             ep = {k: [] for k in ("obs", "reward", "terminated", "truncated", "grid", "agents")}
             for t in range(T):
+                forced = custom_envs.intervene(cname, env, t)          # (tests/custom_envs.py: the replaying tests make the same call)
+                for i, a_i in (forced or {}).items():
+                    acts[t, i] = a_i
                 nbox = int((env.grid.state[..., 0] == 7).sum())
                 o, r, tm, tr, _ = env.step({i: int(acts[t, i]) for i in range(A) if acts[t, i] >= 0})
                 ep["obs"].append(np.stack([o[i]["image"] for i in range(A)]))

@@ -15,17 +15,19 @@ from types import SimpleNamespace
 def multigrid_amd_namespace():
     import multigrid_amd as m
     from multigrid_amd import core
+    from multigrid_amd.core.roomgrid import RoomGrid
     return SimpleNamespace(MultiGridEnv=m.MultiGridEnv, Grid=core.Grid, Goal=core.Goal, Wall=core.Wall, Door=core.Door, Key=core.Key,
                            Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction,
-                           Action=core.Action)
+                           Action=core.Action, RoomGrid=RoomGrid, Type=core.Type)
 
 
 def multigrid_namespace():
     from multigrid.base import MultiGridEnv
     from multigrid import core
+    from multigrid.core.roomgrid import RoomGrid
     return SimpleNamespace(MultiGridEnv=MultiGridEnv, Grid=core.Grid, Goal=core.Goal, Wall=core.Wall, Door=core.Door, Key=core.Key,
                            Ball=core.Ball, Box=core.Box, Floor=core.Floor, Lava=core.Lava, Color=core.Color, Direction=core.Direction,
-                           Action=core.Action)
+                           Action=core.Action, RoomGrid=RoomGrid, Type=core.Type)
 
 
 def define(ns):
@@ -157,13 +159,88 @@ def define(ns):
                         self.on_failure(agent, reward, terminated)
             return obs, reward, terminated, truncated, info
 
-    return {"TwoRoomsEnv": TwoRoomsEnv, "ScatterEnv": ScatterEnv, "BoxTreasureEnv": BoxTreasureEnv, "FetchTrapEnv": FetchTrapEnv}
+    class VaultRoomsEnv(ns.RoomGrid):
+        """A `RoomGrid` subclass (multigrid/core/roomgrid.py:139-495), written the way the reference's own room envs are: 2 x 3 rooms;
+        the vault -- a box of a random colour -- lies in the far corner room behind a LOCKED door whose key lies in the start room; one
+        inner wall is taken out, `connect_all` adds what doors are still needed, `add_distractors` adds what it adds (one object:
+        the reference's bookkeeping fails after the first, roomgrid.py:493), every agent starts in room (0, 0).  The `step` override
+        ends the episode for whoever carries THE vault (its type compared the reference's way: `obj.type == 'box'`)."""
+
+        def __init__(self, room_size=5, **kwargs):
+            super().__init__(room_size=room_size, num_rows=2, num_cols=3, mission_space="carry the vault box",
+                             max_steps=8 * room_size ** 2, **kwargs)
+
+        def _gen_grid(self, width, height):
+            super()._gen_grid(width, height)
+            self.vault, _ = self.add_object(2, 1, kind=ns.Type.box)
+            self.vault_door, _ = self.add_door(2, 1, ns.Direction.left, locked=True)
+            self.add_object(0, 0, ns.Type.key, self.vault_door.color)
+            # the room in front of the vault door counts as locked too (Room.locked): connect_all will not touch it, so it gets its
+            # way out by hand; the start room gets a grey door in the middle of its right wall
+            self.add_door(1, 1, ns.Direction.up, color=ns.Color.blue, locked=False)
+            self.add_door(0, 0, ns.Direction.right, color=ns.Color.grey, locked=False, rand_pos=False)
+            self.extra_doors = self.connect_all(door_colors=[ns.Color.purple, ns.Color.yellow])
+            try:
+                self.add_distractors(1, 0, num_distractors=3)
+            except AttributeError:
+                pass
+            self.n_distractors = len(self.get_room(1, 0).objs)
+            self.add_object(0, 1)                                       # a random key / ball / box of a random colour
+            for agent in self.agents:
+                self.place_agent(agent, 0, 0)
+            assert self.room_from_pos(*self.vault.init_pos) is self.get_room(2, 1) and self.get_room(2, 1).locked
+            assert self.get_room(0, 0).pos_inside(1, 1) and not self.get_room(0, 0).pos_inside(width - 2, 1)
+            # (last: `Room.locked` cannot look at a room with a removed wall, roomgrid.py:85)
+            if self.get_room(0, 0).doors[ns.Direction.down] is None:
+                self.remove_wall(0, 0, ns.Direction.down)
+
+        def step(self, actions):
+            obs, reward, terminated, truncated, info = super().step(actions)
+            for agent in self.agents:
+                held = agent.state.carrying
+                if held is not None and held.type == 'box' and held == self.vault:
+                    self.on_success(agent, reward, terminated)
+            return obs, reward, terminated, truncated, info
+
+    return {"TwoRoomsEnv": TwoRoomsEnv, "ScatterEnv": ScatterEnv, "BoxTreasureEnv": BoxTreasureEnv, "FetchTrapEnv": FetchTrapEnv,
+            "VaultRoomsEnv": VaultRoomsEnv}
+
+
+def intervene(cname, env, t):
+    """What the recording script does to a running episode BESIDES stepping it -- the same call is made by the recorder (over the
+    reference) and by the replaying tests (over multigrid_amd) right before step `t`.  Returns {agent index: action} to play at this
+    step instead of the random ones (the fixtures hold the actions as played), or None.
+
+    VaultRoomsEnv, t = 60: agent 0 is put down next to the vault, facing it, with empty hands (through the state setters:
+    `agent.state.pos / dir / carrying = ...`, multigrid/core/agent.py:286-346) and picks it up -- so that the `step` override's
+    success path is part of what was recorded (a random walk does not get through the locked door in time)."""
+    if cname == "VaultRoomsEnv" and t == 60:
+        vx, vy = (int(v) for v in env.vault.init_pos)
+        box = env.grid.get(vx, vy)
+        assert box is not None and box.type == 'box', "the vault has not moved"
+        taken = {tuple(int(v) for v in a.state.pos) for a in env.agents if a.index != 0}
+        for d, (dx, dy) in enumerate(((-1, 0), (0, -1), (1, 0), (0, 1))):      # stand left of it facing right, above facing down, ...
+            cell = (vx + dx, vy + dy)
+            if env.grid.get(*cell) is None and cell not in taken:
+                agent = env.agents[0]
+                agent.state.carrying = None
+                agent.state.pos = cell
+                agent.state.dir = d
+                return {0: 3}                                                   # Action.pickup
+        raise AssertionError("no free cell next to the vault")
+    return None
 
 
 #: fixture name -> (class name, constructor kwargs)
 CASES = {
     "custom_tworooms_a3": ("TwoRoomsEnv", dict(size=11, agents=3)),
     "custom_scatter_a2_v5": ("ScatterEnv", dict(width=13, height=9, agents=2, agent_view_size=5, allow_agent_overlap=False)),
+}
+#: round 6 -- recorded BEHIND every older fixture (oracle/gen_golden.py gives each env it makes the next construction seed, so the
+#: older fixtures keep theirs and regenerate byte for byte): a RoomGrid subclass
+CASES_R6 = {
+    "custom_vaultrooms_a2": ("VaultRoomsEnv", dict(room_size=5, agents=2)),
+    "custom_vaultrooms_a3_rs6": ("VaultRoomsEnv", dict(room_size=6, agents=3, agent_view_size=5)),
 }
 
 #: step-sequence fixtures (oracle/gen_golden.py: record_custom_steps; tests/test_custom_envs.py: _replay_steps):
@@ -174,3 +251,8 @@ STEP_CASES = {
     "customsteps_fetchtrap_a3_all": ("FetchTrapEnv", dict(size=8, agents=3, success_termination_mode="all",
                                                           failure_termination_mode="any", joint_reward=True), 90),
 }
+STEP_CASES_R6 = {
+    "customsteps_vaultrooms_a2": ("VaultRoomsEnv", dict(room_size=5, agents=2, joint_reward=True), 150),
+}
+ALL_CASES = {**CASES, **CASES_R6}
+ALL_STEP_CASES = {**STEP_CASES, **STEP_CASES_R6}

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     L = _lib.lib()
     for n in names:
         assert getattr(L, n) is not None
-    assert L.mgx_abi_version() == _lib.ABI_VERSION == 10
+    assert L.mgx_abi_version() == _lib.ABI_VERSION == 11
     assert _lib.error_string(0) == "ok" and "action" in _lib.error_string(-2)
 
 

@@ -17,7 +17,7 @@ from tests import custom_envs, util
 
 def _replay(path, **env_kw):
     z = np.load(path)
-    cname, kw = custom_envs.CASES[os.path.basename(path)[:-4]]
+    cname, kw = custom_envs.ALL_CASES[os.path.basename(path)[:-4]]
     cls = custom_envs.define(custom_envs.multigrid_amd_namespace())[cname]
     env = cls(layout_seed=int(z["construct_seed"]), **kw, **env_kw)
     A = env.num_agents
@@ -57,7 +57,7 @@ def _replay_steps(path, **env_kw):
     contents included (the fixture folds them into the state values, include/mgx.h "BOX CONTENTS")."""
     from multigrid_amd import layouts
     z = np.load(path)
-    cname, kw, T = custom_envs.STEP_CASES[os.path.basename(path)[:-4]]
+    cname, kw, T = custom_envs.ALL_STEP_CASES[os.path.basename(path)[:-4]]
     cls = custom_envs.define(custom_envs.multigrid_amd_namespace())[cname]
     env = cls(layout_seed=int(z["construct_seed"]), **kw, **env_kw)
     A = env.num_agents
@@ -71,6 +71,7 @@ def _replay_steps(path, **env_kw):
         for i in range(A):
             np.testing.assert_array_equal(obs[i]["image"], z["obs0"][k][i], err_msg=ctx)
         for t in range(T):
+            custom_envs.intervene(cname, env, t)                       # (what the recorder did to the episode besides stepping it)
             acts = {i: int(z["actions"][k][t, i]) for i in range(A) if z["actions"][k][t, i] >= 0}
             o, r, tm, tr, _ = env.step(acts)
             c = f"{ctx} step {t}"

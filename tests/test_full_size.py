@@ -96,7 +96,8 @@ def test_c4_full_size_four_chains_vs_oracle(form):
     assert wl.batch == 65536
     spec, B, A = wl.spec, wl.batch, wl.spec.num_agents
     env = wl.make_env(DEV, auto_reset=True)
-    assert env.sub_shards_hint(auto_reset=True) == 2                     # (what sub_shards="auto" resolves to on an MI355X: round 5)
+    assert env.sub_shards_hint(auto_reset=True) == 2                     # (what capture_steps(sub_shards="auto") resolves to on an MI355X: round 5)
+    assert env.sub_shards_hint(auto_reset=True, form="eager") == 1       # (round 6: per-step calls from Python are host-bound as chains)
     ref = dict(grid=wl.grid.copy(), agents=wl.agents.copy(), rng=wl.rng.copy(), step_count=np.zeros(B, np.int32), aux=None)
     episode = np.zeros(B, np.int32)
     sd, nt = spec.as_dict(), ob.max_threads()
@@ -148,9 +149,9 @@ def test_c4_full_size_four_chains_vs_oracle(form):
             check(f"eager 4 chains, step {t}", was, outs)
         for t in range(T1, T1 + T2):                                     # free-running chains, joined once
             was, outs = oracle_step(acts[t])
-            env.step(dacts[t], auto_reset=True, sub_shards="auto")
+            env.step(dacts[t], auto_reset=True, sub_shards=2)            # (the graph policy's two chains, issued eagerly)
         env.join()
-        check("eager 4 chains, 12 steps unjoined", was, outs)
+        check("eager 2 chains, 12 steps unjoined", was, outs)
     env.check_errors()
 
 

@@ -103,8 +103,10 @@ def test_sgpr_spill_budgets(kernels):
         V, MODE, HOOKS, AR, OH, GEN, STREAM, DMA, GRP, SHAPE = t
         fam = ("gen" if GEN else ("obs", "step", "rollout", "persistent")[MODE]) + ("_shape" if SHAPE else "")
         worst[fam] = max(worst.get(fam, 0), k.get(".sgpr_spill_count", 0))
-    budget = {"obs": 0, "step": 96, "step_shape": 32, "rollout": 160, "persistent": 260, "persistent_shape": 70, "gen": 600,
-              "gen_shape": 0}
+    # (round 6: + the resident shapes of the rollout / persistent kernels, mgx_fused.h kShapes 7 / 8; the slices' loop moved the
+    # generic rollout kernels from 160 to 162)
+    budget = {"obs": 0, "step": 96, "step_shape": 32, "rollout": 170, "rollout_shape": 48, "persistent": 260, "persistent_shape": 110,
+              "gen": 600, "gen_shape": 0}
     for fam, w in worst.items():
         assert w <= budget[fam], (fam, w, budget[fam])
     # the benchmarked kernels: C4 headline (64 slots, auto-reset), the latency shapes

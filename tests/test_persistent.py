@@ -161,7 +161,9 @@ def test_a_producer_that_goes_away_does_not_hang_the_device():
 
 def test_persistent_refuses_what_it_cannot_hold():
     from multigrid_amd import _lib
-    wl = workloads.make("c4")                         # 65536 envs: more wavefronts than the chip holds at once
+    # 131072 envs of the C4 shape: more wavefronts than the chip holds at once (round 6: its 65536 envs ARE held -- two slices of 16
+    # envs per wavefront, tests/test_resident.py)
+    wl = workloads.make("c4", batch=131072, global_batch=131072)
     env = wl.make_env(dev(), auto_reset=True)
     with pytest.raises(_lib.MgxError) as ei:
         env.persistent(max_steps=4, auto_reset=True)

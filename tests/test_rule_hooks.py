@@ -65,7 +65,7 @@ def test_blockedunlockpickup_as_one_rule_replays_the_reference_on_oracle_and_hos
 
 def _fetchtrap_batched(path, device, backend=None):
     z = np.load(path)
-    cname, kw, T = custom_envs.STEP_CASES[os.path.basename(path)[:-4]]
+    cname, kw, T = custom_envs.ALL_STEP_CASES[os.path.basename(path)[:-4]]
     import json
     d = json.loads(str(z["spec_json"]))
     spec = dataclasses.replace(EnvSpec.from_dict(d), env_kind="rules")

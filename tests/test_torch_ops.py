@@ -311,7 +311,7 @@ def test_ops_are_the_compiled_library_and_step_ordered_follows_the_dict_order():
     fixture recorded with a reversed dict."""
     import os
     from multigrid_amd import layouts
-    assert os.path.basename(ops.TORCH_LIB_PATH) == "libmgx_torch.so" and int(torch.ops.mgx.abi_version()) == 10
+    assert os.path.basename(ops.TORCH_LIB_PATH) == "libmgx_torch.so" and int(torch.ops.mgx.abi_version()) == 11
     with open(f"/proc/{os.getpid()}/maps") as fh:
         assert "libmgx_torch.so" in fh.read()
     z, d_, spec = util.load_golden([p for p in util.GOLDEN if "rbd_a3_dictorder_rev" in p][0])
