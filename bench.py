@@ -524,6 +524,65 @@ def cpu_baseline_python(wl, budget_s=4.0, sample_envs=4):
                       "and the visibility sweep, as the reference's numba kernels run without numba), no auto-reset"}
 
 
+def c1_point(device, T=256):
+    """BASELINE.json configs[0]: MultiGrid-Empty-8x8-v0, 2 agents, ONE env, through the reference's own surface -- `MultiGridEnv.reset`
+    / `step(dict) -> 5 dicts` (multigrid_amd/env.py over the HIP kernels) -- with the survey's C1 inputs (seed 0, actions
+    default_rng(0).integers(0, 7, (T, A))).  What a drop-in user of the dict API pays per step, split into its parts:
+        launch_us     actions host -> device + the fused kernel's launch + its completion (BatchedMultiGridEnv.step, synchronised)
+        d2h_us        ONE device-to-host copy of reward | obs | dir | terminated | truncated | err (outputs_to_host, pinned buffer)
+        dicts_us      the rest of env.step: building the five dicts, int64 images
+    beside oracle/py_oracle.py (the reference's algorithm per env in Python / NumPy, the stand-in for the reference's own speed
+    without numba) on the same episode on one host core."""
+    import multigrid_amd as mg
+    from multigrid_amd import layouts
+    from oracle import py_oracle as po
+    A = 2
+    acts = np.random.default_rng(0).integers(0, 7, (T, A))
+    env = mg.make("MultiGrid-Empty-8x8-v0", agents=A, device=str(device))
+    env.reset(seed=0)
+    for t in range(20):                                        # warm-up (the first launches, the pinned buffer)
+        env.step({i: int(acts[t, i]) for i in range(A)})
+    env.reset(seed=0)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for t in range(T):
+        env.step({i: int(acts[t, i]) for i in range(A)})
+    total = (time.perf_counter() - t0) / T
+    # the parts, each timed by itself over the same episode
+    benv = env._benv
+    env.reset(seed=0)
+    dev_acts = [torch.from_numpy(acts[t].astype(np.int8)[None]) for t in range(T)]
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for t in range(T):
+        benv.step(dev_acts[t].to(benv.device))
+        torch.cuda.current_stream(device).synchronize()
+    launch = (time.perf_counter() - t0) / T
+    t0 = time.perf_counter()
+    for t in range(T):
+        benv.outputs_to_host()
+    d2h = (time.perf_counter() - t0) / T
+    # the Python restatement on the same episode, one core
+    spec = env.spec.as_dict()
+    env.reset(seed=0)
+    g = layouts.grid_from_product(benv.grid[0].cpu().numpy())
+    a9 = layouts.unpack_agents(benv.agents[0].cpu().numpy())
+    rng, sc = np.random.Generator(np.random.PCG64(np.random.SeedSequence(0))), 0
+    t0 = time.perf_counter()
+    for t in range(T):
+        out = po.step(spec, g, a9, rng, sc, acts[t], None)
+        sc = out[5]
+    py = (time.perf_counter() - t0) / T
+    del env
+    return {"workload": workloads.TITLES["c1"], "steps": T, "us_per_step": round(total * 1e6, 2),
+            "value": round(A / total), "unit": "agent-steps/s",
+            "launch_us": round(launch * 1e6, 2), "d2h_us": round(d2h * 1e6, 2),
+            "dicts_us": round(max(0.0, total - launch - d2h) * 1e6, 2), "d2h_copies_per_step": 1,
+            "python_restatement_us_per_step": round(py * 1e6, 2), "python_restatement_value": round(A / py),
+            "note": "the reference's dict API on ONE env is host-bound by construction (a launch and a copy per step for 2 agents); "
+                    "the batched engine is the throughput path -- this is what the drop-in surface costs, not a roofline point"}
+
+
 def cpu_baseline(wl, threads, budget_s, sample_envs):
     """Oracle (C port of the reference algorithm, OpenMP over envs) on this host, bounded sample of the workload."""
     from oracle import binding as ob
@@ -729,6 +788,10 @@ def main():
             del env
             torch.cuda.empty_cache()
             out["configs"] = {c: config_point(c, device, 256, 50) for c in ("c2", "c3", "c5") if c != name}
+            try:
+                out["configs"]["c1"] = c1_point(device)
+            except Exception as e:                          # (the dict API must not take the bench line down)
+                out["configs"]["c1"] = {"error": repr(e)[:200]}
             if name != "c5":      # C5 is stepped on COMPACT cells (include/mgx.h: MgxCell8); the same workload on the 16-bit cells beside it
                 out["configs"]["c5_wide_cells"] = config_point("c5", device, 256, 50, cell_bytes=2)
             out["configs"]["c3_device_generated"] = config_point("c3", device, 256, 50, device_generated=True)

@@ -249,11 +249,14 @@ int mgx_unpack_grid8(const MgxCell8 *packed, int64_t n_cells, uint8_t *cells3, v
 /* Geometry of the plain step's launch (mgx_step / mgx_step_autoreset; mgx_gen_obs bundles as many envs per wavefront or fewer). */
 int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
 
-/* ABI 11: geometry of the launches that keep the envs' state in LDS between steps -- mgx_rollout* and mgx_step_persistent.
- * resident_shape > 0: one of the library's RESIDENT instantiations (64 view slots per wavefront, `slices` groups of
- * `envs_per_slice` envs stepped one after the other by the same wavefront: Empty-16x16 x 4 agents from 16385 envs up; at BASELINE.json
- * configs[3]'s 65536 envs 2048 wavefronts of 2 x 16 envs, 8 per CU, hold every env's tile on the chip); 0: the ordinary rollout
- * kernels (32 view slots, one slice).  Same results either way, bit for bit. */
+/* ABI 11: geometry of the launches that keep the envs' state in LDS between steps -- mgx_rollout* (persistent = 0) and
+ * mgx_step_persistent (persistent = 1).
+ * resident_shape > 0: one of the library's RESIDENT instantiations -- 64 view slots per wavefront, `slices` groups of `envs_per_slice`
+ * envs stepped one after the other by the same wavefront.  Empty-16x16 x 4 agents from 16385 envs up: one slice of 16 envs (12
+ * wavefronts per CU: 49152 envs resident at once; mgx_rollout* at any larger batch too), and for mgx_step_persistent from 49153 to
+ * 65536 envs -- BASELINE.json configs[3] -- two slices: 2048 wavefronts of 2 x 16 envs, 8 per CU, hold every env's tile on the chip
+ * (and every CU's LDS: what runs beside that launch must do without).  0: the ordinary rollout kernels (32 view slots, one slice).
+ * Same results either way, bit for bit. */
 typedef struct MgxRolloutInfo {
     int32_t envs_per_slice;
     int32_t slices;              /* per wavefront; envs per wavefront = envs_per_slice * slices */
@@ -263,7 +266,7 @@ typedef struct MgxRolloutInfo {
     int32_t lds_bytes;           /* per workgroup */
     int32_t resident_shape;
 } MgxRolloutInfo;
-int mgx_rollout_info(const MgxSpec *spec, int64_t batch, MgxRolloutInfo *out);
+int mgx_rollout_info(const MgxSpec *spec, int64_t batch, int32_t persistent, MgxRolloutInfo *out);
 
 /* Replaces OneHotObsWrapper.one_hot (multigrid/wrappers.py:158-190; the wrapper RLlib registration applies to every
  * env, multigrid/rllib/__init__.py:110-111) for a flat array of cells:

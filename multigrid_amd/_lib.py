@@ -177,16 +177,16 @@ def check(code: int, what: str):
         raise MgxError(code, what)
 
 
-def launch_info(spec, batch: int, roll: bool = False) -> dict:
-    """Launch geometry of the plain step (`roll=False`) or of the rollout / persistent launches (`roll=True`: MgxRolloutInfo, with
-    `envs_per_wavefront` added)."""
+def launch_info(spec, batch: int, roll: bool = False, persistent: bool = False) -> dict:
+    """Launch geometry of the plain step, of mgx_rollout* (`roll=True`) or of mgx_step_persistent (`persistent=True`): the latter two
+    as MgxRolloutInfo with `envs_per_wavefront` added."""
     sc = spec.to_c()
-    if roll:
+    if roll or persistent:
         ri = MgxRolloutInfo()
         L = lib()
         L.mgx_rollout_info.restype = C.c_int
-        L.mgx_rollout_info.argtypes = [C.POINTER(MgxSpecC), C.c_int64, C.POINTER(MgxRolloutInfo)]
-        check(L.mgx_rollout_info(C.byref(sc), batch, C.byref(ri)), "mgx_rollout_info")
+        L.mgx_rollout_info.argtypes = [C.POINTER(MgxSpecC), C.c_int64, C.c_int32, C.POINTER(MgxRolloutInfo)]
+        check(L.mgx_rollout_info(C.byref(sc), batch, int(bool(persistent)), C.byref(ri)), "mgx_rollout_info")
         out = {n: getattr(ri, n) for n, _ in MgxRolloutInfo._fields_}
         out["envs_per_wavefront"] = ri.envs_per_slice * ri.slices
         return out

@@ -201,12 +201,22 @@ class BatchedMultiGridEnv:
         self.rng = torch.zeros((B, 4), dtype=torch.int64, device=dev)
         self.step_count = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.aux = torch.zeros((B, 16), dtype=torch.uint8, device=dev)       # the env subclass' hook state (include/mgx.h)
-        self.err = torch.tensor([0, INT32_MAX], dtype=torch.int32, device=dev)
-        self.obs = torch.zeros(spec.obs_shape(B), dtype=torch.uint8, device=dev)
-        self.dir = torch.zeros((B, A), dtype=torch.uint8, device=dev)
-        self.reward = torch.zeros((B, A), dtype=torch.float64, device=dev)
-        self.terminated = torch.zeros((B, A), dtype=torch.uint8, device=dev)
-        self.truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        # Everything a step hands back -- reward, obs, dir, terminated, truncated, the error words -- lies in ONE allocation (16-byte
+        # aligned views of it), so that a host caller that wants all of it pays one device-to-host copy, not six (`outputs_to_host`:
+        # the dict API, multigrid_amd/env.py; round 6)
+        obs_shape = tuple(spec.obs_shape(B))
+        parts = (("reward", torch.float64, (B, A)), ("obs", torch.uint8, obs_shape), ("dir", torch.uint8, (B, A)),
+                 ("terminated", torch.uint8, (B, A)), ("truncated", torch.uint8, (B,)), ("err", torch.int32, (2,)))
+        offs, total = {}, 0
+        for name, dt, shape in parts:
+            offs[name] = total
+            total += (int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() + 15) & ~15
+        self._out = torch.zeros(max(total, 16), dtype=torch.uint8, device=dev)
+        self._out_parts, self._out_host = [(n, dt, sh, offs[n]) for n, dt, sh in parts], None
+        for name, dt, shape in parts:
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            setattr(self, name, self._out[offs[name]:offs[name] + nbytes].view(dt).view(shape))
+        self.err.copy_(torch.tensor([0, INT32_MAX], dtype=torch.int32))
         self._loaded = False
         self._act_shape = torch.Size((B, A))
         self._bound = {}                 # (auto_reset, one_hot, generate[, parts]) -> pre-bound step launcher (ops.HipBackend)
@@ -270,6 +280,7 @@ class BatchedMultiGridEnv:
             an = a.cpu().numpy()
             if (an[..., 2] >= sp.width).any() or (an[..., 3] >= sp.height).any() or (an[..., 1] > 3).any():
                 raise ValueError("agent position / direction out of range")
+        self._refuse_carried_contents(a)
         self.cells.copy_(torch.from_numpy(layouts.pack_cells_for(sp, g.cpu().numpy())))
         self.agents.copy_(a)
         if rng is not None:
@@ -292,6 +303,16 @@ class BatchedMultiGridEnv:
         self._reset_err()
         self._state_written()
         self._loaded = True
+
+    def _refuse_carried_contents(self, agent_rows):
+        """Compact cells (EnvSpec.cell_bytes = 1) have no room for what a box holds (include/mgx.h: MgxCell8): a filled box on the
+        GRID is refused by the packer; one in an agent's HANDS (carry state byte >> 2, include/mgx.h "BOX CONTENTS") would lose its
+        content when it is put down -- refused here, so that both formats give the same results or an error."""
+        if self.spec.cell_bytes == 1:
+            rows = agent_rows.cpu().numpy() if torch.is_tensor(agent_rows) else np.asarray(agent_rows)
+            if (rows[..., 7] >> 2).any():
+                raise ValueError("compact cells (cell_bytes = 1) cannot hold a box's content: an agent carries a filled box; "
+                                 "use cell_bytes = 2 for envs with Box(contains=...)")
 
     def seed(self, seed: int):
         """Per-env `np_random = Generator(PCG64(SeedSequence([seed, global_env_index])))`; global env 0 gets
@@ -591,7 +612,8 @@ class BatchedMultiGridEnv:
                                     hook_order=ho)
                         # candidates (set_layout_generator): a block shorter than the generator launches' cadence may have caught
                         # none of them -- and would then never make a candidate, however often it is replayed: it ends with one
-                        if st and st.get("candidates") and len(shards) == 1 and st.get("launches", 0) == before:
+                        # (every shard makes the candidates of its own slice, on its own chain: ADVICE r5)
+                        if st and st.get("candidates") and st.get("launches", 0) == before:
                             sh.backend.stage_generate(sh.batch, sh._gen, sh.rng, sh.episode)
                 for i, sh in enumerate(shards):                              # (generator streams of side-staged envs: join)
                     gs = ((getattr(sh, "_gen", None) or {}).get("stage") or {}).get("stream")
@@ -671,6 +693,7 @@ class BatchedMultiGridEnv:
         if tuple(g.shape) != (K, sp.height, sp.width, 3) or tuple(a.shape) != (K, sp.num_agents, 8) or K < 1:
             raise ValueError("layout pool has the wrong shape")
         layouts.check_walled(g.numpy())
+        self._refuse_carried_contents(a)
         t = None
         if auxs is not None:
             t = torch.as_tensor(np.asarray(auxs), dtype=torch.uint8)
@@ -824,6 +847,28 @@ class BatchedMultiGridEnv:
         self.backend.reset_done(self.batch, self.first_env, self._pool, self.cells, self.agents, self.step_count,
                                 self.aux, self.episode, self.was_reset)
         return self.was_reset
+
+    def outputs_to_host(self) -> dict:
+        """Everything the last step / gen_obs handed back, on the host after ONE device-to-host copy (into a pinned buffer) and one
+        stream synchronisation: {'reward' f64[B,A], 'obs' u8[B,A,v,v,3], 'dir', 'terminated' u8[B,A], 'truncated' u8[B], 'err'
+        i32[2]} as numpy views of that buffer -- valid until the next call.  For host callers of small batches (the dict API steps one
+        env: six copies of a few bytes each cost six round trips); a batch's 38 MB of observations belong on the device."""
+        self.join()
+        if self._out.device.type == "cpu":
+            host = self._out
+        else:
+            if self._out_host is None:
+                self._out_host = torch.empty(self._out.shape, dtype=torch.uint8, pin_memory=True)
+            self._out_host.copy_(self._out, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            host = self._out_host
+        arr = host.numpy()
+        out = {}
+        for name, dt, shape, off in self._out_parts:
+            npdt = {torch.float64: np.float64, torch.uint8: np.uint8, torch.int32: np.int32}[dt]
+            n = int(np.prod(shape)) * np.dtype(npdt).itemsize
+            out[name] = arr[off:off + n].view(npdt).reshape(shape)
+        return out
 
     def check_errors(self):
         """Synchronises and raises ValueError if any env met an unknown action since the last check."""

@@ -141,25 +141,27 @@ int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot
 }
 
 // Slices per wavefront of the resident rollout / persistent form (0: the ordinary 32-slot kernels).  Empty-16x16 x 4 agents, 7x7 views,
-// 16-bit cells; by batch: up to 16384 envs the 32-slot kernels are one wavefront or two per SIMD and as fast (tools/rollout_probe.py);
-// up to 49152 envs one slice of 16 envs per wavefront is resident at 12 wavefronts per CU; up to 98304 two slices at 8 per CU; beyond
-// that nothing is resident in one round and the single slice packs the CU tighter.  MGX_RESIDENT_SLICES=0/1/2 overrides (tools).
-int resident_slices(const MgxSpec &sp, int64_t batch) {
+// 16-bit cells; by batch (tools/rollout_probe.py, profiles/r6_resident.txt): up to 16384 envs the 32-slot kernels are one wavefront or
+// two per SIMD and as fast; beyond, ONE slice of 16 envs per wavefront (64 view slots, 12 wavefronts per CU): 49152 envs resident in
+// one round, and for mgx_rollout -- whose wavefronts need not all be resident -- also the better kernel for any larger batch (65536
+// envs: 17.4 us per step in 1.33 rounds against 20.1 as two slices at 8 wavefronts per CU: two wavefronts per SIMD hide less of each
+// other's instruction latency than three).  TWO slices only where everything must be resident at once and one slice no longer fits:
+// mgx_step_persistent from 49153 to 65536 envs.  MGX_RESIDENT_SLICES=0/1/2 overrides (tools, tests).
+int resident_slices(const MgxSpec &sp, int64_t batch, bool persist) {
     const FixedShape &f = kShapes[kShapeResident1];
     if (sp.width != f.W || sp.height != f.H || sp.num_agents != f.A || sp.view_size != f.V || sp.env_kind != MGX_KIND_EMPTY
         || cell_bytes_of(sp) != f.cb || sp.cell_bytes == 3)
         return 0;
     if (const char *e = getenv("MGX_RESIDENT_SLICES")) { if (*e) { const int f_ = atoi(e); return f_ > 2 ? 2 : (f_ < 0 ? 0 : f_); } }   // (read per call: the tests switch it)
     if (batch <= 16384) return 0;
-    if (batch <= 49152) return 1;
-    if (batch <= 98304) return 2;
+    if (persist && batch > 49152) return 2;
     return 1;
 }
 
 // `step_plain`: the launch is the plain one-step kernel (mode 1 without one-hot / generation): the only one the small-group
 // latency instantiations exist for (mgx_fused.h: has_small_groups)
 int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, int &lds_bytes, int64_t &nwg,
-              bool roll = false, bool one_hot = false, bool obs_only = false, bool step_plain = false) {
+              bool roll = false, bool one_hot = false, bool obs_only = false, bool step_plain = false, bool persist = false) {
     ka.sp = *sp;
     ka.batch = batch;
     ka.Gw = g_debug_G > 0 ? g_debug_G : choose_Gw(*sp, batch, roll, one_hot, obs_only);
@@ -186,7 +188,7 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     // rollout kernel no longer keeps every env on the chip, Empty-16x16 x 4 agents takes 64 view slots per wavefront and, beyond what
     // 12 such wavefronts per CU hold, two slices of 16 envs per wavefront (8 per CU: 65536 envs, C4, in 2048 wavefronts)
     if (roll && !one_hot && !MGX_NO_FIXED_SHAPES && g_debug_G <= 0) {
-        const int ns = resident_slices(*sp, batch);
+        const int ns = resident_slices(*sp, batch, persist);
         if (ns > 0) {
             const FixedShape &f = kShapes[ns > 1 ? kShapeResident2 : kShapeResident1];
             ka.ns = ns; ka.Gw = f.Gw; ka.vpw = shape_slots(f);
@@ -339,13 +341,13 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out) {
     return MGX_OK;
 }
 
-int mgx_rollout_info(const MgxSpec *spec, int64_t batch, MgxRolloutInfo *out) {
+int mgx_rollout_info(const MgxSpec *spec, int64_t batch, int32_t persistent, MgxRolloutInfo *out) {
     int rc = check_spec(spec, batch, true, false);
     if (rc) return rc;
     if (!out) return MGX_ERR_INVALID_ARGUMENT;
     KernelArgs ka{};
     int threads = 0, lds = 0; int64_t nwg = 0;
-    rc = fill_args(ka, spec, batch, threads, lds, nwg, true, false, false, false);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, true, false, false, false, persistent != 0);
     if (rc) return rc;
     const int64_t epw = (int64_t)ka.Gw * std::max(ka.ns, 1);
     out->envs_per_slice = ka.Gw;
@@ -792,7 +794,7 @@ static int persistent_geometry(const MgxSpec *spec, int64_t batch, const MgxStep
     if (args && (args->one_hot || args->generate || args->hook_order)) return MGX_ERR_UNSUPPORTED;
     const MgxAutoReset *ar = args ? args->auto_reset : nullptr;
     if (ar) ka.pool_grid = reinterpret_cast<const uint8_t *>(ar->pool_grid ? ar->pool_grid : reinterpret_cast<const MgxCell *>(spec));
-    rc = fill_args(ka, spec, batch, threads, lds, nwg, true, false, false, false);
+    rc = fill_args(ka, spec, batch, threads, lds, nwg, true, false, false, false, true);
     if (rc) return rc;
     ka.T = 1;
     int occ = 0;

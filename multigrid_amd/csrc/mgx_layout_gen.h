@@ -14,26 +14,39 @@ namespace mgx_gen {
 using namespace mgx;
 
 // Is (spec, gen) a combination the generators implement?  Shared by mgx_reset_generate and the fused step (MGX_OK or an error).
-// (... and does a layout EXIST with room to spare?  The reference's place_obj samples positions until one fits, without a bound
-// (base.py:604-669, max_tries = inf): in a room too small for what goes into it, it never returns -- and neither would the lane
-// that runs it here, which on a GPU means a hung device.  Such specs are refused: MGX_ERR_UNSUPPORTED.)
+// (... and does a layout EXIST?  The reference's place_obj samples positions until one fits, without a bound (base.py:604-669,
+// max_tries = inf): in a room too small for what goes into it, it never returns -- and neither would the lane that runs it here,
+// which on a GPU means a hung device.  Such specs are refused: MGX_ERR_UNSUPPORTED.  Only those: a room that is exactly FULL is
+// accepted -- the rejection sampling still ends with probability 1, as in the reference (round 6; ADVICE r5: the first form of
+// this check asked for a spare cell and turned away configurations the reference runs).  The demands, by generator:
+//   Empty-Random      the interior minus the goal holds the A agents (place_agent: distinct free cells, empty.py:164-170)
+//   BlockedUnlockPickup  the left room holds the ball in front of the door, the key and the A agents (blockedunlockpickup.py:142-164;
+//                     an agent's front cell must be free or a wall: with two objects in the room some direction always is)
+//   RedBlueDoors      the middle room holds the A agents (redbluedoors.py:150-156)
+//   LockedHallway     the hallway holds up to max_hallway_keys keys and the A agents; a side room up to max_keys_per_room keys for
+//                     every time its colour comes up -- once with at most 6 rooms, ceil(rooms / 6) times beyond (the reference keys
+//                     its rooms by door colour, locked_hallway.py:168-190)
+//   Playground        unchanged (12 objects may draw one room, away from the agents' start; the reference itself gives up after
+//                     1000 tries there: roomgrid.py:255))
 inline int check_layout_gen(const MgxSpec *spec, const MgxLayoutGen *gen) {
     const int W = spec->width, H = spec->height, rs = gen->room_size, A = spec->num_agents;
     const int room = (rs - 2) * (rs - 2);                       // free cells of one room
     switch (gen->kind) {
     case MGX_GEN_EMPTY_RANDOM:
-        if ((W - 2) * (H - 2) - 1 < A + 1) return MGX_ERR_UNSUPPORTED;                 // the agents beside the goal
+        if ((W - 2) * (H - 2) - 1 < A) return MGX_ERR_UNSUPPORTED;
         break;
     case MGX_GEN_BLOCKEDUNLOCKPICKUP:
-        if (rs >= 4 && room < A + 3) return MGX_ERR_UNSUPPORTED;                       // key + ball + the agents in the left room
+        if (rs >= 4 && room < A + 2) return MGX_ERR_UNSUPPORTED;
         break;
     case MGX_GEN_REDBLUEDOORS:
-        if ((W / 2 - 2) * (H - 2) < A + 1) return MGX_ERR_UNSUPPORTED;                 // the agents in the middle room
+        if ((W / 2 - 2) * (H - 2) < A) return MGX_ERR_UNSUPPORTED;
         break;
-    case MGX_GEN_LOCKEDHALLWAY:
-        if (rs >= 4 && (rs - 2) * (H - 2) < A + gen->max_hallway_keys + 1) return MGX_ERR_UNSUPPORTED;   // hallway: keys + agents
-        if (rs >= 4 && room < gen->max_keys_per_room + 1) return MGX_ERR_UNSUPPORTED;
+    case MGX_GEN_LOCKEDHALLWAY: {
+        if (rs >= 4 && (rs - 2) * (H - 2) < A + gen->max_hallway_keys) return MGX_ERR_UNSUPPORTED;
+        const int rooms = rs >= 4 ? 2 * ((H - 1) / (rs - 1)) : 0;
+        if (rs >= 4 && room < gen->max_keys_per_room * ((rooms + 5) / 6)) return MGX_ERR_UNSUPPORTED;
         break;
+    }
     case MGX_GEN_PLAYGROUND:
         if (rs >= 4 && room < 12 + A + 1) return MGX_ERR_UNSUPPORTED;                  // all 12 objects may draw the same room
         break;

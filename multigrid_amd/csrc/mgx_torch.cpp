@@ -92,8 +92,10 @@ struct GridFaults {
     hipEvent_t ev = nullptr;       // recorded behind the copy
     bool pending = false;
     int unreported = 0;            // fused byte-grid steps (the kernel counts into `dev`) since the last queued report: the copy to the
-                                   // host is queued with the first of them and then every 32nd (it is a DMA op on the step's stream),
-                                   // and by check_errors(), which waits
+                                   // host is queued with the FIRST step of every grid tensor (a bad grid is reported by the call after
+                                   // the one that was handed it, not 31 steps later: ADVICE r5) and then every 32nd (it is a DMA op
+                                   // on the step's stream), and by check_errors(), which waits
+    const void *last_grid = nullptr;   // the grid tensor of the previous fused byte-grid step on this device
 };
 std::mutex g_faults_mutex;
 std::map<int, GridFaults> g_faults;
@@ -320,14 +322,24 @@ StepOut step_any(const Tensor &grid, const Tensor &agents, const Tensor &rng, co
     }
     if (fused_bytes) {          // the kernel counts what the pack kernel would have (ring, unpackable values); the report is deferred
         void *st = stream_of(grid);
-        std::lock_guard<std::mutex> lock(g_faults_mutex);
-        GridFaults &f = faults_of(grid.device().index());
-        sa.grid_bad = f.dev;
+        GridFaults *fp = nullptr;
+        bool report = false;
+        {   // (the lock covers the bookkeeping only, not the launch: std::map nodes do not move)
+            std::lock_guard<std::mutex> lock(g_faults_mutex);
+            GridFaults &f = faults_of(grid.device().index());
+            fp = &f;
+            const void *g = grid.data_ptr();
+            report = f.last_grid != g || (f.unreported & 31) == 0;
+            f.last_grid = g;
+            f.unreported = report ? 1 : f.unreported + 1;
+        }
+        sa.grid_bad = fp->dev;
         check(mgx_step_ex(&sc, B, &sa, st), what);
-        if ((f.unreported++ & 31) == 0) {
-            TORCH_CHECK(hip_ok(hipMemcpyAsync(f.host, f.dev, 8, hipMemcpyDeviceToHost, (hipStream_t)st))
-                        && hip_ok(hipEventRecord(f.ev, (hipStream_t)st)), "mgx: could not queue the grid check's report");
-            f.pending = true;
+        if (report) {
+            std::lock_guard<std::mutex> lock(g_faults_mutex);
+            TORCH_CHECK(hip_ok(hipMemcpyAsync(fp->host, fp->dev, 8, hipMemcpyDeviceToHost, (hipStream_t)st))
+                        && hip_ok(hipEventRecord(fp->ev, (hipStream_t)st)), "mgx: could not queue the grid check's report");
+            fp->pending = true;
         }
         return o;
     }

@@ -125,7 +125,7 @@ class AgentStateRow(np.ndarray):
             cell[2] |= int(self._content) << 2
         env = self._env
         if env is not None and env._gen_agents is None:
-            return env._object_for(cell, pos=None)
+            return env._object_for(cell, pos=None, agent=self._index)
         return world.WorldObj.from_array(cell)
 
     @carrying.setter
@@ -141,6 +141,7 @@ class AgentStateRow(np.ndarray):
             env._write_agents(self._index, slice(6, 9), np.asarray(cell))
             if obj is not None:
                 env._adopt(obj, None)
+            env._bind_carried(self._index, obj)
         elif env is not None and self._content:
             env._gen_carry_content[self._index] = self._content
 
@@ -326,6 +327,8 @@ class MultiGridEnv:
         self._gen_carry_content: dict = {}                # ... and the contents of boxes it hands to agents
         self._objects_at: dict = {}                       # (x, y) -> the WorldObj known to lie there (identity of placed objects)
         self._objects_loose: list = []                    # objects known to the env that are not on the grid (carried)
+        self._carried: dict = {}                          # agent index -> THE object it carries, when its identity is known
+        self._carry_seen: np.ndarray | None = None        # (A,3) carried cells (type, color, state) as of the last look
         given_agents = None
         if not isinstance(agents, int):                                       # base.py:170-177: an iterable of Agent objects
             try:
@@ -462,16 +465,39 @@ class MultiGridEnv:
             self._objects_at[pos] = obj
             obj.cur_pos = pos
 
-    def _object_for(self, cell, pos):
+    def _bind_carried(self, index, obj):
+        """Agent `index` now carries `obj` (None: nothing): its slot of `_carried`, and what the next look compares against."""
+        if index is None:
+            return
+        if obj is None:
+            self._carried.pop(index, None)
+        else:
+            self._carried[index] = obj
+        if self._carry_seen is not None:
+            self._carry_seen[index] = (1, 0, 0) if obj is None else [int(v) for v in obj.encode()]
+
+    def _object_for(self, cell, pos, agent=None):
         """The WorldObj for a device cell (type, color, state | content << 2): the known object it identifies, refreshed from the
-        cell, or a new one.  `pos`: where the cell lies (None: carried by an agent).  An object is identified by where it was last
-        seen, or -- once it has left that cell -- by being the only displaced object of its type and colour."""
+        cell, or a new one.  `pos`: where the cell lies (None: carried, by agent `agent`).  An object on the grid is identified by
+        where it was last seen; a carried one by its carrier -- `_refresh_objects` hands the object that left a cell to the agent
+        that stood in front of it and whose hands filled in that step, so two agents carrying look-alikes each hold their own
+        (`agent.state.carrying == self.obj`, blockedunlockpickup.py:172, is an identity test).  Only an object whose move was not
+        witnessed (state loaded from elsewhere) falls back to being the only displaced object of its type and colour."""
         t, c, sb = int(cell[0]), int(cell[1]), int(cell[2])
         if t == Type.empty:
             if pos is not None and pos in self._objects_at:
                 self._objects_loose.append(self._objects_at.pop(pos))     # (it was picked up / replaced)
             return None
         same = lambda o: (int(o.type), int(o.color)) == (t, c)            # noqa: E731
+        if pos is None and agent is not None:
+            if self._objects_at or self._objects_loose or self._carried:
+                self._refresh_objects(scan=False)                         # (binds what was picked up since the last look)
+            held = self._carried.get(agent)
+            if held is not None and same(held):
+                held._v[2] = sb & 3
+                if t == Type.box and (sb >> 2) != world.content_code(held.contains):
+                    held.contains = world.content_from_code(sb >> 2)
+                return held
         known = self._objects_at.get(pos) if pos is not None else None
         if known is None or not same(known):
             displaced = [o for o in self._objects_loose if same(o)]
@@ -483,6 +509,8 @@ class MultiGridEnv:
         if t == Type.box and (sb >> 2) != world.content_code(known.contains):
             known.contains = world.content_from_code(sb >> 2)
         self._adopt(known, pos)
+        if pos is None and agent is not None:
+            self._carried[agent] = known
         return known
 
     def _gen_layout(self, layout_rng: np.random.Generator, np_random: np.random.Generator):
@@ -628,7 +656,7 @@ class MultiGridEnv:
         self.mission = self.mission_space.sample()
         for agent in self.agents:
             agent.mission = self.mission                              # base.py:274-277
-        self._objects_at, self._objects_loose = {}, []
+        self._objects_at, self._objects_loose, self._carried, self._carry_seen = {}, [], {}, None
         grid, agents, aux = self._gen_layout(self._layout_rng, self._np_random)      # base.py:280
         # base.py:283-289: agents placed, not on top of a non-overlappable object
         ag9 = layouts.unpack_agents(agents)
@@ -646,20 +674,29 @@ class MultiGridEnv:
         """multigrid/base.py:303-346.  Returns (observations, rewards, terminations, truncations, infos).  A subclass may extend
         it the reference's way (module docstring): the dicts returned here are plain dicts to update."""
         A = self.num_agents
-        self._benv.step_count += 1                                       # base.py:333
+        # base.py:333 `self.step_count += 1` -- the fused kernel does it; only a subclass that REPLACES handle_actions (and may read
+        # `self.step_count` / `_reward()` inside it) needs the count advanced before the call
+        custom_actions = type(self).handle_actions is not MultiGridEnv.handle_actions
+        if custom_actions:
+            self._benv.step_count += 1
         self._launched = None
+        self._count_advanced = custom_actions
         rewards = self.handle_actions(actions)                           # base.py:334
         if self._launched is None:                # a subclass replaced handle_actions wholesale: render what it left (base.py:337)
+            if not custom_actions:
+                self._benv.step_count += 1
             obs, dirs = self._benv.gen_obs()
-            term = self._benv.agents[0, :, 4]
+            host = self._benv.outputs_to_host()
+            obs, dirs = host["obs"][0].copy(), host["dir"][0].copy()
+            term = self._benv.agents[0, :, 4].cpu().numpy().reshape(-1)
             truncated = self.step_count >= self.max_steps
-        else:                                     # the fused kernel rendered the post-action state in the same launch
-            obs, dirs, term, trunc = self._launched
-            truncated = bool(trunc[0])                                   # base.py:339
-        obs, dirs, term = obs[0].cpu().numpy(), dirs[0].cpu().numpy(), term.cpu().numpy().reshape(-1)
+        else:                                     # the fused kernel rendered the post-action state in the same launch; its outputs
+            host = self._launched                 # came over in handle_actions' ONE device-to-host copy
+            obs, dirs, term = host["obs"][0].copy(), host["dir"][0].copy(), host["terminated"][0].copy()
+            truncated = bool(host["truncated"][0])                       # base.py:339
         terminations = {i: bool(term[i]) for i in range(A)}              # base.py:338
         truncations = {i: truncated for i in range(A)}
-        if self._objects_at or self._objects_loose:
+        if self._objects_at or self._objects_loose or self._carried:
             self._refresh_objects()
         return self._obs_dict(obs, dirs), rewards, terminations, truncations, defaultdict(dict)
 
@@ -682,21 +719,47 @@ class MultiGridEnv:
             # order decides who is visited first when two agents toggle the same door in one step
             order = keys + [i for i in range(A) if i not in keys]        # (absent agents carry NO_ACTION: skipped anyway)
             hook_order = torch.tensor([order], dtype=torch.uint8).to(benv.device)
-        benv.step_count -= 1                      # (the kernel's own `step_count += 1` is the one `step` has already done)
-        obs, dirs, rew, term, trunc = benv.step(torch.from_numpy(act).to(benv.device), hook_order=hook_order)
-        try:
-            benv.check_errors()
-        except ValueError:
+        if getattr(self, "_count_advanced", False):
+            benv.step_count -= 1                  # (the kernel's own `step_count += 1` is the one `step` has already done)
+            self._count_advanced = False
+        benv.step(torch.from_numpy(act).to(benv.device), hook_order=hook_order)
+        host = benv.outputs_to_host()             # ONE copy: reward, obs, dir, terminated, truncated, the error words
+        if int(host["err"][0]):
+            benv._reset_err()
             bad = [int(a) for a in actions.values() if not 0 <= int(a) <= int(Action.done)]
-            raise ValueError(f"Unknown action: {bad[0] if bad else '?'}") from None   # base.py:473-474
-        self._launched = (obs, dirs, term[0], trunc)
-        rew = rew[0].cpu().numpy()
+            raise ValueError(f"Unknown action: {bad[0] if bad else '?'}")          # base.py:473-474
+        self._launched = host
+        rew = host["reward"][0]
         return {i: (float(rew[i]) if rew[i] != 0 else 0) for i in range(A)}       # int 0 unless rewarded (base.py:393)
 
     def _refresh_objects(self, scan: bool = True):
         """After a step: the objects the layout placed follow what the kernel did to their cells (a door's state, a box's content,
         an object picked up or dropped), so that a `step` override reads them as the reference's hook reads its objects."""
         cells = self.grid._cells()
+        # who picked up / put down what since the last look: an agent whose hands filled took the object of the cell in front of it
+        # (pickup leaves the agent where it stood, base.py:436-447), one whose hands emptied left its object there (base.py:449-462)
+        rows = layouts.unpack_agents(self._benv.agents[0].cpu().numpy())
+        now = rows[:, 6:9].copy()
+        now[:, 2] &= 3
+        seen = self._carry_seen if self._carry_seen is not None else np.tile(np.array([1, 0, 0]), (self.num_agents, 1))
+        for i in range(self.num_agents):
+            had, has = int(seen[i, 0]) != int(Type.empty), int(now[i, 0]) != int(Type.empty)
+            if had == has and (not has or tuple(seen[i, :2]) == tuple(now[i, :2])):
+                continue
+            dx, dy = DIR_TO_VEC[int(rows[i, 2]) & 3]
+            front = (int(rows[i, 3] + dx), int(rows[i, 4] + dy))
+            if had:                                                      # put down (or swapped by a user hook): it lies in front
+                obj = self._carried.pop(i, None)
+                if obj is not None and not has and tuple(int(v) for v in cells[front][:2]) == (int(obj.type), int(obj.color)):
+                    self._adopt(obj, front)
+            if has:                                                      # picked up: the object that lay in front, if known
+                obj = self._objects_at.get(front)
+                if obj is not None and (int(obj.type), int(obj.color)) == (int(now[i, 0]), int(now[i, 1])) \
+                        and int(cells[front][0]) != int(obj.type):
+                    del self._objects_at[front]
+                    obj.cur_pos = None
+                    self._carried[i] = obj
+        self._carry_seen = now
         for pos, obj in list(self._objects_at.items()):
             cell = [int(v) for v in cells[pos]]
             if (cell[0], cell[1]) == (int(obj.type), int(obj.color)):

@@ -202,8 +202,36 @@ def define(ns):
                     self.on_success(agent, reward, terminated)
             return obs, reward, terminated, truncated, info
 
+    class TwinBallsEnv(ns.MultiGridEnv):
+        """Two balls that LOOK alike -- same type, same colour -- of which only one counts: `agent.state.carrying == self.prize` is an
+        identity test (multigrid/core/world_object.py:126-127), so when both agents hold a purple ball at the same time exactly one of
+        them has succeeded.  Agent 0 starts in front of the twin, agent 1 in front of the prize; success mode 'all', so the other agent
+        plays on -- putting its ball down, picking either one up again."""
+
+        def __init__(self, size=7, **kwargs):
+            super().__init__(mission_space="fetch the right purple ball", grid_size=size, max_steps=4 * size * size,
+                             success_termination_mode="all", **kwargs)
+
+        def _gen_grid(self, width, height):
+            self.grid = ns.Grid(width, height)
+            self.grid.wall_rect(0, 0, width, height)
+            self.twin, self.prize = ns.Ball(ns.Color.purple), ns.Ball(ns.Color.purple)
+            self.put_obj(self.twin, 1, 2)
+            self.put_obj(self.prize, 3, 2)
+            self.place_obj(ns.Ball(ns.Color.purple), top=(1, 3), size=(width - 2, height - 4))      # a third look-alike, somewhere
+            for agent in self.agents:
+                agent.state.pos = (1 + 2 * agent.index, 1)
+                agent.state.dir = ns.Direction.down
+
+        def step(self, actions):
+            obs, reward, terminated, truncated, info = super().step(actions)
+            for agent in self.agents:
+                if agent.state.carrying == self.prize:
+                    self.on_success(agent, reward, terminated)
+            return obs, reward, terminated, truncated, info
+
     return {"TwoRoomsEnv": TwoRoomsEnv, "ScatterEnv": ScatterEnv, "BoxTreasureEnv": BoxTreasureEnv, "FetchTrapEnv": FetchTrapEnv,
-            "VaultRoomsEnv": VaultRoomsEnv}
+            "VaultRoomsEnv": VaultRoomsEnv, "TwinBallsEnv": TwinBallsEnv}
 
 
 def intervene(cname, env, t):
@@ -228,6 +256,13 @@ def intervene(cname, env, t):
                 agent.state.dir = d
                 return {0: 3}                                                   # Action.pickup
         raise AssertionError("no free cell next to the vault")
+    if cname == "TwinBallsEnv":
+        # step 0: both agents pick up the ball in front of them -- agent 0 the twin, agent 1 the prize; from step 12 on agent 1 (the
+        # one that is done) is left out of the dict while agent 0 swaps balls around: the actions as drawn
+        if t == 0:
+            return {0: 3, 1: 3}
+        if t in (3, 4, 5):                                                      # agent 0: put the twin down, turn away and back
+            return {0: (4, 0, 1)[t - 3]}
     return None
 
 
@@ -253,6 +288,8 @@ STEP_CASES = {
 }
 STEP_CASES_R6 = {
     "customsteps_vaultrooms_a2": ("VaultRoomsEnv", dict(room_size=5, agents=2, joint_reward=True), 150),
+    "customsteps_twinballs_a2": ("TwinBallsEnv", dict(size=7, agents=2), 70),
+    "customsteps_twinballs_a3_joint": ("TwinBallsEnv", dict(size=9, agents=3, joint_reward=True), 90),
 }
 ALL_CASES = {**CASES, **CASES_R6}
 ALL_STEP_CASES = {**STEP_CASES, **STEP_CASES_R6}

@@ -88,6 +88,14 @@ CASES = [
      dict(kind="lockedhallway", room_size=6, max_hallway_keys=2, max_keys_per_room=3), 600),
     ("playground_3x3_a3", EnvSpec(19, 19, 3, 7, max_steps=5), dict(kind="playground", room_size=7), 1000),
     ("playground_2x3_rs6_a2", EnvSpec(16, 11, 2, 5, max_steps=4), dict(kind="playground", room_size=6), 400),
+    # rooms that are exactly FULL (round 6): the rejection sampling still ends, as in the reference
+    ("bup_rs4_a2_full", EnvSpec(7, 4, 2, 3, max_steps=4, joint_reward=True, env_kind="blockedunlockpickup"),
+     dict(kind="blockedunlockpickup", room_size=4), 300),
+    ("bup_rs5_a7_full", EnvSpec(9, 5, 7, 3, max_steps=4, joint_reward=True, env_kind="blockedunlockpickup"),
+     dict(kind="blockedunlockpickup", room_size=5), 200),
+    ("empty_random_4_a3_full", EnvSpec(4, 4, 3, 3, max_steps=3), dict(kind="empty_random"), 300),
+    ("rbd_4_a4_full", EnvSpec(8, 4, 4, 3, max_steps=3, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors"),
+     dict(kind="redbluedoors"), 300),
 ]
 
 
@@ -518,20 +526,30 @@ def test_generators_refuse_layouts_without_room_to_spare():
     from multigrid_amd import _lib
     L = _lib.lib()
 
-    def rc_of(spec, kind, room_size=0, max_hallway_keys=1, max_keys_per_room=2):
+    def rc_of(spec, kind, room_size=0, max_hallway_keys=1, max_keys_per_room=2, aux=4096):
         sc = spec.to_c()
         g = _lib.MgxLayoutGen(_lib.GEN_KINDS[kind], room_size, 1, 1, 0, max_hallway_keys, max_keys_per_room, 4096, 4096)
         fake = 4096                                              # (aligned, never dereferenced: the checks come first)
-        return L.mgx_reset_generate(C.byref(sc), 8, C.byref(g), fake, fake, fake, fake, fake, fake, None, None)
+        return L.mgx_reset_generate(C.byref(sc), 8, C.byref(g), fake, fake, fake, fake, aux, fake, None, None)
 
     bup = lambda rs, A: EnvSpec(2 * rs - 1, rs, A, 7, max_steps=9, joint_reward=True, env_kind="blockedunlockpickup")
-    assert rc_of(bup(4, 2), "blockedunlockpickup", 4) == _lib.ERR_UNSUPPORTED        # 2x2 room: key + ball + 2 agents + nothing spare
-    assert rc_of(bup(5, 7), "blockedunlockpickup", 5) == _lib.ERR_UNSUPPORTED
+    rbd = lambda A: EnvSpec(8, 4, A, 3, max_steps=9, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors")
+    lh = lambda rows, A: EnvSpec(10, 3 * rows + 1, A, 3, max_steps=9, joint_reward=True, env_kind="lockedhallway")
+    assert rc_of(bup(4, 3), "blockedunlockpickup", 4) == _lib.ERR_UNSUPPORTED        # 2x2 room: key + ball + 3 agents do not fit
+    assert rc_of(bup(5, 8), "blockedunlockpickup", 5) == _lib.ERR_UNSUPPORTED
     assert rc_of(EnvSpec(9, 9, 4, 7, max_steps=9), "playground", 5) == _lib.ERR_UNSUPPORTED      # 12 objects may draw one 3x3 room
     assert rc_of(EnvSpec(11, 11, 4, 7, max_steps=9), "playground", 6) == _lib.ERR_UNSUPPORTED
     assert rc_of(EnvSpec(4, 4, 4, 3, max_steps=9), "empty_random") == _lib.ERR_UNSUPPORTED        # 2x2 interior: goal + 4 agents
-    assert rc_of(EnvSpec(8, 4, 4, 3, max_steps=9, joint_reward=True, failure_termination_mode="any", env_kind="redbluedoors"),
-                 "redbluedoors") == _lib.ERR_UNSUPPORTED                                          # a 2x2 middle room for 4 agents
+    assert rc_of(rbd(5), "redbluedoors") == _lib.ERR_UNSUPPORTED                                  # a 2x2 middle room for 5 agents
+    assert rc_of(lh(1, 4), "lockedhallway", 4, 1, 2) == _lib.ERR_UNSUPPORTED                      # a 2x2 hallway: a key + 4 agents
+    assert rc_of(lh(2, 2), "lockedhallway", 4, 1, 5) == _lib.ERR_UNSUPPORTED                      # 5 keys into a 2x2 room
+    assert rc_of(lh(4, 2), "lockedhallway", 4, 1, 3) == _lib.ERR_UNSUPPORTED                      # 8 rooms: a colour comes up twice
+    # ... and a room that is exactly full is NOT refused: the feasibility check passes, and the call then stops at the argument test
+    # behind it -- a hook env without its `aux` -- before any launch (Empty-Random's exact fit: the GPU case `empty_random_4_a3_full`)
+    for rc in (rc_of(bup(4, 2), "blockedunlockpickup", 4, aux=None), rc_of(bup(5, 7), "blockedunlockpickup", 5, aux=None),
+               rc_of(rbd(4), "redbluedoors", aux=None), rc_of(lh(1, 3), "lockedhallway", 4, 1, 2, aux=None),
+               rc_of(lh(2, 2), "lockedhallway", 4, 1, 4, aux=None)):
+        assert rc == _lib.ERR_INVALID_ARGUMENT
 
 
 def test_oracle_shuffle_equals_numpy():

@@ -113,14 +113,17 @@ def test_resident_persistent_equals_repeated_steps(monkeypatch, ns, B):
 
 
 def test_c4_full_size_rollout_vs_oracle():
-    """BASELINE.json configs[3] at its full size through ONE launch of the two-slice resident kernel (what the library picks at this
-    batch by itself), auto-reset fused in, against the CPU oracle: every output of every step, the state afterwards."""
+    """BASELINE.json configs[3] at its full size through ONE launch of the resident kernel the library picks at this batch by itself
+    (one slice of 16 envs per wavefront, 64 view slots: 4096 wavefronts), auto-reset fused in, against the CPU oracle: every output of
+    every step, the state afterwards."""
     wl = workloads.make("c4")
     spec, B, A, T = wl.spec, wl.batch, wl.spec.num_agents, 16
     assert B == 65536
     env = wl.make_env(DEV, auto_reset=True)
     info = _lib.launch_info(spec, B, roll=True)
-    assert info["slices"] == 2 and info["envs_per_wavefront"] == 32 and info["workgroups"] * info["threads_per_workgroup"] // 64 == 2048
+    assert info["resident_shape"] == 7 and info["slices"] == 1 and info["envs_per_wavefront"] == 16 and info["wavefronts"] == 4096
+    info = _lib.launch_info(spec, B, persistent=True)            # (the closed-loop form must hold everything at once: two slices)
+    assert info["resident_shape"] == 8 and info["slices"] == 2 and info["envs_per_wavefront"] == 32 and info["wavefronts"] == 2048
     env.step_count.fill_(spec.max_steps - T // 2)
     ref = dict(grid=wl.grid.copy(), agents=wl.agents.copy(), rng=wl.rng.copy(),
                step_count=np.full(B, spec.max_steps - T // 2, np.int32), aux=None)
@@ -163,12 +166,18 @@ def test_c4_full_size_persistent_closed_loop():
     for t in range(T):
         want.append([x.clone() for x in e_ref.step(a[t], auto_reset=True)] + [e_ref.was_reset.clone()])
     torch.cuda.synchronize()
+    # (copies run beside the launch; a comparison is a REDUCTION, which wants LDS and would wait for the resident launch to end, and a
+    # fresh allocation may wait for the device: the buffers are made before the session opens, the outputs compared after it closes)
+    got = [[torch.empty_like(w) for w in want[t]] for t in range(T)]
+    torch.cuda.synchronize()
     with e_per.persistent(max_steps=T, auto_reset=True) as ps:
         assert ps.waves == 2048
         for t in range(T):
-            got = list(ps.step(a[t])) + [e_per.was_reset]
-            for n, w, g in zip(("obs", "dir", "reward", "terminated", "truncated", "was_reset"), want[t], got):
-                assert torch.equal(w, g), f"step {t}: {n}"
+            for dst, src in zip(got[t], list(ps.step(a[t])) + [e_per.was_reset]):
+                dst.copy_(src)
     assert ps.timeouts == 0 and ps.steps_completed == T
+    for t in range(T):
+        for n, w, g in zip(("obs", "dir", "reward", "terminated", "truncated", "was_reset"), want[t], got[t]):
+            assert torch.equal(w, g), f"step {t}: {n}"
     for n in ("cells", "agents", "rng", "step_count", "episode"):
         assert torch.equal(getattr(e_ref, n), getattr(e_per, n)), n
