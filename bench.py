@@ -268,6 +268,30 @@ def config_point(name, device, K, warmup, device_generated=False, steady=False, 
     return out
 
 
+def one_hot_config_point(name, device, cell_bytes=None, T=128):
+    """A configuration stepped with ONE-HOT observations (u8[B,A,v,v,21], written by the step's own launch) -- what RLlib's default
+    registration of the reference feeds the policy (multigrid/rllib/__init__.py:110-111) -- as hipGraph replays, fused auto-reset.
+    `cell_bytes`: the grid format (round 6: compact cells serve this step too)."""
+    wl = workloads.make(name, cell_bytes=cell_bytes)
+    env = wl.make_env(device, auto_reset=AUTO_RESET)
+    B, A = wl.batch, wl.spec.num_agents
+    acts = random_actions(T, B, A, device, 4321)
+    for t in range(30):
+        env.step(acts[t], auto_reset=AUTO_RESET, one_hot=True)
+    g = env.capture_steps(acts, auto_reset=AUTO_RESET, one_hot=True)
+    g.replay()
+    ms = kernel_time_ms(g.replay, 3, device, warm=1) / T
+    env.check_errors()
+    v2 = wl.spec.view_size ** 2
+    algo = B * A * (wl.spec.bytes_step() + 18 * v2)            # the step's bytes with a 21-byte instead of a 3-byte observation cell
+    out = {"workload": wl.title, "batch": B, "cell_bytes": wl.spec.cell_bytes, "ms_per_step": round(ms, 6),
+           "value": round(B * A / (ms * 1e-3)), "unit": "agent-steps/s", "timed_steps": 3 * T,
+           "algorithmic_bytes": algo, "frac": round(algo / (ms * 1e-3) / 8e12, 4), "launch": env.backend.launch_info(B)}
+    del env, g
+    torch.cuda.empty_cache()
+    return out
+
+
 def eager_point(wl, device, steps=2000, sub_shards=1):
     """env.step called from Python once per step (what an RL loop that cannot capture its policy pays).
     sub_shards="auto": the eager sub-shard form (mgx_step_chains on the env's side streams, joined once at the end)."""
@@ -389,11 +413,13 @@ def generation_point(device, batch=1 << 18):
             "note": "BlockedUnlockPickup 11x6, 2 agents: one lane per env runs the reference's _gen_grid on the device"}
 
 
-def rollout_point(wl, device, steps):
+def rollout_point(wl, device, steps, obs_budget=1 << 30):
     """`steps` steps as ONE mgx_rollout launch (env state stays in LDS between steps).  Open-loop actions only."""
     env = wl.make_env(device, auto_reset=AUTO_RESET)
     spec, batch = wl.spec, wl.batch
-    steps = max(2, min(steps, (1 << 30) // max(1, batch * spec.num_agents * spec.view_size ** 2 * 3)))   # obs[T] <= 1 GiB
+    steps = max(2, min(steps, obs_budget // max(1, batch * spec.num_agents * spec.view_size ** 2 * 3)))   # obs[T] <= 1 GiB by default
+    for t, a in enumerate(random_actions(60, batch, spec.num_agents, device, 99)):      # (leave the cold start: every agent on one cell)
+        env.step(a, auto_reset=AUTO_RESET)
     acts = random_actions(steps, batch, spec.num_agents, device, 1234)
     out = env.rollout(acts[:2].contiguous(), auto_reset=AUTO_RESET)   # warm-up + allocation pattern
     A, v = spec.num_agents, spec.view_size
@@ -416,9 +442,12 @@ def rollout_point(wl, device, steps):
     wall = time.perf_counter() - t0
     env.check_errors()
     n = batch * A * steps
+    from multigrid_amd import _lib
     res = {"workload": wl.name, "batch": batch, "value": round(n / wall), "unit": "agent-steps/s", "steps": steps,
            "launches": 1, "ms_per_step": round(wall * 1e3 / steps, 6),
            "event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 6),
+           "launch": _lib.launch_info(spec, batch, roll=True),
+           "frac_of_hbm_peak_at_the_step_kernels_bytes": round(batch * spec.num_agents * spec.bytes_step() / (ev0.elapsed_time(ev1) / steps * 1e-3) / 8e12, 4),
            "note": "mgx_rollout: the steps in one launch, bit-identical to that many mgx_step calls "
                    "(tests/test_hip_parity.py); valid for open-loop action sequences such as this benchmark's random actions"}
     del env, out
@@ -794,6 +823,12 @@ def main():
                 out["configs"]["c1"] = {"error": repr(e)[:200]}
             if name != "c5":      # C5 is stepped on COMPACT cells (include/mgx.h: MgxCell8); the same workload on the 16-bit cells beside it
                 out["configs"]["c5_wide_cells"] = config_point("c5", device, 256, 50, cell_bytes=2)
+            # (round 6) C5 with one-hot observations -- the reference's default RL path -- on compact and on 16-bit cells
+            for key, cb in (("c5_one_hot", None), ("c5_one_hot_wide_cells", 2)):
+                try:
+                    out["configs"][key] = one_hot_config_point("c5", device, cell_bytes=cb)
+                except Exception as e:
+                    out["configs"][key] = {"error": repr(e)[:200]}
             out["configs"]["c3_device_generated"] = config_point("c3", device, 256, 50, device_generated=True)
             out["configs"]["c3_device_generated_steady"] = config_point("c3", device, 256, 50, device_generated=True, steady=True)
             out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}
@@ -801,13 +836,18 @@ def main():
             out["eager"]["c4_chains"] = eager_point(workloads.make("c4"), device, sub_shards=2)
             out["eager"]["c4_chains"]["auto_eager"] = 1
             out["fused_rollout"] = rollout_point(workloads.make("c2"), device, 1000)
+            # (round 6) the RESIDENT form of C4's shape: 64 view slots per wavefront, the envs' tiles in LDS for the whole launch -- at
+            # the largest batch that is resident in one round (49152 envs, 12 wavefronts per CU) and at C4's own 65536 (1.33 rounds)
+            out["fused_rollout_c4"] = {str(b): rollout_point(workloads.make("c4", batch=b, global_batch=65536), device, 96, obs_budget=4 << 30)
+                                       for b in (49152, 65536)}
             out.update(large_batch_points(device, args.large_batch))
             out["device_generation"] = generation_point(device)
             out["roofline"]["hbm_resident"] = {k: out["roofline_large"][k] for k in ("batch", "frac", "achieved", "ms_per_launch")}
             out["persistent"] = {}
-            for pname, pbase, pbatch in (("c2", "c2", 4096), ("c4_share8", "c4", 8192), ("c3", "c3", 16384)):
+            # (c4: round 6 -- the whole configuration resident, two slices of 16 envs per wavefront; the launch owns every CU's LDS)
+            for pname, pbase, pbatch in (("c2", "c2", 4096), ("c4_share8", "c4", 8192), ("c3", "c3", 16384), ("c4", "c4", 65536)):
                 try:
-                    out["persistent"][pname] = persistent_point(pname, pbase, pbatch, device)
+                    out["persistent"][pname] = persistent_point(pname, pbase, pbatch, device, T=200 if pbatch > 16384 else 400)
                 except Exception as e:                     # (a hand-shake that timed out must not take the bench line down)
                     out["persistent"][pname] = {"error": repr(e)[:200]}
             out["byte_grid_overhead"] = byte_grid_overhead(workloads.make("c4"), device)

@@ -560,7 +560,8 @@ int mgx_shape_register(const MgxShapeKey *key, const void *code_object, size_t b
  * the step during which ctrl[0] became non-zero (stop request), or when a wavefront has waited `timeout_ms` for its granules
  * (ctrl[1] counts those: the producer went away).  Every wait in these kernels is bounded by `timeout_ms`.
  *   ctrl u32[8], zeroed by the caller except [3] = UINT32_MAX: [0] in: stop request; [1] out: wavefronts (or waiters) that timed
- *        out; [2] out: wavefronts that have left; [3] out: min over them of the steps they completed
+ *        out; [2] out: wavefronts that have left; [3] out: min over them of the steps they completed; [4] a waiter of the
+ *        hand-shake kernels timed out (shared by their wavefronts in place of LDS, which a chip-filling launch leaves none of)
  *   done u32[waves], zeroed by the caller
  * Options of `args`: auto_reset (layout pool) yes; one_hot, generate, hook_order no (MGX_ERR_UNSUPPORTED); steps is ignored.
  * Every wavefront of the launch must be resident at once: MGX_ERR_UNSUPPORTED when (spec, batch) needs more workgroups than the

@@ -355,6 +355,10 @@ class BatchedMultiGridEnv:
         self._need_state()
         self.join()
         if one_hot:
+            if self.spec.cell_bytes == 1:          # compact cells: the one-hot STEP is one launch (round 6); the observation of a
+                self.backend.gen_obs(self.batch, self.cells, self.agents, self.obs, self.dir)      # reset is two: gen_obs, then
+                self.backend.one_hot(self.obs, self._one_hot_buffer())                             # the one-hot kernel over it
+                return self._one_hot, self.dir
             self._need_wide_cells("one-hot output")
             self.backend.gen_obs(self.batch, self.cells, self.agents, self._one_hot_buffer(), self.dir, one_hot=True)
             return self._one_hot, self.dir
@@ -415,8 +419,8 @@ class BatchedMultiGridEnv:
         if hook_order is not None and (hook_order.dtype is not torch.uint8 or hook_order.shape != self._act_shape
                                        or hook_order.device != self.cells.device or not hook_order.is_contiguous()):
             raise ValueError(f"hook_order must be a contiguous uint8 tensor of shape {tuple(self._act_shape)} on {self.cells.device}")
-        if one_hot:
-            self._need_wide_cells("one-hot output")
+        if one_hot and not (self.spec.cell_bytes == 1 and self.spec.env_kind == "empty"):
+            self._need_wide_cells("one-hot output")        # (compact cells: the hook-free step has a one-hot instantiation, round 6)
         generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
         if generate:
             # on-device generation: the envs whose episode ends with THIS step are regenerated right after it (in the tail
@@ -429,6 +433,8 @@ class BatchedMultiGridEnv:
         if self._chains_pending and P != self._chains_P:       # (another cut of the batch over other streams: join the old chains)
             self.join()
         key = (bool(auto_reset), bool(one_hot), generate, P)
+        if one_hot:
+            self._one_hot_buffer()
         fast = self._bound.get(key)
         if fast is None:
             fast = self._bind_step(*key)
@@ -899,7 +905,8 @@ class BatchedMultiGridEnv:
             raise RuntimeError(f"{what}: a persistent session is open -- the env state lives in its launch until it is closed")
 
     def _need_wide_cells(self, what: str):
-        """Rollouts, one-hot output, device-side generation and persistent stepping are compiled for the 16-bit cells only."""
+        """Rollouts, device-side generation, persistent stepping -- and one-hot output on byte grids or with env hooks -- are compiled
+        for the 16-bit cells only."""
         if self.spec.compact:
             raise NotImplementedError(f"{what} is not available on compact cells / byte grids (EnvSpec.cell_bytes = 1 or 3: step / "
                                       f"gen_obs / auto-reset from a layout pool / full_obs); build the env with cell_bytes = 2 for it")

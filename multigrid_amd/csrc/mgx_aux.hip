@@ -390,7 +390,9 @@ __device__ __forceinline__ void copy_layouts(int n, int units, uint32_t inv_unit
     } else {                                                      // small layouts: (env, vector) pairs flattened over the lanes
         const int total = n * units;
         for (int k = lane; k < total; k += 64) {
-            const int j = (int)__umulhi((uint32_t)k, inv_units), v = k - j * units;      // k / units, k < 4096
+            // k / units, k < 4096 (units == 1 -- one agent: ceil(2^32 / 1) does not fit the 32-bit reciprocal, which arrived as 0 and
+            // sent every finished env's row to the first one: found by tests/test_instantiations.py, round 6)
+            const int j = units == 1 ? k : (int)__umulhi((uint32_t)k, inv_units), v = k - j * units;
             const VecT *s = reinterpret_cast<const VecT *>(pool + (int64_t)l_lay[j] * env_bytes);
             VecT *d = reinterpret_cast<VecT *>(dstbase + (e0 + l_env[j]) * env_bytes);
             d[v] = s[v];
@@ -476,10 +478,10 @@ __global__ __launch_bounds__(256) void persistent_post_kernel(const int8_t *__re
 // all of done[0 .. waves) >= step?  One workgroup; returns false on timeout (uniform over the workgroup).  Every wavefront polls
 // its own share of the flags on its own (relaxed agent loads, one ballot per pass: no workgroup barrier inside the loop -- it
 // would add its ~0.2 us to every pass, i.e. to the latency of the hand-off); ONE barrier when all have seen theirs.
-__device__ __forceinline__ bool wait_all_done(const uint32_t *done, int waves, uint32_t step, uint32_t timeout_ticks) {
-    __shared__ uint32_t s_fail;
-    if (threadIdx.x == 0) s_fail = 0;
-    __syncthreads();
+// NO LDS (round 6): a persistent launch that holds the whole chip -- C4's 65536 envs, 8 wavefronts x 20112 bytes per CU -- leaves no
+// LDS granule free, and a kernel that asks for four bytes of it would wait for that launch to end.  The "somebody timed out" word
+// the wavefronts of the workgroup share is `fail` = ctrl[4] in memory instead: sticky, which is what a dead hand-shake is.
+__device__ __forceinline__ bool wait_all_done(const uint32_t *done, int waves, uint32_t step, uint32_t timeout_ticks, uint32_t *fail) {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(done, waves * 4);
     const int stride = (int)blockDim.x;
@@ -495,22 +497,20 @@ __device__ __forceinline__ bool wait_all_done(const uint32_t *done, int waves, u
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         if ((spin & 31u) == 0) {
             const bool late = __builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)timeout_ticks;
-            if (late || __hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
-                __hip_atomic_store(&s_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (late || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
         __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
-    const bool good = __hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
-    __syncthreads();                                  // (s_fail is reset by the next call)
-    return good;
+    return __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
 __global__ __launch_bounds__(256) void persistent_wait_kernel(const uint32_t *done, int waves, uint32_t step, uint32_t *ctrl,
                                                               uint32_t timeout_ticks) {
-    if (!wait_all_done(done, waves, step, timeout_ticks) && threadIdx.x == 0) atomicAdd(ctrl + 1, 1u);
+    if (!wait_all_done(done, waves, step, timeout_ticks, ctrl + 4) && threadIdx.x == 0) atomicAdd(ctrl + 1, 1u);
 }
 
 // The recorded sequence's next step is known while the current one runs: its action bytes are fetched into registers behind the
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int
     fetch(0);
     for (int t = 0; t < T; ++t) {
         // the outputs of step t (counted from 1) complete?  (nothing to wait for before the first post)
-        if (t > 0 && !wait_all_done(done, waves, (uint32_t)t, timeout_ticks)) {
+        if (t > 0 && !wait_all_done(done, waves, (uint32_t)t, timeout_ticks, ctrl + 4)) {
             if (threadIdx.x == 0 && lead) { atomicAdd(ctrl + 1, 1u); __hip_atomic_store(ctrl + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             return;
         }
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kFeedThreads) void persistent_feed_kernel(const int
     }
     // (the last step's outputs: so that "the feed kernel has ended" means "the rollout is complete")
     if (!lead) return;
-    if (!wait_all_done(done, waves, (uint32_t)T, timeout_ticks) && threadIdx.x == 0) atomicAdd(ctrl + 1, 1u);
+    if (!wait_all_done(done, waves, (uint32_t)T, timeout_ticks, ctrl + 4) && threadIdx.x == 0) atomicAdd(ctrl + 1, 1u);
     if (trace && threadIdx.x == 0) trace[2 * T] = __builtin_amdgcn_s_memrealtime();
 }
 

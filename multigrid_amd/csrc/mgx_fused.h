@@ -541,6 +541,12 @@ __device__ __forceinline__ uint32_t gather_read(uint32_t addr) {
     if constexpr (C8) return (uint32_t)(int32_t)*(lds_i8_ptr)(uintptr_t)addr;
     else return (uint32_t)*(lds_u16_ptr)(uintptr_t)addr;
 }
+// (type, color, state) -> the 21-bit one-hot mask of OneHotObsWrapper (bit type | bit 11 + color | bit 17 + state, dims (11, 6, 4):
+// multigrid/wrappers.py:139-140, 158-190); out-of-range values set no bit, as mgx_one_hot
+__device__ __forceinline__ uint32_t one_hot_mask21(uint32_t c) {
+    const uint32_t p0 = min(c & 0xffu, 31u), p1 = min((c >> 8) & 0xffu, 31u), p2 = min((c >> 16) & 0xffu, 31u);
+    return ((1u << p0) & 0x7ffu) | (((1u << p1) & 0x3fu) << 11) | (((1u << p2) & 0xfu) << 17);
+}
 // compact cells: byte -> (type, color, state) through the wavefront's decode table (LdsCarve::lut; lut_mid = the LDS address of
 // entry 0, entries -128..127 around it)
 __device__ __forceinline__ uint32_t lut_decode(uint32_t raw, uint32_t lut_mid) {
@@ -848,29 +854,37 @@ const JitShape *jit_shape_lookup(const KernelArgs &ka, bool hooks);
 // Compact cells (C8): the plain step / gen_obs of the throughput and streamed families -- hooks and auto-reset included, no one-hot,
 // generation, rollout or latency (LDS-DMA) instantiation: fill_args never asks for one on such a spec.
 // (... and, with C8 = false / B3 = true, the byte-grid family: the same set of kernels for MgxSpec.cell_bytes = 3)
-template <int V, int MODE, bool STREAM, bool C8 = true>
+template <int V, int MODE, bool STREAM, bool C8 = true, bool OH = false>
 inline int launch_compact(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
     constexpr bool B3 = !C8;
-    if constexpr (MODE > 1) {
+    if constexpr (MODE > 1 || (OH && (MODE != 1 || !C8))) {
         return MGX_ERR_UNSUPPORTED;
     } else {
-        if constexpr (!STREAM) {
-            if (ka.flags & 1) return launch_compact<V, MODE, true, C8>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+        if constexpr (!STREAM && C8) {    // (byte grids have no streamed family: a u8[B,H,W,3] tensor beyond the Infinity Cache is
+                                          // loaded with the default policy -- 35 instantiations nobody asked for, round 6)
+            if (ka.flags & 1) return launch_compact<V, MODE, true, C8, OH>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
         }
         if (ka.grp != kGroup || (ka.flags & 2) || (C8 && ka.vpw > 32)) return MGX_ERR_INVALID_ARGUMENT;     // (C8: 32 view slots: one decoded cell per register)
         void (*kern)(const KernelArgs) = nullptr;
         const bool hooks = MODE != 0 && ka.sp.env_kind != MGX_KIND_EMPTY;
         const bool ar = MODE != 0 && ka.pool_grid != nullptr;
         constexpr bool S = MODE != 0;
-        if constexpr (C8 && MODE == 1 && V == 9 && STREAM && !MGX_NO_FIXED_SHAPES) {
+        if constexpr (C8 && !OH && MODE == 1 && V == 9 && STREAM && !MGX_NO_FIXED_SHAPES) {
             if (match_fixed_shape(ka, hooks) == 5)
                 kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, true, false, kGroup, 5, true>
                           : mgx_fused_kernel<V, 1, false, false, false, false, true, false, kGroup, 5, true>;
         }
-        if constexpr (C8 && MODE == 1 && V == 9 && !STREAM && !MGX_NO_FIXED_SHAPES) {
+        if constexpr (C8 && !OH && MODE == 1 && V == 9 && !STREAM && !MGX_NO_FIXED_SHAPES) {
             if (match_fixed_shape(ka, hooks) == 6)
                 kern = ar ? mgx_fused_kernel<V, 1, false, true, false, false, false, false, kGroup, 6, true>
                           : mgx_fused_kernel<V, 1, false, false, false, false, false, false, kGroup, 6, true>;
+        }
+        if constexpr (OH) {
+            // compact cells, one-hot output (round 6): the hook-free step (big grids are Empty-style arenas; the hook envs are small
+            // and keep the 16-bit cells)
+            if (hooks) return MGX_ERR_UNSUPPORTED;
+            kern = ar ? mgx_fused_kernel<V, 1, false, true, true, false, STREAM, false, kGroup, 0, true, false>
+                      : mgx_fused_kernel<V, 1, false, false, true, false, STREAM, false, kGroup, 0, true, false>;
         }
         if (!kern) {
             // (the byte-grid gen_obs holds its conversion's staging registers: it takes the step kernels' entry point, without the
@@ -906,6 +920,9 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
         if constexpr (!OH && !GEN && !STREAM && !DMA && GRP == kGroup) {
             if (ka.sp.cell_bytes == 1) return launch_compact<V, MODE, false, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
             return launch_compact<V, MODE, false, false>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+        } else if constexpr (OH && MODE == 1 && !GEN && !STREAM && !DMA && GRP == kGroup) {
+            if (ka.sp.cell_bytes == 1) return launch_compact<V, MODE, false, true, true>(ka, threads, lds_bytes, nwg, stream, hip_err, occupancy);
+            return MGX_ERR_UNSUPPORTED;
         } else return MGX_ERR_UNSUPPORTED;
     }
     if constexpr (!STREAM && !DMA && MODE < 2 && !GEN) {    // (rollouts read the tile once per launch; GEN: small envs)

@@ -707,6 +707,11 @@ class MultiGridEnv:
         A = self.num_agents
         act = np.full((1, A), NO_ACTION, dtype=np.int8)
         keys = []
+        if not hasattr(actions, "items"):
+            # a sequence instead of a dict: the reference's loop reads `if i not in actions: continue; action = actions[i]`
+            # (base.py:402-406) -- for a list that is a test on the VALUES: agent i acts iff the number i is among them, and then takes
+            # actions[i].  `step([2, 2])` therefore moves nobody.
+            actions = {i: actions[i] for i in range(A) if i in actions}
         for i, a in actions.items():
             if isinstance(i, (int, np.integer)) and 0 <= i < A:          # other keys are never visited (base.py:402-404)
                 a = int(a)

@@ -57,9 +57,10 @@ class ImgObsWrapper(_ObservationWrapper):
         super().__init__(env)
         for agent in self.env.unwrapped.agents:
             agent.observation_space = agent.observation_space["image"]
+            agent.observation_space.dtype = np.uint8                 # wrappers.py:88-89
 
     def observation(self, obs):
-        return {agent_id: o["image"] for agent_id, o in obs.items()}
+        return {agent_id: o["image"].astype(np.uint8) for agent_id, o in obs.items()}          # wrappers.py:95-96
 
 
 class OneHotObsWrapper(_ObservationWrapper):

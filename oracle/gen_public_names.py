@@ -24,7 +24,29 @@ def public(cls, base=object):
     return sorted(n for n in dir(cls) if not n.startswith("_") and n not in inherited)
 
 
+from multigrid.core.roomgrid import Room, RoomGrid  # noqa: E402
+from multigrid.core.constants import Color, State, Type  # noqa: E402
+import multigrid.core.constants as _constants  # noqa: E402
+import multigrid.core.roomgrid as _roomgrid  # noqa: E402
+
+
+def module_names(mod):
+    """Public names a module DEFINES or re-exports from this package (not its third-party imports)."""
+    return sorted(n for n, v in vars(mod).items() if not n.startswith("_")
+                  and (getattr(v, "__module__", "") or "").startswith("multigrid") or n.isupper())
+
+
 names = {
+    # round 6: the room-grid base class, the indexed enums' API (utils/enum.py:42-89, core/constants.py:34-123)
+    "Room": public(Room),
+    "RoomGrid": public(RoomGrid, MultiGridEnv),
+    "IndexedEnum methods": sorted(n for n in vars(_constants.IndexedEnum) if not n.startswith("_")),
+    "Color methods": sorted(n for n, v in vars(Color).items() if not n.startswith("_") and not isinstance(v, Color)),
+    "Type": public(Type, str),
+    "Color": public(Color, str),
+    "State": public(State, str),
+    "module core.constants": module_names(_constants),
+    "module core.roomgrid": [n for n in module_names(_roomgrid) if n in ("Room", "RoomGrid", "bfs", "reject_next_to")],
     "MultiGridEnv": public(MultiGridEnv),
     "Agent": public(Agent),
     "AgentState": public(AgentState, np.ndarray),

@@ -60,8 +60,14 @@ def test_what_compact_cells_do_not_serve_is_refused_by_name():
     act = torch.zeros((4, 2), dtype=torch.int8)
     with pytest.raises(NotImplementedError, match="compact cells"):
         env.rollout(act[None])
+    oh, *_ = env.step(act, one_hot=True)                       # (round 6: the hook-free step writes one-hot observations on compact cells too)
+    assert tuple(oh.shape) == (4, 2, 7, 7, 21)
+    hooked = compact(EnvSpec(11, 6, 2, 7, max_steps=50, joint_reward=True, env_kind="blockedunlockpickup"))
+    henv = BatchedMultiGridEnv(hooked, 4, "cpu", backend=util.OracleBackend(hooked))
+    hst = util.random_state(hooked, 4, seed=2)
+    henv.load_state(hst["grid"], hst["agents"], hst["rng"], hst["target"], hst["step_count"])
     with pytest.raises(NotImplementedError, match="compact cells"):
-        env.step(act, one_hot=True)
+        henv.step(act, one_hot=True)                            # ... the hook envs (small grids) keep the 16-bit cells for it
     with pytest.raises(NotImplementedError, match="compact cells"):
         env.set_layout_generator("empty_fixed")
     with pytest.raises(NotImplementedError, match="compact cells"):
@@ -234,6 +240,66 @@ def test_c5_full_size_on_both_cell_formats_vs_oracle():
     wl2 = workloads.make("c5", cell_bytes=2)
     assert wl2.spec.cell_bytes == 2 and wl2.make_env(DEV).backend.launch_info(wl2.batch)["fixed_shape"] == 4
     run_vs_oracle(wl2, T=4, seed=56)
+
+
+OH_CASES = [c for c in CASES if c[1].env_kind == "empty"]
+
+
+@gpu
+@pytest.mark.parametrize("name,spec,B,T", OH_CASES, ids=[c[0] + "_one_hot" for c in OH_CASES])
+def test_compact_one_hot_step_vs_oracle(name, spec, B, T):
+    """Round 6: the step with ONE-HOT output on compact cells (the decode table holds the cells' one-hot masks) == the oracle's step
+    + OneHotObsWrapper.one_hot (multigrid/wrappers.py:158-190), every view size, and the state stays the compact one."""
+    sp = compact(spec)
+    st = util.random_state(sp, B, seed=zlib.crc32(name.encode()) % 10000, density=0.25)
+    env = BatchedMultiGridEnv(sp, B, DEV)
+    env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
+    ref = {k: v.copy() for k, v in st.items()}
+    sd = spec.as_dict()
+    o_ref, d_ref = ob.gen_obs_batch(sd, ref["grid"], ref["agents"], nthreads=8)
+    oh, dirs = env.gen_obs(one_hot=True)                       # (two launches on compact cells: gen_obs, one_hot)
+    np.testing.assert_array_equal(oh.cpu().numpy(), ob.one_hot(o_ref))
+    for t in range(min(T, 6)):
+        act = util.random_actions(B, spec.num_agents, seed=1000 + t)
+        o_ref, d_ref, r_ref, te_ref, tr_ref = ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act,
+                                                            ref["target"], nthreads=8)
+        oh, dirs, rew, term, trunc = env.step(torch.from_numpy(act).to(DEV), one_hot=True)
+        ctx = f"{name} step {t}"
+        assert oh.cpu().numpy().tobytes() == ob.one_hot(o_ref).tobytes(), ctx
+        np.testing.assert_array_equal(dirs.cpu().numpy(), d_ref, err_msg=ctx)
+        assert rew.cpu().numpy().tobytes() == r_ref.tobytes(), ctx
+        np.testing.assert_array_equal(term.cpu().numpy(), te_ref, err_msg=ctx)
+        np.testing.assert_array_equal(trunc.cpu().numpy(), tr_ref, err_msg=ctx)
+        np.testing.assert_array_equal(env.grid.cpu().numpy(), ref["grid"], err_msg=ctx)
+        np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"], err_msg=ctx)
+    env.check_errors()
+
+
+@gpu
+def test_c5_full_size_one_hot_with_auto_reset_compact_equals_wide_and_oracle():
+    """BASELINE.json configs[4] at its full size with one-hot output and the fused auto-reset -- the default RL path of the reference
+    (rllib/__init__.py:110-111 wraps every env in OneHotObsWrapper): compact cells == 16-bit cells == the oracle's step + one_hot."""
+    wl_c, wl_w = workloads.make("c5"), workloads.make("c5", cell_bytes=2)
+    assert wl_c.spec.cell_bytes == 1 and wl_c.batch == 32768
+    ec, ew = wl_c.make_env(DEV, auto_reset=True), wl_w.make_env(DEV, auto_reset=True)
+    B, A = wl_c.batch, wl_c.spec.num_agents
+    ref = dict(grid=wl_c.grid.copy(), agents=wl_c.agents.copy(), rng=wl_c.rng.copy(), step_count=np.zeros(B, np.int32), aux=None)
+    sd = wl_w.spec.as_dict()
+    r = np.random.default_rng(77)
+    for t in range(4):
+        act = r.integers(0, 7, size=(B, A)).astype(np.int8)
+        o_ref, d_ref, r_ref, te_ref, tr_ref = ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, None,
+                                                            nthreads=ob.max_threads())
+        a = torch.from_numpy(act).to(DEV)
+        oc = ec.step(a, auto_reset=True, one_hot=True)
+        ow = ew.step(a, auto_reset=True, one_hot=True)
+        for n, x, y in zip(("one_hot", "dir", "reward", "terminated", "truncated"), oc, ow):
+            assert torch.equal(x, y), f"step {t}: {n} (compact vs 16-bit cells)"
+        assert oc[0].cpu().numpy().tobytes() == ob.one_hot(o_ref).tobytes(), f"step {t}: one-hot obs vs oracle"
+        assert oc[2].cpu().numpy().tobytes() == r_ref.tobytes()
+        np.testing.assert_array_equal(ec.grid.cpu().numpy(), ref["grid"])
+        np.testing.assert_array_equal(ec.agents.cpu().numpy(), ref["agents"])
+    ec.check_errors(); ew.check_errors()
 
 
 # ---------------------------------------------------------------------------------------------------- byte grids (cell_bytes = 3)

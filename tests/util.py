@@ -172,7 +172,7 @@ class OracleBackend:
             dirs.copy_(torch.from_numpy(d))
 
     def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated,
-             hook_order=None):
+             hook_order=None, one_hot: bool = False):
         g3 = self._g3(grid)
         try:
             o, d, r, te, tr = ob.step_batch(
@@ -184,7 +184,7 @@ class OracleBackend:
             err[1] = 0
             return
         self._store(grid, g3)
-        obs.copy_(torch.from_numpy(o)); dirs.copy_(torch.from_numpy(d)); reward.copy_(torch.from_numpy(r))
+        obs.copy_(torch.from_numpy(ob.one_hot(o) if one_hot else o)); dirs.copy_(torch.from_numpy(d)); reward.copy_(torch.from_numpy(r))
         terminated.copy_(torch.from_numpy(te)); truncated.copy_(torch.from_numpy(tr))
 
     def rollout(self, B, T, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated,
