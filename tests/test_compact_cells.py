@@ -286,8 +286,11 @@ def test_c5_full_size_one_hot_with_auto_reset_compact_equals_wide_and_oracle():
     ref = dict(grid=wl_c.grid.copy(), agents=wl_c.agents.copy(), rng=wl_c.rng.copy(), step_count=np.zeros(B, np.int32), aux=None)
     sd = wl_w.spec.as_dict()
     r = np.random.default_rng(77)
+    from tests.test_full_size import oracle_reset_done
+    episode = np.zeros(B, np.int32)
     for t in range(4):
         act = r.integers(0, 7, size=(B, A)).astype(np.int8)
+        oracle_reset_done(wl_w, ref, episode)                   # (the fused auto-reset, from its definition: include/mgx.h)
         o_ref, d_ref, r_ref, te_ref, tr_ref = ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], act, None,
                                                             nthreads=ob.max_threads())
         a = torch.from_numpy(act).to(DEV)

@@ -286,34 +286,65 @@ def test_shape_specialised_kernels_with_and_without_auto_reset(name, B, cb, shap
         _check_state(hip, refs, idx, f"shape {shape} ar={ar}")
 
 
-def test_resident_shapes_without_auto_reset(monkeypatch):
-    """kShapes 7 / 8 of the rollout and the persistent launch without the fused auto-reset (tests/test_resident.py runs them with)."""
-    spec = EnvSpec(16, 16, 4, 7, max_steps=1024)
+def test_resident_shapes_of_the_persistent_launch_with_and_without_auto_reset(monkeypatch):
+    """kShapes 7 / 8 of the persistent launch, forced at a small batch, x auto-reset (tests/test_resident.py: the rollouts, the full size)."""
+    spec = EnvSpec(16, 16, 4, 7, max_steps=40)
     for ns in (1, 2):
-        B, T = 80, 3
-        st = util.random_state(spec, B, seed=9 + ns)
-        envs = []
-        for dev, be in ((DEV, None), ("cpu", util.OracleBackend(spec))):
-            e = BatchedMultiGridEnv(spec, B, dev, backend=be)
-            e.load_state(st["grid"], st["agents"], st["rng"], None, st["step_count"], validate=False)
-            envs.append(e)
-        hip, ref = envs
-        acts = np.stack([util.random_actions(B, 4, seed=t) for t in range(T)])
-        monkeypatch.setenv("MGX_RESIDENT_SLICES", str(ns))
-        with hip.persistent(max_steps=T) as ps:
-            for t in range(T):
-                got = ps.step(torch.from_numpy(acts[t]).to(DEV))
-                want = ref.step(torch.from_numpy(acts[t]))
-                for g, w in zip(got, want):
-                    assert g.cpu().numpy().tobytes() == w.numpy().tobytes(), f"persistent ns={ns} step {t}"
-        monkeypatch.setenv("MGX_RESIDENT_SLICES", "0")
-        _check_state(hip, [ref], np.arange(B), f"persistent ns={ns}")
+        for ar in (False, True):
+            B, T = 80, 3
+            hip, ref, idx, st = _envs(16, 16, 4, 7, B, False, 2, ar)
+            monkeypatch.setenv("MGX_RESIDENT_SLICES", str(ns))
+            with hip.persistent(max_steps=T, auto_reset=ar) as ps:
+                for t in range(T):
+                    acts = util.random_actions(B, 4, seed=t)
+                    got = [g.cpu().numpy() for g in ps.step(torch.from_numpy(acts).to(DEV))] + ([hip.was_reset.cpu().numpy()] if ar else [])
+                    want = _ref_step(ref, acts, ar, False, None, B)
+                    for g, w in zip(got, want):
+                        assert g.tobytes() == w.tobytes(), f"persistent ns={ns} ar={ar} step {t}"
+            monkeypatch.setenv("MGX_RESIDENT_SLICES", "0")
+            assert ps.timeouts == 0
+            _check_state(hip, ref, idx, f"persistent ns={ns} ar={ar}")
+
+
+def test_generated_step_at_throughput_batches():
+    """mgx_step_generate beyond 2048 wavefronts at 7x7 views (smaller batches of that view size take the LDS-DMA instantiation):
+    hook-free (Empty-Random) and BlockedUnlockPickup; the oracle backend steps the first and the last envs of the batch."""
+    from tests.test_layout_gen import _make
+    for spec, gen, B in ((EnvSpec(9, 9, 16, 7, max_steps=3), dict(kind="empty_random"), 8400),
+                         (EnvSpec(11, 6, 2, 7, max_steps=4, joint_reward=True, env_kind="blockedunlockpickup"),
+                          dict(kind="blockedunlockpickup", room_size=6), 66000)):
+        hip = _make(spec, gen, B, DEV)
+        assert -(-B // hip.backend.launch_info(B)["envs_per_wavefront"]) > 2048
+        n = 48
+        refs = []
+        for lo in (0, B - n):
+            r = _make(spec, gen, n, "cpu", backend=util.OracleBackend(spec, nthreads=8))
+            refs.append((lo, r))
+        # (the shards of one global job: seeds, generator streams and layouts are functions of the GLOBAL env index)
+        for lo, r in refs:
+            r.first_env = hip.first_env + lo
+            r.seed_synthetic(3)
+            r.set_layout_generator(layout_seed=11, **gen)
+        for t in range(2 * spec.max_steps + 1):
+            acts = util.random_actions(B, spec.num_agents, seed=t, p_missing=0.0)
+            got = hip.step(torch.from_numpy(acts).to(DEV), auto_reset=True)
+            for lo, r in refs:
+                want = [x.clone() for x in r.step(torch.from_numpy(acts[lo:lo + n]))]
+                r.reset_done()
+                for k, (g, w) in enumerate(zip(got, want)):
+                    assert g[lo:lo + n].cpu().numpy().tobytes() == w.numpy().tobytes(), f"{gen['kind']} B={B} step {t} envs {lo}..: {k}"
+                assert torch.equal(hip.was_reset[lo:lo + n].cpu(), r.was_reset)
+        for lo, r in refs:
+            for f in ("grid", "agents", "rng", "step_count", "episode"):
+                assert torch.equal(getattr(hip, f)[lo:lo + n].cpu(), getattr(r, f)), f
 
 
 def test_the_small_kernels_beside_the_fused_one():
     """full_obs on byte grids, the persistent feeder for agent counts that are not multiples of four, auto-reset layouts whose byte
     count is odd / a multiple of 8 only (reset_done_kernel's copy units)."""
-    for (W, H, A, cb) in ((9, 7, 3, 3), (9, 7, 1, 2), (11, 6, 2, 2), (12, 12, 4, 2)):
+    # (9x7x3 on byte grids: full_obs_kernel<3>; 3 agents: persistent_feed_kernel<0>; 1 / 2: <1> / <2>; 6x6: a 72-byte layout, copied
+    # in 8-byte units; 9x7: 126 bytes, 2-byte units)
+    for (W, H, A, cb) in ((9, 7, 3, 3), (9, 7, 3, 2), (9, 7, 1, 2), (11, 6, 2, 2), (6, 6, 2, 2), (12, 12, 4, 2)):
         spec = EnvSpec(W, H, A, 5, max_steps=30, cell_bytes=cb)
         st = util.random_state(spec, 200, seed=3)
         hip = BatchedMultiGridEnv(spec, 200, DEV)

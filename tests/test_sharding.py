@@ -125,3 +125,42 @@ def test_split_views_step_the_parent():
             assert torch.equal(x, y)
         assert torch.equal(parts.cells, whole.cells) and torch.equal(parts.episode, whole.episode)
     assert int(whole.episode.sum()) > B
+
+
+def _node_vs_whole(devices, backend_factory, whole_device, whole_backend):
+    """NodeEnv over `devices` (eager steps, then a captured block) == one BatchedMultiGridEnv over the whole batch."""
+    from multigrid_amd.sharding import NodeEnv
+    spec = EnvSpec(8, 8, 2, 7, max_steps=5)
+    B, K, T = 403, 3, 7
+    pool = util.random_state(spec, K, seed=3, terminated_p=0.0)
+    st = util.random_state(spec, B, seed=4)
+    node = NodeEnv(spec, B, devices, backend_factory=backend_factory)
+    assert [hi - lo for lo, hi in node.ranges] == [shard_range(B, r, len(devices))[1] for r in range(len(devices))]
+    whole = BatchedMultiGridEnv(spec, B, whole_device, backend=whole_backend)
+    for e in (node, whole):
+        e.load_state(st["grid"], st["agents"], st["rng"], None, st["step_count"] % 5)
+        e.set_layout_pool(pool["grid"], pool["agents"])
+    acts = torch.from_numpy(np.stack([util.random_actions(B, 2, seed=t, p_missing=0.0) for t in range(2 * T)]))
+    for t in range(T):                                          # eager, one tensor over the global batch
+        node.step(acts[t], auto_reset=True)
+        whole.step(acts[t].to(whole.device), auto_reset=True)
+    g = node.capture_steps(acts[T:], auto_reset=True)          # then T more as one graph per shard
+    g.replay()
+    for t in range(T, 2 * T):
+        whole.step(acts[t].to(whole.device), auto_reset=True)
+    for name in ("obs", "dir", "reward", "terminated", "truncated", "grid", "agents", "rng", "step_count", "episode"):
+        assert torch.equal(node.gather(name), getattr(whole, name).cpu()), name
+    node.check_errors()
+
+
+def test_node_env_in_one_process_equals_one_env_on_cpu():
+    """sharding.NodeEnv (round 6): the shards of a 3-way split held by ONE process, on the oracle backend."""
+    _node_vs_whole(["cpu"] * 3, lambda spec, dev: util.OracleBackend(spec), "cpu", util.OracleBackend(EnvSpec(8, 8, 2, 7, max_steps=5)))
+
+
+@pytest.mark.gpu
+def test_node_env_in_one_process_equals_one_env_on_gpu():
+    """... on the HIP kernels: eight shards (here all on the one device the box has; on a node: cuda:0 .. cuda:7), eager steps and
+    one captured graph per shard replayed from a single thread."""
+    n = torch.cuda.device_count()
+    _node_vs_whole([f"cuda:{r % n}" for r in range(8)], None, "cuda:0", None)

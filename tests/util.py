@@ -172,7 +172,10 @@ class OracleBackend:
             dirs.copy_(torch.from_numpy(d))
 
     def step(self, B, grid, agents, rng, step_count, actions, target, err, obs, dirs, reward, terminated, truncated,
-             hook_order=None, one_hot: bool = False):
+             hook_order=None, one_hot: bool = False, auto_reset=None):
+        if auto_reset is not None:                 # the fused form == reset_done, then the step (include/mgx.h: mgx_step_autoreset)
+            first_env, pool, episode, was_reset = auto_reset
+            self.reset_done(B, first_env, pool, grid, agents, step_count, target, episode, was_reset)
         g3 = self._g3(grid)
         try:
             o, d, r, te, tr = ob.step_batch(
