@@ -432,22 +432,25 @@ def rollout_point(wl, device, steps, obs_budget=1 << 30):
     for x in out.values():
         x.zero_()                                              # first touch of the fresh allocations, outside the timing
     stream = torch.cuda.current_stream(device)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    env.rollout(acts, out, auto_reset=AUTO_RESET)
-    ev1.record(stream)
-    torch.cuda.synchronize(device)
-    wall = time.perf_counter() - t0
+    wall, ev_ms = float("inf"), float("inf")
+    for rep in range(2):                                       # (the second launch: every page of obs[T] touched by a kernel before)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        env.rollout(acts, out, auto_reset=AUTO_RESET)
+        ev1.record(stream)
+        torch.cuda.synchronize(device)
+        wall = min(wall, time.perf_counter() - t0)
+        ev_ms = min(ev_ms, ev0.elapsed_time(ev1))
     env.check_errors()
     n = batch * A * steps
     from multigrid_amd import _lib
     res = {"workload": wl.name, "batch": batch, "value": round(n / wall), "unit": "agent-steps/s", "steps": steps,
            "launches": 1, "ms_per_step": round(wall * 1e3 / steps, 6),
-           "event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 6),
+           "event_ms_per_step": round(ev_ms / steps, 6),
            "launch": _lib.launch_info(spec, batch, roll=True),
-           "frac_of_hbm_peak_at_the_step_kernels_bytes": round(batch * spec.num_agents * spec.bytes_step() / (ev0.elapsed_time(ev1) / steps * 1e-3) / 8e12, 4),
+           "frac_of_hbm_peak_at_the_step_kernels_bytes": round(batch * spec.num_agents * spec.bytes_step() / (ev_ms / steps * 1e-3) / 8e12, 4),
            "note": "mgx_rollout: the steps in one launch, bit-identical to that many mgx_step calls "
                    "(tests/test_hip_parity.py); valid for open-loop action sequences such as this benchmark's random actions"}
     del env, out

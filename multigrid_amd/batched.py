@@ -642,7 +642,9 @@ class BatchedMultiGridEnv:
         step kernel (as T calls of `step(auto_reset=True)`).  one_hot=True: 'obs' is the one-hot observation u8[T,B,A,v,v,21]
         (multigrid/wrappers.py:158-190), written by the same launch."""
         self._need_state()
-        self._need_wide_cells("rollout (the steps of one launch)")
+        generate = bool(auto_reset) and getattr(self, "_gen", None) is not None
+        if not (self.spec.cell_bytes == 1 and self.spec.env_kind == "empty" and not one_hot and not generate):
+            self._need_wide_cells("rollout (the steps of one launch)")      # (compact cells: the hook-free rollout, round 6)
         self.join()
         sp, B = self.spec, self.batch
         if actions.dtype != torch.int8 or actions.dim() != 3 or tuple(actions.shape[1:]) != (B, sp.num_agents) \
@@ -905,8 +907,8 @@ class BatchedMultiGridEnv:
             raise RuntimeError(f"{what}: a persistent session is open -- the env state lives in its launch until it is closed")
 
     def _need_wide_cells(self, what: str):
-        """Rollouts, device-side generation, persistent stepping -- and one-hot output on byte grids or with env hooks -- are compiled
-        for the 16-bit cells only."""
+        """Device-side generation, anything with env hooks beyond the plain step, one-hot rollouts -- and everything but the plain step
+        and gen_obs on byte grids -- are compiled for the 16-bit cells only."""
         if self.spec.compact:
             raise NotImplementedError(f"{what} is not available on compact cells / byte grids (EnvSpec.cell_bytes = 1 or 3: step / "
                                       f"gen_obs / auto-reset from a layout pool / full_obs); build the env with cell_bytes = 2 for it")
@@ -921,7 +923,8 @@ class BatchedMultiGridEnv:
         """A `PersistentSession` over this env: closed-loop stepping with ONE resident launch instead of one launch per step
         (include/mgx.h: mgx_step_persistent).  Same results as `step()` bit for bit.  `max_steps` bounds the launch; every wait
         inside it gives up after `timeout_ms`."""
-        self._need_wide_cells("persistent stepping")
+        if not (self.spec.cell_bytes == 1 and self.spec.env_kind == "empty"):
+            self._need_wide_cells("persistent stepping")                    # (compact cells: the hook-free persistent launch, round 6)
         return PersistentSession(self, max_steps, auto_reset, timeout_ms)
 
     # ------------------------------------------------------------------------------------------ checkpoint

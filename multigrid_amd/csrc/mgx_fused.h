@@ -857,7 +857,27 @@ const JitShape *jit_shape_lookup(const KernelArgs &ka, bool hooks);
 template <int V, int MODE, bool STREAM, bool C8 = true, bool OH = false>
 inline int launch_compact(const KernelArgs &ka, int threads, int lds_bytes, int64_t nwg, hipStream_t stream, int *hip_err, int *occupancy) {
     constexpr bool B3 = !C8;
-    if constexpr (MODE > 1 || (OH && (MODE != 1 || !C8))) {
+    if constexpr (MODE > 1 && C8 && !OH && !STREAM) {
+        // compact cells, round 6: the hook-free rollout / persistent kernels (32 view slots, the tile resident as bytes)
+        if (ka.grp != kGroup || ka.vpw > 32) return MGX_ERR_INVALID_ARGUMENT;
+        if (ka.sp.env_kind != MGX_KIND_EMPTY) return MGX_ERR_UNSUPPORTED;
+        const bool ar = ka.pool_grid != nullptr;
+        void (*kern)(const KernelArgs) = ar ? mgx_fused_kernel<V, MODE, false, true, false, false, false, false, kGroup, 0, true, false>
+                                            : mgx_fused_kernel<V, MODE, false, false, false, false, false, false, kGroup, 0, true, false>;
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) { *hip_err = (int)e; (void)hipGetLastError(); return MGX_ERR_LAUNCH; }
+        }
+        if (occupancy) {
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, reinterpret_cast<const void *>(kern), threads, (size_t)lds_bytes);
+            if (e != hipSuccess) { *hip_err = (int)e; (void)hipGetLastError(); return MGX_ERR_LAUNCH; }
+            return MGX_OK;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), (size_t)lds_bytes, stream, ka);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { *hip_err = (int)e; return MGX_ERR_LAUNCH; }
+        return MGX_OK;
+    } else if constexpr (MODE > 1 || (OH && (MODE != 1 || !C8))) {
         return MGX_ERR_UNSUPPORTED;
     } else {
         if constexpr (!STREAM && C8) {    // (byte grids have no streamed family: a u8[B,H,W,3] tensor beyond the Infinity Cache is

@@ -135,8 +135,9 @@ int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot
     // compact cells (include/mgx.h: MgxCell8) and byte grids (cell_bytes = 3): the plain step and gen_obs; rollouts and one-hot
     // output keep the 16-bit cells
     // (round 6: compact cells also take the hook-free STEP with one-hot output; gen_obs with one-hot output stays two launches)
+    // (... and the hook-free rollout / persistent launch)
     if ((sp->cell_bytes == 1 || sp->cell_bytes == 3) && (roll || one_hot)
-        && !(sp->cell_bytes == 1 && one_hot && !roll && !obs_only && sp->env_kind == MGX_KIND_EMPTY))
+        && !(sp->cell_bytes == 1 && (one_hot != roll) && !obs_only && sp->env_kind == MGX_KIND_EMPTY))
         return MGX_ERR_UNSUPPORTED;
     if (wave_lds_bytes(*sp, 1, roll, one_hot, obs_only) > kLdsPerCU) return MGX_ERR_UNSUPPORTED;   // one env must fit one CU's LDS (the
                                                                                      // rollout carve is the larger one)

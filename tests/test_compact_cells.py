@@ -58,8 +58,10 @@ def test_what_compact_cells_do_not_serve_is_refused_by_name():
     st = util.random_state(sp, 4, seed=1)
     env.load_state(st["grid"], st["agents"], st["rng"], st["target"], st["step_count"])
     act = torch.zeros((4, 2), dtype=torch.int8)
+    out = env.rollout(act[None])                               # (round 6: the hook-free rollout / persistent launch run on compact cells)
+    assert tuple(out["obs"].shape) == (1, 4, 2, 7, 7, 3)
     with pytest.raises(NotImplementedError, match="compact cells"):
-        env.rollout(act[None])
+        env.rollout(act[None], one_hot=True)
     oh, *_ = env.step(act, one_hot=True)                       # (round 6: the hook-free step writes one-hot observations on compact cells too)
     assert tuple(oh.shape) == (4, 2, 7, 7, 21)
     hooked = compact(EnvSpec(11, 6, 2, 7, max_steps=50, joint_reward=True, env_kind="blockedunlockpickup"))
@@ -71,7 +73,9 @@ def test_what_compact_cells_do_not_serve_is_refused_by_name():
     with pytest.raises(NotImplementedError, match="compact cells"):
         env.set_layout_generator("empty_fixed")
     with pytest.raises(NotImplementedError, match="compact cells"):
-        env.persistent(4)
+        henv.rollout(act[None])
+    with pytest.raises(NotImplementedError, match="compact cells"):
+        henv.persistent(4)
     with pytest.raises(ValueError):
         EnvSpec(8, 8, cell_bytes=4)
     bad = st["grid"].copy()
@@ -86,7 +90,9 @@ def test_c_abi_refuses_the_unsupported_entry_points_without_a_gpu():
     from multigrid_amd import _lib
     L = _lib.lib()
     sc = compact(EnvSpec(64, 64, 16, 9)).to_c()
-    assert L.mgx_rollout(C.byref(sc), 8, 0, *([None] * 13)) == _lib.ERR_UNSUPPORTED          # (steps = 0: the spec check alone)
+    hsc = compact(EnvSpec(11, 6, 2, 7, env_kind="blockedunlockpickup")).to_c()
+    assert L.mgx_rollout(C.byref(hsc), 8, 0, *([None] * 13)) == _lib.ERR_UNSUPPORTED         # (steps = 0: the spec check alone; hook envs)
+    assert L.mgx_rollout(C.byref(sc), 8, 0, *([None] * 13)) != _lib.ERR_UNSUPPORTED          # (round 6: hook-free rollouts are served)
     key = (C.c_int32 * 16)()
     assert L.mgx_shape_key(C.byref(sc), 64, key) == _lib.ERR_UNSUPPORTED
     sc.cell_bytes = 5
@@ -272,6 +278,75 @@ def test_compact_one_hot_step_vs_oracle(name, spec, B, T):
         np.testing.assert_array_equal(trunc.cpu().numpy(), tr_ref, err_msg=ctx)
         np.testing.assert_array_equal(env.grid.cpu().numpy(), ref["grid"], err_msg=ctx)
         np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"], err_msg=ctx)
+    env.check_errors()
+
+
+ROLL_CASES8 = [c for c in OH_CASES if c[1].width <= 64]
+
+
+@gpu
+@pytest.mark.parametrize("name,spec,B,T", ROLL_CASES8, ids=[c[0] + "_rollout_persistent" for c in ROLL_CASES8])
+def test_compact_rollout_and_persistent_equal_repeated_steps(name, spec, B, T):
+    """Round 6: mgx_rollout* and mgx_step_persistent on compact cells (the 4 KiB tile of a 64x64 env resident in LDS) == T x mgx_step on
+    the same cells == the oracle (tests above), with the fused auto-reset."""
+    sp = compact(spec)
+    st = util.random_state(sp, B, seed=zlib.crc32(name.encode()) % 10000, density=0.25)
+    pool = util.random_state(sp, 3, seed=5, terminated_p=0.0)
+    T = min(T, 5)
+    envs = []
+    for _ in range(3):
+        e = BatchedMultiGridEnv(sp, B, DEV, first_env=3)
+        e.load_state(st["grid"], st["agents"], st["rng"], None, st["step_count"])
+        e.set_layout_pool(pool["grid"], pool["agents"])
+        e.step_count[::2] = sp.max_steps - 2
+        envs.append(e)
+    e_step, e_roll, e_per = envs
+    acts = torch.from_numpy(np.stack([util.random_actions(B, spec.num_agents, seed=300 + t) for t in range(T)])).to(DEV)
+    out = e_roll.rollout(acts, auto_reset=True)
+    try:
+        ps = e_per.persistent(max_steps=T, auto_reset=True)
+        ps.__enter__()
+    except Exception as exc:                                    # (batches beyond what is resident: the rollout alone)
+        from multigrid_amd import _lib
+        assert isinstance(exc, _lib.MgxError) and exc.code == _lib.ERR_UNSUPPORTED, exc
+        ps = None
+    for t in range(T):
+        want = [x.clone() for x in e_step.step(acts[t], auto_reset=True)] + [e_step.was_reset.clone()]
+        for k, n in enumerate(("obs", "dir", "reward", "terminated", "truncated", "was_reset")):
+            assert torch.equal(out[n][t], want[k]), f"{name} rollout step {t}: {n}"
+        if ps is not None:
+            got = list(ps.step(acts[t])) + [e_per.was_reset]
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert torch.equal(g, w), f"{name} persistent step {t}: output {k}"
+    if ps is not None:
+        ps.close()
+        assert ps.timeouts == 0
+    for e in (e_roll,) + ((e_per,) if ps is not None else ()):
+        for n in ("cells", "agents", "rng", "step_count", "episode"):
+            assert torch.equal(getattr(e, n), getattr(e_step, n)), n
+
+
+@gpu
+def test_c5_full_size_rollout_on_compact_cells_vs_oracle():
+    """BASELINE.json configs[4] at its full size as ONE launch on compact cells, auto-reset fused in, against the oracle."""
+    from tests.test_full_size import oracle_reset_done
+    wl = workloads.make("c5")
+    B, A, T = wl.batch, wl.spec.num_agents, 3
+    env = wl.make_env(DEV, auto_reset=True)
+    ref = dict(grid=wl.grid.copy(), agents=wl.agents.copy(), rng=wl.rng.copy(), step_count=np.zeros(B, np.int32), aux=None)
+    episode = np.zeros(B, np.int32)
+    sd = dataclasses.replace(wl.spec, cell_bytes=2).as_dict()
+    acts = np.random.default_rng(8).integers(0, 7, size=(T, B, A)).astype(np.int8)
+    out = env.rollout(torch.from_numpy(acts).to(DEV), auto_reset=True)
+    for t in range(T):
+        was = oracle_reset_done(wl, ref, episode)
+        o, d, rw, te, tr = ob.step_batch(sd, ref["grid"], ref["agents"], ref["rng"], ref["step_count"], acts[t], None, nthreads=ob.max_threads())
+        assert out["obs"][t].cpu().numpy().tobytes() == o.tobytes(), f"step {t}: obs"
+        assert out["reward"][t].cpu().numpy().tobytes() == rw.tobytes(), f"step {t}: reward"
+        np.testing.assert_array_equal(out["terminated"][t].cpu().numpy(), te)
+        np.testing.assert_array_equal(out["was_reset"][t].cpu().numpy(), was)
+    np.testing.assert_array_equal(env.grid.cpu().numpy(), ref["grid"])
+    np.testing.assert_array_equal(env.agents.cpu().numpy(), ref["agents"])
     env.check_errors()
 
 

@@ -162,6 +162,25 @@ def test_rollout_and_persistent_family(V):
                     assert g.tobytes() == w.tobytes(), f"persistent v{V} hooks={hooks} ar={ar} step {t}: output {k}"
         assert ps.timeouts == 0
         _check_state(hip, ref, idx, f"persistent v{V}")
+    for ar in (False, True):                                   # compact cells: the hook-free rollout and persistent launch (round 6)
+        hip, ref, idx, st = _envs(W, H, A, V, B, False, 1, ar)
+        acts = np.stack([util.random_actions(B, A, seed=70 + t) for t in range(T)])
+        out = hip.rollout(torch.from_numpy(acts).to(DEV), auto_reset=ar)
+        for t in range(T):
+            want = _ref_step(ref, acts[t], ar, False, None, B)
+            got = [out[k][t].cpu().numpy() for k in ("obs", "dir", "reward", "terminated", "truncated")] + ([out["was_reset"][t].cpu().numpy()] if ar else [])
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert g.tobytes() == w.tobytes(), f"compact rollout v{V} ar={ar} step {t}: output {k}"
+        hip, ref, idx, st = _envs(W, H, A, V, B, False, 1, ar)
+        with hip.persistent(max_steps=T, auto_reset=ar) as ps:
+            for t in range(T):
+                acts1 = util.random_actions(B, A, seed=90 + t)
+                got = [g.cpu().numpy() for g in ps.step(torch.from_numpy(acts1).to(DEV))] + ([hip.was_reset.cpu().numpy()] if ar else [])
+                want = _ref_step(ref, acts1, ar, False, None, B)
+                for k, (g, w) in enumerate(zip(got, want)):
+                    assert g.tobytes() == w.tobytes(), f"compact persistent v{V} ar={ar} step {t}: output {k}"
+        assert ps.timeouts == 0
+        _check_state(hip, ref, idx, f"compact persistent v{V}")
 
 
 @pytest.mark.parametrize("V", VIEWS)
