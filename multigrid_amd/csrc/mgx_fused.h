@@ -87,6 +87,7 @@ struct KernelArgs {
     int32_t inv_A;      // ceil(2^16 / A): (lane * inv_A) >> 16 == lane / A for lane < 64
     int32_t ns;         // rollout / persistent launches: slices of Gw envs per wavefront (LdsCarve); 0 = the ordinary kernels, 1 / 2 = a
                         // resident shape (kShapes[].ns): host-side geometry, the kernels have it as a constant
+    int32_t rshape;     // ... which one (kShapes index; fill_args chose it)
     // fused auto-reset (mgx_step_autoreset / mgx_rollout_autoreset; include/mgx.h: MgxAutoReset)
     int32_t pool_size;
     int64_t first_env;
@@ -287,6 +288,8 @@ struct LdsCarve {
     bool has_aux;   // env kinds with hook state
     bool c8;        // compact cells: + the decode table
     int ns = 1;     // slices per wavefront (above)
+    bool sliced = false;   // the layout described above (shared block + per-slice blocks, staging over the view records): every ns > 1
+                           // kernel, and the one-slice kernel that must fit 16 wavefronts per CU (kShapes 9)
     __host__ __device__ __attribute__((always_inline)) int tile_pad() const { return (tile_bytes & 15) ? 32 : 0; }
     // -- ns > 1: the shared block [0, sh_end()), then one block of pstride() bytes per slice --
     __host__ __device__ __attribute__((always_inline)) int sh_end() const { return 22 * vpw + 32 * A + 16; }
@@ -294,10 +297,10 @@ struct LdsCarve {
         return 8 * vpw + 32 * Gw + ((4 * Gw + 15) & ~15) + (has_aux ? 16 * Gw : 0) + tile_bytes + tile_pad();
     }
     __host__ __device__ __attribute__((always_inline)) int pers(int s) const { return sh_end() + s * pstride(); }
-    __host__ __device__ __attribute__((always_inline)) int rows(int s = 0) const { return ns > 1 ? pers(s) : 0; }   // u64  [vpw]
+    __host__ __device__ __attribute__((always_inline)) int rows(int s = 0) const { return sliced ? pers(s) : 0; }   // u64  [vpw]
     // -- per-step temporaries, all dead once P2 has gathered the cells --
     // (the view records, written in P1d, lie over the draws and the rewards, both dead by then)
-    __host__ __device__ __attribute__((always_inline)) int rec() const { return ns > 1 ? 0 : 8 * vpw; }            // ViewRec [vpw]  (P1d -> P2)
+    __host__ __device__ __attribute__((always_inline)) int rec() const { return sliced ? 0 : 8 * vpw; }            // ViewRec [vpw]  (P1d -> P2)
     __host__ __device__ __attribute__((always_inline)) int rnd() const { return rec(); }                            // u64  [vpw]     (P1a -> P1b), same space
     __host__ __device__ __attribute__((always_inline)) int rew() const { return rec() + 8 * vpw; }                  // f64  [vpw]     (P0 -> hooks), same space
     __host__ __device__ __attribute__((always_inline)) int woff() const { return rec() + 16 * vpw; }                // i32  [vpw]     (P1s)
@@ -305,10 +308,10 @@ struct LdsCarve {
     // -- state that lives across phases / steps --
     __host__ __device__ __attribute__((always_inline)) int act() const { return temps_end(); }                      // i8   [vpw]
     __host__ __device__ __attribute__((always_inline)) int ord() const { return act() + vpw; }                      // u8   [vpw]
-    __host__ __device__ __attribute__((always_inline)) int rng(int s = 0) const { return ns > 1 ? pers(s) + 8 * vpw : ord() + vpw; }   // u64  [Gw][4]   (rollout only)
+    __host__ __device__ __attribute__((always_inline)) int rng(int s = 0) const { return sliced ? pers(s) + 8 * vpw : ord() + vpw; }   // u64  [Gw][4]   (rollout only)
     __host__ __device__ __attribute__((always_inline)) int scnt(int s = 0) const { return rng(s) + (roll ? 32 * Gw : 0); }    // i32  [Gw]
     __host__ __device__ __attribute__((always_inline)) int aux(int s = 0) const { return scnt(s) + ((4 * Gw + 15) & ~15); }   // u8   [Gw][16]  (hook envs only)
-    __host__ __device__ __attribute__((always_inline)) int own_jump() const { return ns > 1 ? ord() + vpw : aux() + (has_aux ? 16 * Gw : 0); }
+    __host__ __device__ __attribute__((always_inline)) int own_jump() const { return sliced ? ord() + vpw : aux() + (has_aux ? 16 * Gw : 0); }
     __host__ __device__ __attribute__((always_inline)) int jump() const { return own_jump(); }                      // u64  [A][4]: k = 1..A   (rollout only: the
     __host__ __device__ __attribute__((always_inline)) int wall() const { return own_jump() + (roll ? 32 * A : 0); }   // one-step kernels keep them in registers)
                                                                                      // wall: one WALL cell + the dword after it
@@ -318,26 +321,29 @@ struct LdsCarve {
     __host__ __device__ __attribute__((always_inline)) int lut() const { return wall() + 16; }                         // u32 [256] (compact cells only)
     __host__ __device__ __attribute__((always_inline)) int own_out() const { return lut() + (c8 ? kLutBytes : 0); }
     __host__ __device__ __attribute__((always_inline)) int tile(int s = 0) const {                                      // grid bytes, skew + over-read
-        return ns > 1 ? aux(s) + (has_aux ? 16 * Gw : 0) : (roll ? own_out() + out_bytes() : own_out());
+        return sliced ? aux(s) + (has_aux ? 16 * Gw : 0) : (roll ? own_out() + out_bytes() : own_out());
     }
-    __host__ __device__ __attribute__((always_inline)) int out() const { return ns > 1 ? rec() : (roll ? own_out() : tile()); }
+    __host__ __device__ __attribute__((always_inline)) int out() const { return sliced ? rec() : (roll ? own_out() : tile()); }
     __host__ __device__ __attribute__((always_inline)) int total() const {
-        if (ns > 1) return (pers(ns) + 15) & ~15;
+        if (sliced) return (pers(ns) + 15) & ~15;
         // (the tile's 32 bytes of skew + over-read exist only when a wavefront's grid bytes are not whole 16-byte vectors: a 64x64
         // env's 8 KiB tile + 512 bytes of slots is then exactly 17 x 512 bytes of LDS)
         const int t = tile_bytes + tile_pad() > out_bytes() || roll ? tile_bytes + tile_pad() : out_bytes();
         return (tile() + t + 15) & ~15;
     }
     // (ns > 1: the staging must fit the records + the written-cell offsets it lies over)
-    __host__ __device__ __attribute__((always_inline)) bool slices_ok() const { return ns <= 1 || (roll && !c8 && out_bytes() <= 20 * vpw); }
+    __host__ __device__ __attribute__((always_inline)) bool slices_ok() const { return !sliced || (roll && !c8 && out_bytes() <= 20 * vpw); }
 };
 
 // one_hot: the round's staging holds one 32-bit one-hot mask per cell (+ a pad dword either side) instead of 3 obs bytes
 // `round`: slots staged per P4/P5 round (kRound, or the group size of a small-group latency instantiation)
 __host__ __device__ __attribute__((always_inline)) inline LdsCarve make_carve(int W, int H, int A, int V, int Gw, int vpw, bool roll, bool has_aux,
-                                               bool one_hot = false, int round = kRound, int cb = kCellBytes, int ns = 1) {
-    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, Gw * H * W * cb, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
-                    roll, has_aux, cb == 1, ns};
+                                               bool one_hot = false, int round = kRound, int cb = kCellBytes, int ns = 1, bool sliced = false,
+                                               int pitch = 0) {
+    // (pitch: a tile whose rows and envs SHARE the WALL ring -- row pitch W - 1, env stride (W - 1)(H - 1) cells, W more at the end)
+    const int tile_bytes = pitch ? (Gw * pitch * (H - 1) + W) * cb : Gw * H * W * cb;
+    return LdsCarve{vpw, (V * V + 63) / 64, Gw, A, tile_bytes, one_hot ? round * V * V * 4 + 16 : round * V * V * 3,
+                    roll, has_aux, cb == 1, ns, sliced || ns > 1};
 }
 inline int cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 1 ? 1 : kCellBytes; }        // the LDS tile's cells
 inline int grid_cell_bytes_of(const MgxSpec &sp) { return sp.cell_bytes == 3 ? 3 : cell_bytes_of(sp); }   // the HBM tensors' cells
@@ -393,7 +399,7 @@ inline int choose_group(const MgxSpec &sp, int64_t batch) {
 // BlockedUnlockPickup at 16384 envs 5.08 -> 4.45 us (step 9.6 -> 8.2); the throughput instantiation of C4 gains 1 % (its scalar work
 // runs beside four waves' VALU work) and has none.  The table holds the shapes BASELINE.json names, at the envs-per-wavefront
 // choose_Gw gives them in the latency regime; every other shape, and these at other launch geometries, run the generic kernels.
-struct FixedShape { int W, H, A, Gw; bool hooks; int V; bool dma, stream; int cb = kCellBytes; int ns = 0; };   // (dma / stream: the
+struct FixedShape { int W, H, A, Gw; bool hooks; int V; bool dma, stream; int cb = kCellBytes; int ns = 0; int pitch = 0; };   // (dma / stream: the
                                                   // instantiation family, launch_mode; cb: bytes per grid cell; ns > 0: a RESIDENT shape of the
                                                   // rollout / persistent kernels -- 64 view slots, ns slices per wavefront, LdsCarve)
 constexpr FixedShape kShapes[] = {
@@ -413,6 +419,12 @@ constexpr FixedShape kShapes[] = {
     // wavefronts hold the 65536 envs of C4, tiles and all, for the whole launch)
     {16, 16, 4, 16, false, 7, false, false, kCellBytes, 1},
     {16, 16, 4, 16, false, 7, false, false, kCellBytes, 2},
+    // 9 (round 6): one slice in 9872 B of LDS and 127 VGPRs -> SIXTEEN wavefronts per CU, four per SIMD: all 4096 wavefronts of C4's
+    // 65536 envs resident in one round.  The bytes come from the tile: every env's outer ring is WALL (include/mgx.h PRECONDITION), so
+    // column W - 1 of row y and column 0 of row y + 1, and the last row of env e and the first of env e + 1, can be the SAME cells --
+    // row pitch 15, env stride 225 cells: 7232 B instead of 8192 -- with the per-step temporaries laid out as for the sliced kernels;
+    // the registers from asking for the occupancy (amdgpu_waves_per_eu(4): the compiler rematerialises instead of holding)
+    {16, 16, 4, 16, false, 7, false, false, kCellBytes, 1, 15},
 #ifdef MGX_JIT_SHAPE
     {MGX_JIT_SHAPE},                            // 5: ANY other shape, compiled at run time (hipRTC) from these same headers with its
                                                 //    launch geometry as MGX_JIT_SHAPE (multigrid_amd/jit.py, mgx_shape_register)
@@ -421,9 +433,14 @@ constexpr FixedShape kShapes[] = {
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 constexpr int shape_slots(const FixedShape &f) { return (f.Gw * f.A + 15) / 16 * 16; }   // == slots_in_use() (all entries: <= 32 slots, the
                                                                                          // resident shapes 64)
-constexpr int kShapeResident1 = 7, kShapeResident2 = 8;
+constexpr int kShapeResident1 = 7, kShapeResident2 = 8, kShapeResident4 = 9;
 constexpr int kRoundResident = 8;        // P4/P5 round of the sliced resident kernels (their staging lies over the view records)
-constexpr int shape_round(const FixedShape &f) { return f.ns > 1 ? kRoundResident : kRound; }
+constexpr bool shape_sliced(const FixedShape &f) { return f.ns > 1 || f.pitch != 0; }
+constexpr int shape_round(const FixedShape &f) { return shape_sliced(f) ? kRoundResident : kRound; }
+__host__ __device__ __attribute__((always_inline)) inline LdsCarve shape_carve(const FixedShape &f, bool roll) {
+    return make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), roll, f.hooks, false, shape_round(f), f.cb, f.ns > 0 ? f.ns : 1,
+                      shape_sliced(f), f.pitch);
+}
 
 static __device__ const JumpTable kJump{};
 
@@ -786,6 +803,16 @@ __global__ __launch_bounds__(kMaxThreads) void mgx_fused_kernel(const KernelArgs
 #include "mgx_fused_body.inc"
 }
 
+// The one-slice resident kernel that must leave FOUR wavefronts per SIMD (kShapes 9): its own entry point carries the occupancy request
+// (128 VGPRs; left to itself the allocator takes 146-153 for this body: profiles/r6_resident.txt).
+template <int MODE, bool AR>
+__global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(4)))
+void mgx_resident_kernel(const KernelArgs a) {
+    constexpr int V = 7, GRP = kGroup, SHAPE = kShapeResident4;
+    constexpr bool HOOKS = false, OH = false, GEN = false, STREAM = false, DMA = false, C8 = false, B3 = false;
+#include "mgx_fused_body.inc"
+}
+
 // gen_obs for views up to 7x7 is a pure stream and wants the 6th wavefront per SIMD, i.e. <= 80 VGPRs: left to itself the
 // register allocator lands on 78 or 86 depending on unrelated code (measured: 196 vs 204 us at 1M envs).  Its own entry point
 // carries the occupancy request; the step kernels are issue-bound and take the registers they want (forcing them costs
@@ -834,15 +861,11 @@ inline int match_fixed_shape(const KernelArgs &ka, bool hooks, bool persist = fa
 // ... and which RESIDENT shape (kShapes[].ns > 0) the geometry of a rollout / persistent launch is: fill_args chose it (ka.ns), this
 // re-checks every number the instantiation was compiled for.
 inline int match_resident_shape(const KernelArgs &ka, bool hooks) {
-    if (MGX_NO_FIXED_SHAPES || ka.grp != kGroup || ka.ns < 1) return 0;
-    for (int k = 1; k < kNumShapes; ++k) {
-        const FixedShape &f = kShapes[k];
-        if (f.ns != ka.ns) continue;
-        if (ka.sp.view_size == f.V && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw
-            && hooks == f.hooks && ka.vpw == shape_slots(f) && cell_bytes_of(ka.sp) == f.cb
-            && ka.wave_lds == make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), true, f.hooks, false, shape_round(f), f.cb, f.ns).total())
-            return k;
-    }
+    if (MGX_NO_FIXED_SHAPES || ka.grp != kGroup || ka.ns < 1 || ka.rshape < 1 || ka.rshape >= kNumShapes) return 0;
+    const FixedShape &f = kShapes[ka.rshape];
+    if (f.ns == ka.ns && ka.sp.view_size == f.V && ka.sp.width == f.W && ka.sp.height == f.H && ka.sp.num_agents == f.A && ka.Gw == f.Gw
+        && hooks == f.hooks && ka.vpw == shape_slots(f) && cell_bytes_of(ka.sp) == f.cb && ka.wave_lds == shape_carve(f, true).total())
+        return ka.rshape;
     return 0;
 }
 
@@ -998,6 +1021,12 @@ inline int launch_mode(const KernelArgs &ka, int threads, int lds_bytes, int64_t
                                         : mgx_fused_kernel<V, MODE, false, false, false, false, false, false, kGroup, kShapeResident1>; break;
         case kShapeResident2: kern = ar ? mgx_fused_kernel<V, MODE, false, true, false, false, false, false, kGroup, kShapeResident2>
                                         : mgx_fused_kernel<V, MODE, false, false, false, false, false, false, kGroup, kShapeResident2>; break;
+        case kShapeResident4:
+            // (rollouts only.  A persistent launch of 4 x 128 VGPRs per SIMD would leave the producer / consumer kernels of its own
+            // hand-shake no register to run in -- resident_shape() keeps that launch on shapes 7 / 8)
+            if constexpr (MODE == 2) kern = ar ? mgx_resident_kernel<2, true> : mgx_resident_kernel<2, false>;
+            else return MGX_ERR_INVALID_ARGUMENT;
+            break;
         default: if (ka.ns > 0) return MGX_ERR_INVALID_ARGUMENT;               // (fill_args chose a geometry no instantiation has)
         }
     } else if (ka.ns > 0) return MGX_ERR_INVALID_ARGUMENT;

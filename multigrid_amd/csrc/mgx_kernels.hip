@@ -144,22 +144,39 @@ int check_spec(const MgxSpec *sp, int64_t batch, bool roll = false, bool one_hot
     return MGX_OK;
 }
 
-// Slices per wavefront of the resident rollout / persistent form (0: the ordinary 32-slot kernels).  Empty-16x16 x 4 agents, 7x7 views,
-// 16-bit cells; by batch (tools/rollout_probe.py, profiles/r6_resident.txt): up to 16384 envs the 32-slot kernels are one wavefront or
-// two per SIMD and as fast; beyond, ONE slice of 16 envs per wavefront (64 view slots, 12 wavefronts per CU): 49152 envs resident in
-// one round, and for mgx_rollout -- whose wavefronts need not all be resident -- also the better kernel for any larger batch (65536
-// envs: 17.4 us per step in 1.33 rounds against 20.1 as two slices at 8 wavefronts per CU: two wavefronts per SIMD hide less of each
-// other's instruction latency than three).  TWO slices only where everything must be resident at once and one slice no longer fits:
-// mgx_step_persistent from 49153 to 65536 envs.  MGX_RESIDENT_SLICES=0/1/2 overrides (tools, tests).
-int resident_slices(const MgxSpec &sp, int64_t batch, bool persist) {
+// Which RESIDENT shape (mgx_fused.h: kShapes 7 / 8 / 9; 0: the ordinary 32-slot kernels) a rollout / persistent launch of (spec,
+// batch) takes.  Empty-16x16 x 4 agents, 7x7 views, 16-bit cells; by batch (tools/rollout_probe.py, profiles/r6_resident.txt):
+//   up to 16384 envs   the 32-slot kernels: one wavefront or two per SIMD, as fast
+//   up to 49152        kShapes 7 -- one slice of 16 envs per wavefront, 13216 B of LDS: 12 wavefronts per CU
+//   up to 65536 (C4)   kShapes 9 -- the same slice in 9872 B (tile rows share their wall ring) and <= 128 VGPRs: SIXTEEN wavefronts per
+//                      CU, so C4's 4096 wavefronts are ONE resident round (15.3 us per step against 17.2 for shape 7's round and a third)
+//   beyond             kShapes 7 again (rollouts run in rounds)
+// kShapes 8 (two slices, 20112 B: 8 per CU) was the first form that held C4 (19.7-20.1 us): the persistent launch of 32768 < batch
+// <= 65536 envs takes it (see below)
+// (MGX_RESIDENT_SHAPE=0/7/8/9 overrides; MGX_RESIDENT_SLICES=1/2 = shapes 7 / 8: the tests force them at small batches).
+int resident_shape(const MgxSpec &sp, int64_t batch, bool persist) {
     const FixedShape &f = kShapes[kShapeResident1];
     if (sp.width != f.W || sp.height != f.H || sp.num_agents != f.A || sp.view_size != f.V || sp.env_kind != MGX_KIND_EMPTY
         || cell_bytes_of(sp) != f.cb || sp.cell_bytes == 3)
         return 0;
-    if (const char *e = getenv("MGX_RESIDENT_SLICES")) { if (*e) { const int f_ = atoi(e); return f_ > 2 ? 2 : (f_ < 0 ? 0 : f_); } }   // (read per call: the tests switch it)
+    if (const char *e = getenv("MGX_RESIDENT_SHAPE")) {                  // (read per call: the tests and tools switch it)
+        if (*e) { const int k = atoi(e); return (k == kShapeResident1 || k == kShapeResident2 || k == kShapeResident4) ? k : 0; }
+    }
+    if (const char *e = getenv("MGX_RESIDENT_SLICES")) {
+        if (*e) { const int n = atoi(e); return n <= 0 ? 0 : (n == 1 ? kShapeResident1 : kShapeResident2); }
+    }
     if (batch <= 16384) return 0;
-    if (persist && batch > 49152) return 2;
-    return 1;
+    // 12 wavefronts per CU step faster than 16 while they hold the batch (49152 envs: 10.5 against 12.3 us per step), and a
+    // rollout beyond one round of shape 9 is as well off in rounds of shape 7 (98304: 22.7 / 24.1, 131072: 29.6 / 31.2).
+    // The persistent launch cannot run in rounds and must leave registers for the kernels that feed it: 16 wavefronts x 128 VGPRs
+    // are a SIMD's whole file (mgx_persistent_post / _wait would never be scheduled), so beyond shape 7 it takes the two-slice
+    // shape 8 -- 8 wavefronts per CU x 144 VGPRs
+    // (... and its residency check counts 4 workgroups = 8 wavefronts per CU, whatever the shape: 32768 envs of shape 7.  Twelve
+    // persistent wavefronts of shape 7 per CU -- 4 workgroups x 3, 456 of a SIMD's 512 VGPRs -- were tried at 49152 envs: the hand-shake
+    // kernels were not scheduled beside them and every wavefront timed out, profiles/r6_resident.txt)
+    if (persist) return batch <= 32768 ? kShapeResident1 : kShapeResident2;
+    if (batch <= 49152) return kShapeResident1;
+    return batch <= 65536 ? kShapeResident4 : kShapeResident1;
 }
 
 // `step_plain`: the launch is the plain one-step kernel (mode 1 without one-hot / generation): the only one the small-group
@@ -187,16 +204,16 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     ka.vpw = slots_in_use(*sp, ka.Gw, roll || obs_only, ka.grp);
     ka.inv_A = (65536 + sp->num_agents - 1) / sp->num_agents;
     ka.wave_lds = wave_lds_bytes(*sp, ka.Gw, roll, one_hot, obs_only, ka.grp);
-    ka.ns = 0;
+    ka.ns = 0; ka.rshape = 0;
     // RESIDENT shapes of the rollout / persistent kernels (mgx_fused.h: kShapes[].ns > 0; round 6): at the batches where the 32-slot
     // rollout kernel no longer keeps every env on the chip, Empty-16x16 x 4 agents takes 64 view slots per wavefront and, beyond what
     // 12 such wavefronts per CU hold, two slices of 16 envs per wavefront (8 per CU: 65536 envs, C4, in 2048 wavefronts)
     if (roll && !one_hot && !MGX_NO_FIXED_SHAPES && g_debug_G <= 0) {
-        const int ns = resident_slices(*sp, batch, persist);
-        if (ns > 0) {
-            const FixedShape &f = kShapes[ns > 1 ? kShapeResident2 : kShapeResident1];
-            ka.ns = ns; ka.Gw = f.Gw; ka.vpw = shape_slots(f);
-            ka.wave_lds = make_carve(f.W, f.H, f.A, f.V, f.Gw, shape_slots(f), true, f.hooks, false, shape_round(f), f.cb, f.ns).total();
+        const int rs = resident_shape(*sp, batch, persist);
+        if (rs > 0) {
+            const FixedShape &f = kShapes[rs];
+            ka.ns = f.ns; ka.rshape = rs; ka.Gw = f.Gw; ka.vpw = shape_slots(f);
+            ka.wave_lds = shape_carve(f, true).total();
         }
     }
     struct { int total; } p{ka.wave_lds};
@@ -207,7 +224,7 @@ int fill_args(KernelArgs &ka, const MgxSpec *sp, int64_t batch, int &threads, in
     // (... for the plain step's wavefronts, which hold more than 8 KiB of LDS each; the gen_obs kernel's small slices and the
     // one-hot step stay at 2: 1 M envs gen_obs 203 us for 1 against 190-193 for 2, fused one-hot step 1.03-1.06 ms against 0.99)
     int wpb = ((batch + ka.Gw - 1) / ka.Gw >= 16384) ? ((p.total > 8192 && !one_hot && !obs_only) ? 1 : 2) : 4;
-    if (ka.ns > 0) wpb = 2;                                   // (resident shapes: 12 / 8 wavefronts per CU as 6 / 4 workgroups)
+    if (ka.ns > 0) wpb = ka.rshape == kShapeResident4 ? 4 : 2;   // (resident shapes: 12 / 8 / 16 wavefronts per CU as 6 / 4 / 4 workgroups)
     while (wpb > 1 && wpb * p.total > 64 * 1024) wpb >>= 1;
     if (g_debug_wpb > 0) wpb = g_debug_wpb;
     threads = 64 * wpb;

@@ -317,11 +317,13 @@ struct StepCfg {
     int W, H, A, max_steps;
     bool allow_overlap, joint_reward, success_any, failure_any;
     int cb;               // bytes per grid cell: 2 (MgxCell) or 1 (MgxCell8)
+    int P;                // row pitch of the TILE in cells: W, or W - 1 in the resident kernels whose tile shares the WALL ring between
+                          // rows and envs (mgx_fused.h: kShapes[].pitch): cell (x, y) lies at (y * P + x) * cb
 };
 
 MGX_HD StepCfg make_cfg(const MgxSpec &sp) {
     return StepCfg{sp.width, sp.height, sp.num_agents, sp.max_steps, sp.allow_agent_overlap != 0,
-                   sp.joint_reward != 0, sp.success_any != 0, sp.failure_any != 0, sp.cell_bytes == 1 ? 1 : kCellBytes};
+                   sp.joint_reward != 0, sp.success_any != 0, sp.failure_any != 0, sp.cell_bytes == 1 ? 1 : kCellBytes, sp.width};
 }
 
 MGX_HD void set_terminated(uint64_t *rows, int A, int i, bool all) {
@@ -379,7 +381,7 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
     const int d = row_dir(row), x = row_x(row), y = row_y(row);
     const int fx = x + dir_dx(d), fy = y + dir_dy(d);                       // agent.py:111-118
     const bool inb = ((unsigned)fx < (unsigned)cf.W) & ((unsigned)fy < (unsigned)cf.H);  // walled grids: always
-    ev.off = inb ? (fy * cf.W + fx) * cf.cb : 0;
+    ev.off = inb ? (fy * cf.P + fx) * cf.cb : 0;
     const uint32_t raw = load_cell_raw(cf.cb, tile + ev.off);
     const uint32_t cell = cf.cb == 1 ? cell8_unpack(raw) : cell_unpack(raw);       // what the cell shows (a box's content: below)
     const uint32_t type = cell & 0xff, gstate = cell_state(cell);
@@ -439,7 +441,7 @@ MGX_HD AgentEval eval_agent(const StepCfg &cf, const uint8_t *tile, const uint64
 // The reference's loop (base.py:402-474): agents act one after the other in `ord`, each seeing the previous ones' effects.
 // `stale` points at the env's stale-door flag (aux[4] of a RedBlueDoors env) or is NULL.
 MGX_HD int stale_offset(const StepCfg &cf, const uint8_t *aux, int env_kind) {
-    return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.W + aux[0]) * cf.cb : -1;
+    return (env_kind == MGX_KIND_REDBLUEDOORS && aux[4]) ? (aux[1] * cf.P + aux[0]) * cf.cb : -1;
 }
 
 // ONE iteration of that loop: agent `i` takes its turn against the CURRENT tile and rows and its effects are committed.
@@ -556,7 +558,7 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
         for (int a = 0; a < A; ++a)
             if ((row_carry(rows[a]) & 0xffffu) == want) on_success(cf, rows, a, step_count, rew);
     } else if (env_kind == MGX_KIND_REDBLUEDOORS) {
-        const int boff = (aux[1] * cf.W + aux[0]) * cf.cb, roff = (aux[3] * cf.W + aux[2]) * cf.cb;
+        const int boff = (aux[1] * cf.P + aux[0]) * cf.cb, roff = (aux[3] * cf.P + aux[2]) * cf.cb;
         for (int ko = 0; ko < A; ++ko) {                                        // `for agent_id, action in actions.items()`
             const int a = order ? (int)order[ko] : ko;
             if (a >= A || act[a] != ACT_TOGGLE) continue;
@@ -586,7 +588,7 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
             const uint64_t r = rows[a];
             const int d = row_dir(r), fx = row_x(r) + dir_dx(d), fy = row_y(r) + dir_dy(d);
             if ((unsigned)fx >= (unsigned)cf.W || (unsigned)fy >= (unsigned)cf.H) continue;
-            const uint32_t c = load_cell(cf.cb, tile + (fy * cf.W + fx) * cf.cb);
+            const uint32_t c = load_cell(cf.cb, tile + (fy * cf.P + fx) * cf.cb);
             if ((c & 0xff) != T_DOOR || cell_state(c) == S_LOCKED) continue;                   // isinstance(Door) and not is_locked
             int k = -1;
             if (geo) {
@@ -630,7 +632,7 @@ MGX_HD void post_step_hook(const StepCfg &cf, int env_kind, uint8_t *tile, uint6
                     const int d = row_dir(row), fx = row_x(row) + dir_dx(d), fy = row_y(row) + dir_dy(d);
                     hit = (fx == r[1]) & (fy == r[2]);
                     if (hit && cond != MGX_COND_ALWAYS) {
-                        const uint32_t c = load_cell(cf.cb, tile + (r[2] * cf.W + r[1]) * cf.cb);
+                        const uint32_t c = load_cell(cf.cb, tile + (r[2] * cf.P + r[1]) * cf.cb);
                         const bool open = ((c & 0xff) == T_DOOR) & (cell_state(c) == S_OPEN);
                         hit = (c & 0xff) == T_DOOR && (cond == MGX_COND_DOOR_OPEN ? open : !open);
                     }
@@ -652,7 +654,7 @@ MGX_HD void overlay_agents(const StepCfg &cf, uint8_t *tile, const uint64_t *row
         if (row_term(r)) continue;
         const int x = row_x(r), y = row_y(r);
         if (x >= cf.W || y >= cf.H) continue;
-        store_cell_raw(cf.cb, tile + (y * cf.W + x) * cf.cb, agent_cell_raw(cf.cb, r));
+        store_cell_raw(cf.cb, tile + (y * cf.P + x) * cf.cb, agent_cell_raw(cf.cb, r));
     }
 }
 
@@ -670,7 +672,7 @@ MGX_HD int overlay_offset(const StepCfg &cf, const uint64_t *rows, int ai) {
     }
     const int x = row_x(r), y = row_y(r);
     if (row_term(r) | shadowed | (x >= cf.W) | (y >= cf.H)) return -1;
-    return (y * cf.W + x) * cf.cb;
+    return (y * cf.P + x) * cf.cb;
 }
 
 // Layout of a restarting env (include/mgx.h: MgxAutoReset): (first_env + b + episode * 7919) mod K.  The 64-bit remainder costs
@@ -703,12 +705,13 @@ MGX_HD int pool_index(int64_t first_env, int64_t b, int32_t ep, int32_t K, uint6
 struct ViewGeom { int origin, stepF, stepL, fmax, imin, imax; };
 
 template <int V>
-MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d, int cb = kCellBytes) {
+MGX_HD ViewGeom view_geom(int W, int H, int x, int y, int d, int cb = kCellBytes, int pitch = 0) {
     const int dx = dir_dx(d), dy = dir_dy(d), h = V / 2;
+    const int P = pitch ? pitch : W;                      // (the tile's row pitch: StepCfg::P)
     ViewGeom g;
-    g.origin = (y * W + x) * cb;
-    g.stepF = (dy * W + dx) * cb;
-    g.stepL = (dx * W - dy) * cb;
+    g.origin = (y * P + x) * cb;
+    g.stepF = (dy * P + dx) * cb;
+    g.stepL = (dx * P - dy) * cb;
     // room ahead and to both sides, as selects (one lane per view: the lanes hold all four directions)
     const bool d0 = d == 0, d1 = d == 1, d2 = d == 2;
     g.fmax = d0 ? W - 1 - x : (d1 ? H - 1 - y : (d2 ? x : y));

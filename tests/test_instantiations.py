@@ -312,7 +312,7 @@ def test_resident_shapes_of_the_persistent_launch_with_and_without_auto_reset(mo
         for ar in (False, True):
             B, T = 80, 3
             hip, ref, idx, st = _envs(16, 16, 4, 7, B, False, 2, ar)
-            monkeypatch.setenv("MGX_RESIDENT_SLICES", str(ns))
+            monkeypatch.setenv("MGX_RESIDENT_SHAPE", {1: "7", 2: "8", 9: "9"}[ns])
             with hip.persistent(max_steps=T, auto_reset=ar) as ps:
                 for t in range(T):
                     acts = util.random_actions(B, 4, seed=t)
@@ -320,7 +320,7 @@ def test_resident_shapes_of_the_persistent_launch_with_and_without_auto_reset(mo
                     want = _ref_step(ref, acts, ar, False, None, B)
                     for g, w in zip(got, want):
                         assert g.tobytes() == w.tobytes(), f"persistent ns={ns} ar={ar} step {t}"
-            monkeypatch.setenv("MGX_RESIDENT_SLICES", "0")
+            monkeypatch.setenv("MGX_RESIDENT_SHAPE", "")
             assert ps.timeouts == 0
             _check_state(hip, ref, idx, f"persistent ns={ns} ar={ar}")
 

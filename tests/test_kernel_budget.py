@@ -105,7 +105,8 @@ def test_sgpr_spill_budgets(kernels):
         worst[fam] = max(worst.get(fam, 0), k.get(".sgpr_spill_count", 0))
     # (round 6: + the resident shapes of the rollout / persistent kernels, mgx_fused.h kShapes 7 / 8; the slices' loop moved the
     # generic rollout kernels from 160 to 162)
-    budget = {"obs": 0, "step": 96, "step_shape": 32, "rollout": 170, "rollout_shape": 48, "persistent": 260, "persistent_shape": 110,
+    # (... and the persistent kernels stopped holding their ten output descriptors across the step loop: 256 -> 179, shaped 100 -> 46)
+    budget = {"obs": 0, "step": 96, "step_shape": 32, "rollout": 170, "rollout_shape": 48, "persistent": 190, "persistent_shape": 56,
               "gen": 600, "gen_shape": 0}
     for fam, w in worst.items():
         assert w <= budget[fam], (fam, w, budget[fam])
@@ -141,3 +142,29 @@ def test_persistent_producer_fits_beside_the_persistent_wavefronts(kernels):
     # one feeder wavefront per SIMD + two persistent wavefronts per SIMD within the 512 VGPRs of a SIMD lane (8-register granules)
     g = lambda n: (n + 7) // 8 * 8
     assert max(g(k[".vgpr_count"]) for k in feed) + 2 * max(g(k[".vgpr_count"]) for k in pers) <= 512
+
+
+def test_resident_c4_kernels_hold_their_batch(kernels):
+    """The resident forms of BASELINE.json configs[3]'s shape (mgx_fused.h kShapes 7 / 8 / 9; VERDICT r5 item 1: <= 128 VGPRs, no
+    scratch, 4096 co-resident wavefronts).  Registers are allocated in granules of 8, 512 per SIMD lane."""
+    g = lambda n: (n + 7) // 8 * 8
+    res = [k for k in kernels if "mgx_resident_kernel" in k[".name"]]
+    assert len(res) == 2                                            # the rollout, with and without auto-reset (MODE 2 only)
+    for k in res:
+        # kShapes 9: FOUR wavefronts per SIMD x 256 CUs x 4 SIMDs = 4096 = C4's 65536 envs at 16 per wavefront, in one round
+        assert g(k[".vgpr_count"]) <= 128 and k.get(".agpr_count", 0) == 0, (k[".name"], k[".vgpr_count"])
+        assert k.get(".private_segment_fixed_size", 0) == 0 and k.get(".vgpr_spill_count", 0) == 0
+        assert k.get(".sgpr_spill_count", 0) <= 48, k[".sgpr_spill_count"]
+    by = {_targs(k[".name"]): k for k in kernels if _targs(k[".name"]) and not _c8(k[".name"]) and not _b3(k[".name"])}
+    small = max(g(k[".vgpr_count"]) for k in kernels if "persistent_post" in k[".name"] or "persistent_wait" in k[".name"])
+    feed = max(g(k[".vgpr_count"]) for k in kernels if "persistent_feed_kernel" in k[".name"])
+    for ar in (0, 1):
+        r7, r8 = by[(7, 2, 0, ar, 0, 0, 0, 0, 16, 7)], by[(7, 2, 0, ar, 0, 0, 0, 0, 16, 8)]
+        assert 3 * g(r7[".vgpr_count"]) <= 512 and 2 * g(r8[".vgpr_count"]) <= 512       # 12 / 8 wavefronts per CU (their LDS)
+        # the persistent launches (8 wavefronts per CU of either shape: mgx_kernels.hip resident_shape) must leave registers for the
+        # kernels that feed them -- post / wait / the fused producer beside two persistent wavefronts per SIMD
+        p7, p8 = by[(7, 3, 0, ar, 0, 0, 0, 0, 16, 7)], by[(7, 3, 0, ar, 0, 0, 0, 0, 16, 8)]
+        assert 2 * g(p7[".vgpr_count"]) + max(small, feed) <= 512, (p7[".vgpr_count"], small, feed)
+        assert 2 * g(p8[".vgpr_count"]) + max(small, feed) <= 512
+        for k in (r7, r8, p7, p8):
+            assert k.get(".private_segment_fixed_size", 0) == 0 and k.get(".vgpr_spill_count", 0) == 0

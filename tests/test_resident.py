@@ -46,14 +46,23 @@ CASES = [
 ]
 
 
+CASES += [(9, b, t, m, d) for (n, b, t, m, d) in CASES if n == 1]      # kShapes 9: the ring-sharing tile, 16 wavefronts per CU
+
+
+def _force(monkeypatch, ns):
+    """ns = 1 / 2: kShapes 7 / 8 (MGX_RESIDENT_SLICES); 9: kShapes 9; 0: none."""
+    monkeypatch.setenv("MGX_RESIDENT_SHAPE", "9" if ns == 9 else "")
+    monkeypatch.setenv("MGX_RESIDENT_SLICES", "" if ns == 9 else str(ns))
+
+
 @pytest.mark.parametrize("ns,B,T,max_steps,density", CASES, ids=[f"ns{c[0]}_b{c[1]}" for c in CASES])
 def test_resident_rollout_equals_repeated_steps(monkeypatch, ns, B, T, max_steps, density):
     spec = EnvSpec(16, 16, 4, 7, max_steps=max_steps)
     e1, e2 = _pair(spec, B, seed=100 + B + ns, density=density)
     a = _acts(B, 4, T, 300)
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", str(ns))
+    _force(monkeypatch, ns)
     out = e2.rollout(a)
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", "0")
+    _force(monkeypatch, 0)
     for t in range(T):
         want = e1.step(a[t])
         for n, w in zip(("obs", "dir", "reward", "terminated", "truncated"), want):
@@ -61,16 +70,16 @@ def test_resident_rollout_equals_repeated_steps(monkeypatch, ns, B, T, max_steps
     for n in ("grid", "agents", "rng", "step_count"):
         assert torch.equal(getattr(e1, n), getattr(e2, n)), n
     e1.check_errors(); e2.check_errors()
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", str(ns))
+    _force(monkeypatch, ns)
     out2 = e2.rollout(a[:3].contiguous())                   # ... and on from the written-back state
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", "0")
+    _force(monkeypatch, 0)
     for t in range(3):
         obs, *_ = e1.step(a[t])
         assert torch.equal(out2["obs"][t], obs)
     assert torch.equal(e1.grid, e2.grid)
 
 
-@pytest.mark.parametrize("ns,B", [(1, 1003), (2, 1003), (2, 4096)])
+@pytest.mark.parametrize("ns,B", [(1, 1003), (2, 1003), (2, 4096), (9, 1003), (9, 4096 + 7)])
 def test_resident_rollout_with_auto_reset(monkeypatch, ns, B):
     """Layout pool + fused auto-reset inside the resident launch, the episodes about to truncate."""
     wl = workloads.make("c4", batch=B, global_batch=65536)
@@ -79,9 +88,9 @@ def test_resident_rollout_with_auto_reset(monkeypatch, ns, B):
     for e in (e1, e2):
         e.step_count.fill_(wl.spec.max_steps - T // 2)
     a = _acts(B, 4, T, 900)
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", str(ns))
+    _force(monkeypatch, ns)
     out = e2.rollout(a, auto_reset=True)
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", "0")
+    _force(monkeypatch, 0)
     for t in range(T):
         want = e1.step(a[t], auto_reset=True)
         for n, w in zip(("obs", "dir", "reward", "terminated", "truncated"), want):
@@ -98,15 +107,15 @@ def test_resident_persistent_equals_repeated_steps(monkeypatch, ns, B):
     e_ref, e_per = _pair(spec, B, seed=7 + ns, density=0.25)
     T = 50
     a = _acts(B, 4, T, 700)
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", str(ns))
+    _force(monkeypatch, ns)
     with e_per.persistent(max_steps=T + 3) as ps:
-        assert ps.waves == -(-B // (16 * ns))
+        assert ps.waves == -(-B // (16 * (2 if ns == 2 else 1)))
         for t in range(T):
             want = [x.clone() for x in e_ref.step(a[t])]
             got = ps.step(a[t])
             for n, w, g in zip(("obs", "dir", "reward", "terminated", "truncated"), want, got):
                 assert torch.equal(w, g), f"ns={ns} step {t}: {n}"
-    monkeypatch.setenv("MGX_RESIDENT_SLICES", "0")
+    _force(monkeypatch, 0)
     assert ps.timeouts == 0 and ps.waves_left == ps.waves and ps.steps_completed == T
     for n in ("cells", "agents", "rng", "step_count"):
         assert torch.equal(getattr(e_ref, n), getattr(e_per, n)), n
@@ -121,8 +130,11 @@ def test_c4_full_size_rollout_vs_oracle():
     assert B == 65536
     env = wl.make_env(DEV, auto_reset=True)
     info = _lib.launch_info(spec, B, roll=True)
-    assert info["resident_shape"] == 7 and info["slices"] == 1 and info["envs_per_wavefront"] == 16 and info["wavefronts"] == 4096
-    info = _lib.launch_info(spec, B, persistent=True)            # (the closed-loop form must hold everything at once: two slices)
+    assert info["resident_shape"] == 9 and info["slices"] == 1 and info["envs_per_wavefront"] == 16 and info["wavefronts"] == 4096
+    assert info["lds_bytes"] == 4 * 9872                           # 16 wavefronts per CU: the whole batch is ONE resident round
+    assert _lib.launch_info(spec, 49152, roll=True)["resident_shape"] == 7      # (12 wavefronts per CU while they hold the batch)
+    assert _lib.launch_info(spec, 16384, roll=True)["resident_shape"] == 0
+    info = _lib.launch_info(spec, B, persistent=True)            # (the closed loop must also leave VGPRs to its feeders: two slices)
     assert info["resident_shape"] == 8 and info["slices"] == 2 and info["envs_per_wavefront"] == 32 and info["wavefronts"] == 2048
     env.step_count.fill_(spec.max_steps - T // 2)
     ref = dict(grid=wl.grid.copy(), agents=wl.agents.copy(), rng=wl.rng.copy(),
@@ -151,13 +163,15 @@ def test_c4_full_size_rollout_vs_oracle():
     env.check_errors()
 
 
-def test_c4_full_size_persistent_closed_loop():
+@pytest.mark.parametrize("B,waves", [(65536, 2048), (49152, 1536), (32768, 2048)], ids=["c4", "c4_49152", "c4_32768"])
+def test_c4_full_size_persistent_closed_loop(B, waves):
     """... and the closed loop: mgx_step_persistent holds all 65536 envs (round 5 refused this batch); T steps driven through
     post / wait == T x mgx_step_autoreset.  The resident launch owns every CU's LDS (8 wavefronts x 20112 B of 160 KiB), so a kernel
     that needs LDS cannot run BESIDE it -- the reference steps are therefore taken before the session opens; the producer / consumer
-    kernels of the hand-shake (and any policy between them) must get by on what is left: 2944 B of LDS per CU, 144 VGPRs per SIMD."""
-    wl = workloads.make("c4")
-    B, T = wl.batch, 20
+    kernels of the hand-shake (and any policy between them) must get by on what is left: 2944 B of LDS per CU, 224 VGPRs per SIMD.
+    (That is also why this launch does not take kShapes 9 as the rollout does: 16 wavefronts x 128 VGPRs leave no register at all.)"""
+    wl = workloads.make("c4", batch=B)              # (32768: the one-slice shape 7 at the 8 wavefronts per CU the launch may count on)
+    T = 20
     e_ref, e_per = wl.make_env(DEV, auto_reset=True), wl.make_env(DEV, auto_reset=True)
     for e in (e_ref, e_per):
         e.step_count.fill_(wl.spec.max_steps - T // 2)
@@ -171,7 +185,7 @@ def test_c4_full_size_persistent_closed_loop():
     got = [[torch.empty_like(w) for w in want[t]] for t in range(T)]
     torch.cuda.synchronize()
     with e_per.persistent(max_steps=T, auto_reset=True) as ps:
-        assert ps.waves == 2048
+        assert ps.waves == waves
         for t in range(T):
             for dst, src in zip(got[t], list(ps.step(a[t])) + [e_per.was_reset]):
                 dst.copy_(src)
