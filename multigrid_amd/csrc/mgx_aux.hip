@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void one_hot_kernel(const uint8_t *__restrict_
 // instead of the two reciprocal multiplies when W is a power of two.)
 template <int CB>
 __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int G, int wave_lds, int in_buf, uint32_t inv_W,
-                                                       uint32_t inv_HW, int64_t batch, const uint8_t *__restrict__ grid,
+                                                       uint32_t inv_H, uint32_t inv_HW, int64_t batch, const uint8_t *__restrict__ grid,
                                                        const uint8_t *__restrict__ agents, uint8_t *__restrict__ out) {
     constexpr int cb = CB;
     extern __shared__ __align__(16) uint8_t lds[];
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
     const int ncell = Gc * HW;
     const bool pow2 = (W & (W - 1)) == 0 && (HW & (HW - 1)) == 0;                         // (wave-uniform)
     const int shW = 31 - __builtin_clz((unsigned)W), shHW = 31 - __builtin_clz((unsigned)HW);
+    const bool pow2h = (H & (H - 1)) == 0 && (HW & (HW - 1)) == 0;
+    const int shH = 31 - __builtin_clz((unsigned)H);
     auto move = [&](const int i, const uint32_t c) {
         int e, r, y, xx;
         if (pow2) { e = i >> shHW; r = i & (HW - 1); y = r >> shW; xx = r & (W - 1); }
@@ -171,6 +173,46 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
         d[0] = (uint8_t)c; d[1] = (uint8_t)(c >> 8); d[2] = (uint8_t)(c >> 16);
     };
     int i = lane;
+#ifndef MGX_FULL_OBS_BY_OUTPUT
+#define MGX_FULL_OBS_BY_OUTPUT 1
+#endif
+    // (round 6) OUTPUT order when the wavefront's slice of the output starts on a dword: a lane owns four consecutive output cells --
+    // twelve bytes, three aligned dwords -- and gathers their packed cells from [y][x]: one LDS read per cell and three dword writes
+    // per four cells instead of three byte writes per cell, the (e, x, y) decomposition once per four cells (same box: profiles/
+    // r6_full_obs.txt).  The ragged last cells and slices that start off a dword keep the input-ordered pass below.
+    if (MGX_FULL_OBS_BY_OUTPUT && (oskew & 3) == 0) {
+        const int ngrp = ncell >> 2;
+        auto gather4 = [&](const int k, uint32_t (&c)[4]) {
+            const int o = 4 * k;
+            int e, r, xx, y;
+            if (pow2h) { e = o >> shHW; r = o & (HW - 1); xx = r >> shH; y = r & (H - 1); }
+            else {
+                e = (int)__umulhi((uint32_t)o, inv_HW); r = o - e * HW;
+                xx = (int)__umulhi((uint32_t)r, inv_H); y = r - xx * H;
+            }
+            int src = e * HW + y * W + xx;                              // cell index [e][y][x]
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c[u] = load_cell_shown(cb, in_cells + src * cb);
+                ++y; src += W;
+                if (y == H) { y = 0; ++xx; src += 1 - HW; if (xx == W) { xx = 0; src += HW - W; } }   // next column / next env
+            }
+        };
+        auto put4 = [&](const int k, const uint32_t (&c)[4]) {
+            uint32_t *d = reinterpret_cast<uint32_t *>(out_cells + 12 * k);
+            d[0] = c[0] | (c[1] << 24);
+            d[1] = (c[1] >> 8) | (c[2] << 16);
+            d[2] = (c[2] >> 16) | (c[3] << 8);
+        };
+        int k = lane;
+        for (; k + 64 < ngrp; k += 128) {                                                  // eight cells in flight per lane
+            uint32_t c0[4], c1[4];
+            gather4(k, c0); gather4(k + 64, c1);
+            put4(k, c0); put4(k + 64, c1);
+        }
+        for (; k < ngrp; k += 64) { uint32_t c0[4]; gather4(k, c0); put4(k, c0); }
+        i = 4 * ngrp + lane;                                                               // (<= 3 cells left)
+    }
     for (; i + 192 < ncell; i += 256) {                                                    // four cells in flight per lane
         uint32_t c[4];
 #pragma unroll
@@ -706,12 +748,13 @@ int mgx_full_obs(const MgxSpec *spec, int64_t batch, const MgxCell *grid, const 
     const int64_t blocks = (nwaves + wpb - 1) / wpb;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     const uint32_t inv_W = (uint32_t)(((1ull << 32) + spec->width - 1) / spec->width);
+    const uint32_t inv_H = (uint32_t)(((1ull << 32) + spec->height - 1) / spec->height);
     const uint32_t hw = (uint32_t)HW;
     const uint32_t inv_HW = (uint32_t)(((1ull << 32) + hw - 1) / hw);
     auto *kern = cb == 1 ? full_obs_kernel<1> : cb == 3 ? full_obs_kernel<3> : full_obs_kernel<2>;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), (size_t)(wpb * wave_lds),
                        static_cast<hipStream_t>(stream), spec->width, spec->height, spec->num_agents, G, wave_lds, in_buf, inv_W,
-                       inv_HW, batch, reinterpret_cast<const uint8_t *>(grid), agents, out);
+                       inv_H, inv_HW, batch, reinterpret_cast<const uint8_t *>(grid), agents, out);
     return finish_launch();
 }
 
