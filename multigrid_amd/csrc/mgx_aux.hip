@@ -211,7 +211,17 @@ __global__ __launch_bounds__(256) void full_obs_kernel(int W, int H, int A, int 
             put4(k, c0); put4(k + 64, c1);
         }
         for (; k < ngrp; k += 64) { uint32_t c0[4]; gather4(k, c0); put4(k, c0); }
-        i = 4 * ngrp + lane;                                                               // (<= 3 cells left)
+        const int o = 4 * ngrp + lane;                                                     // (<= 3 OUTPUT cells left: the last env's last column)
+        if (o < ncell) {
+            int e, r, xx, y;
+            if (pow2h) { e = o >> shHW; r = o & (HW - 1); xx = r >> shH; y = r & (H - 1); }
+            else {
+                e = (int)__umulhi((uint32_t)o, inv_HW); r = o - e * HW;
+                xx = (int)__umulhi((uint32_t)r, inv_H); y = r - xx * H;
+            }
+            store_obs_cell(out_cells + 3 * o, load_cell_shown(cb, in_cells + (e * HW + y * W + xx) * cb));
+        }
+        i = ncell;
     }
     for (; i + 192 < ncell; i += 256) {                                                    // four cells in flight per lane
         uint32_t c[4];
