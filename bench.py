@@ -268,6 +268,45 @@ def config_point(name, device, K, warmup, device_generated=False, steady=False, 
     return out
 
 
+def short_episode_point(device, max_steps=32, lead=32):
+    """C3's shape with episodes of at most `max_steps` steps, out of phase (B / max_steps envs restart EVERY step: 512 at 32), each
+    restart generated on the device.  staged="candidates" with a generator launch every lead / 2 steps (round 6: that launch is
+    ~15 us, mgx_layout_gen.h place_group) against generation in the tail of the step's own launch.  `adopted`: of the restarts of an
+    eager, untimed pass, the share whose candidates were all current when the episode ended (those copy a staged layout; the others
+    run the generator in the step's tail) -- candidates do not depend on WHEN the episode ends, so an early end adopts like a
+    truncation as long as a generator launch came by since the env's previous restart."""
+    import dataclasses
+    from multigrid_amd.batched import BatchedMultiGridEnv
+    wl = workloads.make("c3")
+    spec = dataclasses.replace(wl.spec, max_steps=max_steps)
+    B, A = wl.batch, spec.num_agents
+    out = {"workload": f"{wl.title}, max_steps={max_steps}", "batch": B, "restarts_per_step": B // max_steps}
+    for key, staged in (("candidates", "candidates"), ("in_tail", False)):
+        env = BatchedMultiGridEnv(spec, B, device)
+        env.load_state(wl.grid, wl.agents, rng=wl.rng, aux=wl.aux, validate=False)
+        env.set_layout_generator("blockedunlockpickup", layout_seed=5, room_size=6, staged=staged, lead=lead if staged else None)
+        env.step_count.copy_(torch.arange(B, device=device, dtype=torch.int32) % max_steps)
+        if staged:                                              # the untimed accounting pass (also the warm-up)
+            acts = random_actions(4 * max_steps, B, A, device, 77)
+            ready_n = total_n = 0
+            for t in range(4 * max_steps):
+                tag = env._gen["stage"]["tag"]
+                ready = (tag == env.episode[:, None]).all(1)
+                env.step(acts[t], auto_reset=True)
+                if t >= max_steps:                              # (the first episode's candidates come with the first generator launch)
+                    wr = env.was_reset.bool()
+                    ready_n += int((ready & wr).sum()); total_n += int(wr.sum())
+            out["adopted"] = round(ready_n / max(total_n, 1), 4)
+            out["restarts_counted"] = total_n
+        m = measure_steps(env, 256, 50, "graph", lambda: None, seed=4321, min_region_ms=30.0)
+        env.check_errors()
+        out[key + "_us_per_step"] = round(m["event_ms"] / m["timed_steps"] * 1e3, 3)
+        del env
+        torch.cuda.empty_cache()
+    out["generator_launch_every_steps"] = lead // 2
+    return out
+
+
 def one_hot_config_point(name, device, cell_bytes=None, T=128):
     """A configuration stepped with ONE-HOT observations (u8[B,A,v,v,21], written by the step's own launch) -- what RLlib's default
     registration of the reference feeds the policy (multigrid/rllib/__init__.py:110-111) -- as hipGraph replays, fused auto-reset.
@@ -834,6 +873,10 @@ def main():
                     out["configs"][key] = {"error": repr(e)[:200]}
             out["configs"]["c3_device_generated"] = config_point("c3", device, 256, 50, device_generated=True)
             out["configs"]["c3_device_generated_steady"] = config_point("c3", device, 256, 50, device_generated=True, steady=True)
+            try:
+                out["configs"]["c3_short_episodes"] = short_episode_point(device)
+            except Exception as e:
+                out["configs"]["c3_short_episodes"] = {"error": repr(e)[:300]}
             out["eager"] = {c: eager_point(workloads.make(c), device) for c in ("c4", "c2")}
             # (round 6: sub_shards="auto" answers 1 for per-step calls from Python -- the explicit two chains stay measured here)
             out["eager"]["c4_chains"] = eager_point(workloads.make("c4"), device, sub_shards=2)

@@ -134,6 +134,80 @@ __device__ __forceinline__ uint32_t np_interval(NpGen &g, uint32_t max) {
     return value;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Group-cooperative rejection sampling (round 6; stage_candidates_kernel, mgx_layout_gen.hip).  place_obj draws (x, y) until the
+// cell fits: a serial loop of unknown length per lane, and a wavefront of 64 such lanes runs as long as its unluckiest one -- 6-7
+// tries per call where one lane alone needs 1.2 (profiles/r5_candidates.txt).  Here kGroupLanes lanes share ONE candidate: lane j
+// evaluates try j of the call -- PCG64 is an LCG, so the state j tries ahead is mult^j * state + (1 + ... + mult^(j-1)) * inc,
+// one 128-bit multiply-add with per-lane constants -- and the group adopts the first try that fits (a ballot) together with the
+// generator state behind it.  Everything else of the generation runs redundantly on the group's lanes (same values, same stores).
+// A try is exactly two 32-bit draws = one 64-bit word, whichever half the stream stands at -- unless Lemire's bounded draw
+// re-samples (probability < range / 2^32 per draw): a lane that sees that reports it, and the group re-runs the call serially.
+constexpr int kGroupLanes = 8;
+
+struct GroupCtx {
+    int j, base;                  // this lane's try index; the group's first lane in the wavefront
+    uint64_t a_lo, a_hi;          // mult^j
+    uint64_t d_lo, d_hi;          // (1 + mult + ... + mult^(j-1)) * inc of THIS stream
+};
+
+__device__ __forceinline__ uint64_t pcg64_output(uint64_t lo, uint64_t hi) {        // XSL-RR of the (new) state
+    const uint64_t x = hi ^ lo;
+    const unsigned rot = (unsigned)(hi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
+__device__ __forceinline__ void group_init(GroupCtx &c, int lane, const NpGen &g) {
+    // {mult^j, 1 + mult + ... + mult^(j-1)} mod 2^128, mult = 0x2360ED051FC65DA44385DF649FCCF645 (PCG_DEFAULT_MULTIPLIER_128)
+    static constexpr uint64_t T[kGroupLanes][4] = {
+        {0x0000000000000001ull, 0x0000000000000000ull, 0x0000000000000000ull, 0x0000000000000000ull},
+        {0x4385DF649FCCF645ull, 0x2360ED051FC65DA4ull, 0x0000000000000001ull, 0x0000000000000000ull},
+        {0x529ED9EB20E0AE99ull, 0x17BCE35BDF69743Cull, 0x4385DF649FCCF646ull, 0x2360ED051FC65DA4ull},
+        {0xEB5AE837ED42153Dull, 0x25F041404BD80E82ull, 0x9624B94FC0ADA4DFull, 0x3B1DD060FF2FD1E0ull},
+        {0xD194DFBE42D45771ull, 0xF4DD417327DB7A9Bull, 0x817FA187ADEFBA1Cull, 0x610E11A14B07E063ull},
+        {0x1712DD28EC4E2775ull, 0x16C406E9FBE6C01Full, 0x53148145F0C4118Dull, 0x55EB531472E35AFFull},
+        {0x81AB1C97E7371089ull, 0x19B2ADD48DEFCDA8ull, 0x6A275E6EDD123902ull, 0x6CAF59FE6ECA1B1Eull},
+        {0x3D56ECCA7FE71AEDull, 0x9C49933E0E7F5995ull, 0xEBD27B06C449498Bull, 0x866207D2FCB9E8C6ull}};
+    typedef unsigned __int128 u128;
+    c.j = lane & (kGroupLanes - 1);
+    c.base = lane & ~(kGroupLanes - 1);
+    c.a_lo = T[c.j][0]; c.a_hi = T[c.j][1];
+    const u128 d = (((u128)T[c.j][3] << 64) | T[c.j][2]) * (((u128)g.s[3] << 64) | g.s[2]);
+    c.d_lo = (uint64_t)d; c.d_hi = (uint64_t)(d >> 64);
+}
+
+// the generator as c.j tries (two 32-bit draws each) later: j whole words further, the same half pending (has_uint32 keeps its value;
+// `uinteger` is always the high half of the last word made, pending or spent: distributions.h next_uint32)
+__device__ __forceinline__ void group_skip(NpGen &t, const GroupCtx &c) {
+    if (c.j == 0) return;
+    typedef unsigned __int128 u128;
+    const u128 st = (((u128)t.s[1] << 64) | t.s[0]) * (((u128)c.a_hi << 64) | c.a_lo) + (((u128)c.d_hi << 64) | c.d_lo);
+    t.s[0] = (uint64_t)st; t.s[1] = (uint64_t)(st >> 64);
+    t.buf = (t.buf & (1ull << 32)) | (pcg64_output(t.s[0], t.s[1]) >> 32);
+}
+
+// np_integers that REPORTS a re-sample instead of making it (the value is then meaningless)
+__device__ __forceinline__ int np_integers_once(NpGen &g, int lo, int hi, bool &resample) {
+    const uint32_t rng = (uint32_t)(hi - 1 - lo);
+    const uint32_t rng_excl = rng + 1u;
+    const uint64_t m = (uint64_t)np_next32(g) * rng_excl;
+    const uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) resample |= leftover < (0xFFFFFFFFu - rng) % rng_excl;
+#if defined(MGX_BOUNDS_CHECK) && MGX_BOUNDS_CHECK
+    // (the checked build, lib/libmgx_chk.so: one draw in 32 CLAIMS a re-sample -- in the product that is one in ~10^9, never seen by a
+    // test.  The group then re-runs the call serially from the same state, which must give the same layout: tests/test_checked_build.py)
+    resample |= ((leftover >> 10) & 31u) == 0u;
+#endif
+    return lo + (int)(m >> 32);
+}
+
+__device__ __forceinline__ uint32_t lane_read32(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+__device__ __forceinline__ uint64_t lane_read64(uint64_t v, int src_lane) {
+    return (uint64_t)lane_read32((uint32_t)v, src_lane) | ((uint64_t)lane_read32((uint32_t)(v >> 32), src_lane) << 32);
+}
+
 // numpy Generator.shuffle of a Python list of n <= 21 colours (RandomMixin._rand_perm, multigrid/utils/random.py:75-83: the
 // untyped path, `for i in reversed(range(1, n)): j = random_interval(bitgen, i); x[i], x[j] = x[j], x[i]`), the list kept as 3-bit
 // fields of ONE 64-bit register (field k = bits [3k, 3k+3)): no per-lane array, no scratch memory
@@ -167,7 +241,11 @@ constexpr int kMaxObjects = 4;
 
 // What the owning lane knows about its env while placing: the blank template (global, read-only), the objects placed so
 // far (registers) and the agents' positions (LDS, 2 bytes per agent).
-struct Placer {
+template <bool GROUP> struct PlacerGroup {};
+template <> struct PlacerGroup<true> { GroupCtx gc; };
+
+template <bool GROUP = false>
+struct Placer : PlacerGroup<GROUP> {
     int kind, rs;                         // the blank layout is a closed form of the kind: no memory round trip per test
     int W, H, A;
     int n_obj;
@@ -196,10 +274,50 @@ struct Placer {
             if (k == n_obj) { obj_pos[k] = p; obj_cell[k] = cell; }
         ++n_obj;
     }
+    __device__ bool agents_reject(int x, int y, bool next_to) const {
+        bool bad = false;
+        for (int a = 0; a < A; ++a) {
+            const int ax = apos[2 * a] == 0xff ? -1 : apos[2 * a], ay = apos[2 * a + 1] == 0xff ? -1 : apos[2 * a + 1];
+            const int dx = x - ax, dy = y - ay;
+            bad |= (dx == 0) & (dy == 0);
+            bad |= next_to & (dx * dx + dy * dy <= 1);
+        }
+        return bad;
+    }
+    // GROUP: the group's lanes evaluate tries 0 .. kGroupLanes - 1 of the call at once (see GroupCtx); `type_of(x, y)` is the grid
+    // test of the serial forms below.  Returns false when the call must be made serially (a re-sample before the first fit).
+    template <class F>
+    __device__ bool place_group(NpGen &g, int tx, int xhi, int ty, int yhi, bool next_to, F type_of, uint32_t &pos) const {
+        if constexpr (GROUP) {
+            const GroupCtx &c = this->gc;
+            for (;;) {
+                NpGen t = g;
+                group_skip(t, c);
+                bool resample = false;
+                const int x = np_integers_once(t, tx, xhi, resample), y = np_integers_once(t, ty, yhi, resample);
+                const bool fits = !resample && type_of(x, y) == T_EMPTY && !agents_reject(x, y, next_to);
+                const uint32_t all = (1u << kGroupLanes) - 1u;
+                const uint32_t fit8 = (uint32_t)(__builtin_amdgcn_ballot_w64(fits) >> c.base) & all;
+                const uint32_t rs8 = (uint32_t)(__builtin_amdgcn_ballot_w64(resample) >> c.base) & all;
+                const int f = fit8 ? __builtin_ctz(fit8) : kGroupLanes - 1;          // the try the group goes on from
+                if (rs8 & ((2u << f) - 1u)) return false;                               // (a re-sample shifts every later try)
+                const int src = c.base + f;
+                g.s[0] = lane_read64(t.s[0], src); g.s[1] = lane_read64(t.s[1], src); g.buf = lane_read64(t.buf, src);
+                pos = lane_read32((uint32_t)x | ((uint32_t)y << 8), src);
+                if (fit8) return true;
+            }
+        }
+        return false;
+    }
     // the same against the grid in memory (GridIO) instead of the closed form + register objects
     __device__ uint32_t place_io(NpGen &g, const GridIO &io, int tx, int ty, int sw, int sh, bool next_to) const {
         tx = max(tx, 0); ty = max(ty, 0);
         const int xhi = min(tx + sw, W), yhi = min(ty + sh, H);
+        if constexpr (GROUP) {
+            uint32_t pos;
+            if (xhi - tx >= 2 && yhi - ty >= 2 && place_group(g, tx, xhi, ty, yhi, next_to, [&](int x, int y) { return io.type_at(x, y); }, pos))
+                return pos;
+        }
         for (;;) {
             const int x = np_integers(g, tx, xhi), y = np_integers(g, ty, yhi);
             if (io.type_at(x, y) != T_EMPTY) continue;
@@ -218,6 +336,11 @@ struct Placer {
     __device__ uint32_t place(NpGen &g, int tx, int ty, int sw, int sh, bool next_to) const {
         tx = max(tx, 0); ty = max(ty, 0);
         const int xhi = min(tx + sw, W), yhi = min(ty + sh, H);
+        if constexpr (GROUP) {                     // (a range of one cell draws nothing: such a try is not "two draws" -- serial)
+            uint32_t pos;
+            if (xhi - tx >= 2 && yhi - ty >= 2 && place_group(g, tx, xhi, ty, yhi, next_to, [&](int x, int y) { return type_at(x, y); }, pos))
+                return pos;
+        }
         for (;;) {
             const int x = np_integers(g, tx, xhi), y = np_integers(g, ty, yhi);
             if (type_at(x, y) != T_EMPTY) continue;                                  // grid.get(*pos) is not None
@@ -239,9 +362,14 @@ struct Placer {
 // blank layout is already in `grid`); `apos`: 2 * A bytes of LDS scratch.  Returns the env's new hook state.
 // `door_row` > 0: the value of the generator's ONE draw from env.np_random is given (a candidate of MgxGenStage.candidates: `npr` is
 // not touched); 0: it is drawn.
+// GROUP: run by the kGroupLanes lanes of a group in step (`gc`: the lane's GroupCtx) -- every lane computes and stores the same
+// values; only the place_obj tries differ per lane (Placer::place_group).
+template <bool GROUP = false>
 __device__ __forceinline__ uint4 generate_episode(const MgxLayoutGen &gen, int W, int H, int A, NpGen &lay, NpGen &npr,
-                                                  uint8_t *apos, uint8_t *grid, uint64_t *rows, int door_row = 0) {
-    Placer P;
+                                                  uint8_t *apos, uint8_t *grid, uint64_t *rows, int door_row = 0,
+                                                  const GroupCtx *gc = nullptr) {
+    Placer<GROUP> P;
+    if constexpr (GROUP) P.gc = *gc;
     P.kind = gen.kind; P.rs = gen.room_size; P.W = W; P.H = H; P.A = A; P.n_obj = 0;
     P.apos = apos;
     for (int k = 0; k < kMaxObjects; ++k) { P.obj_pos[k] = 0xffffffffu; P.obj_cell[k] = 0; }

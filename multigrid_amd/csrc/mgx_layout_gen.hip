@@ -82,37 +82,52 @@ __global__ __launch_bounds__(64) void reset_generate_kernel(const GenArgs a) {
 }
 
 
-// MgxGenStage.candidates (include/mgx.h): one lane per (env, value of the generator's env.np_random draw).  An env whose candidate
-// k is not its CURRENT episode's successor gets it made from the layout stream as that episode's generation left it.  Launched
-// between two steps on their stream (external == 2): nothing reads or writes a slot beside this launch, the kernel boundary
-// publishes it.  KIND is a template argument so that each instantiation carries ONE generator's code: this launch is as long as its
-// slowest wavefront, and that one's time is mostly instruction fetch (profiles/r5_candidates.txt).
+// MgxGenStage.candidates (include/mgx.h): kGroupLanes lanes per (env, value of the generator's env.np_random draw) -- a group makes ONE
+// candidate, its lanes the tries of every place_obj call at once (mgx_layout_gen.h: GroupCtx; rounds 5: one lane per candidate, the
+// launch as long as the unluckiest lane of 64).  An env whose candidate k is not its CURRENT episode's successor gets it made from the
+// layout stream as that episode's generation left it.  Launched between two steps on their stream (external == 2): nothing reads or
+// writes a slot beside this launch, the kernel boundary publishes it.  KIND is a template argument so that each instantiation
+// carries ONE generator's code.
 template <int KIND>
 __global__ __launch_bounds__(64) void stage_candidates_kernel(const GenArgs a) {
     extern __shared__ uint8_t lds[];
-    const int lane = threadIdx.x;
+    constexpr int GS = kGroupLanes, CPW = 64 / GS;                                   // candidates per wavefront
+    const int lane = threadIdx.x, grp = lane / GS, j = lane % GS;
     const int W = a.sp.width, H = a.sp.height, A = a.sp.num_agents, HWB = H * W * kCellBytes;
     const MgxGenStage &st = a.gen.stage;
     const int K = st.candidates;
-    const int64_t s0 = (int64_t)blockIdx.x * 64, s = s0 + lane, b = s / K;
+    const int64_t s = (int64_t)blockIdx.x * CPW + grp, b = s / K;
     const int k = (int)(s - b * K);
     const bool go = b < a.batch && st.tag[b * 4 + k] != a.episode[b];
-    const uint64_t gom = __builtin_amdgcn_ballot_w64(go);
-    if (gom == 0) return;
+    if (__builtin_amdgcn_ballot_w64(go) == 0) return;
     MgxLayoutGen gen = a.gen;
     gen.kind = KIND;
-    uint8_t *const st_grid = reinterpret_cast<uint8_t *>(st.grid);
-    copy_blank(gen, st_grid, s0, HWB, gom, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                           // (the owning lane overwrites cells the other lanes stored)
+    uint8_t *const cand_grid = reinterpret_cast<uint8_t *>(st.grid) + s * HWB;
+    // (the layout stream's words and the lane's jump constants are requested BEFORE the blank copy: one memory round trip for the three)
+    NpGen lay, npr;
+    GroupCtx gc;
+    {
+        const uint64_t *gs = gen.gen_state + (go ? b : 0) * 6;
+        for (int q = 0; q < 4; ++q) { lay.s[q] = gs[q]; npr.s[q] = 0; }
+        lay.buf = gs[4]; npr.buf = 0;                                                // (npr: not drawn from -- door_row is given)
+        group_init(gc, lane, lay);
+    }
+    if (go) {                                                                        // the blank layout: the group copies its own
+        const uint8_t *blank = reinterpret_cast<const uint8_t *>(gen.blank);
+        if (((HWB | (int)(uintptr_t)blank | (int)(uintptr_t)st.grid) & 3) == 0) {
+            for (int i = j; i < HWB / 4; i += GS)
+                reinterpret_cast<uint32_t *>(cand_grid)[i] = reinterpret_cast<const uint32_t *>(blank)[i];
+        } else {
+            for (int i = j; i < HWB; i += GS) cand_grid[i] = blank[i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                           // (every lane overwrites cells the group's other lanes stored)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_wave_barrier();
     if (!go) return;
-    const uint64_t *gs = gen.gen_state + b * 6;
-    NpGen lay, npr;
-    for (int q = 0; q < 4; ++q) { lay.s[q] = gs[q]; npr.s[q] = 0; }
-    lay.buf = gs[4]; npr.buf = 0;                                                    // (npr: not drawn from -- door_row is given)
-    const uint4 naux = generate_episode(gen, W, H, A, lay, npr, lds + lane * (2 * A), st_grid + s * HWB,
-                                        reinterpret_cast<uint64_t *>(st.agents) + s * A, k + 1);
+    const uint4 naux = generate_episode<true>(gen, W, H, A, lay, npr, lds + grp * (2 * A), cand_grid,
+                                              reinterpret_cast<uint64_t *>(st.agents) + s * A, k + 1, &gc);
+    if (j != 0) return;
     if (st.aux) reinterpret_cast<uint4 *>(st.aux)[s] = naux;
     uint64_t *const words = st.words + s * 6;
     for (int q = 0; q < 4; ++q) words[q] = lay.s[q];
@@ -127,7 +142,8 @@ inline bool misaligned(const void *p, uintptr_t al) { return (reinterpret_cast<u
 // mgx_stage_generate with MgxGenStage.candidates > 0 (mgx_kernels.hip validated the arguments)
 extern "C" int mgx_internal_stage_candidates(const MgxSpec *spec, int64_t batch, const MgxLayoutGen *gen, const int32_t *episode,
                                              void *stream) {
-    const int64_t blocks = (batch * gen->stage.candidates + 63) / 64;
+    constexpr int64_t cpw = 64 / kGroupLanes;
+    const int64_t blocks = (batch * gen->stage.candidates + cpw - 1) / cpw;
     if (blocks > INT_MAX) return MGX_ERR_UNSUPPORTED;
     GenArgs ga{*spec, batch, *gen, nullptr, nullptr, nullptr, nullptr, nullptr, const_cast<int32_t *>(episode), nullptr};
     const size_t lds = (size_t)(64 * 2 * spec->num_agents);

@@ -24,6 +24,18 @@ def test_soak_on_the_bounds_checked_build():
     assert "bounds check: 0 LDS accesses" in out.stdout, out.stdout[-500:]
 
 
+@pytest.mark.gpu
+def test_generation_soak_on_the_checked_build():
+    """The group-cooperative candidate generation (mgx_layout_gen.h: place_group) falls back to the serial place_obj loop when a lane's
+    bounded draw would re-sample -- one draw in ~10^9 in the product.  In the checked build one draw in 32 claims it, so the fallback
+    runs in about every tenth place_obj call: the staged generation must still equal the unstaged one, env for env, bit for bit."""
+    from multigrid_amd import build
+    env = dict(os.environ, MGX_LIBMGX=build.LIB_CHK)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_generate.py"), "15", "4242"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_checked_build_exports_the_counter_and_product_does_not():
     """No GPU needed: the symbol tables."""
     import ctypes
