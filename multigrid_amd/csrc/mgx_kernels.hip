@@ -92,7 +92,7 @@ int launch(int mode, const KernelArgs &ka_in, int threads, int lds_bytes, int64_
     KernelArgs ka = ka_in;
     lds_bytes += g_debug_lds_pad;
 #if MGX_BOUNDS_CHECK
-    if (!g_bounds) {
+    if (!g_bounds) {                      // (normally made by mgx_abi_version(), which the binding calls when it loads the library)
         hipError_t eb = hipMalloc(reinterpret_cast<void **>(&g_bounds), 8);
         if (eb == hipSuccess) eb = hipMemset(g_bounds, 0, 8);
         if (eb != hipSuccess) return hip_failed(eb);
@@ -273,7 +273,21 @@ extern "C" int mgx_internal_stage_candidates(const MgxSpec *spec, int64_t batch,
 
 extern "C" {
 
-int mgx_abi_version(void) { return MGX_ABI_VERSION; }
+int mgx_abi_version(void) {
+#if MGX_BOUNDS_CHECK
+    // (checked build: the violation counter is allocated HERE -- the process' first launch may be one that a stream capture records
+    // (tools/fuzz_generate.py opens some cases with a captured block), and an allocation + memset inside a capture is an error.  On a box
+    // without a GPU the calls fail and nothing is kept.)
+    if (!g_bounds) {
+        int32_t *p = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&p), 8) == hipSuccess) {
+            if (hipMemset(p, 0, 8) == hipSuccess) g_bounds = p; else (void)hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
+#endif
+    return MGX_ABI_VERSION;
+}
 
 const char *mgx_error_string(int code) {
     switch (code) {
