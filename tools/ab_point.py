@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B of two builds of the library on the bench's points (kernel time per step as hipGraph replays):
-    python tools/ab_point.py libA.so libB.so [rounds]     -> alternating runs, C4 / C2 / C3 lock step + the resident rollout at 49152 envs
+    python tools/ab_point.py libA.so libB.so [libC.so ...] [rounds]     -> alternating runs, C4 / C2 / C3 lock step + the resident rollout at 49152 envs
 Each measurement runs in its own process (the library is chosen at import: MGX_LIBMGX)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ import bench
 from multigrid_amd import workloads
 dev = torch.device("cuda", 0)
 out = []
-for name, B in (("c4", 65536), ("c2", 4096), ("c3", 16384), ("c4", 8192)):
+for name, B in (("c4", 65536), ("c2", 4096), ("c3", 16384), ("c4", 8192)) + ((("c5", 32768),) if os.environ.get("AB_C5") else ()):
     wl = workloads.make(name, batch=B, global_batch=max(B, workloads.GLOBAL_BATCH[name]))
     env = wl.make_env(dev, auto_reset=True)
     T = 256
@@ -35,8 +35,8 @@ for r in range(3):
 out.append(f"rollout49152 {best:.3f}")
 print(" | ".join(out))
 ''' % ROOT
-libs = sys.argv[1:3]
-rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]          # two or more builds, measured in alternation
+rounds = next((int(a) for a in sys.argv[1:] if a.isdigit()), 3)
 for r in range(rounds):
     for lib in libs:
         p = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, MGX_LIBMGX=os.path.join(ROOT, lib)), capture_output=True, text=True)

@@ -5,7 +5,17 @@ set -e
 cd "$(dirname "$0")/.."
 OBJ=build/libmgx.so.obj
 mkdir -p build/ab
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -DMGX_INST_V=7 "$@" -Iinclude -c multigrid_amd/csrc/mgx_fused_inst.hip -o build/ab/mgx_fused_v7.o
-OBJS=$(ls $OBJ/*.o | grep -v mgx_fused_v7.o)
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS build/ab/mgx_fused_v7.o -o multigrid_amd/lib/libmgx_ab.so
-echo built multigrid_amd/lib/libmgx_ab.so with "$@"
+OUT=${AB_OUT:-multigrid_amd/lib/libmgx_ab.so}          # AB_OUT=<path>: several variants side by side
+TAG=$(basename "$OUT" .so)
+VS=${AB_V:-7}                                          # AB_V="7 9": the view-size units to recompile (default: 7x7 only)
+SKIP=""
+NEW=""
+for V in $VS; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -DMGX_INST_V=$V "$@" -Iinclude -c multigrid_amd/csrc/mgx_fused_inst.hip -o build/ab/${TAG}_v$V.o &
+    SKIP="$SKIP -e mgx_fused_v$V.o"
+    NEW="$NEW build/ab/${TAG}_v$V.o"
+done
+wait
+OBJS=$(ls $OBJ/*.o | grep -v $SKIP)
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $NEW -o "$OUT"
+echo built "$OUT" with "$@" "(units: $VS)"
