@@ -35,6 +35,47 @@ def test_oracle_integers_equal_numpy():
         assert int(g2.integers(0, 1000)) == int(g.integers(0, 1000))
 
 
+def test_group_jump_constants_and_the_skipped_generator_equal_numpy():
+    """mgx_layout_gen.h `group_init`'s table (lane j of a candidate's group evaluates try j of a place_obj call): row j must be
+    {mult^j, 1 + mult + ... + mult^(j-1)} mod 2^128 -- and a generator advanced that way must stand where numpy's stands after j tries
+    of two bounded 32-bit draws each, whichever half of a word was pending (has_uint32 kept, uinteger = the high half of the last word)."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multigrid_amd", "csrc", "mgx_layout_gen.h")).read()
+    body = src[src.index("static constexpr uint64_t T[kGroupLanes][4]"):]
+    body = body[:body.index("};")]
+    rows = [[int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]{16})ull", line)] for line in body.splitlines() if "0x" in line]
+    assert len(rows) == 8 and all(len(r) == 4 for r in rows)
+    mult, mask = 0x2360ED051FC65DA44385DF649FCCF645, (1 << 128) - 1
+    a, c = 1, 0
+    for j in range(8):
+        assert rows[j][0] | (rows[j][1] << 64) == a and rows[j][2] | (rows[j][3] << 64) == c, j
+        a, c = (a * mult) & mask, (c * mult + 1) & mask
+    r = np.random.default_rng(5)
+    for trial in range(50):
+        g = np.random.Generator(np.random.PCG64(int(r.integers(0, 2 ** 40))))
+        if trial & 1:
+            g.integers(0, 5)                                   # a pending high half
+        st = g.bit_generator.state
+        state, inc, has, uint = st["state"]["state"], st["state"]["inc"], st["has_uint32"], st["uinteger"]
+        for j in range(8):
+            if j:                                              # group_skip: j words on, the pending flag kept
+                aj, cj = rows[j][0] | (rows[j][1] << 64), rows[j][2] | (rows[j][3] << 64)
+                s2 = (state * aj + cj * inc) & mask
+                hi, lo = s2 >> 64, s2 & ((1 << 64) - 1)
+                rot = hi >> 58
+                x = hi ^ lo
+                out = ((x >> rot) | (x << ((64 - rot) & 63))) & ((1 << 64) - 1)
+                want = dict(state=s2, has=has, uint=out >> 32)
+            else:
+                want = dict(state=state, has=has, uint=uint)
+            st2 = g.bit_generator.state
+            assert st2["state"]["state"] == want["state"] and st2["has_uint32"] == want["has"], (trial, j)
+            if j or has:
+                assert st2["uinteger"] == want["uint"], (trial, j)
+            g.integers(0, 7); g.integers(0, 11)                # one try: two bounded draws (a re-sample is ~1e-9: not here)
+
+
 def test_layout_oracle_equals_layouts_py():
     r = np.random.default_rng(7)
     blank = layouts.roomgrid_blank(6, 1, 2)
