@@ -252,11 +252,14 @@ int mgx_launch_info(const MgxSpec *spec, int64_t batch, MgxLaunchInfo *out);
 /* ABI 11: geometry of the launches that keep the envs' state in LDS between steps -- mgx_rollout* (persistent = 0) and
  * mgx_step_persistent (persistent = 1).
  * resident_shape > 0: one of the library's RESIDENT instantiations -- 64 view slots per wavefront, `slices` groups of `envs_per_slice`
- * envs stepped one after the other by the same wavefront.  Empty-16x16 x 4 agents from 16385 envs up: one slice of 16 envs (12
- * wavefronts per CU: 49152 envs resident at once; mgx_rollout* at any larger batch too), and for mgx_step_persistent from 49153 to
- * 65536 envs -- BASELINE.json configs[3] -- two slices: 2048 wavefronts of 2 x 16 envs, 8 per CU, hold every env's tile on the chip
- * (and every CU's LDS: what runs beside that launch must do without).  0: the ordinary rollout kernels (32 view slots, one slice).
- * Same results either way, bit for bit. */
+ * envs stepped one after the other by the same wavefront.  Empty-16x16 x 4 agents from 16385 envs up (the value names the shape):
+ *   7  one slice of 16 envs, 13216 B of LDS: 12 wavefronts per CU, 49152 envs resident at once -- mgx_rollout* up to that batch and
+ *      beyond 65536 (in rounds), mgx_step_persistent up to 32768 envs (its residency check counts 8 wavefronts per CU)
+ *   9  one slice in 9872 B and <= 128 VGPRs (the tile's rows share the grid's wall ring): 16 wavefronts per CU -- mgx_rollout* of 49153
+ *      to 65536 envs: BASELINE.json configs[3] is ONE resident round of 4096 wavefronts
+ *   8  two slices: 2048 wavefronts of 2 x 16 envs, 8 per CU -- mgx_step_persistent of 32769 to 65536 envs (a persistent launch must
+ *      leave registers for the kernels that feed it; it owns every CU's LDS: what runs beside it must do without)
+ * 0: the ordinary rollout kernels (32 view slots, one slice).  Same results either way, bit for bit. */
 typedef struct MgxRolloutInfo {
     int32_t envs_per_slice;
     int32_t slices;              /* per wavefront; envs per wavefront = envs_per_slice * slices */
